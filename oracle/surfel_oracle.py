@@ -1,0 +1,395 @@
+"""CPU oracle for the Gaussian-surfel tile rasterizer (forward; backward via autograd).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product: only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import it, and there only as the checker.  The product path (``active-gs_amd/``)
+never imports this file and fails loudly when the HIP library is missing.
+
+PARITY UNPINNED.  The arithmetic of this path lives in the un-vendored, un-pinned
+pip dependency ``git+https://github.com/liren-jin/diff-gaussian-rasterization_2d``
+(/root/reference/envs/requirements.txt:15, imported at
+/root/reference/utils/operations.py:22-25).  Its source is not on this filesystem
+and the reference ships no tests or golden vectors for it, so this file restates
+the *published* algorithm (3D Gaussian Splatting tile rasterizer, Kerbl et al.
+2023; Gaussian Surfels, Dai et al. 2024 — the lineage named at
+/root/reference/README.md:120) and fixes the open choices as decisions D1..D12
+below.  What IS pinned is the boundary: argument/return schema and camera
+conventions of /root/reference/utils/operations.py:645-720,724-778, exercised by
+driving the reference's own ``GaussianRenderer`` / ``GaussianMap.train()`` over this
+oracle (tests/golden/make_golden.py).
+
+Decisions:
+  D1  near cull: view-space z <= 0.2 is culled (upstream constant), no x/y cull.
+  D2  EWA cov2D = J W Sigma W^T J^T + 0.3*I, with the view-space x/z, y/z clamped
+      to 1.3*tan(fov/2) inside J only.
+  D3  radius = ceil(3*sqrt(lambda_max)), lambda_max = mid + sqrt(max(0.1, mid^2-det));
+      16x16 tiles; tile rect = [ (m-r)/16 , (m+r+15)/16 ) clamped to the grid.
+  D4  alpha = min(0.99, o*exp(power)); skip power>0 and alpha<1/255; a pixel stops
+      *before* the first Gaussian that would push T*(1-alpha) below 1e-4.
+  D5  per-pixel surfel depth (config[2]): first-order ray/plane expansion
+      d_i(u) = z_c + gx*(u_x-m_x) + gy*(u_y-m_y),
+      gx = -z_c^2 n_x / (ncc*fx), gy = -z_c^2 n_y / (ncc*fy),
+      ncc = min(n.c, -0.02*|c|) (grazing clamp); config[2]==0 -> centre depth.
+  D6  depth image (config[1]) = sum(w d) / max(A, 1e-6) with A = accumulated
+      opacity; normal image = sum(w n) UN-normalised (the facade normalises it,
+      operations.py:715, so the two are equivalent after the facade).
+  D7  rgb = sum(w c) + T_final * bg[:3]; no background on any other channel.
+  D8  confidence image = sum(w conf_i), un-normalised (empty pixel -> 0).
+  D9  importance_i = sum_px w, count_i = #px with w > weight_thres, both over pixels
+      with render_mask > 0 when a mask is given; only when config[3] == 1.
+  D10 front_only (config[4]): surfels whose raw normal faces away from the camera
+      (n.c > 0) are culled in preprocessing (radii = 0).
+  D11 normal = 3rd column of R(q) in view space, flipped to face the camera.
+  D12 radii > 0 <=> passed the cull with a non-empty tile rect; the gradient of
+      means2D is dL/d(pixel-space mean) in [:, :2], zero in [:, 2].
+Outputs are bit-comparable to the HIP path only up to fp32 re-association; the sort
+key (view-space depth) is made bit-identical by evaluating the view transform as an
+explicit fmaf chain on both sides (``_affine_rowvec``).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+TILE = 16
+NEAR_CULL = 0.2
+LOWPASS = 0.3
+ALPHA_MAX = 0.99
+ALPHA_MIN = 1.0 / 255.0
+T_EPS = 1e-4
+COS_MIN = 0.02
+DEPTH_A_EPS = 1e-6
+FRUSTUM_CLAMP = 1.3
+
+
+@dataclass
+class OracleSettings:
+    """Mirror of the 15 fields built at /root/reference/utils/operations.py:682-700."""
+
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int = 0
+    campos: Optional[torch.Tensor] = None
+    prefiltered: bool = False
+    render_mask: Optional[torch.Tensor] = None
+    weight_thres: float = 0.03
+    debug: bool = False
+    config: torch.Tensor = field(default_factory=lambda: torch.tensor([1.0, 1.0, 1.0, 0.0, 0.0]))
+
+
+def _fma32(a, b, c):
+    """fmaf(a,b,c) for float32 tensors: the fp32 product is exact in fp64."""
+    return (a.double() * b.double() + c.double()).float()
+
+
+def _affine_rowvec(p, M):
+    """[x y z 1] @ M for row-vector matrices (operations.py:759-762).
+
+    In float32 the VALUE is the fmaf chain fmaf(x,M0j,fmaf(y,M1j,fmaf(z,M2j,M3j)))
+    (what the HIP kernel evaluates), attached straight-through to the
+    differentiable expression, so depth sort keys agree bit for bit.
+    """
+    out = p @ M[:3, :] + M[3]
+    if p.dtype == torch.float32:
+        with torch.no_grad():
+            x, y, z = p.unbind(-1)
+            cols = []
+            for j in range(4):
+                v = _fma32(z, M[2, j], M[3, j].expand_as(z))
+                v = _fma32(y, M[1, j], v)
+                v = _fma32(x, M[0, j], v)
+                cols.append(v)
+            exact = torch.stack(cols, -1)
+        out = out + (exact - out).detach()
+    return out
+
+
+def quat_to_rotmat(q):
+    """(w,x,y,z) -> R, same formula as operations.py:261-278 (no normalisation)."""
+    r, x, y, z = q.unbind(-1)
+    R = torch.stack(
+        [
+            1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+            2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+            2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y),
+        ],
+        -1,
+    ).reshape(-1, 3, 3)
+    return R
+
+
+def preprocess(means3D, means2D, opacities, confidences, colors, scales, rotations, S: OracleSettings):
+    """Per-Gaussian stage (F1). Returns a dict; differentiable entries are indexed by
+    ``vis`` (ids of Gaussians that passed the cull, ascending)."""
+    dt = means3D.dtype
+    dev = means3D.device
+    H, W = int(S.image_height), int(S.image_width)
+    N = means3D.shape[0]
+    cfg = [float(v) for v in S.config.detach().cpu().tolist()]
+    normalize_depth, perpix_depth, front_only = cfg[1] > 0, cfg[2] > 0, cfg[4] > 0
+    V = S.viewmatrix.detach().to(dt).to(dev)
+    PM = S.projmatrix.detach().to(dt).to(dev)
+    fx = W / (2.0 * S.tanfovx)
+    fy = H / (2.0 * S.tanfovy)
+    gx_tiles = (W + TILE - 1) // TILE
+    gy_tiles = (H + TILE - 1) // TILE
+
+    radii = torch.zeros(N, dtype=torch.int32, device=dev)
+    out = dict(N=N, H=H, W=W, grid=(gx_tiles, gy_tiles), radii=radii,
+               normalize_depth=normalize_depth)
+
+    with torch.no_grad():
+        tz_all = _affine_rowvec(means3D.detach(), V)[:, 2]
+        keep = torch.nonzero(tz_all > NEAR_CULL).flatten()
+    if keep.numel() == 0:
+        out["vis"] = keep
+        return out
+
+    p = means3D[keep]
+    t = _affine_rowvec(p, V)[:, :3]
+    tx, ty, tz = t.unbind(-1)
+    ph = _affine_rowvec(p, PM)
+    pw = 1.0 / (ph[:, 3] + 1e-7)
+    mx = ((ph[:, 0] * pw + 1.0) * W - 1.0) * 0.5 + means2D[keep, 0]
+    my = ((ph[:, 1] * pw + 1.0) * H - 1.0) * 0.5 + means2D[keep, 1]
+
+    R = quat_to_rotmat(rotations[keep])
+    s = scales[keep] * S.scale_modifier
+    M = R * s[:, None, :]
+    Sigma = M @ M.transpose(1, 2)
+    A = V[:3, :3].t()  # t = A p + b
+    Sv = A @ Sigma @ A.t()
+    limx = FRUSTUM_CLAMP * S.tanfovx
+    limy = FRUSTUM_CLAMP * S.tanfovy
+    txc = torch.clamp(tx / tz, -limx, limx) * tz
+    tyc = torch.clamp(ty / tz, -limy, limy) * tz
+    zero = torch.zeros_like(tz)
+    J = torch.stack(
+        [fx / tz, zero, -fx * txc / (tz * tz), zero, fy / tz, -fy * tyc / (tz * tz)], -1
+    ).reshape(-1, 2, 3)
+    cov = J @ Sv @ J.transpose(1, 2)
+    ca = cov[:, 0, 0] + LOWPASS
+    cb = cov[:, 0, 1]
+    cc = cov[:, 1, 1] + LOWPASS
+    det = ca * cc - cb * cb
+    det_safe = torch.where(det > 0, det, torch.ones_like(det))
+    conic = torch.stack([cc / det_safe, -cb / det_safe, ca / det_safe], -1)
+    mid = 0.5 * (ca + cc)
+    lam = mid + torch.sqrt(torch.clamp(mid * mid - det, min=0.1))
+    rad = torch.ceil(3.0 * torch.sqrt(lam)).detach()
+
+    nw = R[:, :, 2]
+    nv = nw @ A.t()
+    dotnc = (nv * t).sum(-1)
+    back = dotnc.detach() > 0
+    sgn = torch.where(back, -torch.ones_like(dotnc), torch.ones_like(dotnc))
+    nv = nv * sgn[:, None]
+    nc = dotnc * sgn
+    if perpix_depth:
+        ncc = torch.minimum(nc, -COS_MIN * t.norm(dim=-1))
+        gx = -(tz * tz) * nv[:, 0] / (ncc * fx)
+        gy = -(tz * tz) * nv[:, 1] / (ncc * fy)
+    else:
+        gx = torch.zeros_like(tz)
+        gy = torch.zeros_like(tz)
+
+    with torch.no_grad():
+        ok = det > 0
+        if front_only:
+            ok &= ~back
+        mxd, myd = mx.detach(), my.detach()
+        # C-style (int) truncation then clamp, D3
+        x0 = torch.clamp(torch.trunc((mxd - rad) / TILE), 0, gx_tiles).long()
+        x1 = torch.clamp(torch.trunc((mxd + rad + TILE - 1) / TILE), 0, gx_tiles).long()
+        y0 = torch.clamp(torch.trunc((myd - rad) / TILE), 0, gy_tiles).long()
+        y1 = torch.clamp(torch.trunc((myd + rad + TILE - 1) / TILE), 0, gy_tiles).long()
+        ntiles = (x1 - x0) * (y1 - y0)
+        ok &= ntiles > 0
+        sel = torch.nonzero(ok).flatten()
+        vis = keep[sel]
+        radii[vis] = rad[sel].to(torch.int32)
+
+    out.update(
+        vis=vis,
+        mean2D=torch.stack([mx, my], -1)[sel],
+        conic=conic[sel],
+        opacity=opacities.reshape(-1)[vis],
+        depth=tz[sel],
+        slope=torch.stack([gx, gy], -1)[sel],
+        normal=nv[sel],
+        color=colors[vis],
+        conf=confidences.reshape(-1)[vis],
+        rect=torch.stack([x0, y0, x1, y1], -1)[sel],
+        ntiles=ntiles[sel],
+    )
+    return out
+
+
+def bin_instances(G):
+    """F2..F5: duplicate per touched tile, stable sort by (tile, depth bits), ranges.
+
+    Returns (sorted local index into ``vis`` per instance, ranges (T,2) int64)."""
+    gx_tiles, gy_tiles = G["grid"]
+    T = gx_tiles * gy_tiles
+    vis = G["vis"]
+    if vis.numel() == 0:
+        return torch.zeros(0, dtype=torch.long), torch.zeros(T, 2, dtype=torch.long)
+    nt = G["ntiles"]
+    rect = G["rect"]
+    Vn = vis.numel()
+    owner = torch.repeat_interleave(torch.arange(Vn), nt)
+    offs = torch.cumsum(nt, 0) - nt
+    local = torch.arange(owner.numel()) - offs[owner]
+    wrect = (rect[:, 2] - rect[:, 0])[owner]
+    tyy = rect[owner, 1] + local // wrect
+    txx = rect[owner, 0] + local % wrect
+    tile = tyy * gx_tiles + txx
+    dbits = G["depth"].detach().float().contiguous().view(torch.int32).long()[owner]
+    key = (tile << 32) | dbits
+    order = torch.sort(key, stable=True).indices
+    sorted_owner = owner[order]
+    sorted_tile = tile[order]
+    counts = torch.bincount(sorted_tile, minlength=T)
+    ends = torch.cumsum(counts, 0)
+    ranges = torch.stack([ends - counts, ends], -1)
+    return sorted_owner, ranges
+
+
+def render_tiles(G, sorted_owner, ranges, S: OracleSettings, tiles=None):
+    """F6 as dense [K, P] algebra per tile (cumprod transmittance)."""
+    H, W = G["H"], G["W"]
+    N = G["N"]
+    dt = G["mean2D"].dtype if G["vis"].numel() else torch.float32
+    gx_tiles, gy_tiles = G["grid"]
+    cfg = [float(v) for v in S.config.detach().cpu().tolist()]
+    want_stats = cfg[3] > 0
+    bg = S.bg.detach().to(dt)[:3]
+    final_T = torch.ones(H, W, dtype=dt)
+    n_contrib = torch.zeros(H, W, dtype=torch.int32)
+    importance = torch.zeros(N, dtype=dt)
+    count = torch.zeros(N, dtype=torch.int32)
+    mask = None
+    if S.render_mask is not None and S.render_mask.numel() > 0:
+        mask = (S.render_mask.reshape(H, W) > 0)
+    # every tile yields a (9,16,16) block [rgb3, normal3, depth, opacity, conf];
+    # blocks are stacked and un-tiled once, so autograd sees one cheap graph.
+    empty = torch.zeros(9, TILE, TILE, dtype=dt)
+    empty[:3] = bg[:, None, None]
+    blocks = [empty] * (gx_tiles * gy_tiles)
+    tile_iter = range(gx_tiles * gy_tiles) if tiles is None else tiles
+    for tid in tile_iter:
+        s0, s1 = int(ranges[tid, 0]), int(ranges[tid, 1])
+        if s1 <= s0:
+            continue
+        ty, tx = divmod(tid, gx_tiles)
+        xs = torch.arange(tx * TILE, min((tx + 1) * TILE, W))
+        ys = torch.arange(ty * TILE, min((ty + 1) * TILE, H))
+        yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+        px = xx.reshape(-1).to(dt)
+        py = yy.reshape(-1).to(dt)
+        idx = sorted_owner[s0:s1]
+        m = G["mean2D"][idx]
+        con = G["conic"][idx]
+        o = G["opacity"][idx]
+        dx = px[None, :] - m[:, 0:1]
+        dy = py[None, :] - m[:, 1:2]
+        power = -0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy) - con[:, 1:2] * dx * dy
+        alpha = torch.clamp(o[:, None] * torch.exp(power), max=ALPHA_MAX)
+        live = (power.detach() <= 0) & (alpha.detach() >= ALPHA_MIN)
+        a_eff = torch.where(live, alpha, torch.zeros_like(alpha))
+        one_m = 1.0 - a_eff
+        T_incl = torch.cumprod(one_m, 0)
+        T_excl = torch.cat([torch.ones_like(T_incl[:1]), T_incl[:-1]], 0)
+        alive = T_incl.detach() >= T_EPS  # monotone: first failure stops the pixel
+        w = a_eff * T_excl * alive
+        n_alive = alive.sum(0)
+        Tf = torch.where(
+            n_alive > 0,
+            torch.gather(T_incl, 0, (n_alive - 1).clamp(min=0)[None, :])[0],
+            torch.ones_like(px),
+        )
+        contrib = (live & alive)
+        kidx = torch.arange(1, idx.numel() + 1)[:, None].expand_as(contrib)
+        last = torch.where(contrib, kidx, torch.zeros_like(kidx)).amax(0)
+
+        sl_ = G["slope"][idx]
+        dpix = G["depth"][idx][:, None] + sl_[:, 0:1] * dx + sl_[:, 1:2] * dy
+        C = (w[:, None, :] * G["color"][idx][:, :, None]).sum(0) + Tf[None, :] * bg[:, None]
+        Nn = (w[:, None, :] * G["normal"][idx][:, :, None]).sum(0)
+        D = (w * dpix).sum(0)
+        Aacc = w.sum(0)
+        Cf = (w * G["conf"][idx][:, None]).sum(0)
+        if G["normalize_depth"]:
+            D = D / torch.clamp(Aacc, min=DEPTH_A_EPS)
+        shp = (ys.numel(), xs.numel())
+        blk = torch.cat([C, Nn, D[None], Aacc[None], Cf[None]], 0).reshape(9, *shp)
+        if shp != (TILE, TILE):
+            blk = torch.nn.functional.pad(blk, (0, TILE - shp[1], 0, TILE - shp[0]))
+        blocks[tid] = blk
+        sl = (slice(ys[0].item(), ys[-1].item() + 1), slice(xs[0].item(), xs[-1].item() + 1))
+        final_T[sl] = Tf.detach().reshape(shp)
+        n_contrib[sl] = last.reshape(shp).to(torch.int32)
+        if want_stats:
+            wd = w.detach()
+            if mask is not None:
+                wd = wd * mask[sl].reshape(-1)[None, :].to(dt)
+            gid = G["vis"][idx]
+            importance.index_add_(0, gid, wd.sum(1))
+            count.index_add_(0, gid, (wd > S.weight_thres).sum(1).to(torch.int32))
+
+    img = torch.stack(blocks, 0).reshape(gy_tiles, gx_tiles, 9, TILE, TILE)
+    img = img.permute(2, 0, 3, 1, 4).reshape(9, gy_tiles * TILE, gx_tiles * TILE)[:, :H, :W]
+    return dict(
+        rgb=img[0:3], normal=img[3:6], depth=img[6:7], opacity=img[7:8], confidence=img[8:9],
+        importance=importance, count=count, final_T=final_T, n_contrib=n_contrib,
+    )
+
+
+def rasterize(means3D, means2D, opacities, confidences, colors_precomp, scales, rotations,
+              S: OracleSettings, return_aux: bool = False):
+    """Same call contract as ``GaussianRasterizer.__call__`` at operations.py:703-713.
+
+    Returns (rgb, normal, depth, opacity, confidence, importance, count, radii)."""
+    G = preprocess(means3D, means2D, opacities, confidences, colors_precomp, scales, rotations, S)
+    so, ranges = bin_instances(G)
+    if G["vis"].numel() == 0:
+        H, W = G["H"], G["W"]
+        dt = means3D.dtype
+        bg = S.bg.detach().to(dt)[:3]
+        zero = (means3D.sum() + opacities.sum() + colors_precomp.sum() + scales.sum()
+                + rotations.sum() + means2D.sum()) * 0
+        R = dict(rgb=bg[:, None, None].expand(3, H, W) + zero, normal=torch.zeros(3, H, W, dtype=dt) + zero,
+                 depth=torch.zeros(1, H, W, dtype=dt) + zero, opacity=torch.zeros(1, H, W, dtype=dt) + zero,
+                 confidence=torch.zeros(1, H, W, dtype=dt) + zero,
+                 importance=torch.zeros(G["N"], dtype=dt), count=torch.zeros(G["N"], dtype=torch.int32),
+                 final_T=torch.ones(H, W, dtype=dt), n_contrib=torch.zeros(H, W, dtype=torch.int32))
+    else:
+        R = render_tiles(G, so, ranges, S)
+    outs = (R["rgb"], R["normal"], R["depth"], R["opacity"], R["confidence"],
+            R["importance"], R["count"], G["radii"])
+    if return_aux:
+        aux = dict(G=G, sorted_owner=so, ranges=ranges, final_T=R["final_T"], n_contrib=R["n_contrib"])
+        return outs, aux
+    return outs
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lrs, step, beta1=0.9, beta2=0.999, eps=1e-15):
+    """torch.optim.Adam single-tensor update as configured at
+    /root/reference/mapping/gaussian_map.py:259-292 (eps 1e-15, no weight decay,
+    no amsgrad), one lr per tensor.  In place; ``step`` is 1-based."""
+    bc1 = 1.0 - beta1 ** step
+    bc2_sqrt = math.sqrt(1.0 - beta2 ** step)
+    for p, g, m, v, lr in zip(params, grads, exp_avg, exp_avg_sq, lrs):
+        m.lerp_(g, 1.0 - beta1)
+        v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+        denom = (v.sqrt() / bc2_sqrt).add_(eps)
+        p.addcdiv_(m, denom, value=-(lr / bc1))
