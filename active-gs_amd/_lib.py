@@ -1,0 +1,125 @@
+"""ctypes binding of libags_raster.so (include/ags_raster.h).
+
+There is no CPU fallback: if the library is missing or cannot be loaded every entry
+point raises.  torch is imported first on purpose so the library binds to the HIP
+runtime torch already loaded (same SONAME, one runtime per process)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
+
+from . import build as _build
+
+c_f32p = C.c_void_p
+
+
+class AgsCamera(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float),
+                ("tanfovy", C.c_float), ("scale_modifier", C.c_float), ("weight_thres", C.c_float),
+                ("normalize_depth", C.c_int32), ("perpix_depth", C.c_int32), ("want_stats", C.c_int32),
+                ("front_only", C.c_int32), ("viewmatrix", c_f32p), ("projmatrix", c_f32p), ("bg", c_f32p),
+                ("render_mask", c_f32p)]
+
+
+class AgsGaussians(C.Structure):
+    _fields_ = [("n", C.c_int32), ("means3D", c_f32p), ("scales", c_f32p), ("rotations", c_f32p),
+                ("opacities", c_f32p), ("colors", c_f32p), ("confidences", c_f32p)]
+
+
+class AgsImages(C.Structure):
+    _fields_ = [("rgb", c_f32p), ("normal", c_f32p), ("depth", c_f32p), ("opacity", c_f32p), ("confidence", c_f32p)]
+
+
+class AgsPerGaussian(C.Structure):
+    _fields_ = [("importance", c_f32p), ("count", C.c_void_p), ("radii", C.c_void_p)]
+
+
+class AgsImageGrads(C.Structure):
+    _fields_ = [("d_rgb", c_f32p), ("d_normal", c_f32p), ("d_depth", c_f32p), ("d_opacity", c_f32p),
+                ("d_confidence", c_f32p)]
+
+
+class AgsGaussianGrads(C.Structure):
+    _fields_ = [("d_means3D", c_f32p), ("d_scales", c_f32p), ("d_rotations", c_f32p), ("d_opacities", c_f32p),
+                ("d_colors", c_f32p), ("d_means2D", c_f32p), ("accumulate", C.c_int32)]
+
+
+class AgsWorkspace(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_size_t), ("max_instances", C.c_int64)]
+
+
+class AgsStatus(C.Structure):
+    _fields_ = [("num_instances", C.c_uint32), ("num_sorted", C.c_uint32), ("overflow", C.c_uint32),
+                ("num_visible", C.c_uint32), ("reserved", C.c_uint32 * 12)]
+
+
+class AgsAdamTensors(C.Structure):
+    _fields_ = [("param", c_f32p * 5), ("grad", c_f32p * 5), ("exp_avg", c_f32p * 5), ("exp_avg_sq", c_f32p * 5),
+                ("numel", C.c_int64 * 5), ("lr", C.c_float * 5)]
+
+
+class AgsActivation(C.Structure):
+    _fields_ = [("n", C.c_int32), ("scale_factor", C.c_float), ("max_scale", C.c_float), ("raw_scales", c_f32p),
+                ("raw_rotations", c_f32p), ("raw_opacities", c_f32p)]
+
+
+EXPORTS = ["ags_workspace_bytes", "ags_forward", "ags_backward", "ags_read_status", "ags_adam_step",
+           "ags_activate", "ags_activate_backward", "ags_profile_enable", "ags_profile_read",
+           "ags_error_string", "ags_version"]
+
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load() -> C.CDLL:
+    """Load (never build) the shared library; raise if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the rasterizer.")
+    lib = C.CDLL(path)
+    lib.ags_workspace_bytes.restype = C.c_size_t
+    lib.ags_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64]
+    lib.ags_forward.restype = C.c_int
+    lib.ags_forward.argtypes = [C.POINTER(AgsCamera), C.POINTER(AgsGaussians), C.POINTER(AgsImages),
+                                C.POINTER(AgsPerGaussian), C.POINTER(AgsWorkspace), C.c_void_p]
+    lib.ags_backward.restype = C.c_int
+    lib.ags_backward.argtypes = [C.POINTER(AgsCamera), C.POINTER(AgsGaussians), C.POINTER(AgsImages),
+                                 C.POINTER(AgsPerGaussian), C.POINTER(AgsImageGrads), C.POINTER(AgsGaussianGrads),
+                                 C.POINTER(AgsWorkspace), C.c_void_p]
+    lib.ags_read_status.restype = C.c_int
+    lib.ags_read_status.argtypes = [C.POINTER(AgsWorkspace), C.POINTER(AgsStatus), C.c_void_p]
+    lib.ags_adam_step.restype = C.c_int
+    lib.ags_adam_step.argtypes = [C.POINTER(AgsAdamTensors), C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]
+    lib.ags_activate.restype = C.c_int
+    lib.ags_activate.argtypes = [C.POINTER(AgsActivation), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ags_activate_backward.restype = C.c_int
+    lib.ags_activate_backward.argtypes = [C.POINTER(AgsActivation), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ags_profile_enable.restype = C.c_int
+    lib.ags_profile_enable.argtypes = [C.c_int32]
+    lib.ags_profile_read.restype = C.c_int
+    lib.ags_profile_read.argtypes = [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    lib.ags_error_string.restype = C.c_char_p
+    lib.ags_error_string.argtypes = [C.c_int]
+    lib.ags_version.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what} failed: {load().ags_error_string(code).decode()} ({code})")
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,103 @@
+// Fused Adam over the five Gaussian parameter tensors (means, scales, rotations,
+// opacities, harmonics) in ONE launch: the 14*N floats are one flat index space, each
+// element reads g,m,v,p once and writes m,v,p once (28 B/float = 392 B per Gaussian).
+// Semantics: torch.optim.Adam as configured at /root/reference/mapping/gaussian_map.py:259-292
+// (betas 0.9/0.999 by default, eps 1e-15, no weight decay, no amsgrad; per-tensor lr from
+// /root/reference/config/mapper/incremental.yaml:27-32).  Zero-gradient rows still decay
+// their moments and move, exactly like the dense torch update.
+#include "ags_internal.h"
+
+struct AgsAdamArgs {
+    float* p[5];
+    const float* g[5];
+    float* m[5];
+    float* v[5];
+    long long end[5]; // cumulative element counts
+    float step_size[5]; // lr / (1 - beta1^t)
+};
+
+__global__ __launch_bounds__(256) void ags_k_adam(AgsAdamArgs a, float beta1, float beta2, float eps,
+                                                  float inv_bc2_sqrt, long long total) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int seg = (i >= a.end[0]) + (i >= a.end[1]) + (i >= a.end[2]) + (i >= a.end[3]);
+        const long long j = i - (seg ? a.end[seg - 1] : 0);
+        const float g = a.g[seg][j];
+        float m = a.m[seg][j], v = a.v[seg][j];
+        m = m + (1.f - beta1) * (g - m);                 // exp_avg.lerp_(grad, 1-beta1)
+        v = v * beta2 + (1.f - beta2) * g * g;           // mul_(beta2).addcmul_(g, g, 1-beta2)
+        const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+        a.m[seg][j] = m;
+        a.v[seg][j] = v;
+        a.p[seg][j] -= a.step_size[seg] * (m / denom);   // addcdiv_(m, denom, -step_size)
+    }
+}
+
+void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, hipStream_t s) {
+    AgsAdamArgs a;
+    long long run = 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    for (int k = 0; k < 5; ++k) {
+        a.p[k] = t.param[k]; a.g[k] = t.grad[k]; a.m[k] = t.exp_avg[k]; a.v[k] = t.exp_avg_sq[k];
+        run += t.numel[k];
+        a.end[k] = run;
+        a.step_size[k] = (float)((double)t.lr[k] / bc1);
+    }
+    if (run <= 0) return;
+    long long blocks = (run + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(ags_k_adam, dim3((unsigned)blocks), dim3(256), 0, s, a, beta1, beta2, eps,
+                       (float)(1.0 / sqrt(bc2)), run);
+}
+
+// ---------------------------------------------------------------------------------------
+// Activations (gaussian_map.py:529-549) and their chain rule, one lane per Gaussian.
+__global__ __launch_bounds__(256) void ags_k_activate(AgsActivation a, float* __restrict__ scales,
+                                                      float* __restrict__ rotations, float* __restrict__ opacities) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = a.scale_factor * expf(a.raw_scales[3 * i + k]);
+        scales[3 * i + k] = fminf(fmaxf(v, 0.f), a.max_scale);
+    }
+    const float4 q = reinterpret_cast<const float4*>(a.raw_rotations)[i];
+    const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    reinterpret_cast<float4*>(rotations)[i] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+    opacities[i] = 1.0f / (1.0f + expf(-a.raw_opacities[i]));
+}
+
+__global__ __launch_bounds__(256) void ags_k_activate_bwd(AgsActivation a, float* __restrict__ d_scales,
+                                                          float* __restrict__ d_rotations,
+                                                          float* __restrict__ d_opacities) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = a.scale_factor * expf(a.raw_scales[3 * i + k]);
+        // torch.clamp passes the gradient on the closed interval [0, max]
+        d_scales[3 * i + k] = (v >= 0.f && v <= a.max_scale) ? d_scales[3 * i + k] * v : 0.f;
+    }
+    const float4 q = reinterpret_cast<const float4*>(a.raw_rotations)[i];
+    const float4 d = reinterpret_cast<const float4*>(d_rotations)[i];
+    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+    const float hx = q.x * inv, hy = q.y * inv, hz = q.z * inv, hw = q.w * inv;
+    const float dot = hx * d.x + hy * d.y + hz * d.z + hw * d.w;
+    reinterpret_cast<float4*>(d_rotations)[i] =
+        make_float4((d.x - hx * dot) * inv, (d.y - hy * dot) * inv, (d.z - hz * dot) * inv, (d.w - hw * dot) * inv);
+    const float o = 1.0f / (1.0f + expf(-a.raw_opacities[i]));
+    d_opacities[i] = d_opacities[i] * o * (1.0f - o);
+}
+
+void ags_launch_activate(const AgsActivation& a, float* scales, float* rotations, float* opacities, hipStream_t s) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(ags_k_activate, dim3((a.n + 255) / 256), dim3(256), 0, s, a, scales, rotations, opacities);
+}
+void ags_launch_activate_bwd(const AgsActivation& a, float* d_scales, float* d_rotations, float* d_opacities,
+                             hipStream_t s) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(ags_k_activate_bwd, dim3((a.n + 255) / 256), dim3(256), 0, s, a, d_scales, d_rotations,
+                       d_opacities);
+}

@@ -1,0 +1,161 @@
+// Internal declarations shared by the HIP translation units of libags_raster.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ags_raster.h"
+#include "surfel_math.h"
+
+#define AGS_SORT_THREADS 256
+#define AGS_SORT_ITEMS 16
+#define AGS_SORT_TILE (AGS_SORT_THREADS * AGS_SORT_ITEMS) // keys per block per pass
+#define AGS_SORT_MAX_PASSES 8
+#define AGS_PRE_THREADS 256
+
+// Byte offsets of the workspace regions (all 256-B aligned). The first three regions are
+// contiguous so one hipMemsetAsync clears them at the start of a forward pass.
+struct AgsLayout {
+    size_t status;      // 256 B: AgsStatus + padding
+    size_t totals;      // AGS_SORT_MAX_PASSES * 256 u32 digit totals
+    size_t ranges;      // T * uint2
+    size_t clear_bytes; // status..ranges end
+    size_t geom;        // n * AgsGeom
+    size_t tiles;       // n * u32 tiles touched
+    size_t rect;        // n * ushort4
+    size_t block_sums;  // (ceil(n/256)+1) * u32
+    size_t keys0, keys1;// cap * u64
+    size_t vals0, vals1;// cap * u32
+    size_t hist;        // 256 * nb_cap * u32
+    size_t final_T;     // P * f32
+    size_t n_contrib;   // P * u32
+    size_t dgeom;       // n * AgsGeomGrad (backward)
+    size_t total;
+    int64_t cap;
+    int nb_cap;         // sort blocks at capacity
+    int n_blocks;       // preprocess blocks
+    int num_tiles;
+};
+
+static inline size_t ags_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static inline AgsLayout ags_make_layout(int n, int h, int w, int64_t cap) {
+    AgsLayout L;
+    const int tiles_x = (w + AGS_TILE - 1) / AGS_TILE, tiles_y = (h + AGS_TILE - 1) / AGS_TILE;
+    L.num_tiles = tiles_x * tiles_y;
+    L.cap = cap < 1 ? 1 : cap;
+    L.nb_cap = (int)((L.cap + AGS_SORT_TILE - 1) / AGS_SORT_TILE);
+    L.n_blocks = (n + AGS_PRE_THREADS - 1) / AGS_PRE_THREADS;
+    const size_t P = (size_t)h * w;
+    size_t o = 0;
+    L.status = o; o += 256;
+    L.totals = o; o += (size_t)AGS_SORT_MAX_PASSES * 256 * 4;
+    L.ranges = o; o += ags_align256((size_t)L.num_tiles * 8);
+    L.clear_bytes = o;
+    L.geom = o; o += ags_align256((size_t)n * sizeof(AgsGeom));
+    L.tiles = o; o += ags_align256((size_t)n * 4);
+    L.rect = o; o += ags_align256((size_t)n * 8);
+    L.block_sums = o; o += ags_align256((size_t)(L.n_blocks + 1) * 4);
+    L.keys0 = o; o += ags_align256((size_t)L.cap * 8);
+    L.keys1 = o; o += ags_align256((size_t)L.cap * 8);
+    L.vals0 = o; o += ags_align256((size_t)L.cap * 4);
+    L.vals1 = o; o += ags_align256((size_t)L.cap * 4);
+    L.hist = o; o += ags_align256((size_t)256 * L.nb_cap * 4);
+    L.final_T = o; o += ags_align256(P * 4);
+    L.n_contrib = o; o += ags_align256(P * 4);
+    L.dgeom = o; o += ags_align256((size_t)n * sizeof(AgsGeomGrad));
+    L.total = o;
+    return L;
+}
+
+static inline AgsFrame ags_make_frame(const AgsCamera* c) {
+    AgsFrame F;
+    F.H = c->image_height; F.W = c->image_width;
+    F.tiles_x = (F.W + AGS_TILE - 1) / AGS_TILE; F.tiles_y = (F.H + AGS_TILE - 1) / AGS_TILE;
+    F.tanfovx = c->tanfovx; F.tanfovy = c->tanfovy;
+    F.fx = F.W / (2.0f * c->tanfovx); F.fy = F.H / (2.0f * c->tanfovy);
+    F.scale_mod = c->scale_modifier;
+    F.perpix_depth = c->perpix_depth; F.front_only = c->front_only;
+    return F;
+}
+
+// ---- launchers (one per translation unit; each enqueues on `s` and never synchronises)
+void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
+                           const AgsLayout& L, int* radii, hipStream_t s);
+void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s,
+                        uint64_t** keys_sorted, uint32_t** vals_sorted);
+void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
+                           const uint32_t* vals_sorted, const AgsImages& out, const AgsPerGaussian& pg,
+                           hipStream_t s);
+void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
+                           const uint32_t* vals_sorted, const AgsImages& fwd, const AgsImageGrads& dout,
+                           hipStream_t s);
+void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
+                               const AgsLayout& L, const int* radii, const AgsGaussianGrads& din, hipStream_t s);
+void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, hipStream_t s);
+void ags_launch_activate(const AgsActivation& a, float* scales, float* rotations, float* opacities, hipStream_t s);
+void ags_launch_activate_bwd(const AgsActivation& a, float* d_scales, float* d_rotations, float* d_opacities,
+                             hipStream_t s);
+int ags_sort_passes(int num_tiles);
+
+#if defined(__HIPCC__)
+// ---- wave64 helpers (gfx950): DPP reductions, no LDS, no ds_bpermute
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int ags_dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float ags_dpp_f(float v) {
+    return __builtin_bit_cast(float, ags_dpp_i<CTRL, ROW_MASK>(__builtin_bit_cast(int, v)));
+}
+// after this every lane of row 3 (lanes 48..63) holds the wave total; lane 63 is read back
+__device__ __forceinline__ float ags_wave_sum_lane63(float v) {
+    v += ags_dpp_f<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += ags_dpp_f<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += ags_dpp_f<0x141>(v);      // row_half_mirror
+    v += ags_dpp_f<0x140>(v);      // row_mirror
+    v += ags_dpp_f<0x142, 0xA>(v); // row_bcast15 -> rows 1,3
+    v += ags_dpp_f<0x143, 0xC>(v); // row_bcast31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ float ags_wave_sum(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ags_wave_sum_lane63(v)), 63));
+}
+__device__ __forceinline__ uint32_t ags_wave_sum_u32(uint32_t x) {
+    int v = (int)x;
+    v += ags_dpp_i<0xB1>(v);
+    v += ags_dpp_i<0x4E>(v);
+    v += ags_dpp_i<0x141>(v);
+    v += ags_dpp_i<0x140>(v);
+    v += ags_dpp_i<0x142, 0xA>(v);
+    v += ags_dpp_i<0x143, 0xC>(v);
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t ags_wave_max_u32(uint32_t x) {
+    // values are < 2^31 here, so signed max on the zero-filled DPP sources is exact
+    int v = (int)x;
+    v = max(v, ags_dpp_i<0xB1>(v));
+    v = max(v, ags_dpp_i<0x4E>(v));
+    v = max(v, ags_dpp_i<0x141>(v));
+    v = max(v, ags_dpp_i<0x140>(v));
+    v = max(v, ags_dpp_i<0x142, 0xA>(v));
+    v = max(v, ags_dpp_i<0x143, 0xC>(v));
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+// inclusive prefix sum across the wave (Hillis-Steele on DPP row shifts + row broadcasts)
+__device__ __forceinline__ uint32_t ags_wave_incl_scan_u32(uint32_t x) {
+    int v = (int)x;
+    v += ags_dpp_i<0x111>(v); // row_shr:1
+    v += ags_dpp_i<0x112>(v); // row_shr:2
+    v += ags_dpp_i<0x114>(v); // row_shr:4
+    v += ags_dpp_i<0x118>(v); // row_shr:8
+    v += ags_dpp_i<0x142, 0xA>(v); // row_bcast15 into rows 1,3
+    v += ags_dpp_i<0x143, 0xC>(v); // row_bcast31 into rows 2,3
+    return (uint32_t)v;
+}
+// block -> tile map: block b runs on XCD b%8 (observed dispatch order); give every XCD one
+// contiguous run of row-major tiles so neighbouring tiles share that XCD's L2. Bijective.
+__device__ __forceinline__ int ags_xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+#endif

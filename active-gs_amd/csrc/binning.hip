@@ -1,0 +1,268 @@
+// Tile binning: F2 scan of tiles-touched, F3 duplicate-with-keys, F4 radix sort of
+// (tile | depth-bits) keys with gaussian-id payloads, F5 per-tile ranges.
+//
+// Counterpart of the cub::DeviceScan / duplicateWithKeys / cub::DeviceRadixSort /
+// identifyTileRanges stages of the CUDA lineage — written from scratch
+// for wave64: the instance count lives ONLY on the device (status[1]); every kernel is
+// launched for the workspace capacity and trims itself, so the host never reads it back.
+// The sort is a stable LSD radix sort, 8-bit digits: per pass a block histogram, a
+// digit-major scan (one workgroup per digit) and a scatter whose in-block ranks come from
+// wave-wide digit matching with __ballot (64-bit) — no LDS sort, no atomics in the ranks.
+#include "ags_internal.h"
+
+// ------------------------------------------------------------------ F2: scan of block sums
+__global__ __launch_bounds__(1024) void ags_k_scan_blocks(uint32_t* __restrict__ block_sums, int nblk,
+                                                          uint32_t* __restrict__ status, uint32_t cap) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + tid;
+        const uint32_t x = (i < nblk) ? block_sums[i] : 0u;
+        const uint32_t inc = ags_wave_incl_scan_u32(x);
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < wave; ++k) woff += wtot[k];
+        const uint32_t carry = carry_s;
+        if (i < nblk) block_sums[i] = carry + woff + inc - x; // exclusive
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t total = carry_s;
+        status[0] = total;
+        status[1] = total < cap ? total : cap;
+        status[2] = total > cap ? 1u : 0u;
+    }
+}
+
+// ------------------------------------------------------------------ F3: duplicate with keys
+__global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_duplicate(
+    int n, int tiles_x, const uint32_t* __restrict__ tiles, const ushort4* __restrict__ rect,
+    const AgsGeom* __restrict__ geom, const uint32_t* __restrict__ block_prefix, uint64_t* __restrict__ keys,
+    uint32_t* __restrict__ vals, uint32_t cap) {
+    __shared__ uint32_t wtot[AGS_PRE_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * AGS_PRE_THREADS + tid;
+    const uint32_t cnt = (i < n) ? tiles[i] : 0u;
+    const uint32_t inc = ags_wave_incl_scan_u32(cnt);
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t off = block_prefix[blockIdx.x] + inc - cnt;
+    for (int k = 0; k < wave; ++k) off += wtot[k];
+    // Large footprints are emitted by the whole wave (coalesced), small ones per lane.
+    uint4 mine = make_uint4(0, 0, 0, 0); // x0 | y0<<16, width, off, depth bits
+    if (cnt) {
+        const ushort4 rc = rect[i];
+        mine = make_uint4((uint32_t)rc.x | ((uint32_t)rc.y << 16), (uint32_t)(rc.z - rc.x), off,
+                          __float_as_uint(geom[i].dc));
+    }
+    const uint32_t COOP = 32;
+    unsigned long long big = __ballot(cnt > COOP);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const uint32_t xy = __shfl(mine.x, src), wd = __shfl(mine.y, src), o = __shfl(mine.z, src);
+        const uint32_t db = __shfl(mine.w, src), c = __shfl(cnt, src);
+        const uint32_t gid = (uint32_t)(blockIdx.x * AGS_PRE_THREADS + (wave << 6) + src);
+        for (uint32_t t = lane; t < c; t += 64) {
+            const uint32_t ty = (xy >> 16) + t / wd, tx = (xy & 0xFFFF) + t % wd;
+            const uint32_t idx = o + t;
+            if (idx < cap) {
+                keys[idx] = ((uint64_t)(ty * tiles_x + tx) << 32) | db;
+                vals[idx] = gid;
+            }
+        }
+    }
+    if (cnt && cnt <= COOP) {
+        const uint32_t x0 = mine.x & 0xFFFF, y0 = mine.x >> 16, wd = mine.y;
+        for (uint32_t t = 0; t < cnt; ++t) {
+            const uint32_t ty = y0 + t / wd, tx = x0 + t % wd;
+            const uint32_t idx = off + t;
+            if (idx < cap) {
+                keys[idx] = ((uint64_t)(ty * tiles_x + tx) << 32) | mine.w;
+                vals[idx] = (uint32_t)i;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ F4: radix sort passes
+// Layout of one block's keys: wave w owns [w*1024, (w+1)*1024) of the block's 4096 keys,
+// item j of lane l sits at w*1024 + j*64 + l, so (wave, item, lane) order == memory order
+// and the per-wave running counters give a stable rank.
+__global__ __launch_bounds__(AGS_SORT_THREADS) void ags_k_sort_hist(
+    const uint64_t* __restrict__ keys, const uint32_t* __restrict__ status, uint32_t* __restrict__ hist,
+    uint32_t* __restrict__ totals, int nb_cap, int shift, uint32_t mask) {
+    const uint32_t n = status[1];
+    const uint32_t nb = (n + AGS_SORT_TILE - 1) / AGS_SORT_TILE;
+    if (blockIdx.x >= nb) return;
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * AGS_SORT_TILE + (threadIdx.x >> 6) * (64 * AGS_SORT_ITEMS) + (threadIdx.x & 63);
+#pragma unroll
+    for (int j = 0; j < AGS_SORT_ITEMS; ++j) {
+        const uint32_t idx = base + j * 64;
+        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    const uint32_t c = h[threadIdx.x];
+    hist[(size_t)threadIdx.x * nb_cap + blockIdx.x] = c;
+    if (c) atomicAdd(&totals[threadIdx.x], c);
+}
+
+// one workgroup per digit: digit base = sum of totals of smaller digits, then an exclusive
+// scan along the digit's row of per-block counts.
+__global__ __launch_bounds__(256) void ags_k_sort_scan(const uint32_t* __restrict__ status,
+                                                       uint32_t* __restrict__ hist,
+                                                       const uint32_t* __restrict__ totals, int nb_cap) {
+    const uint32_t n = status[1];
+    const int nb = (int)((n + AGS_SORT_TILE - 1) / AGS_SORT_TILE);
+    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t carry_s;
+    const uint32_t part = ags_wave_sum_u32(tid < d ? totals[tid] : 0u);
+    if (lane == 0) wtot[wave] = part;
+    __syncthreads();
+    if (tid == 0) carry_s = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+    uint32_t* row = hist + (size_t)d * nb_cap;
+    for (int base = 0; base < nb; base += 256) {
+        const int i = base + tid;
+        const uint32_t x = (i < nb) ? row[i] : 0u;
+        const uint32_t inc = ags_wave_incl_scan_u32(x);
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < wave; ++k) woff += wtot[k];
+        const uint32_t carry = carry_s;
+        if (i < nb) row[i] = carry + woff + inc - x;
+        __syncthreads();
+        if (tid == 255) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(AGS_SORT_THREADS) void ags_k_sort_scatter(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ status, const uint32_t* __restrict__ hist,
+    int nb_cap, int shift, uint32_t mask, int bits) {
+    const uint32_t n = status[1];
+    const uint32_t nb = (n + AGS_SORT_TILE - 1) / AGS_SORT_TILE;
+    if (blockIdx.x >= nb) return;
+    __shared__ uint32_t cnt[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) cnt[w][tid] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * AGS_SORT_TILE + wave * (64 * AGS_SORT_ITEMS) + lane;
+    uint64_t k[AGS_SORT_ITEMS];
+    uint32_t v[AGS_SORT_ITEMS];
+    uint32_t rk[AGS_SORT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < AGS_SORT_ITEMS; ++j) {
+        const uint32_t idx = base + j * 64;
+        const bool valid = idx < n;
+        k[j] = valid ? keys_in[idx] : ~0ull;
+        v[j] = valid ? vals_in[idx] : 0u;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < AGS_SORT_ITEMS; ++j) {
+        const bool valid = (base + j * 64) < n;
+        const uint32_t d = (uint32_t)(k[j] >> shift) & mask;
+        unsigned long long peers = __ballot(valid);
+        for (int b = 0; b < bits; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t r = __popcll(peers & lt);
+        uint32_t prev = 0;
+        if (valid && r == 0) { // lowest lane of each digit group bumps the wave's counter
+            prev = cnt[wave][d];
+            cnt[wave][d] = prev + __popcll(peers);
+        }
+        const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+        prev = __shfl(prev, leader);
+        rk[j] = prev + r;
+    }
+    __syncthreads();
+    { // per digit: global base of this block + exclusive offsets of the four waves
+        uint32_t run = hist[(size_t)tid * nb_cap + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < AGS_SORT_ITEMS; ++j) {
+        if ((base + j * 64) < n) {
+            const uint32_t d = (uint32_t)(k[j] >> shift) & mask;
+            const uint32_t pos = cnt[wave][d] + rk[j];
+            keys_out[pos] = k[j];
+            vals_out[pos] = v[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ F5: tile ranges
+__global__ __launch_bounds__(256) void ags_k_ranges(const uint64_t* __restrict__ keys,
+                                                    const uint32_t* __restrict__ status,
+                                                    uint2* __restrict__ ranges) {
+    const uint32_t n = status[1];
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const uint32_t t = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0) ranges[t].x = 0;
+    else {
+        const uint32_t p = (uint32_t)(keys[idx - 1] >> 32);
+        if (p != t) { ranges[p].y = idx; ranges[t].x = idx; }
+    }
+    if (idx == n - 1) ranges[t].y = n;
+}
+
+int ags_sort_passes(int num_tiles) {
+    int tb = 0;
+    while ((1 << tb) < num_tiles) ++tb;
+    return (32 + tb + 7) / 8;
+}
+
+void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s,
+                        uint64_t** keys_sorted, uint32_t** vals_sorted) {
+    uint32_t* status = (uint32_t*)(ws + L.status);
+    uint32_t* bsum = (uint32_t*)(ws + L.block_sums);
+    uint64_t* keys[2] = {(uint64_t*)(ws + L.keys0), (uint64_t*)(ws + L.keys1)};
+    uint32_t* vals[2] = {(uint32_t*)(ws + L.vals0), (uint32_t*)(ws + L.vals1)};
+    uint32_t* hist = (uint32_t*)(ws + L.hist);
+    uint32_t* totals = (uint32_t*)(ws + L.totals);
+    const uint32_t cap = (uint32_t)L.cap;
+    hipLaunchKernelGGL(ags_k_scan_blocks, dim3(1), dim3(1024), 0, s, bsum, L.n_blocks, status, cap);
+    hipLaunchKernelGGL(ags_k_duplicate, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, in.n, F.tiles_x,
+                       (const uint32_t*)(ws + L.tiles), (const ushort4*)(ws + L.rect),
+                       (const AgsGeom*)(ws + L.geom), bsum, keys[0], vals[0], cap);
+    int tb = 0;
+    while ((1 << tb) < L.num_tiles) ++tb;
+    const int total_bits = 32 + tb;
+    int cur = 0, pass = 0;
+    for (int shift = 0; shift < total_bits; shift += 8, ++pass) {
+        const int bits = (total_bits - shift) < 8 ? (total_bits - shift) : 8;
+        const uint32_t mask = (1u << bits) - 1u;
+        uint32_t* tot = totals + pass * 256;
+        hipLaunchKernelGGL(ags_k_sort_hist, dim3(L.nb_cap), dim3(AGS_SORT_THREADS), 0, s, keys[cur], status, hist,
+                           tot, L.nb_cap, shift, mask);
+        hipLaunchKernelGGL(ags_k_sort_scan, dim3(256), dim3(256), 0, s, status, hist, tot, L.nb_cap);
+        hipLaunchKernelGGL(ags_k_sort_scatter, dim3(L.nb_cap), dim3(AGS_SORT_THREADS), 0, s, keys[cur], vals[cur],
+                           keys[cur ^ 1], vals[cur ^ 1], status, hist, L.nb_cap, shift, mask, bits);
+        cur ^= 1;
+    }
+    const int rblocks = (int)((L.cap + 255) / 256);
+    hipLaunchKernelGGL(ags_k_ranges, dim3(rblocks), dim3(256), 0, s, keys[cur], status,
+                       (uint2*)(ws + L.ranges));
+    *keys_sorted = keys[cur];
+    *vals_sorted = vals[cur];
+}

@@ -1,0 +1,156 @@
+// extern "C" entry points of libags_raster.so (include/ags_raster.h).
+#include "ags_internal.h"
+
+#define AGS_VERSION 100
+
+static int ags_check_launch() { return hipGetLastError() == hipSuccess ? AGS_OK : AGS_E_LAUNCH; }
+
+// ---- optional stage timing (process-global; see ags_profile_enable in the header)
+#include <vector>
+namespace {
+struct StageEvents { std::vector<hipEvent_t> a, b; int used = 0; };
+StageEvents g_prof[AGS_NUM_STAGES];
+int g_prof_slots = 0;
+struct StageScope {
+    hipStream_t s; int stage; bool on;
+    StageScope(int st, hipStream_t stream) : s(stream), stage(st), on(false) {
+        if (g_prof_slots > 0 && g_prof[st].used < g_prof_slots) { on = true; hipEventRecord(g_prof[st].a[g_prof[st].used], s); }
+    }
+    ~StageScope() { if (on) { hipEventRecord(g_prof[stage].b[g_prof[stage].used], s); g_prof[stage].used++; } }
+};
+} // namespace
+
+extern "C" {
+
+size_t ags_workspace_bytes(int32_t n, int32_t h, int32_t w, int64_t max_instances) {
+    if (n < 0 || h <= 0 || w <= 0) return 0;
+    return ags_make_layout(n, h, w, max_instances).total;
+}
+
+int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* out,
+                const AgsPerGaussian* pg, const AgsWorkspace* ws, ags_stream_t stream) {
+    if (!cam || !in || !out || !pg || !ws || !ws->ptr) return AGS_E_INVALID;
+    if (in->n < 0 || cam->image_height <= 0 || cam->image_width <= 0) return AGS_E_INVALID;
+    if (!cam->viewmatrix || !cam->projmatrix || !cam->bg) return AGS_E_INVALID;
+    if (in->n > 0 && !pg->radii) return AGS_E_INVALID;
+    if (!out->rgb || !out->normal || !out->depth || !out->opacity || !out->confidence) return AGS_E_INVALID;
+    if (in->n > 0 && cam->want_stats && (!pg->importance || !pg->count)) return AGS_E_INVALID;
+    if (in->n > 0 && (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences))
+        return AGS_E_INVALID;
+    if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll) return AGS_E_INVALID;
+    const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
+    if (ws->bytes < L.total) return AGS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* base = (char*)ws->ptr;
+    const AgsFrame F = ags_make_frame(cam);
+    if (hipMemsetAsync(base + L.status, 0, L.clear_bytes, s) != hipSuccess) return AGS_E_LAUNCH;
+    uint64_t* keys_sorted = nullptr;
+    uint32_t* vals_sorted = (uint32_t*)(base + L.vals0);
+    if (in->n > 0) {
+        { StageScope t(AGS_STAGE_PREPROCESS, s); ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, s); }
+        { StageScope t(AGS_STAGE_BINNING, s); ags_launch_binning(F, *in, base, L, s, &keys_sorted, &vals_sorted); }
+    }
+    { StageScope t(AGS_STAGE_RENDER_FWD, s); ags_launch_render_fwd(F, *cam, base, L, vals_sorted, *out, *pg, s); }
+    return ags_check_launch();
+}
+
+int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* fwd,
+                 const AgsPerGaussian* pg, const AgsImageGrads* dout, const AgsGaussianGrads* din,
+                 const AgsWorkspace* ws, ags_stream_t stream) {
+    if (!cam || !in || !fwd || !pg || !dout || !din || !ws || !ws->ptr) return AGS_E_INVALID;
+    if (in->n == 0) return AGS_OK;
+    if (!pg->radii || !fwd->depth || !fwd->opacity) return AGS_E_INVALID;
+    if (!din->d_means3D || !din->d_scales || !din->d_rotations || !din->d_opacities || !din->d_colors)
+        return AGS_E_INVALID;
+    const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
+    if (ws->bytes < L.total) return AGS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* base = (char*)ws->ptr;
+    const AgsFrame F = ags_make_frame(cam);
+    // the sorted payloads sit in buffer (passes & 1), the same place the forward left them
+    const uint32_t* vals_sorted = (const uint32_t*)(base + ((ags_sort_passes(L.num_tiles) & 1) ? L.vals1 : L.vals0));
+    if (hipMemsetAsync(base + L.dgeom, 0, (size_t)in->n * sizeof(AgsGeomGrad), s) != hipSuccess) return AGS_E_LAUNCH;
+    { StageScope t(AGS_STAGE_RENDER_BWD, s); ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, s); }
+    { StageScope t(AGS_STAGE_PREPROCESS_BWD, s); ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, s); }
+    return ags_check_launch();
+}
+
+int ags_read_status(const AgsWorkspace* ws, AgsStatus* host_out, ags_stream_t stream) {
+    if (!ws || !ws->ptr || !host_out) return AGS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(host_out, ws->ptr, sizeof(AgsStatus), hipMemcpyDeviceToHost, s) != hipSuccess) return AGS_E_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return AGS_E_LAUNCH;
+    return AGS_OK;
+}
+
+int ags_adam_step(const AgsAdamTensors* t, float beta1, float beta2, float eps, int32_t step, ags_stream_t stream) {
+    if (!t || step < 1) return AGS_E_INVALID;
+    for (int k = 0; k < 5; ++k) {
+        if (t->numel[k] < 0) return AGS_E_INVALID;
+        if (t->numel[k] > 0 && (!t->param[k] || !t->grad[k] || !t->exp_avg[k] || !t->exp_avg_sq[k])) return AGS_E_INVALID;
+    }
+    ags_launch_adam(*t, beta1, beta2, eps, step, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_activate(const AgsActivation* a, float* scales, float* rotations, float* opacities, ags_stream_t stream) {
+    if (!a || a->n < 0) return AGS_E_INVALID;
+    if (a->n > 0 && (!a->raw_scales || !a->raw_rotations || !a->raw_opacities || !scales || !rotations || !opacities))
+        return AGS_E_INVALID;
+    ags_launch_activate(*a, scales, rotations, opacities, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_activate_backward(const AgsActivation* a, float* d_scales, float* d_rotations, float* d_opacities,
+                          ags_stream_t stream) {
+    if (!a || a->n < 0) return AGS_E_INVALID;
+    if (a->n > 0 && (!a->raw_scales || !a->raw_rotations || !a->raw_opacities || !d_scales || !d_rotations || !d_opacities))
+        return AGS_E_INVALID;
+    ags_launch_activate_bwd(*a, d_scales, d_rotations, d_opacities, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_profile_enable(int32_t slots) {
+    if (slots < 0) return AGS_E_INVALID;
+    for (int st = 0; st < AGS_NUM_STAGES; ++st) {
+        for (hipEvent_t e : g_prof[st].a) hipEventDestroy(e);
+        for (hipEvent_t e : g_prof[st].b) hipEventDestroy(e);
+        g_prof[st].a.clear(); g_prof[st].b.clear(); g_prof[st].used = 0;
+        for (int k = 0; k < slots; ++k) {
+            hipEvent_t x, y;
+            if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return AGS_E_LAUNCH;
+            g_prof[st].a.push_back(x); g_prof[st].b.push_back(y);
+        }
+    }
+    g_prof_slots = slots;
+    return AGS_OK;
+}
+
+int ags_profile_read(int32_t stage, float* avg_ms, int32_t* samples) {
+    if (stage < 0 || stage >= AGS_NUM_STAGES || !avg_ms || !samples) return AGS_E_INVALID;
+    StageEvents& e = g_prof[stage];
+    double sum = 0.0;
+    for (int k = 0; k < e.used; ++k) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.b[k]) != hipSuccess) return AGS_E_LAUNCH;
+        if (hipEventElapsedTime(&ms, e.a[k], e.b[k]) != hipSuccess) return AGS_E_LAUNCH;
+        sum += ms;
+    }
+    *samples = e.used;
+    *avg_ms = e.used ? (float)(sum / e.used) : 0.f;
+    e.used = 0;
+    return AGS_OK;
+}
+
+const char* ags_error_string(int code) {
+    switch (code) {
+        case AGS_OK: return "ok";
+        case AGS_E_INVALID: return "invalid argument";
+        case AGS_E_WORKSPACE: return "workspace too small (see ags_workspace_bytes)";
+        case AGS_E_LAUNCH: return "HIP enqueue failed";
+        default: return "unknown error";
+    }
+}
+
+int ags_version(void) { return AGS_VERSION; }
+}

@@ -1,0 +1,112 @@
+// Per-Gaussian kernels: F1 (cull + project + conic + tile rect) and B2+B3 fused
+// (conic/mean2D/depth/normal gradients -> means3D, scales, rotations, opacity, colour).
+// One lane per Gaussian; the camera matrices are wave-uniform (scalar loads).
+// Counterpart of the preprocess / preprocess-backward stages listed in SURVEY.md §2.3.
+#include "ags_internal.h"
+
+__global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
+    AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
+    AgsGeom* __restrict__ geom, uint32_t* __restrict__ tiles, ushort4* __restrict__ rect,
+    int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ status) {
+    __shared__ uint32_t wsum[AGS_PRE_THREADS / 64], wvis[AGS_PRE_THREADS / 64];
+    float V[16], P[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
+    const int i = blockIdx.x * AGS_PRE_THREADS + threadIdx.x;
+    uint32_t cnt = 0, vis = 0;
+    if (i < in.n) {
+        const float p[3] = {in.means3D[3 * i], in.means3D[3 * i + 1], in.means3D[3 * i + 2]};
+        const float sc[3] = {in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]};
+        const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
+        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float col[3] = {in.colors[3 * i], in.colors[3 * i + 1], in.colors[3 * i + 2]};
+        AgsGeom g;
+        int radius = 0, rc[4];
+        if (ags_preprocess_fwd(F, V, P, p, sc, q, in.opacities[i], col, in.confidences[i], 0.f, 0.f, g, radius, rc)) {
+            float4* dst = reinterpret_cast<float4*>(geom + i);
+            dst[0] = make_float4(g.mx, g.my, g.ca, g.cb);
+            dst[1] = make_float4(g.cc, g.o, g.dc, g.gx);
+            dst[2] = make_float4(g.gy, g.r, g.g, g.b);
+            dst[3] = make_float4(g.nx, g.ny, g.nz, g.conf);
+            rect[i] = make_ushort4((unsigned short)rc[0], (unsigned short)rc[1], (unsigned short)rc[2], (unsigned short)rc[3]);
+            cnt = (uint32_t)((rc[2] - rc[0]) * (rc[3] - rc[1]));
+            vis = 1;
+        }
+        radii[i] = radius;
+        tiles[i] = cnt;
+    }
+    const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { wsum[wave] = ws; wvis[wave] = wv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < AGS_PRE_THREADS / 64; ++k) { a += wsum[k]; b += wvis[k]; }
+        block_sums[blockIdx.x] = a;
+        if (b) atomicAdd(&status[3], b);
+    }
+}
+
+__global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
+    AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
+    const int* __restrict__ radii, const AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out) {
+    float V[16], P[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
+    const int i = blockIdx.x * AGS_PRE_THREADS + threadIdx.x;
+    if (i >= in.n) return;
+    float dm[3] = {0, 0, 0}, ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0}, dm2[2] = {0, 0};
+    const bool vis = radii[i] > 0;
+    if (vis) {
+        const float p[3] = {in.means3D[3 * i], in.means3D[3 * i + 1], in.means3D[3 * i + 2]};
+        const float sc[3] = {in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]};
+        const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
+        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float4* src = reinterpret_cast<const float4*>(dgeom + i);
+        const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+        AgsGeomGrad dg;
+        dg.dmx = a.x; dg.dmy = a.y; dg.dca = a.z; dg.dcb = a.w;
+        dg.dcc = b.x; dg.dop = b.y; dg.ddc = b.z; dg.dgx = b.w;
+        dg.dgy = c.x; dg.dr = c.y; dg.dg = c.z; dg.db = c.w;
+        dg.dnx = d.x; dg.dny = d.y; dg.dnz = d.z; dg.pad = 0.f;
+        ags_preprocess_bwd(F, V, P, p, sc, q, dg, dm, ds, dq, &dop, dcol, dm2);
+    } else if (out.accumulate) {
+        return; // nothing to add
+    }
+    if (out.accumulate) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            out.d_means3D[3 * i + k] += dm[k];
+            out.d_scales[3 * i + k] += ds[k];
+            out.d_colors[3 * i + k] += dcol[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out.d_rotations[4 * i + k] += dq[k];
+        out.d_opacities[i] += dop;
+        if (out.d_means2D) { out.d_means2D[3 * i] += dm2[0]; out.d_means2D[3 * i + 1] += dm2[1]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            out.d_means3D[3 * i + k] = dm[k];
+            out.d_scales[3 * i + k] = ds[k];
+            out.d_colors[3 * i + k] = dcol[k];
+        }
+        reinterpret_cast<float4*>(out.d_rotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        out.d_opacities[i] = dop;
+        if (out.d_means2D) { out.d_means2D[3 * i] = dm2[0]; out.d_means2D[3 * i + 1] = dm2[1]; out.d_means2D[3 * i + 2] = 0.f; }
+    }
+}
+
+void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
+                           const AgsLayout& L, int* radii, hipStream_t s) {
+    hipLaunchKernelGGL(ags_k_preprocess, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
+                       cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
+                       (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.status));
+}
+
+void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
+                               const AgsLayout& L, const int* radii, const AgsGaussianGrads& din, hipStream_t s) {
+    hipLaunchKernelGGL(ags_k_preprocess_bwd, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
+                       cam.projmatrix, in, radii, (const AgsGeomGrad*)(ws + L.dgeom), din);
+}

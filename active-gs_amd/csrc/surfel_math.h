@@ -299,21 +299,28 @@ AGS_HD bool ags_alpha(const AgsGeom& g, float px, float py, float& dx, float& dy
     return (power <= 0.f) && (alpha >= AGS_ALPHA_MIN);
 }
 
-// returns blend weight w (0 when skipped); `pos1` = 1-based position in the tile list
-AGS_HD float ags_blend_fwd(AgsPix& s, const AgsGeom& g, float px, float py, uint32_t pos1) {
-    if (s.done) return 0.f;
-    float dx, dy, alpha;
-    if (!ags_alpha(g, px, py, dx, dy, alpha)) return 0.f;
+// Blend a Gaussian whose alpha test passed; returns weight w (0 when the pixel stops).
+// `pos1` = 1-based position in the tile list.
+AGS_HD float ags_blend_apply(AgsPix& s, const AgsGeom& g, float dx, float dy, float alpha, uint32_t pos1) {
+    // branchless on purpose: per-lane selects, and no conditional stores into `s`
     const float testT = s.T * (1.f - alpha);
-    if (testT < AGS_T_EPS) { s.done = 1; return 0.f; }
-    const float w = alpha * s.T;
+    const bool stop = testT < AGS_T_EPS;
+    const float w = stop ? 0.f : alpha * s.T;
     s.c0 += w * g.r; s.c1 += w * g.g; s.c2 += w * g.b;
     s.n0 += w * g.nx; s.n1 += w * g.ny; s.n2 += w * g.nz;
     s.d += w * (g.dc + g.gx * dx + g.gy * dy);
     s.cf += w * g.conf;
-    s.T = testT;
-    s.last = pos1;
+    s.T = stop ? s.T : testT;
+    s.last = stop ? s.last : pos1;
+    s.done = stop ? 1 : s.done;
     return w;
+}
+
+AGS_HD float ags_blend_fwd(AgsPix& s, const AgsGeom& g, float px, float py, uint32_t pos1) {
+    if (s.done) return 0.f;
+    float dx, dy, alpha;
+    if (!ags_alpha(g, px, py, dx, dy, alpha)) return 0.f;
+    return ags_blend_apply(s, g, dx, dy, alpha, pos1);
 }
 
 // Per-pixel constants of the backward pass, derived from the incoming image gradients.
@@ -343,12 +350,9 @@ AGS_HD void ags_pixgrad_init(AgsPixGrad& s, const float dC[3], const float dN[3]
     s.last = last;
 }
 
-// One back-to-front step; accumulates this pixel's contribution into `acc`.
-// `pos1` is the Gaussian's 1-based position in the tile list. Returns true if it contributed.
-AGS_HD bool ags_blend_bwd(AgsPixGrad& s, const AgsGeom& g, float px, float py, uint32_t pos1, AgsGeomGrad& acc) {
-    if (pos1 > s.last) return false;
-    float dx, dy, alpha;
-    if (!ags_alpha(g, px, py, dx, dy, alpha)) return false;
+// One back-to-front step for a Gaussian whose alpha test passed at this pixel
+// (and pos1 <= s.last); accumulates the pixel's contribution into `acc`.
+AGS_HD void ags_blend_bwd_apply(AgsPixGrad& s, const AgsGeom& g, float dx, float dy, float alpha, AgsGeomGrad& acc) {
     const float om = 1.f - alpha;
     s.T = s.T / om; // transmittance in front of this Gaussian
     const float w = alpha * s.T;
@@ -373,5 +377,13 @@ AGS_HD bool ags_blend_bwd(AgsPixGrad& s, const AgsGeom& g, float px, float py, u
         ddy += gp * (-g.cc * dy - g.cb * dx);
     }
     acc.dmx -= ddx; acc.dmy -= ddy; // dx = px - mx
+}
+
+// `pos1` is the Gaussian's 1-based position in the tile list. Returns true if it contributed.
+AGS_HD bool ags_blend_bwd(AgsPixGrad& s, const AgsGeom& g, float px, float py, uint32_t pos1, AgsGeomGrad& acc) {
+    if (pos1 > s.last) return false;
+    float dx, dy, alpha;
+    if (!ags_alpha(g, px, py, dx, dy, alpha)) return false;
+    ags_blend_bwd_apply(s, g, dx, dy, alpha, acc);
     return true;
 }

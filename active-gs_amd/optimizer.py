@@ -1,0 +1,51 @@
+"""Fused Adam over the five Gaussian parameter tensors (C ABI ``ags_adam_step``).
+
+Mirror of ``init_training`` + ``optimizer.step()`` at
+/root/reference/mapping/gaussian_map.py:259-292,126: torch.optim.Adam semantics, eps 1e-15,
+one learning rate per tensor (mean, scale, rotation, opacity, harmonic), state created at
+construction (the reference rebuilds the optimizer at every keyframe)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ptr
+
+
+class FusedAdam:
+    def __init__(self, params: Sequence[torch.Tensor], lrs: Sequence[float], betas=(0.9, 0.999), eps: float = 1e-15):
+        if len(params) != 5 or len(lrs) != 5:
+            raise ValueError("FusedAdam takes the five map tensors (means, scales, rotations, opacities, harmonics)")
+        for p in params:
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("FusedAdam parameters must be contiguous float32 GPU tensors (no CPU fallback)")
+        self.params = list(params)
+        self.lrs = [float(x) for x in lrs]
+        self.betas = betas
+        self.eps = eps
+        self.exp_avg = [torch.zeros_like(p) for p in params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in params]
+        self.step_count = 0
+
+    def step(self, grads: Sequence[torch.Tensor]) -> None:
+        lib = _lib.load()
+        self.step_count += 1
+        t = _lib.AgsAdamTensors()
+        for k in range(5):
+            g = grads[k]
+            if g.shape != self.params[k].shape and g.numel() == self.params[k].numel():
+                g = g.reshape(self.params[k].shape)
+            if not g.is_contiguous():
+                g = g.contiguous()
+            t.param[k] = ptr(self.params[k])
+            t.grad[k] = ptr(g)
+            t.exp_avg[k] = ptr(self.exp_avg[k])
+            t.exp_avg_sq[k] = ptr(self.exp_avg_sq[k])
+            t.numel[k] = self.params[k].numel()
+            t.lr[k] = self.lrs[k]
+        self._keep = grads
+        _lib.check(lib.ags_adam_step(C.byref(t), self.betas[0], self.betas[1], self.eps, self.step_count,
+                                     torch.cuda.current_stream().cuda_stream), "ags_adam_step")

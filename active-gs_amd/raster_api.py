@@ -1,0 +1,178 @@
+"""Functional host API over the C ABI (include/ags_raster.h): no autograd, no host sync.
+
+``forward`` / ``backward`` enqueue the HIP kernels on the current torch stream and return
+immediately; buffers are torch tensors only because torch owns device memory here.
+Used directly by bench.py and the trainer, and wrapped by ``rasterizer.py`` for the
+drop-in ``diff_gaussian_rasterization_2d`` module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ptr
+
+
+@dataclass
+class Camera:
+    """What GaussianRasterizationSettings carries (operations.py:682-700), flags decoded."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    bg: torch.Tensor
+    scale_modifier: float = 1.0
+    weight_thres: float = 0.03
+    normalize_depth: bool = True
+    perpix_depth: bool = True
+    want_stats: bool = False
+    front_only: bool = False
+    render_mask: Optional[torch.Tensor] = None
+
+    def c_struct(self) -> _lib.AgsCamera:
+        m = self.render_mask
+        if m is not None and m.numel() == 0:
+            m = None
+        if m is not None and m.numel() != self.image_height * self.image_width:
+            raise ValueError("render_mask must hold image_height*image_width values")
+        return _lib.AgsCamera(self.image_height, self.image_width, self.tanfovx, self.tanfovy,
+                              self.scale_modifier, self.weight_thres, int(self.normalize_depth),
+                              int(self.perpix_depth), int(self.want_stats), int(self.front_only),
+                              ptr(self.viewmatrix), ptr(self.projmatrix), ptr(self.bg), ptr(m))
+
+
+@dataclass
+class Gaussians:
+    means3D: torch.Tensor
+    scales: torch.Tensor
+    rotations: torch.Tensor
+    opacities: torch.Tensor
+    colors: torch.Tensor
+    confidences: torch.Tensor
+
+    @property
+    def n(self) -> int:
+        return self.means3D.shape[0]
+
+    def c_struct(self) -> _lib.AgsGaussians:
+        return _lib.AgsGaussians(self.n, ptr(self.means3D), ptr(self.scales), ptr(self.rotations),
+                                 ptr(self.opacities), ptr(self.colors), ptr(self.confidences))
+
+
+@dataclass
+class ForwardState:
+    rgb: torch.Tensor
+    normal: torch.Tensor
+    depth: torch.Tensor
+    opacity: torch.Tensor
+    confidence: torch.Tensor
+    importance: torch.Tensor
+    count: torch.Tensor
+    radii: torch.Tensor
+    workspace: torch.Tensor
+    max_instances: int
+
+    def images_struct(self) -> _lib.AgsImages:
+        return _lib.AgsImages(ptr(self.rgb), ptr(self.normal), ptr(self.depth), ptr(self.opacity), ptr(self.confidence))
+
+    def per_gaussian_struct(self) -> _lib.AgsPerGaussian:
+        return _lib.AgsPerGaussian(ptr(self.importance), ptr(self.count), ptr(self.radii))
+
+    def ws_struct(self) -> _lib.AgsWorkspace:
+        return _lib.AgsWorkspace(ptr(self.workspace), self.workspace.numel(), self.max_instances)
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: the rasterizer has no CPU path")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous float32")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace_bytes(n: int, h: int, w: int, max_instances: int) -> int:
+    return int(_lib.load().ags_workspace_bytes(n, h, w, max_instances))
+
+
+def alloc_state(n: int, h: int, w: int, max_instances: int, device) -> ForwardState:
+    f = dict(device=device, dtype=torch.float32)
+    return ForwardState(
+        rgb=torch.empty(3, h, w, **f), normal=torch.empty(3, h, w, **f), depth=torch.empty(1, h, w, **f),
+        opacity=torch.empty(1, h, w, **f), confidence=torch.empty(1, h, w, **f),
+        importance=torch.zeros(n, **f), count=torch.zeros(n, device=device, dtype=torch.int32),
+        radii=torch.empty(n, device=device, dtype=torch.int32),
+        workspace=torch.empty(workspace_bytes(n, h, w, max_instances), device=device, dtype=torch.uint8),
+        max_instances=int(max_instances))
+
+
+def forward(cam: Camera, g: Gaussians, state: ForwardState) -> ForwardState:
+    """Enqueue one forward pass into ``state`` (see ``alloc_state``). Asynchronous."""
+    lib = _lib.load()
+    for name in ("means3D", "scales", "rotations", "opacities", "colors", "confidences"):
+        _require_cuda(getattr(g, name), name)
+    if cam.want_stats:
+        state.importance.zero_()
+        state.count.zero_()
+    cs, gs = cam.c_struct(), g.c_struct()
+    im, pg, ws = state.images_struct(), state.per_gaussian_struct(), state.ws_struct()
+    _lib.check(lib.ags_forward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(ws), _stream()),
+               "ags_forward")
+    return state
+
+
+def read_status(state: ForwardState) -> dict:
+    """Blocking read of the device status block (instances needed, overflow flag, ...)."""
+    lib = _lib.load()
+    st = _lib.AgsStatus()
+    ws = state.ws_struct()
+    _lib.check(lib.ags_read_status(C.byref(ws), C.byref(st), _stream()), "ags_read_status")
+    return dict(num_instances=st.num_instances, num_sorted=st.num_sorted, overflow=bool(st.overflow),
+                num_visible=st.num_visible)
+
+
+@dataclass
+class GaussianGrads:
+    means3D: torch.Tensor
+    scales: torch.Tensor
+    rotations: torch.Tensor
+    opacities: torch.Tensor
+    colors: torch.Tensor
+    means2D: Optional[torch.Tensor] = None
+
+
+def alloc_grads(n: int, device, with_means2d: bool = False, zero: bool = False) -> GaussianGrads:
+    mk = torch.zeros if zero else torch.empty
+    f = dict(device=device, dtype=torch.float32)
+    return GaussianGrads(mk(n, 3, **f), mk(n, 3, **f), mk(n, 4, **f), mk(n, **f), mk(n, 3, **f),
+                         mk(n, 3, **f) if with_means2d else None)
+
+
+def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_normal=None, d_depth=None,
+             d_opacity=None, d_confidence=None, grads: Optional[GaussianGrads] = None,
+             accumulate: bool = False) -> GaussianGrads:
+    """Enqueue the backward pass of the view held in ``state``. Asynchronous."""
+    lib = _lib.load()
+    if grads is None:
+        grads = alloc_grads(g.n, g.means3D.device)
+        accumulate = False
+    for name, t in (("d_rgb", d_rgb), ("d_normal", d_normal), ("d_depth", d_depth), ("d_opacity", d_opacity),
+                    ("d_confidence", d_confidence)):
+        if t is not None:
+            _require_cuda(t, name)
+    cs, gs = cam.c_struct(), g.c_struct()
+    im, pg, ws = state.images_struct(), state.per_gaussian_struct(), state.ws_struct()
+    dout = _lib.AgsImageGrads(ptr(d_rgb), ptr(d_normal), ptr(d_depth), ptr(d_opacity), ptr(d_confidence))
+    din = _lib.AgsGaussianGrads(ptr(grads.means3D), ptr(grads.scales), ptr(grads.rotations), ptr(grads.opacities),
+                                ptr(grads.colors), ptr(grads.means2D), int(accumulate))
+    _lib.check(lib.ags_backward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(dout), C.byref(din),
+                                C.byref(ws), _stream()), "ags_backward")
+    return grads

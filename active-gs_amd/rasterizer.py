@@ -1,0 +1,118 @@
+"""Drop-in replacement for ``diff_gaussian_rasterization_2d`` (the un-vendored CUDA
+extension imported at /root/reference/utils/operations.py:22-25).
+
+Same public names and call contract as the single call site operations.py:682-713:
+``GaussianRasterizationSettings(**15 keyword fields)`` and
+``GaussianRasterizer(settings)(means3D, means2D, opacities, confidences, shs,
+colors_precomp, scales, rotations, cov3D_precomp)`` returning the 8-tuple
+``(rgb, normal, depth, opacity, confidence, importance, count, radii)``.
+The arithmetic runs in libags_raster.so (HIP, gfx950); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import raster_api as api
+
+SH_C0 = 0.28209479177387814
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    render_mask: torch.Tensor
+    weight_thres: float
+    debug: bool
+    config: torch.Tensor
+
+
+# Tile-instance capacity remembered per (device, image size): the forward pass sizes its
+# workspace from the last view's need and re-runs only when a view overflows it.
+_capacity_hint: dict = {}
+
+
+def _camera_from_settings(s: GaussianRasterizationSettings, device) -> api.Camera:
+    cfg = [float(v) for v in s.config.detach().cpu().tolist()] if s.config is not None else [1, 1, 1, 0, 0]
+    while len(cfg) < 5:
+        cfg.append(0.0)
+    f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+    mask = None
+    if s.render_mask is not None and s.render_mask.numel() > 0:
+        mask = f32(s.render_mask)
+    return api.Camera(int(s.image_height), int(s.image_width), float(s.tanfovx), float(s.tanfovy),
+                      f32(s.viewmatrix), f32(s.projmatrix), f32(s.bg), float(s.scale_modifier),
+                      float(s.weight_thres), cfg[1] > 0, cfg[2] > 0, cfg[3] > 0, cfg[4] > 0, mask)
+
+
+class _RasterizeSurfels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, opacities, confidences, colors, scales, rotations, settings):
+        dev = means3D.device
+        if not means3D.is_cuda:
+            raise RuntimeError("diff_gaussian_rasterization_2d (MI355X build): tensors must be on the GPU; "
+                               "there is no CPU fallback")
+        cam = _camera_from_settings(settings, dev)
+        f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
+        g = api.Gaussians(f32(means3D), f32(scales), f32(rotations), f32(opacities).reshape(-1), f32(colors),
+                          f32(confidences).reshape(-1))
+        n, h, w = g.n, cam.image_height, cam.image_width
+        key = (dev.index, h, w)
+        cap = max(_capacity_hint.get(key, 0), 1 << 16, 2 * n)
+        while True:
+            state = api.alloc_state(n, h, w, cap, dev)
+            api.forward(cam, g, state)
+            st = api.read_status(state)  # one 64-byte D2H, like upstream's num_rendered read-back
+            if not st["overflow"]:
+                break
+            cap = int(st["num_instances"] * 1.25) + 1024
+        _capacity_hint[key] = max(int(st["num_instances"] * 1.5) + 1024, 1 << 16)
+        ctx.cam, ctx.g, ctx.state = cam, g, state
+        ctx.need_m2d = means2D.requires_grad
+        ctx.opac_shape = opacities.shape
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(state.importance, state.count, state.radii)
+        return (state.rgb, state.normal, state.depth, state.opacity, state.confidence, state.importance,
+                state.count, state.radii)
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_normal, d_depth, d_opacity, d_conf, *_unused):
+        cam, g, state = ctx.cam, ctx.g, ctx.state
+        c = lambda t: None if t is None else t.to(dtype=torch.float32).contiguous()
+        grads = api.alloc_grads(g.n, g.means3D.device, with_means2d=ctx.need_m2d)
+        api.backward(cam, g, state, c(d_rgb), c(d_normal), c(d_depth), c(d_opacity), c(d_conf), grads)
+        return (grads.means3D, grads.means2D, grads.opacities.reshape(ctx.opac_shape), None, grads.colors,
+                grads.scales, grads.rotations, None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, confidences, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if cov3D_precomp is not None:
+            raise NotImplementedError("surfels need scale+rotation (the normal is R[:,2]); cov3D_precomp is unsupported")
+        if shs is not None:
+            if int(self.raster_settings.sh_degree) != 0:
+                raise NotImplementedError("only SH degree 0 is supported (the reference uses colors_precomp)")
+            colors_precomp = torch.clamp_min(SH_C0 * shs[:, 0, :] + 0.5, 0.0)
+        return _RasterizeSurfels.apply(means3D, means2D, opacities, confidences, colors_precomp, scales, rotations,
+                                       self.raster_settings)

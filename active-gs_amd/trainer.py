@@ -1,0 +1,121 @@
+"""Host-side mirror of the optimisation inner loop of ``GaussianMap.train()``
+(/root/reference/mapping/gaussian_map.py:66-127) over the C ABI:
+
+    get_attr() activations (:529-581)      -> ags_activate
+    render_view_all(require_grad=True)     -> ags_forward per view (operations.py:854)
+    total_loss.backward() (:125)           -> ags_backward per view, accumulating in place,
+                                              then ags_activate_backward
+    optimizer.step() (:126, Adam :259-292) -> ags_adam_step on the raw parameters
+
+Views are independent until the loss mean (:113-124), so with ``torch.distributed``
+initialised each rank renders its own views and ONE all-reduce(sum) of the contiguous
+14*N-float gradient slab precedes the replicated Adam step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional, Sequence
+
+import torch
+
+from . import _lib, raster_api as api
+from ._lib import ptr
+
+DEFAULT_LRS = dict(mean=5e-4, scale=1e-2, rotation=5e-4, opacity=1e-2, harmonic=1e-4)  # incremental.yaml:27-32
+
+
+def _pad4(x: int) -> int:
+    return (x + 3) & ~3
+
+
+class GradSlab:
+    """One contiguous buffer for the five gradients (segments start on 16-byte
+    boundaries) so the data-parallel exchange is a single collective."""
+
+    def __init__(self, n: int, device):
+        sizes = [3 * n, 3 * n, 4 * n, n, 3 * n]
+        offs, o = [], 0
+        for s in sizes:
+            offs.append(o)
+            o += _pad4(s)
+        self.flat = torch.zeros(max(o, 4), device=device, dtype=torch.float32)
+        v = [self.flat[a:a + s] for a, s in zip(offs, sizes)]
+        self.grads = api.GaussianGrads(v[0].view(n, 3), v[1].view(n, 3), v[2].view(n, 4), v[3], v[4].view(n, 3))
+
+    def as_list(self):
+        g = self.grads
+        return [g.means3D, g.scales, g.rotations, g.opacities, g.colors]
+
+
+class SurfelTrainer:
+    """Raw map parameters + fused train step. ``raw`` holds means (N,3), scales (N,3),
+    rotations (N,4), opacities (N), harmonics (N,1,3), confidences (N) on the GPU."""
+
+    def __init__(self, raw: dict, lrs: Optional[dict] = None, scale_factor: float = 0.01, max_scale: float = 0.05,
+                 eps: float = 1e-15, process_group=None):
+        from .optimizer import FusedAdam
+        lrs = {**DEFAULT_LRS, **(lrs or {})}
+        self.raw = {k: v.contiguous() for k, v in raw.items()}
+        dev = self.raw["means"].device
+        if dev.type != "cuda":
+            raise RuntimeError("SurfelTrainer needs GPU tensors: the rasterizer has no CPU fallback")
+        self.n = self.raw["means"].shape[0]
+        self.device = dev
+        self.scale_factor, self.max_scale = scale_factor, max_scale
+        self.act_scales = torch.empty_like(self.raw["scales"])
+        self.act_rot = torch.empty_like(self.raw["rotations"])
+        self.act_opac = torch.empty_like(self.raw["opacities"])
+        self.slab = GradSlab(self.n, dev)
+        self.params = [self.raw["means"], self.raw["scales"], self.raw["rotations"], self.raw["opacities"],
+                       self.raw["harmonics"]]
+        self.optim = FusedAdam(self.params, [lrs["mean"], lrs["scale"], lrs["rotation"], lrs["opacity"],
+                                             lrs["harmonic"]], eps=eps)
+        self.pg = process_group
+        self._state = {}
+
+    # -- pieces --------------------------------------------------------------------------
+    def _act_struct(self) -> _lib.AgsActivation:
+        return _lib.AgsActivation(self.n, self.scale_factor, self.max_scale, ptr(self.raw["scales"]),
+                                  ptr(self.raw["rotations"]), ptr(self.raw["opacities"]))
+
+    def activate(self) -> api.Gaussians:
+        a = self._act_struct()
+        _lib.check(_lib.load().ags_activate(C.byref(a), ptr(self.act_scales), ptr(self.act_rot), ptr(self.act_opac),
+                                            torch.cuda.current_stream().cuda_stream), "ags_activate")
+        return api.Gaussians(self.raw["means"], self.act_scales, self.act_rot, self.act_opac,
+                             self.raw["harmonics"].view(self.n, 3), self.raw["confidences"])
+
+    def activate_backward(self) -> None:
+        a = self._act_struct()
+        g = self.slab.grads
+        _lib.check(_lib.load().ags_activate_backward(C.byref(a), ptr(g.scales), ptr(g.rotations), ptr(g.opacities),
+                                                     torch.cuda.current_stream().cuda_stream), "ags_activate_backward")
+
+    def state_for(self, h: int, w: int, max_instances: int, slot: int = 0) -> api.ForwardState:
+        key = (h, w, slot)
+        st = self._state.get(key)
+        if st is None or st.max_instances < max_instances or st.radii.shape[0] != self.n:
+            st = api.alloc_state(self.n, h, w, max_instances, self.device)
+            self._state[key] = st
+        return st
+
+    # -- one optimisation step -----------------------------------------------------------
+    def step(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int,
+             world_views: Optional[int] = None) -> None:
+        """``cams``: this rank's views. ``image_grads(view_index, state)`` returns the five
+        image gradients (d_rgb, d_normal, d_depth, d_opacity, d_confidence; None = zero)
+        for that view, already divided by the GLOBAL number of views where the loss is a
+        batch mean.  Asynchronous except for the collective."""
+        g = self.activate()
+        for v, cam in enumerate(cams):
+            st = self.state_for(cam.image_height, cam.image_width, max_instances)
+            api.forward(cam, g, st)
+            d = image_grads(v, st)
+            api.backward(cam, g, st, *d, grads=self.slab.grads, accumulate=(v > 0))
+        if len(cams) == 0:
+            self.slab.flat.zero_()
+        self.activate_backward()
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size(self.pg) > 1:
+            torch.distributed.all_reduce(self.slab.flat, group=self.pg)
+        self.optim.step(self.slab.as_list())

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — splatted-Gaussians/s (fwd+bwd) @1200x680 on MI355X (BASELINE.json metric).
+
+One step = one optimisation step of the hot path on resident data: activations ->
+forward rasterization -> backward rasterization (with fixed synthetic image gradients) ->
+activation backward -> [all-reduce of the gradient slab when N>1] -> fused Adam.
+Workload at every N: BASELINE.json configs[1] per GPU (office0 stand-in, 200k surfels,
+1200x680, one view per rank, weak scaling).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+N_GAUSS = 200_000
+H, W = 680, 1200
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def stage_bytes(N, V, I, P, T):
+    """ALGORITHMIC bytes per launch of each stage: every logical
+    array moved once."""
+    return {
+        "preprocess": 60 * N + 8 * N + 72 * V,                 # inputs; radii+tiles; geom 64 + rect 8
+        "binning": 8 * N + 12 * I + 24 * I + 8 * I + 8 * T,    # scan r/w; dup write; sort r+w once; ranges
+        "render_fwd": 8 * T + 68 * I + 44 * P,                  # ranges; id 4 + record 64; 9 ch + T + n_contrib
+        "render_bwd": 8 * T + 68 * I + 52 * P + 64 * N + 64 * V,  # + 9 grads, depth, opac, T, n; zero + accumulate dgeom
+        "preprocess_bwd": 44 * N + 64 * V + 68 * N,             # means/scales/rot/radii; dgeom; 5 grads (+means2D)
+    }
+
+
+STAGE_IDS = {"preprocess": 0, "binning": 1, "render_fwd": 2, "render_bwd": 3, "preprocess_bwd": 4}
+
+
+def cpu_baseline(raw_cpu, cam_cpu, n_tiles_sample=512):
+    """The oracle (oracle/surfel_oracle.py, PyTorch CPU, fp32) timed on this host: full
+    per-Gaussian stage + binning of the same view, then fwd+bwd of a strided sample of
+    tiles, extrapolated to all non-empty tiles."""
+    from active_gs_amd.synthetic import activate
+    from oracle.surfel_oracle import OracleSettings, bin_instances, preprocess, render_tiles
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    a = activate(raw_cpu)
+    S = OracleSettings(H, W, cam_cpu["tanx"], cam_cpu["tany"], cam_cpu["bg"], 1.0, cam_cpu["view"], cam_cpu["proj"])
+    ins = [a["means"].clone().requires_grad_(True), torch.zeros(N_GAUSS, 3), a["opacities"][:, None].clone().requires_grad_(True),
+           a["confidences"], a["colors"].clone().requires_grad_(True), a["scales"].clone().requires_grad_(True),
+           a["rotations"].clone().requires_grad_(True)]
+    t0 = time.perf_counter()
+    G = preprocess(*ins, S)
+    so, ranges = bin_instances(G)
+    t_pre = time.perf_counter() - t0
+    nonempty = torch.nonzero(ranges[:, 1] > ranges[:, 0]).flatten().tolist()
+    step = max(1, len(nonempty) // n_tiles_sample)
+    sample = nonempty[::step][:n_tiles_sample]
+    t0 = time.perf_counter()
+    R = render_tiles(G, so, ranges, S, tiles=sample)
+    loss = R["rgb"].sum() + R["depth"].sum() + R["normal"].sum()
+    loss.backward()
+    t_tiles = time.perf_counter() - t0
+    est = t_pre + t_tiles * len(nonempty) / max(len(sample), 1)
+    return {"value": N_GAUSS / est, "unit": "Gaussians/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (PyTorch CPU fp32): full preprocess+binning of the 200k-surfel 1200x680 view "
+                      f"({t_pre:.1f}s) + fwd+bwd of {len(sample)} of {len(nonempty)} non-empty tiles ({t_tiles:.1f}s), "
+                      f"extrapolated to all tiles"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from active_gs_amd import _lib, raster_api as api
+    from active_gs_amd.camera import camera_matrices
+    from active_gs_amd.synthetic import make_camera, make_room_scene
+    from active_gs_amd.trainer import SurfelTrainer
+
+    lib = _lib.load()
+    raw_cpu = make_room_scene(N_GAUSS, "office0", seed=0)
+    raw = {k: v.to(dev) for k, v in raw_cpu.items()}
+    c2w, K = make_camera(rank, H, W)            # one view per rank (weak scaling)
+    cm = camera_matrices(c2w[None], K[None], 0.001, 10.0)
+    tanx, tany = cm["tanfov"][0, 0].item(), cm["tanfov"][0, 1].item()
+    bg = torch.zeros(4)
+    cam = api.Camera(H, W, tanx, tany, cm["viewmatrix"][0].to(dev), cm["projmatrix"][0].to(dev), bg.to(dev))
+    trainer = SurfelTrainer(raw)
+
+    # size the workspace from one probing forward (outside the timed region)
+    g = trainer.activate()
+    probe = api.alloc_state(N_GAUSS, H, W, 16_000_000, dev)
+    api.forward(cam, g, probe)
+    info = api.read_status(probe)
+    assert not info["overflow"], info
+    I, V = info["num_instances"], info["num_visible"]
+    del probe
+    cap = int(I * 1.3) + 4096
+
+    gen = torch.Generator().manual_seed(1234 + rank)
+    P = H * W
+    scale = 1.0 / (P * world)
+    d_img = [(torch.randn(c, H, W, generator=gen) * scale).to(dev) for c in (3, 3, 1)]
+    grads_fn = lambda v, st: (d_img[0], d_img[1], d_img[2], None, None)
+
+    def one_step():
+        trainer.step([cam], grads_fn, cap, world_views=world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    _lib.check(lib.ags_profile_enable(args.steps), "ags_profile_enable")
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    st = trainer.state_for(H, W, cap)
+    info = api.read_status(st)
+
+    import ctypes as C
+    stage_ms = {}
+    for name, sid in STAGE_IDS.items():
+        ms, cnt = C.c_float(), C.c_int32()
+        _lib.check(lib.ags_profile_read(sid, C.byref(ms), C.byref(cnt)), "ags_profile_read")
+        stage_ms[name] = ms.value
+    lib.ags_profile_enable(0)
+
+    if rank == 0:
+        T = ((H + 15) // 16) * ((W + 15) // 16)
+        sb = stage_bytes(N_GAUSS, V, I, P, T)
+        dom = max(stage_ms, key=lambda k: stage_ms[k])
+        ach = sb[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_hbm_bytes.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get(dom)
+            except Exception:
+                traffic = None
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "splatted-Gaussians/s (fwd+bwd) @1200x680; achieved HBM GB/s vs peak",
+            "value": N_GAUSS * world / (elapsed / args.steps),
+            "unit": "Gaussians/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "office0 stand-in (seeded box room), 200k surfels, 1200x680, 1 view per GPU, "
+                                   "step = activations + fwd + bwd + grad all-reduce (N>1) + fused Adam",
+                       "gaussians": N_GAUSS, "image": [H, W], "views_per_gpu": 1, "visible": V,
+                       "tile_instances": I, "parallelism": f"view-parallel dp{world}",
+                       "overflow": bool(info["overflow"]),
+                       "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": sb[dom],
+                         "all_stages_GBps": {k: (sb[k] / (stage_ms[k] * 1e-3) / 1e9 if stage_ms[k] > 0 else 0.0)
+                                             for k in sb}},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(raw_cpu, dict(tanx=tanx, tany=tany, bg=bg, view=cm["viewmatrix"][0],
+                                                             proj=cm["projmatrix"][0]))
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,195 @@
+/* ags_raster.h — C ABI of libags_raster.so, the MI355X (gfx950) Gaussian-surfel rasterizer.
+ *
+ * This is the drop-in boundary for ActiveGS's hot path.  The reference binds the path
+ * through ONE Python import and ONE call site:
+ *   /root/reference/utils/operations.py:22-25   from diff_gaussian_rasterization_2d import
+ *                                               GaussianRasterizationSettings, GaussianRasterizer
+ *   /root/reference/utils/operations.py:682-713 settings construction + rasterizer(**9 kwargs)
+ *   /root/reference/mapping/gaussian_map.py:125 total_loss.backward()  (-> extension backward)
+ *   /root/reference/mapping/gaussian_map.py:126 optimizer.step()       (torch.optim.Adam, :259-292)
+ * The extension behind that import (pip git+https://github.com/liren-jin/diff-gaussian-rasterization_2d,
+ * /root/reference/envs/requirements.txt:15) is CUDA-only and not vendored; this library replaces it.
+ * The Python module of the same name (diff_gaussian_rasterization_2d/ in this repo) binds these
+ * entry points with ctypes — see INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer inside the structs is a DEVICE pointer (HBM) unless stated; the structs
+ *    themselves are host memory and are read during the call only;
+ *  - all float arrays are contiguous row-major fp32; images are planar (C,H,W);
+ *  - matrices are 4x4 row-major in the row-vector convention of operations.py:759-762
+ *    (p_view = [x y z 1] * viewmatrix, p_hom = [x y z 1] * projmatrix);
+ *  - quaternions are (w,x,y,z), used un-normalised like operations.py:261-278;
+ *  - the library never allocates, frees or synchronises: all device memory (including the
+ *    workspace) is owned by the caller, every kernel is enqueued on `stream`, and the calls
+ *    are hipGraph-capturable.  The instance count is never read back: if the caller's
+ *    workspace is too small for the tile instances of a view, the kernels clamp, raise
+ *    AgsStatus.overflow on the device and the images are invalid (re-run with more room);
+ *  - re-entrant and stateless: one process per GPU, any number of streams;
+ *  - errors are return codes (0 = ok, <0 = AGS_E_*), never exceptions.
+ */
+#ifndef AGS_RASTER_H
+#define AGS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGS_OK 0
+#define AGS_E_INVALID (-1)   /* null pointer / non-positive size */
+#define AGS_E_WORKSPACE (-2) /* workspace smaller than ags_workspace_bytes() */
+#define AGS_E_LAUNCH (-3)    /* hipGetLastError() != hipSuccess after enqueue */
+
+typedef void* ags_stream_t; /* hipStream_t */
+
+/* Replaces GaussianRasterizationSettings (operations.py:682-700). */
+typedef struct AgsCamera {
+    int32_t image_height;    /* image_height */
+    int32_t image_width;     /* image_width  */
+    float tanfovx;           /* tanfovx */
+    float tanfovy;           /* tanfovy */
+    float scale_modifier;    /* scale_modifier */
+    float weight_thres;      /* weight_thres: count_i counts pixels with blend weight > this */
+    int32_t normalize_depth; /* config[1] */
+    int32_t perpix_depth;    /* config[2] */
+    int32_t want_stats;      /* config[3]: fill importance / count */
+    int32_t front_only;      /* config[4] */
+    const float* viewmatrix; /* viewmatrix, 16 floats */
+    const float* projmatrix; /* projmatrix, 16 floats */
+    const float* bg;         /* bg, >= 3 floats (the reference passes 4) */
+    const float* render_mask;/* render_mask: H*W floats {0,1}, or NULL when unused */
+} AgsCamera;
+
+/* Replaces the tensor kwargs of GaussianRasterizer.__call__ (operations.py:703-713).
+ * means2D is a gradient placeholder in the reference (always zeros) and is not read. */
+typedef struct AgsGaussians {
+    int32_t n;
+    const float* means3D;     /* (n,3) */
+    const float* scales;      /* (n,3) */
+    const float* rotations;   /* (n,4) */
+    const float* opacities;   /* (n)   */
+    const float* colors;      /* (n,3) colors_precomp */
+    const float* confidences; /* (n)   */
+} AgsGaussians;
+
+/* The five image outputs of the 8-tuple (operations.py:703). */
+typedef struct AgsImages {
+    float* rgb;        /* (3,H,W) */
+    float* normal;     /* (3,H,W) un-normalised sum(w n) */
+    float* depth;      /* (1,H,W) */
+    float* opacity;    /* (1,H,W) */
+    float* confidence; /* (1,H,W) */
+} AgsImages;
+
+/* The three per-Gaussian outputs of the 8-tuple. importance/count are written only when
+ * want_stats != 0 (they must be zero-filled by the caller before the call). */
+typedef struct AgsPerGaussian {
+    float* importance; /* (n) */
+    int32_t* count;    /* (n) */
+    int32_t* radii;    /* (n) */
+} AgsPerGaussian;
+
+/* Incoming image gradients of the backward pass (any may be NULL = zeros). */
+typedef struct AgsImageGrads {
+    const float* d_rgb;
+    const float* d_normal;
+    const float* d_depth;
+    const float* d_opacity;
+    const float* d_confidence;
+} AgsImageGrads;
+
+/* Gradients wrt the tensor kwargs; d_means2D is (n,3) with z = 0 and may be NULL. */
+typedef struct AgsGaussianGrads {
+    float* d_means3D;
+    float* d_scales;
+    float* d_rotations;
+    float* d_opacities;
+    float* d_colors;
+    float* d_means2D;
+    int32_t accumulate; /* 0: overwrite, 1: += (sum over views without an extra pass) */
+} AgsGaussianGrads;
+
+typedef struct AgsWorkspace {
+    void* ptr;    /* device, 256-byte aligned */
+    size_t bytes; /* >= ags_workspace_bytes(n,h,w,max_instances) */
+    int64_t max_instances; /* capacity in (Gaussian,tile) instances */
+} AgsWorkspace;
+
+/* Device-side status block = the first 64 bytes of the workspace. */
+typedef struct AgsStatus {
+    uint32_t num_instances; /* tile instances the view needs */
+    uint32_t num_sorted;    /* min(num_instances, max_instances) */
+    uint32_t overflow;      /* 1 when num_instances > max_instances */
+    uint32_t num_visible;   /* Gaussians that passed the cull */
+    uint32_t reserved[12];
+} AgsStatus;
+
+/* Bytes of workspace for n Gaussians, an h x w image and room for max_instances instances.
+ * The forward pass leaves its state there; the backward pass of the same view reads it. */
+size_t ags_workspace_bytes(int32_t n, int32_t h, int32_t w, int64_t max_instances);
+
+/* Forward: cull+project, tile binning, radix sort, per-tile blend. */
+int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* out,
+                const AgsPerGaussian* per_gaussian, const AgsWorkspace* ws, ags_stream_t stream);
+
+/* Backward of the same view; `fwd` are the images ags_forward wrote. */
+int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* fwd,
+                 const AgsPerGaussian* per_gaussian, const AgsImageGrads* dout,
+                 const AgsGaussianGrads* din, const AgsWorkspace* ws, ags_stream_t stream);
+
+/* Copies the status block to host memory: enqueues a D2H copy and waits for the stream. */
+int ags_read_status(const AgsWorkspace* ws, AgsStatus* host_out, ags_stream_t stream);
+
+/* Fused Adam over the five parameter tensors of gaussian_map.py:259-292
+ * (means 3n, scales 3n, rotations 4n, opacities n, harmonics 3n), torch.optim.Adam
+ * semantics (no weight decay, no amsgrad); `step` is 1-based. */
+typedef struct AgsAdamTensors {
+    float* param[5];
+    const float* grad[5];
+    float* exp_avg[5];
+    float* exp_avg_sq[5];
+    int64_t numel[5];
+    float lr[5];
+} AgsAdamTensors;
+int ags_adam_step(const AgsAdamTensors* t, float beta1, float beta2, float eps, int32_t step,
+                  ags_stream_t stream);
+
+/* Activations of /root/reference/mapping/gaussian_map.py:529-549 (get_scales / get_rotations /
+ * get_opacities): scales = clamp(scale_factor*exp(raw), 0, max_scale), rotations =
+ * raw/max(|raw|,1e-12), opacities = sigmoid(raw).  One lane per Gaussian. */
+typedef struct AgsActivation {
+    int32_t n;
+    float scale_factor;        /* cfg.scale_factor, 0.01 */
+    float max_scale;           /* 0.05 */
+    const float* raw_scales;   /* (n,3) */
+    const float* raw_rotations;/* (n,4) */
+    const float* raw_opacities;/* (n)   */
+} AgsActivation;
+int ags_activate(const AgsActivation* a, float* scales, float* rotations, float* opacities,
+                 ags_stream_t stream);
+/* Chain rule through the activations, IN PLACE: on entry d_* hold gradients wrt the
+ * activated values, on exit wrt the raw parameters (what Adam consumes). */
+int ags_activate_backward(const AgsActivation* a, float* d_scales, float* d_rotations,
+                          float* d_opacities, ags_stream_t stream);
+
+/* Optional stage timing with library-owned hipEvents (process-global, for bench/profiling
+ * only; off by default so the normal path records nothing).  `slots` event pairs are kept
+ * per stage; each forward/backward call consumes one slot per stage it runs. */
+#define AGS_STAGE_PREPROCESS 0
+#define AGS_STAGE_BINNING 1     /* scan + duplicate + radix sort + ranges */
+#define AGS_STAGE_RENDER_FWD 2
+#define AGS_STAGE_RENDER_BWD 3
+#define AGS_STAGE_PREPROCESS_BWD 4
+#define AGS_NUM_STAGES 5
+int ags_profile_enable(int32_t slots);                 /* 0 frees the events */
+int ags_profile_read(int32_t stage, float* avg_ms, int32_t* samples); /* waits for the events; resets */
+
+const char* ags_error_string(int code);
+int ags_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGS_RASTER_H */

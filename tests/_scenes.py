@@ -1,0 +1,40 @@
+"""Shared seeded scenes for the parity tests (oracle side on CPU, product side on GPU)."""
+import torch
+
+from active_gs_amd.camera import camera_matrices
+from active_gs_amd.synthetic import activate, make_camera, make_room_scene
+from oracle.surfel_oracle import OracleSettings
+
+
+def room_case(n, h, w, view=0, seed=0, scale_mult=1.0, bg=(0.1, 0.2, 0.3, 0.0), config=(1, 1, 1, 0, 0),
+              mask=None, focal_px=None):
+    a = activate(make_room_scene(n, seed=seed))
+    a["scales"] = a["scales"] * scale_mult
+    c2w, K = make_camera(view, h, w, focal_px=focal_px)
+    cm = camera_matrices(c2w[None], K[None], 0.001, 10.0)
+    S = OracleSettings(h, w, cm["tanfov"][0, 0].item(), cm["tanfov"][0, 1].item(), torch.tensor(bg), 1.0,
+                       cm["viewmatrix"][0].contiguous(), cm["projmatrix"][0].contiguous(),
+                       campos=cm["campos"][0], render_mask=mask,
+                       config=torch.tensor([float(c) for c in config]))
+    return a, S
+
+
+def oracle_inputs(a, requires_grad=True):
+    n = a["means"].shape[0]
+    ins = [a["means"].clone(), torch.zeros(n, 3), a["opacities"][:, None].clone(), a["confidences"].clone(),
+           a["colors"].clone(), a["scales"].clone(), a["rotations"].clone()]
+    if requires_grad:
+        for i in (0, 1, 2, 4, 5, 6):
+            ins[i].requires_grad_(True)
+    return ins
+
+
+def product_settings(S, dev):
+    from diff_gaussian_rasterization_2d import GaussianRasterizationSettings
+    mask = S.render_mask if S.render_mask is not None else torch.tensor([])
+    return GaussianRasterizationSettings(
+        image_height=S.image_height, image_width=S.image_width, tanfovx=S.tanfovx, tanfovy=S.tanfovy,
+        bg=S.bg.to(dev), scale_modifier=S.scale_modifier, viewmatrix=S.viewmatrix.to(dev),
+        projmatrix=S.projmatrix.to(dev), sh_degree=0, campos=(S.campos if S.campos is not None else torch.zeros(3)).to(dev),
+        prefiltered=False, render_mask=mask.to(dev), weight_thres=S.weight_thres, debug=False,
+        config=S.config.to(dev))

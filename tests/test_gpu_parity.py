@@ -1,0 +1,142 @@
+"""HIP path (through the drop-in module -> ctypes -> C ABI) vs the CPU oracle.
+
+Tolerances are BASELINE.json's: <= 1e-4 mean-L1 on rendered RGB, <= 1e-3 relative L1 on
+gradients (the backward's atomics make summation order nondeterministic)."""
+import pytest
+import torch
+
+from _scenes import oracle_inputs, product_settings, room_case
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-4
+GRAD_TOL = 1e-3
+
+
+def _run_both(a, S, seed=0, grad_channels=(1, 1, 1, 1, 1)):
+    from diff_gaussian_rasterization_2d import GaussianRasterizer
+    from oracle.surfel_oracle import rasterize
+    dev = torch.device("cuda:0")
+    ins = oracle_inputs(a)
+    ref = rasterize(*ins, S)
+    gen = torch.Generator().manual_seed(seed)
+    gr = [torch.randn(o.shape, generator=gen) * c for o, c in zip(ref[:5], grad_channels)]
+    sum((o * g).sum() for o, g in zip(ref[:5], gr)).backward()
+    gin = [t.detach().clone().to(dev).requires_grad_(t.requires_grad) for t in ins]
+    out = GaussianRasterizer(product_settings(S, dev))(
+        means3D=gin[0], means2D=gin[1], opacities=gin[2], confidences=gin[3], shs=None, colors_precomp=gin[4],
+        scales=gin[5], rotations=gin[6], cov3D_precomp=None)
+    sum((o * g.to(dev)).sum() for o, g in zip(out[:5], gr)).backward()
+    torch.cuda.synchronize()
+    return ins, ref, gin, out
+
+
+def _check_images(ref, out):
+    names = ["rgb", "normal", "depth", "opacity", "confidence"]
+    for n, r, o in zip(names, ref[:5], out[:5]):
+        assert o.shape == r.shape and o.dtype == torch.float32
+        err = (o.cpu() - r.detach()).abs().mean().item()
+        tol = RGB_TOL if n != "depth" else 1e-3  # depth carries metres and a division by opacity
+        assert err < tol, f"{n}: mean L1 {err}"
+
+
+def _check_grads(ins, gin):
+    names = {0: "means3D", 1: "means2D", 2: "opacities", 4: "colors", 5: "scales", 6: "rotations"}
+    for i, n in names.items():
+        r, o = ins[i].grad, gin[i].grad.cpu()
+        denom = r.abs().sum().item()
+        rel = (o - r).abs().sum().item() / max(denom, 1e-12)
+        assert rel < GRAD_TOL, f"d_{n}: relative L1 {rel} (ref L1 {denom})"
+
+
+@pytest.mark.parametrize("n,h,w,view,mult", [(3000, 120, 160, 0, 3.0), (5000, 170, 300, 1, 2.0), (800, 64, 64, 2, 4.0),
+                                             (2000, 100, 150, 3, 3.0)])
+def test_forward_backward_matches_oracle(agslib, n, h, w, view, mult):
+    a, S = room_case(n, h, w, view=view, seed=view, scale_mult=mult)
+    ins, ref, gin, out = _run_both(a, S, seed=view)
+    _check_images(ref, out)
+    assert out[7].dtype == torch.int32 and out[6].dtype == torch.int32
+    mism = (out[7].cpu() != ref[7]).float().mean().item()
+    assert mism < 1e-3, f"radii mismatch fraction {mism}"
+    _check_grads(ins, gin)
+
+
+def test_importance_count_front_only_mask(agslib):
+    h, w = 96, 128
+    gen = torch.Generator().manual_seed(5)
+    mask = (torch.rand(1, h, w, generator=gen) > 0.3).float()
+    a, S = room_case(2500, h, w, view=4, seed=4, scale_mult=3.0, config=(1, 1, 1, 1, 1), mask=mask)
+    ins, ref, gin, out = _run_both(a, S, seed=9)
+    _check_images(ref, out)
+    imp_err = (out[5].cpu() - ref[5]).abs().sum().item() / max(ref[5].abs().sum().item(), 1e-9)
+    assert imp_err < 1e-3, imp_err
+    cnt_mism = (out[6].cpu() != ref[6]).float().mean().item()
+    assert cnt_mism < 2e-3, cnt_mism
+    assert (out[7].cpu() != ref[7]).float().mean().item() < 1e-3
+
+
+def test_config_flags_center_depth_unnormalized(agslib):
+    a, S = room_case(1500, 80, 112, view=5, seed=5, scale_mult=3.0, config=(1, 0, 0, 0, 0))
+    ins, ref, gin, out = _run_both(a, S, seed=2)
+    _check_images(ref, out)
+    _check_grads(ins, gin)
+
+
+def test_empty_and_culled_inputs(agslib):
+    from diff_gaussian_rasterization_2d import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    a, S = room_case(64, 48, 64, view=0, seed=0)
+    # everything behind the camera -> nothing visible, background only
+    ins = oracle_inputs(a, requires_grad=False)
+    ins[0] = ins[0] * 0 + torch.tensor([100.0, 100.0, 100.0])
+    gin = [t.to(dev) for t in ins]
+    gin[0].requires_grad_(True)
+    out = GaussianRasterizer(product_settings(S, dev))(gin[0], gin[1], gin[2], gin[3], None, gin[4], gin[5], gin[6], None)
+    torch.cuda.synchronize()
+    assert torch.allclose(out[0].cpu(), S.bg[:3, None, None].expand(3, 48, 64))
+    assert out[3].abs().max().item() == 0 and (out[7] == 0).all()
+    out[0].sum().backward()
+    assert gin[0].grad.abs().max().item() == 0
+    # N = 0
+    z = lambda *s: torch.zeros(*s, device=dev)
+    out = GaussianRasterizer(product_settings(S, dev))(z(0, 3), z(0, 3), z(0, 1), z(0), None, z(0, 3), z(0, 3), z(0, 4), None)
+    torch.cuda.synchronize()
+    assert out[0].shape == (3, 48, 64) and out[5].shape == (0,)
+
+
+def test_argument_validation(agslib):
+    from diff_gaussian_rasterization_2d import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    a, S = room_case(16, 32, 32)
+    r = GaussianRasterizer(product_settings(S, dev))
+    z = lambda *s: torch.zeros(*s, device=dev)
+    with pytest.raises(Exception):
+        r(z(4, 3), z(4, 3), z(4, 1), z(4), None, None, z(4, 3), z(4, 4), None)
+    with pytest.raises(Exception):
+        r(z(4, 3), z(4, 3), z(4, 1), z(4), z(4, 1, 3), z(4, 3), z(4, 3), z(4, 4), None)
+    with pytest.raises(Exception):
+        r(z(4, 3), z(4, 3), z(4, 1), z(4), None, z(4, 3), None, None, None)
+
+
+def test_adam_matches_torch(agslib):
+    from active_gs_amd.optimizer import FusedAdam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    n = 1000
+    shapes = [(n, 3), (n, 3), (n, 4), (n,), (n, 1, 3)]
+    lrs = [5e-4, 1e-2, 5e-4, 1e-2, 1e-4]
+    ref_p = [torch.randn(*s) for s in shapes]
+    dev_p = [p.clone().to(dev) for p in ref_p]
+    topt = torch.optim.Adam([{"params": [torch.nn.Parameter(p)], "lr": lr} for p, lr in zip(ref_p, lrs)], eps=1e-15)
+    tparams = [g["params"][0] for g in topt.param_groups]
+    fopt = FusedAdam(dev_p, lrs, eps=1e-15)
+    for step in range(3):
+        grads = [torch.randn(*s) for s in shapes]
+        grads[0][::2] = 0  # zero-gradient rows still decay m, v and move
+        for p, g in zip(tparams, grads):
+            p.grad = g.clone()
+        topt.step()
+        fopt.step([g.to(dev) for g in grads])
+    torch.cuda.synchronize()
+    for p, q in zip(tparams, dev_p):
+        assert torch.allclose(p.detach(), q.cpu(), rtol=1e-5, atol=1e-7)
