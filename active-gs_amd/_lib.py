@@ -47,7 +47,8 @@ class AgsGaussianGrads(C.Structure):
 
 
 class AgsWorkspace(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_size_t), ("max_instances", C.c_int64)]
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_size_t), ("max_instances", C.c_int64),
+                ("binning_mode", C.c_int32)]
 
 
 class AgsStatus(C.Structure):

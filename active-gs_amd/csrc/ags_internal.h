@@ -18,7 +18,9 @@ struct AgsLayout {
     size_t status;      // 256 B: AgsStatus + padding
     size_t totals;      // AGS_SORT_MAX_PASSES * 256 u32 digit totals
     size_t ranges;      // T * uint2
-    size_t clear_bytes; // status..ranges end
+    size_t tile_count;  // T * u32 (tile-sort mode)
+    size_t tile_fill;   // T * u32 (tile-sort mode)
+    size_t clear_bytes; // status..tile_fill end
     size_t geom;        // n * AgsGeom
     size_t tiles;       // n * u32 tiles touched
     size_t rect;        // n * ushort4
@@ -50,6 +52,8 @@ static inline AgsLayout ags_make_layout(int n, int h, int w, int64_t cap) {
     L.status = o; o += 256;
     L.totals = o; o += (size_t)AGS_SORT_MAX_PASSES * 256 * 4;
     L.ranges = o; o += ags_align256((size_t)L.num_tiles * 8);
+    L.tile_count = o; o += ags_align256((size_t)L.num_tiles * 4);
+    L.tile_fill = o; o += ags_align256((size_t)L.num_tiles * 4);
     L.clear_bytes = o;
     L.geom = o; o += ags_align256((size_t)n * sizeof(AgsGeom));
     L.tiles = o; o += ags_align256((size_t)n * 4);
@@ -79,16 +83,18 @@ static inline AgsFrame ags_make_frame(const AgsCamera* c) {
 }
 
 // ---- launchers (one per translation unit; each enqueues on `s` and never synchronises)
+// `ids` + `id_stride`: sorted Gaussian ids per instance; stride 2 when they are the low
+// words of the 64-bit (depth|id) keys of the tile-sort mode.
+struct AgsIdList { const uint32_t* ids; int stride; };
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
-                           const AgsLayout& L, int* radii, hipStream_t s);
-void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s,
-                        uint64_t** keys_sorted, uint32_t** vals_sorted);
+                           const AgsLayout& L, int* radii, bool count_tiles, hipStream_t s);
+void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s);
+void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s);
+AgsIdList ags_sorted_ids(char* ws, const AgsLayout& L, int binning_mode);
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
-                           const uint32_t* vals_sorted, const AgsImages& out, const AgsPerGaussian& pg,
-                           hipStream_t s);
+                           AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, hipStream_t s);
 void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
-                           const uint32_t* vals_sorted, const AgsImages& fwd, const AgsImageGrads& dout,
-                           hipStream_t s);
+                           AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, hipStream_t s);
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
                                const AgsLayout& L, const int* radii, const AgsGaussianGrads& din, hipStream_t s);
 void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, hipStream_t s);
@@ -152,6 +158,26 @@ __device__ __forceinline__ uint32_t ags_wave_incl_scan_u32(uint32_t x) {
     v += ags_dpp_i<0x143, 0xC>(v); // row_bcast31 into rows 2,3
     return (uint32_t)v;
 }
+// Visit every tile of a Gaussian's rect. Footprints above COOP tiles are walked by the whole
+// wave (lane-strided, coalesced side effects), small ones by their own lane.  `f(tile, a, b)`
+// gets the owner's two payload words.  Must be called by all 64 lanes (cnt = 0 when idle).
+template <typename Fn>
+__device__ __forceinline__ void ags_for_each_tile(uint32_t cnt, uint32_t x0, uint32_t y0, uint32_t wd,
+                                                  uint32_t pa, uint32_t pb, int tiles_x, Fn&& f) {
+    const uint32_t COOP = 32;
+    const int lane = threadIdx.x & 63;
+    unsigned long long big = __ballot(cnt > COOP);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const uint32_t sx = __shfl(x0, src), sy = __shfl(y0, src), sw = __shfl(wd, src), sc = __shfl(cnt, src);
+        const uint32_t sa = __shfl(pa, src), sb = __shfl(pb, src);
+        for (uint32_t t = lane; t < sc; t += 64) f((sy + t / sw) * tiles_x + sx + t % sw, sa, sb);
+    }
+    if (cnt && cnt <= COOP)
+        for (uint32_t t = 0; t < cnt; ++t) f((y0 + t / wd) * tiles_x + x0 + t % wd, pa, pb);
+}
+
 // block -> tile map: block b runs on XCD b%8 (observed dispatch order); give every XCD one
 // contiguous run of row-major tiles so neighbouring tiles share that XCD's L2. Bijective.
 __device__ __forceinline__ int ags_xcd_remap(int b, int n) {

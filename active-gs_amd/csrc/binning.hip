@@ -232,8 +232,13 @@ int ags_sort_passes(int num_tiles) {
     return (32 + tb + 7) / 8;
 }
 
-void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s,
-                        uint64_t** keys_sorted, uint32_t** vals_sorted) {
+AgsIdList ags_sorted_ids(char* ws, const AgsLayout& L, int binning_mode) {
+    if (binning_mode == AGS_BIN_RADIX)  // payloads end in buffer (passes & 1)
+        return AgsIdList{(const uint32_t*)(ws + ((ags_sort_passes(L.num_tiles) & 1) ? L.vals1 : L.vals0)), 1};
+    return AgsIdList{(const uint32_t*)(ws + L.keys0), 2}; // low word of (depth<<32 | id), little endian
+}
+
+void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s) {
     uint32_t* status = (uint32_t*)(ws + L.status);
     uint32_t* bsum = (uint32_t*)(ws + L.block_sums);
     uint64_t* keys[2] = {(uint64_t*)(ws + L.keys0), (uint64_t*)(ws + L.keys1)};
@@ -263,6 +268,123 @@ void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, con
     const int rblocks = (int)((L.cap + 255) / 256);
     hipLaunchKernelGGL(ags_k_ranges, dim3(rblocks), dim3(256), 0, s, keys[cur], status,
                        (uint2*)(ws + L.ranges));
-    *keys_sorted = keys[cur];
-    *vals_sorted = vals[cur];
+}
+
+// =======================================================================================
+// Tile-sort binning (default): launch-lean alternative to the global radix sort.
+//   preprocess<COUNT_TILES>  tile_count[t] += 1 per touched tile            (atomics)
+//   ags_k_scan_tiles         ranges[t] = exclusive scan of tile_count       (1 workgroup)
+//   ags_k_bucket             key (depth_bits<<32 | id) -> slot ranges[t].x + fill[t]++
+//   ags_k_tile_sort          per tile: bitonic sort of its keys in LDS (<= 4096 keys) or in
+//                            place in HBM/L2 (larger), one 256-thread workgroup per tile
+// Keys are unique (the id is in the low word), so the result does not depend on the order
+// the atomics were served in: same per-tile order as the stable radix path.
+__global__ __launch_bounds__(1024) void ags_k_scan_tiles(const uint32_t* __restrict__ tile_count, int T,
+                                                         uint2* __restrict__ ranges, uint32_t* __restrict__ status,
+                                                         uint32_t cap) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < T; base += 1024) {
+        const int i = base + tid;
+        const uint32_t x = (i < T) ? tile_count[i] : 0u;
+        const uint32_t inc = ags_wave_incl_scan_u32(x);
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < wave; ++k) woff += wtot[k];
+        const uint32_t carry = carry_s;
+        if (i < T) {
+            const uint32_t b = carry + woff + inc - x, e = b + x;
+            ranges[i] = make_uint2(b < cap ? b : cap, e < cap ? e : cap);
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t total = carry_s;
+        status[0] = total;
+        status[1] = total < cap ? total : cap;
+        status[2] = total > cap ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
+    int n, int tiles_x, const uint32_t* __restrict__ tiles, const ushort4* __restrict__ rect,
+    const AgsGeom* __restrict__ geom, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill,
+    uint64_t* __restrict__ keys) {
+    const int i = blockIdx.x * AGS_PRE_THREADS + threadIdx.x;
+    const uint32_t cnt = (i < n) ? tiles[i] : 0u;
+    uint32_t x0 = 0, y0 = 0, wd = 1, db = 0;
+    if (cnt) {
+        const ushort4 rc = rect[i];
+        x0 = rc.x; y0 = rc.y; wd = (uint32_t)(rc.z - rc.x);
+        db = __float_as_uint(geom[i].dc);
+    }
+    ags_for_each_tile(cnt, x0, y0, wd, db, (uint32_t)i, tiles_x, [&](uint32_t t, uint32_t depth_bits, uint32_t gid) {
+        const uint2 rg = ranges[t];
+        const uint32_t slot = rg.x + atomicAdd(&tile_fill[t], 1u);
+        if (slot < rg.y) keys[slot] = ((uint64_t)depth_bits << 32) | gid;
+    });
+}
+
+#define AGS_TSORT_LDS_KEYS 4096
+// ascending-only bitonic network (mirrored first sub-step), so indices >= K behave as +inf
+// padding without being stored: works for any K, in LDS or in global memory.
+template <typename Ptr>
+__device__ __forceinline__ void ags_bitonic_256(Ptr a, uint32_t K, int tid) {
+    uint32_t Kp = 1;
+    while (Kp < K) Kp <<= 1;
+    const uint32_t half = Kp >> 1;
+    for (uint32_t k = 2; k <= Kp; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t t = tid; t < half; t += 256) {
+            const uint32_t blk = t / hk, off = t % hk;
+            const uint32_t i = blk * k + off, l = blk * k + (k - 1 - off);
+            if (l < K) { const uint64_t x = a[i], y = a[l]; if (x > y) { a[i] = y; a[l] = x; } }
+        }
+        __syncthreads();
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < half; t += 256) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;
+                if (l < K) { const uint64_t x = a[i], y = a[l]; if (x > y) { a[i] = y; a[l] = x; } }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ags_k_tile_sort(const uint2* __restrict__ ranges, uint64_t* keys, int num_tiles) {
+    __shared__ uint64_t sk[AGS_TSORT_LDS_KEYS];
+    const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
+    const uint2 rg = ranges[tile];
+    const uint32_t K = rg.y - rg.x;
+    if (K < 2) return;
+    const int tid = threadIdx.x;
+    uint64_t* g = keys + rg.x;
+    if (K <= AGS_TSORT_LDS_KEYS) {
+        for (uint32_t t = tid; t < K; t += 256) sk[t] = g[t];
+        __syncthreads();
+        ags_bitonic_256(sk, K, tid);
+        for (uint32_t t = tid; t < K; t += 256) g[t] = sk[t];
+    } else {
+        // rare: one tile holds more keys than the LDS stage; same network on the (L2-resident)
+        // global slice. __syncthreads() orders a workgroup's global accesses on its own CU.
+        ags_bitonic_256((volatile uint64_t*)g, K, tid);
+    }
+}
+
+void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s) {
+    uint32_t* status = (uint32_t*)(ws + L.status);
+    uint2* ranges = (uint2*)(ws + L.ranges);
+    uint64_t* keys = (uint64_t*)(ws + L.keys0);
+    hipLaunchKernelGGL(ags_k_scan_tiles, dim3(1), dim3(1024), 0, s, (const uint32_t*)(ws + L.tile_count), L.num_tiles,
+                       ranges, status, (uint32_t)L.cap);
+    hipLaunchKernelGGL(ags_k_bucket, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, in.n, F.tiles_x,
+                       (const uint32_t*)(ws + L.tiles), (const ushort4*)(ws + L.rect), (const AgsGeom*)(ws + L.geom),
+                       (const uint2*)ranges, (uint32_t*)(ws + L.tile_fill), keys);
+    hipLaunchKernelGGL(ags_k_tile_sort, dim3(L.num_tiles), dim3(256), 0, s, (const uint2*)ranges, keys, L.num_tiles);
 }

@@ -38,19 +38,21 @@ int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* o
     if (in->n > 0 && (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences))
         return AGS_E_INVALID;
     if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll) return AGS_E_INVALID;
+    if (ws->binning_mode != AGS_BIN_TILE_SORT && ws->binning_mode != AGS_BIN_RADIX) return AGS_E_INVALID;
     const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
     if (ws->bytes < L.total) return AGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char* base = (char*)ws->ptr;
     const AgsFrame F = ags_make_frame(cam);
     if (hipMemsetAsync(base + L.status, 0, L.clear_bytes, s) != hipSuccess) return AGS_E_LAUNCH;
-    uint64_t* keys_sorted = nullptr;
-    uint32_t* vals_sorted = (uint32_t*)(base + L.vals0);
+    const bool radix = ws->binning_mode == AGS_BIN_RADIX;
     if (in->n > 0) {
-        { StageScope t(AGS_STAGE_PREPROCESS, s); ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, s); }
-        { StageScope t(AGS_STAGE_BINNING, s); ags_launch_binning(F, *in, base, L, s, &keys_sorted, &vals_sorted); }
+        { StageScope t(AGS_STAGE_PREPROCESS, s); ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, !radix, s); }
+        { StageScope t(AGS_STAGE_BINNING, s);
+          if (radix) ags_launch_binning(F, *in, base, L, s); else ags_launch_tile_binning(F, *in, base, L, s); }
     }
-    { StageScope t(AGS_STAGE_RENDER_FWD, s); ags_launch_render_fwd(F, *cam, base, L, vals_sorted, *out, *pg, s); }
+    { StageScope t(AGS_STAGE_RENDER_FWD, s);
+      ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, s); }
     return ags_check_launch();
 }
 
@@ -67,8 +69,7 @@ int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* 
     hipStream_t s = (hipStream_t)stream;
     char* base = (char*)ws->ptr;
     const AgsFrame F = ags_make_frame(cam);
-    // the sorted payloads sit in buffer (passes & 1), the same place the forward left them
-    const uint32_t* vals_sorted = (const uint32_t*)(base + ((ags_sort_passes(L.num_tiles) & 1) ? L.vals1 : L.vals0));
+    const AgsIdList vals_sorted = ags_sorted_ids(base, L, ws->binning_mode); // where the forward left them
     if (hipMemsetAsync(base + L.dgeom, 0, (size_t)in->n * sizeof(AgsGeomGrad), s) != hipSuccess) return AGS_E_LAUNCH;
     { StageScope t(AGS_STAGE_RENDER_BWD, s); ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, s); }
     { StageScope t(AGS_STAGE_PREPROCESS_BWD, s); ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, s); }

@@ -4,16 +4,19 @@
 // Counterpart of the preprocess / preprocess-backward stages listed in SURVEY.md §2.3.
 #include "ags_internal.h"
 
+template <bool COUNT_TILES>
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     AgsGeom* __restrict__ geom, uint32_t* __restrict__ tiles, ushort4* __restrict__ rect,
-    int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ status) {
+    int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ status,
+    uint32_t* __restrict__ tile_count) {
     __shared__ uint32_t wsum[AGS_PRE_THREADS / 64], wvis[AGS_PRE_THREADS / 64];
     float V[16], P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
     const int i = blockIdx.x * AGS_PRE_THREADS + threadIdx.x;
     uint32_t cnt = 0, vis = 0;
+    uint32_t rx0 = 0, ry0 = 0, rwd = 1;
     if (i < in.n) {
         const float p[3] = {in.means3D[3 * i], in.means3D[3 * i + 1], in.means3D[3 * i + 2]};
         const float sc[3] = {in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]};
@@ -30,11 +33,15 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
             dst[3] = make_float4(g.nx, g.ny, g.nz, g.conf);
             rect[i] = make_ushort4((unsigned short)rc[0], (unsigned short)rc[1], (unsigned short)rc[2], (unsigned short)rc[3]);
             cnt = (uint32_t)((rc[2] - rc[0]) * (rc[3] - rc[1]));
+            rx0 = (uint32_t)rc[0]; ry0 = (uint32_t)rc[1]; rwd = (uint32_t)(rc[2] - rc[0]);
             vis = 1;
         }
         radii[i] = radius;
         tiles[i] = cnt;
     }
+    if (COUNT_TILES)  // tile-sort binning: how many surfels touch each tile
+        ags_for_each_tile(cnt, rx0, ry0, rwd, 0u, 0u, F.tiles_x,
+                          [&](uint32_t t, uint32_t, uint32_t) { atomicAdd(&tile_count[t], 1u); });
     const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { wsum[wave] = ws; wvis[wave] = wv; }
@@ -99,10 +106,17 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
 }
 
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
-                           const AgsLayout& L, int* radii, hipStream_t s) {
-    hipLaunchKernelGGL(ags_k_preprocess, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
-                       cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
-                       (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.status));
+                           const AgsLayout& L, int* radii, bool count_tiles, hipStream_t s) {
+    if (count_tiles)
+        hipLaunchKernelGGL(ags_k_preprocess<true>, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
+                           cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
+                           (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums),
+                           (uint32_t*)(ws + L.status), (uint32_t*)(ws + L.tile_count));
+    else
+        hipLaunchKernelGGL(ags_k_preprocess<false>, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
+                           cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
+                           (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums),
+                           (uint32_t*)(ws + L.status), (uint32_t*)(ws + L.tile_count));
 }
 
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,

@@ -20,7 +20,7 @@ template <bool STATS>
 __global__ __launch_bounds__(64) void ags_k_render_fwd(
     AgsFrame F, int normalize_depth, float weight_thres, const float* __restrict__ bgp,
     const float* __restrict__ mask, const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
-    const AgsGeom* __restrict__ geom, AgsImages out, float* __restrict__ final_T,
+    int id_stride, const AgsGeom* __restrict__ geom, AgsImages out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ importance, int* __restrict__ count, int num_tiles) {
     __shared__ AgsGeom sg[64];
     __shared__ uint32_t sid[64];
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
         __syncthreads();
         const uint32_t idx = base + lane;
         if (idx < rg.y) {
-            const uint32_t gid = vals[idx];
+            const uint32_t gid = vals[(size_t)idx * id_stride];
             const float4* src = reinterpret_cast<const float4*>(geom + gid);
             float4* dst = reinterpret_cast<float4*>(&sg[lane]);
             dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
 
 __global__ __launch_bounds__(64) void ags_k_render_bwd(
     AgsFrame F, int normalize_depth, const float* __restrict__ bgp, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ vals, const AgsGeom* __restrict__ geom, const float* __restrict__ depth_out,
+    const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
+    const float* __restrict__ depth_out,
     const float* __restrict__ opac_out, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     AgsImageGrads dout, float* __restrict__ dgeom, int num_tiles) {
     __shared__ AgsGeom sg[64];
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64) void ags_k_render_bwd(
         const uint32_t k0 = (uint32_t)r << 6;
         __syncthreads();
         if (k0 + lane < maxlast) {
-            const uint32_t gid = vals[rg.x + k0 + lane];
+            const uint32_t gid = vals[(size_t)(rg.x + k0 + lane) * id_stride];
             const float4* src = reinterpret_cast<const float4*>(geom + gid);
             float4* dst = reinterpret_cast<float4*>(&sg[lane]);
             dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
@@ -194,27 +195,25 @@ __global__ __launch_bounds__(64) void ags_k_render_bwd(
 }
 
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
-                           const uint32_t* vals_sorted, const AgsImages& out, const AgsPerGaussian& pg,
-                           hipStream_t s) {
+                           AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, hipStream_t s) {
     const uint2* ranges = (const uint2*)(ws + L.ranges);
     const AgsGeom* geom = (const AgsGeom*)(ws + L.geom);
     float* fT = (float*)(ws + L.final_T);
     uint32_t* nc = (uint32_t*)(ws + L.n_contrib);
     if (cam.want_stats)
         hipLaunchKernelGGL(ags_k_render_fwd<true>, dim3(L.num_tiles), dim3(64), 0, s, F, cam.normalize_depth,
-                           cam.weight_thres, cam.bg, cam.render_mask, ranges, vals_sorted, geom, out, fT, nc,
+                           cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles);
     else
         hipLaunchKernelGGL(ags_k_render_fwd<false>, dim3(L.num_tiles), dim3(64), 0, s, F, cam.normalize_depth,
-                           cam.weight_thres, cam.bg, cam.render_mask, ranges, vals_sorted, geom, out, fT, nc,
+                           cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles);
 }
 
 void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
-                           const uint32_t* vals_sorted, const AgsImages& fwd, const AgsImageGrads& dout,
-                           hipStream_t s) {
+                           AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, hipStream_t s) {
     hipLaunchKernelGGL(ags_k_render_bwd, dim3(L.num_tiles), dim3(64), 0, s, F, cam.normalize_depth, cam.bg,
-                       (const uint2*)(ws + L.ranges), vals_sorted, (const AgsGeom*)(ws + L.geom), fwd.depth,
+                       (const uint2*)(ws + L.ranges), ids.ids, ids.stride, (const AgsGeom*)(ws + L.geom), fwd.depth,
                        fwd.opacity, (const float*)(ws + L.final_T), (const uint32_t*)(ws + L.n_contrib), dout,
                        (float*)(ws + L.dgeom), L.num_tiles);
 }

@@ -77,6 +77,7 @@ class ForwardState:
     radii: torch.Tensor
     workspace: torch.Tensor
     max_instances: int
+    binning_mode: int = 0  # AGS_BIN_TILE_SORT (default) | 1 = AGS_BIN_RADIX
 
     def images_struct(self) -> _lib.AgsImages:
         return _lib.AgsImages(ptr(self.rgb), ptr(self.normal), ptr(self.depth), ptr(self.opacity), ptr(self.confidence))
@@ -85,7 +86,8 @@ class ForwardState:
         return _lib.AgsPerGaussian(ptr(self.importance), ptr(self.count), ptr(self.radii))
 
     def ws_struct(self) -> _lib.AgsWorkspace:
-        return _lib.AgsWorkspace(ptr(self.workspace), self.workspace.numel(), self.max_instances)
+        return _lib.AgsWorkspace(ptr(self.workspace), self.workspace.numel(), self.max_instances,
+                                 int(self.binning_mode))
 
 
 def _require_cuda(t: torch.Tensor, name: str) -> None:
@@ -103,7 +105,10 @@ def workspace_bytes(n: int, h: int, w: int, max_instances: int) -> int:
     return int(_lib.load().ags_workspace_bytes(n, h, w, max_instances))
 
 
-def alloc_state(n: int, h: int, w: int, max_instances: int, device) -> ForwardState:
+BIN_TILE_SORT, BIN_RADIX = 0, 1
+
+
+def alloc_state(n: int, h: int, w: int, max_instances: int, device, binning_mode: int = BIN_TILE_SORT) -> ForwardState:
     f = dict(device=device, dtype=torch.float32)
     return ForwardState(
         rgb=torch.empty(3, h, w, **f), normal=torch.empty(3, h, w, **f), depth=torch.empty(1, h, w, **f),
@@ -111,7 +116,7 @@ def alloc_state(n: int, h: int, w: int, max_instances: int, device) -> ForwardSt
         importance=torch.zeros(n, **f), count=torch.zeros(n, device=device, dtype=torch.int32),
         radii=torch.empty(n, device=device, dtype=torch.int32),
         workspace=torch.empty(workspace_bytes(n, h, w, max_instances), device=device, dtype=torch.uint8),
-        max_instances=int(max_instances))
+        max_instances=int(max_instances), binning_mode=int(binning_mode))
 
 
 def forward(cam: Camera, g: Gaussians, state: ForwardState) -> ForwardState:

@@ -38,6 +38,9 @@ class GaussianRasterizationSettings(NamedTuple):
     config: torch.Tensor
 
 
+# Binning algorithm used by the drop-in module (raster_api.BIN_TILE_SORT | BIN_RADIX).
+BINNING_MODE = api.BIN_TILE_SORT
+
 # Tile-instance capacity remembered per (device, image size): the forward pass sizes its
 # workspace from the last view's need and re-runs only when a view overflows it.
 _capacity_hint: dict = {}
@@ -71,7 +74,7 @@ class _RasterizeSurfels(torch.autograd.Function):
         key = (dev.index, h, w)
         cap = max(_capacity_hint.get(key, 0), 1 << 16, 2 * n)
         while True:
-            state = api.alloc_state(n, h, w, cap, dev)
+            state = api.alloc_state(n, h, w, cap, dev, BINNING_MODE)
             api.forward(cam, g, state)
             st = api.read_status(state)  # one 64-byte D2H, like upstream's num_rendered read-back
             if not st["overflow"]:

@@ -111,10 +111,13 @@ typedef struct AgsGaussianGrads {
     int32_t accumulate; /* 0: overwrite, 1: += (sum over views without an extra pass) */
 } AgsGaussianGrads;
 
+#define AGS_BIN_TILE_SORT 0 /* tile counting + bucket scatter + per-tile LDS bitonic sort (default) */
+#define AGS_BIN_RADIX 1     /* duplicate-with-keys + global stable LSD radix sort */
 typedef struct AgsWorkspace {
     void* ptr;    /* device, 256-byte aligned */
     size_t bytes; /* >= ags_workspace_bytes(n,h,w,max_instances) */
     int64_t max_instances; /* capacity in (Gaussian,tile) instances */
+    int32_t binning_mode;  /* AGS_BIN_*; both give the same per-tile (depth, id) order */
 } AgsWorkspace;
 
 /* Device-side status block = the first 64 bytes of the workspace. */
