@@ -67,7 +67,7 @@ class AgsActivation(C.Structure):
 
 
 EXPORTS = ["ags_workspace_bytes", "ags_forward", "ags_backward", "ags_read_status", "ags_adam_step",
-           "ags_activate", "ags_activate_backward", "ags_profile_enable", "ags_profile_read",
+           "ags_adam_step_device", "ags_activate", "ags_activate_backward", "ags_profile_enable", "ags_profile_read",
            "ags_error_string", "ags_version"]
 
 _lib = None
@@ -101,6 +101,9 @@ def load() -> C.CDLL:
     lib.ags_read_status.argtypes = [C.POINTER(AgsWorkspace), C.POINTER(AgsStatus), C.c_void_p]
     lib.ags_adam_step.restype = C.c_int
     lib.ags_adam_step.argtypes = [C.POINTER(AgsAdamTensors), C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]
+    lib.ags_adam_step_device.restype = C.c_int
+    lib.ags_adam_step_device.argtypes = [C.POINTER(AgsAdamTensors), C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                         C.c_void_p]
     lib.ags_activate.restype = C.c_int
     lib.ags_activate.argtypes = [C.POINTER(AgsActivation), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ags_activate_backward.restype = C.c_int

@@ -13,11 +13,29 @@ struct AgsAdamArgs {
     float* m[5];
     float* v[5];
     long long end[5]; // cumulative element counts
-    float step_size[5]; // lr / (1 - beta1^t)
+    float lr[5];
 };
 
-__global__ __launch_bounds__(256) void ags_k_adam(AgsAdamArgs a, float beta1, float beta2, float eps,
-                                                  float inv_bc2_sqrt, long long total) {
+// Device-resident optimiser clock: { int step; float step_size[5]; float inv_sqrt_bc2; }.
+struct AgsAdamClock { int step; float step_size[5]; float inv_bc2_sqrt; float pad[9]; };
+
+__global__ void ags_k_adam_tick(AgsAdamClock* c, float lr0, float lr1, float lr2, float lr3, float lr4,
+                                float beta1, float beta2, int host_step) {
+    // host_step > 0: the caller supplies the step; otherwise the device counter advances.
+    const int step = host_step > 0 ? host_step : c->step + 1;
+    c->step = step;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float lr[5] = {lr0, lr1, lr2, lr3, lr4};
+    for (int k = 0; k < 5; ++k) c->step_size[k] = (float)((double)lr[k] / bc1);
+    c->inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ __launch_bounds__(256) void ags_k_adam(AgsAdamArgs a, AgsAdamClock host_clk,
+                                                  const AgsAdamClock* __restrict__ dev_clk, float beta1,
+                                                  float beta2, float eps, long long total) {
+    const AgsAdamClock* clk = dev_clk ? dev_clk : &host_clk; // wave-uniform
+    const float inv_bc2_sqrt = clk->inv_bc2_sqrt;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         int seg = (i >= a.end[0]) + (i >= a.end[1]) + (i >= a.end[2]) + (i >= a.end[3]);
@@ -29,26 +47,36 @@ __global__ __launch_bounds__(256) void ags_k_adam(AgsAdamArgs a, float beta1, fl
         const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
         a.m[seg][j] = m;
         a.v[seg][j] = v;
-        a.p[seg][j] -= a.step_size[seg] * (m / denom);   // addcdiv_(m, denom, -step_size)
+        a.p[seg][j] -= clk->step_size[seg] * (m / denom); // addcdiv_(m, denom, -step_size)
     }
 }
 
-void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, hipStream_t s) {
+void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, void* dev_state,
+                     hipStream_t s) {
     AgsAdamArgs a;
     long long run = 0;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
     for (int k = 0; k < 5; ++k) {
         a.p[k] = t.param[k]; a.g[k] = t.grad[k]; a.m[k] = t.exp_avg[k]; a.v[k] = t.exp_avg_sq[k];
         run += t.numel[k];
         a.end[k] = run;
-        a.step_size[k] = (float)((double)t.lr[k] / bc1);
+        a.lr[k] = t.lr[k];
     }
     if (run <= 0) return;
+    AgsAdamClock* clk = (AgsAdamClock*)dev_state;
+    AgsAdamClock hc = {};
+    if (clk) {
+        hipLaunchKernelGGL(ags_k_adam_tick, dim3(1), dim3(1), 0, s, clk, t.lr[0], t.lr[1], t.lr[2], t.lr[3], t.lr[4],
+                           beta1, beta2, 0);
+    } else { // host-side clock: scalars travel as kernel arguments
+        const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+        hc.step = step;
+        for (int k = 0; k < 5; ++k) hc.step_size[k] = (float)((double)t.lr[k] / bc1);
+        hc.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    }
     long long blocks = (run + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(ags_k_adam, dim3((unsigned)blocks), dim3(256), 0, s, a, beta1, beta2, eps,
-                       (float)(1.0 / sqrt(bc2)), run);
+    hipLaunchKernelGGL(ags_k_adam, dim3((unsigned)blocks), dim3(256), 0, s, a, hc, (const AgsAdamClock*)clk, beta1,
+                       beta2, eps, run);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -97,7 +97,8 @@ void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
                            AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, hipStream_t s);
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
                                const AgsLayout& L, const int* radii, const AgsGaussianGrads& din, hipStream_t s);
-void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, hipStream_t s);
+void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, void* dev_state,
+                     hipStream_t s);
 void ags_launch_activate(const AgsActivation& a, float* scales, float* rotations, float* opacities, hipStream_t s);
 void ags_launch_activate_bwd(const AgsActivation& a, float* d_scales, float* d_rotations, float* d_opacities,
                              hipStream_t s);

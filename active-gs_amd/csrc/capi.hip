@@ -84,13 +84,25 @@ int ags_read_status(const AgsWorkspace* ws, AgsStatus* host_out, ags_stream_t st
     return AGS_OK;
 }
 
-int ags_adam_step(const AgsAdamTensors* t, float beta1, float beta2, float eps, int32_t step, ags_stream_t stream) {
-    if (!t || step < 1) return AGS_E_INVALID;
+static int ags_adam_check(const AgsAdamTensors* t) {
+    if (!t) return AGS_E_INVALID;
     for (int k = 0; k < 5; ++k) {
         if (t->numel[k] < 0) return AGS_E_INVALID;
         if (t->numel[k] > 0 && (!t->param[k] || !t->grad[k] || !t->exp_avg[k] || !t->exp_avg_sq[k])) return AGS_E_INVALID;
     }
-    ags_launch_adam(*t, beta1, beta2, eps, step, (hipStream_t)stream);
+    return AGS_OK;
+}
+
+int ags_adam_step(const AgsAdamTensors* t, float beta1, float beta2, float eps, int32_t step, ags_stream_t stream) {
+    if (ags_adam_check(t) != AGS_OK || step < 1) return AGS_E_INVALID;
+    ags_launch_adam(*t, beta1, beta2, eps, step, nullptr, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_adam_step_device(const AgsAdamTensors* t, float beta1, float beta2, float eps, void* state,
+                         ags_stream_t stream) {
+    if (ags_adam_check(t) != AGS_OK || !state) return AGS_E_INVALID;
+    ags_launch_adam(*t, beta1, beta2, eps, 0, state, (hipStream_t)stream);
     return ags_check_launch();
 }
 

@@ -29,10 +29,15 @@ class FusedAdam:
         self.exp_avg = [torch.zeros_like(p) for p in params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in params]
         self.step_count = 0
+        # device-resident clock {int step; float step_size[5]; float inv_sqrt_bc2; ...} for graph replay
+        self.device_clock = torch.zeros(16, device=params[0].device, dtype=torch.int32)
 
-    def step(self, grads: Sequence[torch.Tensor]) -> None:
+    def step(self, grads: Sequence[torch.Tensor], device_clock: bool = False) -> None:
+        """One Adam update. With ``device_clock=True`` the step counter lives on the GPU
+        (``ags_adam_step_device``), so the call can be captured in a hipGraph and replayed."""
         lib = _lib.load()
-        self.step_count += 1
+        if not device_clock:
+            self.step_count += 1
         t = _lib.AgsAdamTensors()
         for k in range(5):
             g = grads[k]
@@ -47,5 +52,10 @@ class FusedAdam:
             t.numel[k] = self.params[k].numel()
             t.lr[k] = self.lrs[k]
         self._keep = grads
-        _lib.check(lib.ags_adam_step(C.byref(t), self.betas[0], self.betas[1], self.eps, self.step_count,
-                                     torch.cuda.current_stream().cuda_stream), "ags_adam_step")
+        stream = torch.cuda.current_stream().cuda_stream
+        if device_clock:
+            _lib.check(lib.ags_adam_step_device(C.byref(t), self.betas[0], self.betas[1], self.eps,
+                                                ptr(self.device_clock), stream), "ags_adam_step_device")
+        else:
+            _lib.check(lib.ags_adam_step(C.byref(t), self.betas[0], self.betas[1], self.eps, self.step_count,
+                                         stream), "ags_adam_step")

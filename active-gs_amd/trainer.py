@@ -52,7 +52,7 @@ class SurfelTrainer:
     rotations (N,4), opacities (N), harmonics (N,1,3), confidences (N) on the GPU."""
 
     def __init__(self, raw: dict, lrs: Optional[dict] = None, scale_factor: float = 0.01, max_scale: float = 0.05,
-                 eps: float = 1e-15, process_group=None):
+                 eps: float = 1e-15, process_group=None, binning_mode: int = api.BIN_TILE_SORT):
         from .optimizer import FusedAdam
         lrs = {**DEFAULT_LRS, **(lrs or {})}
         self.raw = {k: v.contiguous() for k, v in raw.items()}
@@ -71,6 +71,7 @@ class SurfelTrainer:
         self.optim = FusedAdam(self.params, [lrs["mean"], lrs["scale"], lrs["rotation"], lrs["opacity"],
                                              lrs["harmonic"]], eps=eps)
         self.pg = process_group
+        self.binning_mode = binning_mode
         self._state = {}
 
     # -- pieces --------------------------------------------------------------------------
@@ -95,17 +96,16 @@ class SurfelTrainer:
         key = (h, w, slot)
         st = self._state.get(key)
         if st is None or st.max_instances < max_instances or st.radii.shape[0] != self.n:
-            st = api.alloc_state(self.n, h, w, max_instances, self.device)
+            st = api.alloc_state(self.n, h, w, max_instances, self.device, self.binning_mode)
             self._state[key] = st
         return st
 
     # -- one optimisation step -----------------------------------------------------------
-    def step(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int,
-             world_views: Optional[int] = None) -> None:
-        """``cams``: this rank's views. ``image_grads(view_index, state)`` returns the five
-        image gradients (d_rgb, d_normal, d_depth, d_opacity, d_confidence; None = zero)
-        for that view, already divided by the GLOBAL number of views where the loss is a
-        batch mean.  Asynchronous except for the collective."""
+    def _distributed(self) -> bool:
+        return torch.distributed.is_available() and torch.distributed.is_initialized() and \
+            torch.distributed.get_world_size(self.pg) > 1
+
+    def _local_pass(self, cams, image_grads, max_instances) -> None:
         g = self.activate()
         for v, cam in enumerate(cams):
             st = self.state_for(cam.image_height, cam.image_width, max_instances)
@@ -115,7 +115,48 @@ class SurfelTrainer:
         if len(cams) == 0:
             self.slab.flat.zero_()
         self.activate_backward()
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size(self.pg) > 1:
+
+    def step(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int,
+             world_views: Optional[int] = None, device_clock: bool = False) -> None:
+        """``cams``: this rank's views. ``image_grads(view_index, state)`` returns the five
+        image gradients (d_rgb, d_normal, d_depth, d_opacity, d_confidence; None = zero)
+        for that view, already divided by the GLOBAL number of views where the loss is a
+        batch mean.  Asynchronous except for the collective."""
+        self._local_pass(cams, image_grads, max_instances)
+        if self._distributed():
             torch.distributed.all_reduce(self.slab.flat, group=self.pg)
-        self.optim.step(self.slab.as_list())
+        self.optim.step(self.slab.as_list(), device_clock=device_clock)
+
+    def capture(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int) -> Callable:
+        """Capture one optimisation step into hipGraphs and return a ``replay()`` callable.
+
+        The library never allocates or synchronises and every per-view input that changes
+        between iterations sits behind a device pointer (camera matrices, image gradients,
+        parameters), so a step is a fixed launch sequence: new views are rendered by copying
+        their matrices into the captured ``Camera`` tensors before ``replay()``.  With more
+        than one rank the all-reduce stays outside the graphs (graph | collective | graph).
+        Call after at least one eager ``step`` so every buffer exists."""
+        dist_on = self._distributed()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g_local, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            if dist_on:
+                with torch.cuda.graph(g_local, stream=side):
+                    self._local_pass(cams, image_grads, max_instances)
+                with torch.cuda.graph(g_opt, stream=side):
+                    self.optim.step(self.slab.as_list(), device_clock=True)
+            else:
+                with torch.cuda.graph(g_local, stream=side):
+                    self._local_pass(cams, image_grads, max_instances)
+                    self.optim.step(self.slab.as_list(), device_clock=True)
+        torch.cuda.current_stream().wait_stream(side)
+
+        def replay():
+            g_local.replay()
+            if dist_on:
+                torch.distributed.all_reduce(self.slab.flat, group=self.pg)
+                g_opt.replay()
+
+        self._graphs = (g_local, g_opt)
+        return replay

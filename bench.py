@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--binning", choices=["tile_sort", "radix"], default="tile_sort")
+    ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +106,7 @@ def main():
     tanx, tany = cm["tanfov"][0, 0].item(), cm["tanfov"][0, 1].item()
     bg = torch.zeros(4)
     cam = api.Camera(H, W, tanx, tany, cm["viewmatrix"][0].to(dev), cm["projmatrix"][0].to(dev), bg.to(dev))
-    trainer = SurfelTrainer(raw)
+    trainer = SurfelTrainer(raw, binning_mode=api.BIN_RADIX if args.binning == "radix" else api.BIN_TILE_SORT)
 
     # size the workspace from one probing forward (outside the timed region)
     g = trainer.activate()
@@ -122,8 +124,13 @@ def main():
     d_img = [(torch.randn(c, H, W, generator=gen) * scale).to(dev) for c in (3, 3, 1)]
     grads_fn = lambda v, st: (d_img[0], d_img[1], d_img[2], None, None)
 
-    def one_step():
-        trainer.step([cam], grads_fn, cap, world_views=world)
+    def eager_step():
+        trainer.step([cam], grads_fn, cap, world_views=world, device_clock=True)
+
+    for _ in range(3):
+        eager_step()  # creates every buffer before capture
+    torch.cuda.synchronize()
+    one_step = eager_step if args.eager else trainer.capture([cam], grads_fn, cap)
 
     def barrier():
         if world > 1:
@@ -132,12 +139,12 @@ def main():
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
-    _lib.check(lib.ags_profile_enable(args.steps), "ags_profile_enable")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    enqueue_s = time.perf_counter() - t0
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -147,6 +154,16 @@ def main():
         elapsed = t.item()
     st = trainer.state_for(H, W, cap)
     info = api.read_status(st)
+
+    # per-stage kernel time: the same K steps launched eagerly with library-owned HIP events
+    # around every stage (events cannot be timed inside a replayed graph)
+    _lib.check(lib.ags_profile_enable(args.steps), "ags_profile_enable")
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        eager_step()
+    torch.cuda.synchronize()
+    eager_elapsed = time.perf_counter() - t1
 
     import ctypes as C
     stage_ms = {}
@@ -180,7 +197,10 @@ def main():
                                    "step = activations + fwd + bwd + grad all-reduce (N>1) + fused Adam",
                        "gaussians": N_GAUSS, "image": [H, W], "views_per_gpu": 1, "visible": V,
                        "tile_instances": I, "parallelism": f"view-parallel dp{world}",
-                       "overflow": bool(info["overflow"]),
+                       "overflow": bool(info["overflow"]), "binning": args.binning,
+                       "launch": "eager" if args.eager else "hipGraph replay",
+                       "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
+                       "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

@@ -159,6 +159,14 @@ typedef struct AgsAdamTensors {
 int ags_adam_step(const AgsAdamTensors* t, float beta1, float beta2, float eps, int32_t step,
                   ags_stream_t stream);
 
+/* Graph-replayable form: the 1-based step counter lives on the device.  `state` is a
+ * caller-owned, zero-initialised 64-byte device buffer { int32 step; float step_size[5];
+ * float inv_sqrt_bc2; ... }; each call first bumps the counter and refreshes the bias
+ * corrections on the device (in double), then runs the same update.  Capturing this call in
+ * a hipGraph and replaying it k times performs Adam steps 1..k. */
+int ags_adam_step_device(const AgsAdamTensors* t, float beta1, float beta2, float eps, void* state,
+                         ags_stream_t stream);
+
 /* Activations of /root/reference/mapping/gaussian_map.py:529-549 (get_scales / get_rotations /
  * get_opacities): scales = clamp(scale_factor*exp(raw), 0, max_scale), rotations =
  * raw/max(|raw|,1e-12), opacities = sigmoid(raw).  One lane per Gaussian. */
