@@ -111,7 +111,7 @@ def load() -> C.CDLL:
     lib.ags_profile_enable.restype = C.c_int
     lib.ags_profile_enable.argtypes = [C.c_int32]
     lib.ags_profile_read.restype = C.c_int
-    lib.ags_profile_read.argtypes = [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    lib.ags_profile_read.argtypes = [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     lib.ags_error_string.restype = C.c_char_p
     lib.ags_error_string.argtypes = [C.c_int]
     lib.ags_version.restype = C.c_int

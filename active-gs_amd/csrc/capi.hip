@@ -6,6 +6,7 @@
 static int ags_check_launch() { return hipGetLastError() == hipSuccess ? AGS_OK : AGS_E_LAUNCH; }
 
 // ---- optional stage timing (process-global; see ags_profile_enable in the header)
+#include <algorithm>
 #include <vector>
 namespace {
 struct StageEvents { std::vector<hipEvent_t> a, b; int used = 0; };
@@ -139,18 +140,22 @@ int ags_profile_enable(int32_t slots) {
     return AGS_OK;
 }
 
-int ags_profile_read(int32_t stage, float* avg_ms, int32_t* samples) {
-    if (stage < 0 || stage >= AGS_NUM_STAGES || !avg_ms || !samples) return AGS_E_INVALID;
+int ags_profile_read(int32_t stage, float* avg_ms, float* median_ms, int32_t* samples) {
+    if (stage < 0 || stage >= AGS_NUM_STAGES || !avg_ms || !median_ms || !samples) return AGS_E_INVALID;
     StageEvents& e = g_prof[stage];
     double sum = 0.0;
+    std::vector<float> all;
     for (int k = 0; k < e.used; ++k) {
         float ms = 0.f;
         if (hipEventSynchronize(e.b[k]) != hipSuccess) return AGS_E_LAUNCH;
         if (hipEventElapsedTime(&ms, e.a[k], e.b[k]) != hipSuccess) return AGS_E_LAUNCH;
         sum += ms;
+        all.push_back(ms);
     }
+    std::sort(all.begin(), all.end());
     *samples = e.used;
     *avg_ms = e.used ? (float)(sum / e.used) : 0.f;
+    *median_ms = e.used ? all[all.size() / 2] : 0.f;
     e.used = 0;
     return AGS_OK;
 }

@@ -1,0 +1,168 @@
+"""Host-side mirror of the renderer facade and loss head around the rasterizer.
+
+  SurfelRenderer        <-> GaussianRenderer            (/root/reference/utils/operations.py:723-904)
+  render_core           <-> render_cuda_core            (operations.py:645-720)
+  depth_to_normal       <-> depth2normal                (operations.py:172-219)
+  training_losses       <-> the loss head of train()    (/root/reference/mapping/gaussian_map.py:106-124,
+                                                         /root/reference/mapping/utils.py:14-62,120-121)
+
+Same names of arguments, same 9-tuple order, same quirks (noted inline).  The rasterizer is
+the drop-in module of this repository; a different module object can be injected (the
+CPU tests inject an adapter over the oracle) — the default never falls back to anything.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .camera import camera_matrices
+
+
+def _default_module():
+    import diff_gaussian_rasterization_2d as m
+    return m
+
+
+def depth_to_normal(depth: torch.Tensor, mask: torch.Tensor, fov) -> torch.Tensor:
+    """(1,H,W) depth, (1,H,W) bool mask -> (3,H,W) unit normals from the four neighbouring
+    back-projected points.  Quirk kept from the reference: the x focal is derived from
+    fov[0] and the image HEIGHT, the y focal from fov[1] and the WIDTH."""
+    _, H, W = depth.shape
+    d = depth[0]
+    m = mask[0].to(d.dtype)
+    fx = H / (2.0 * math.tan(float(fov[0]) / 2.0))
+    fy = W / (2.0 * math.tan(float(fov[1]) / 2.0))
+    ys, xs = torch.meshgrid(torch.arange(H, device=d.device, dtype=d.dtype),
+                            torch.arange(W, device=d.device, dtype=d.dtype), indexing="ij")
+    pts = torch.stack([(xs - 0.5 * W) * d / fx, (ys - 0.5 * H) * d / fy, d], 0)  # (3,H,W)
+    pp = F.pad(pts[None], (1, 1, 1, 1), mode="replicate")[0]
+    mp = F.pad(m[None, None], (1, 1, 1, 1), mode="replicate")[0, 0] > 0
+    c = pts * mp[1:-1, 1:-1]
+    up = (pp[:, :-2, 1:-1] - c) * mp[:-2, 1:-1]
+    left = (pp[:, 1:-1, :-2] - c) * mp[1:-1, :-2]
+    down = (pp[:, 2:, 1:-1] - c) * mp[2:, 1:-1]
+    right = (pp[:, 1:-1, 2:] - c) * mp[1:-1, 2:]
+    cr = lambda a, b: torch.linalg.cross(a, b, dim=0)
+    n = cr(up, left) + cr(right, up) + cr(down, right) + cr(left, down)
+    n = F.normalize(n, dim=0)
+    return n * mask
+
+
+def render_core(module, cam_pos, fov, view_matrix, projection_matrix, render_mask, image_shape, background_color,
+                means, harmonics, opacities, confidences, scales, rotations, front_only=False,
+                require_importance=False, weight_thres=0.03):
+    """One view through the rasterizer + the facade's post-processing; returns the 9-tuple
+    (rgb, depth, normal, opacity, d2n, confidence, importance, count, radii)."""
+    device = means.device
+    tan_fov = (0.5 * fov).tan()
+    means_2d = torch.zeros_like(means, requires_grad=True)
+    settings = module.GaussianRasterizationSettings(
+        image_height=image_shape[0], image_width=image_shape[1], tanfovx=tan_fov[0].item(),
+        tanfovy=tan_fov[1].item(), bg=background_color, scale_modifier=1.0, viewmatrix=view_matrix,
+        projmatrix=projection_matrix, sh_degree=0, campos=cam_pos, prefiltered=False, render_mask=render_mask,
+        weight_thres=weight_thres, debug=False,
+        config=torch.tensor([1.0, 1.0, 1.0, 1.0 if require_importance else 0.0, 1.0 if front_only else 0.0]).to(device))
+    rgb, normal, depth, opacity, confidence, importance, count, radii = module.GaussianRasterizer(settings)(
+        means3D=means, means2D=means_2d, opacities=opacities[..., None], confidences=confidences, shs=None,
+        colors_precomp=harmonics[:, 0, :], scales=scales, rotations=rotations, cov3D_precomp=None)
+    mask = opacity.detach() > 1e-2
+    normal = F.normalize(normal, dim=0) * mask
+    d2n = depth_to_normal(depth, mask, fov)
+    return rgb, depth, normal, opacity, d2n, confidence, importance, count, radii
+
+
+class SurfelRenderer:
+    def __init__(self, extrinsics, intrinsics, gaussians_attr, background_color, near_far, resolution, device,
+                 render_masks=None, rasterizer_module=None):
+        self.module = rasterizer_module if rasterizer_module is not None else _default_module()
+        self.device = device
+        (self.gaussian_means, self.gaussian_harmonics, self.gaussian_opacities, self.gaussian_confidences,
+         self.gaussian_scales, self.gaussian_rotations) = gaussians_attr
+        self.background_color = background_color
+        self.h, self.w = resolution
+        self.batch_size = extrinsics.shape[0]
+        cm = camera_matrices(extrinsics, intrinsics, near_far[0], near_far[1])
+        self.cam_pos = cm["campos"]
+        self.view_matrices = cm["viewmatrix"]
+        self.projection_matrices = cm["projmatrix"]
+        self.fovs = 2.0 * torch.atan(cm["tanfov"])
+        if render_masks is None:
+            self.render_masks = [torch.tensor([], device=device) for _ in range(self.batch_size)]
+        else:
+            self.render_masks = render_masks
+
+    def update_attr(self, gaussians_attr):
+        (self.gaussian_means, self.gaussian_harmonics, self.gaussian_opacities, self.gaussian_confidences,
+         self.gaussian_scales, self.gaussian_rotations) = gaussians_attr
+
+    def _core(self, i, front_only, require_importance):
+        return render_core(self.module, self.cam_pos[i], self.fovs[i], self.view_matrices[i],
+                           self.projection_matrices[i], self.render_masks[i], (self.h, self.w),
+                           self.background_color, self.gaussian_means, self.gaussian_harmonics,
+                           self.gaussian_opacities, self.gaussian_confidences, self.gaussian_scales,
+                           self.gaussian_rotations, front_only=front_only, require_importance=require_importance)
+
+    def render_view(self, i=0, require_grad=False, require_importance=False, front_only=False):
+        with torch.set_grad_enabled(require_grad):
+            rgb, depth, normal, opacity, d2n, confidence, importance, count, radii = self._core(
+                i, front_only, require_importance)
+        return rgb, depth, normal, opacity, d2n, confidence, importance, count, radii > 0
+
+    def render_view_all(self, require_grad=False, require_importance=False, front_only=False):
+        per_view = []
+        radii_sum = torch.zeros(len(self.gaussian_means), device=self.device, dtype=torch.int32)
+        with torch.set_grad_enabled(require_grad):
+            for i in range(self.batch_size):
+                out = self._core(i, front_only, require_importance)
+                per_view.append(out[:8])
+                radii_sum = radii_sum + out[8].to(radii_sum.device)
+        stack = lambda k: torch.stack([v[k] for v in per_view], 0)
+        return (stack(0), stack(1), stack(2), stack(3), stack(4), stack(5), stack(6), stack(7), radii_sum > 0)
+
+
+# ------------------------------------------------------------------------- loss head
+def _directional_sq_diffs(x: torch.Tensor) -> torch.Tensor:
+    """(B,C,H,W) -> (B,4,H,W): squared norm over C of the difference with the right, left,
+    lower and upper neighbour (zero where the neighbour is outside)."""
+    z = torch.zeros_like(x)
+    to_right = z.clone(); to_right[..., :, :-1] = x[..., :, :-1] - x[..., :, 1:]
+    to_left = z.clone(); to_left[..., :, 1:] = x[..., :, 1:] - x[..., :, :-1]
+    to_down = z.clone(); to_down[..., :-1, :] = x[..., :-1, :] - x[..., 1:, :]
+    to_up = z.clone(); to_up[..., 1:, :] = x[..., 1:, :] - x[..., :-1, :]
+    return torch.stack([to_right, to_left, to_down, to_up], 2).pow(2).sum(1)
+
+
+def normal_tv_loss(normals, depths, mask, sigma=0.3, batch_total=None):
+    nd = _directional_sq_diffs(normals)
+    dd = _directional_sq_diffs(depths.detach())
+    flat = (dd <= 1e-4).to(nd.dtype)
+    term = flat * torch.exp(-nd / (2 * sigma ** 2)) * nd * mask
+    if batch_total is None:
+        return torch.mean(term)
+    return term.sum() / (batch_total * term[0].numel())
+
+
+def training_losses(rgb_preds, depth_preds, normal_preds, opacity_preds, d2n_preds, rgb_gts, depth_gts,
+                    batch_total=None, mask_vis_sum=None):
+    """Returns (total, per_frame_error). Weights 1 / 0.8 / 0.1 / 0.1 (gaussian_map.py:119-124).
+
+    Quirk kept from the reference: the consistency term (B,H,W) is multiplied by the
+    visibility mask (B,1,H,W), which broadcasts to (B,B,H,W) before the mean, i.e.
+    mean_{b,b'} cons[b'] * mask[b] = sum_{b'} cons[b'] * (sum_b mask[b]) / (B*B*H*W).
+    View-parallel ranks pass ``batch_total`` = global B and ``mask_vis_sum`` = the
+    all-reduced sum over ALL views of the visibility mask; every term is then this rank's
+    additive share of the reference's batch loss."""
+    B = rgb_preds.shape[0] if batch_total is None else batch_total
+    mask_vis = opacity_preds.detach() > 1e-3
+    mask_depth = depth_gts > 0.0
+    rgb_l = torch.abs((rgb_preds - rgb_gts) * mask_vis)
+    depth_l = torch.abs((depth_preds - depth_gts) * mask_depth)
+    per_frame = rgb_l.detach().mean(dim=[1, 2, 3]) + depth_l.detach().mean(dim=[1, 2, 3])
+    tv = normal_tv_loss(normal_preds, depth_preds, mask_depth, batch_total=B)
+    cons = 1 - torch.sum(normal_preds * d2n_preds, 1)  # (b,H,W)
+    msum = mask_vis.long().sum(0) if mask_vis_sum is None else mask_vis_sum  # (1,H,W)
+    cons = (cons * msum).sum() / (B * B * cons[0].numel())
+    total = rgb_l.sum() / (B * rgb_l[0].numel()) + 0.8 * depth_l.sum() / (B * depth_l[0].numel()) + 0.1 * cons + 0.1 * tv
+    return total, per_frame

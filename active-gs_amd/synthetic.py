@@ -113,5 +113,5 @@ def make_camera(view: int, height: int, width: int, focal_px: float | None = Non
     c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, pos
     if focal_px is None:
         focal_px = 0.5 * width  # 90 deg horizontal, as 600 px at 1200x680
-    K = torch.tensor([[focal_px / width, 0, 0.5], [0, focal_px / height, 0.5], [0, 0, 1.0]])
+    K = torch.tensor([[focal_px / width, 0, 0.5], [0, focal_px / height, 0.5], [0, 0, 1.0]], dtype=torch.float32)
     return c2w, K

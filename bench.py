@@ -166,11 +166,12 @@ def main():
     eager_elapsed = time.perf_counter() - t1
 
     import ctypes as C
-    stage_ms = {}
+    stage_ms, stage_mean_ms = {}, {}
     for name, sid in STAGE_IDS.items():
-        ms, cnt = C.c_float(), C.c_int32()
-        _lib.check(lib.ags_profile_read(sid, C.byref(ms), C.byref(cnt)), "ags_profile_read")
-        stage_ms[name] = ms.value
+        ms, med, cnt = C.c_float(), C.c_float(), C.c_int32()
+        _lib.check(lib.ags_profile_read(sid, C.byref(ms), C.byref(med), C.byref(cnt)), "ags_profile_read")
+        stage_ms[name] = med.value       # median over the K eager steps (robust to host stalls)
+        stage_mean_ms[name] = ms.value
     lib.ags_profile_enable(0)
 
     if rank == 0:
@@ -201,7 +202,8 @@ def main():
                        "launch": "eager" if args.eager else "hipGraph replay",
                        "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                        "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
-                       "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},
+                       "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                       "stage_mean_ms": {k: round(v, 4) for k, v in stage_mean_ms.items()}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": sb[dom],

@@ -195,7 +195,9 @@ int ags_activate_backward(const AgsActivation* a, float* d_scales, float* d_rota
 #define AGS_STAGE_PREPROCESS_BWD 4
 #define AGS_NUM_STAGES 5
 int ags_profile_enable(int32_t slots);                 /* 0 frees the events */
-int ags_profile_read(int32_t stage, float* avg_ms, int32_t* samples); /* waits for the events; resets */
+/* waits for the events; mean and median stage time over the recorded slots; resets. The median
+ * ignores slots in which the HOST stalled between two launches of an eager stage. */
+int ags_profile_read(int32_t stage, float* avg_ms, float* median_ms, int32_t* samples);
 
 const char* ags_error_string(int code);
 int ags_version(void);

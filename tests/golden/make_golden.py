@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.pt.  Run ONLY in the build container (needs /root/reference).
+
+Imports the reference's host-side Python (utils.operations, mapping.gaussian_map,
+mapping.utils) with its absent third-party imports stubbed, plugs the CPU oracle in under
+the module name ``diff_gaussian_rasterization_2d`` and records
+  camera.pt     K, c2w -> fov / view / proj / campos from the reference's GaussianRenderer.__init__
+  facade.pt     the 9-tuple of GaussianRenderer.render_view_all() + gradients of a fixed scalar
+  train.pt      one GaussianMap.train() (3 iterations x 4 views + post_processing): inputs,
+                raw parameters after Adam, training_performance, counts-derived state
+  adam.pt       torch.optim.Adam (eps 1e-15, 5 groups) for 3 steps incl. zero-gradient rows
+  oracle_*.pt   oracle forward/backward vectors on seeded scenes (detects oracle drift and is
+                the fixed target of the GPU parity tests)
+Only tensors (inputs and expected outputs) are stored; no reference source text.
+"""
+import json
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = "/root/reference"
+
+from oracle.surfel_oracle import OracleSettings, rasterize  # noqa: E402
+from _scenes import oracle_inputs, room_case  # noqa: E402
+
+
+def install_reference():
+    for name in ["jaxtyping", "cv2", "trimesh", "torchvision", "torchvision.transforms", "open3d", "torchmetrics",
+                 "torchmetrics.image", "torchmetrics.image.lpip", "imgviz", "PIL", "PIL.Image"]:
+        sys.modules[name] = MagicMock()
+    mod = types.ModuleType("diff_gaussian_rasterization_2d")
+
+    class GaussianRasterizationSettings:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    class GaussianRasterizer:
+        calls = []
+
+        def __init__(self, raster_settings):
+            self.s = raster_settings
+
+        def __call__(self, means3D, means2D, opacities, confidences, shs, colors_precomp, scales, rotations,
+                     cov3D_precomp):
+            s = self.s
+            S = OracleSettings(s.image_height, s.image_width, s.tanfovx, s.tanfovy, s.bg, s.scale_modifier,
+                               s.viewmatrix, s.projmatrix, s.sh_degree, s.campos, s.prefiltered, s.render_mask,
+                               s.weight_thres, s.debug, s.config)
+            GaussianRasterizer.calls.append(dict(config=s.config.tolist(), mask=tuple(s.render_mask.shape)))
+            return rasterize(means3D, means2D, opacities, confidences, colors_precomp, scales, rotations, S)
+
+    mod.GaussianRasterizationSettings = GaussianRasterizationSettings
+    mod.GaussianRasterizer = GaussianRasterizer
+    sys.modules["diff_gaussian_rasterization_2d"] = mod
+    sys.path.insert(0, REF)
+    import utils.operations as ops
+    import mapping.gaussian_map as gm
+    torch.cuda.empty_cache = lambda: None
+    return ops, gm, GaussianRasterizer
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+
+
+def mapper_cfg(steps):
+    # values of /root/reference/config/mapper/incremental.yaml:12-32
+    return AttrDict(use_view_distribution=True, bound=[0.001, 10.0], sparse_ratio=1.0, scale_factor=0.01,
+                    error_thres=0.25, prune_interval=5, optimization_steps=steps, background=[0.0, 0.0, 0.0, 0.0],
+                    sampler=AttrDict(sampler_type="weighted", batch_size=8, active_size=3),
+                    optimizer=AttrDict(mean_lr=5e-4, scale_lr=1e-2, rotation_lr=5e-4, opacity_lr=1e-2,
+                                       harmonic_lr=1e-4))
+
+
+def main():
+    ops, gm, Rast = install_reference()
+    from active_gs_amd.synthetic import activate, make_camera, make_room_scene
+    torch.manual_seed(0)
+    np.random.seed(0)
+
+    # ---------------------------------------------------------------- camera.pt
+    cams = []
+    for (h, w, f) in [(512, 512, 0.5 * 512 / np.tan(np.pi / 6)), (680, 1200, 600.0), (64, 64, 55.4)]:
+        c2w, K = zip(*[make_camera(v, h, w, focal_px=float(f)) for v in range(3)])
+        c2w, K = torch.stack(c2w), torch.stack(K)
+        attr = tuple(torch.zeros(1, 3) for _ in range(6))
+        r = ops.GaussianRenderer(c2w, K, attr, torch.zeros(4), (0.001, 10.0), (h, w), "cpu")
+        cams.append(dict(h=h, w=w, c2w=c2w, K=K, near=0.001, far=10.0, fovs=r.fovs.clone(),
+                         view_matrices=r.view_matrices.clone(), projection_matrices=r.projection_matrices.clone(),
+                         cam_pos=r.cam_pos.clone()))
+    torch.save(cams, os.path.join(HERE, "camera.pt"))
+
+    # ---------------------------------------------------------------- facade.pt
+    n, h, w = 400, 48, 64
+    raw = make_room_scene(n, seed=11)
+    raw["scales"][:, :2] += 1.2
+    a = activate(raw)
+    c2w, K = zip(*[make_camera(v, h, w) for v in range(2)])
+    c2w, K = torch.stack(c2w), torch.stack(K)
+    leaves = dict(means=a["means"].clone().requires_grad_(True), harmonics=raw["harmonics"].clone().requires_grad_(True),
+                  opacities=a["opacities"].clone().requires_grad_(True), scales=a["scales"].clone().requires_grad_(True),
+                  rotations=a["rotations"].clone().requires_grad_(True))
+    attr = (leaves["means"], leaves["harmonics"], leaves["opacities"], a["confidences"], leaves["scales"],
+            leaves["rotations"])
+    bgc = torch.tensor([0.05, 0.1, 0.15, 0.0])
+    r = ops.GaussianRenderer(c2w, K, attr, bgc, (0.001, 10.0), (h, w), "cpu")
+    outs = r.render_view_all(require_grad=True)
+    gen = torch.Generator().manual_seed(5)
+    wts = [torch.randn(o.shape, generator=gen) for o in outs[:6]]
+    scalar = sum((o * g).sum() for o, g in zip(outs[:6], wts))
+    scalar.backward()
+    torch.save(dict(h=h, w=w, c2w=c2w, K=K, bg=bgc, near=0.001, far=10.0,
+                    attr={k: v.detach().clone() for k, v in leaves.items()}, confidences=a["confidences"],
+                    outputs=[o.detach().clone() for o in outs], weights=wts, scalar=scalar.detach(),
+                    grads={k: v.grad.clone() for k, v in leaves.items()}), os.path.join(HERE, "facade.pt"))
+
+    # ---------------------------------------------------------------- train.pt
+    n, h, w, nframes, steps = 1500, 64, 64, 4, 3
+    raw = make_room_scene(n, seed=21)
+    raw["scales"][:, :2] += 1.0
+    gt_raw = {k: v.clone() for k, v in raw.items()}
+    gjit = torch.Generator().manual_seed(2)
+    gt_raw["means"] = gt_raw["means"] + 0.01 * torch.randn(n, 3, generator=gjit)
+    gt_raw["harmonics"] = (gt_raw["harmonics"] + 0.1 * torch.randn(n, 1, 3, generator=gjit)).clamp(0, 1)
+    ga = activate(gt_raw)
+    frames = []
+    for v in range(nframes):
+        c2w, K = make_camera(v, h, w)
+        with torch.no_grad():
+            rr = ops.GaussianRenderer(c2w[None], K[None], (ga["means"], gt_raw["harmonics"], ga["opacities"],
+                                                           ga["confidences"], ga["scales"], ga["rotations"]),
+                                      torch.zeros(4), (0.001, 10.0), (h, w), "cpu").render_view_all()
+        frames.append(dict(rgb=rr[0][0].clone(), depth=rr[1][0].clone(), extrinsic=c2w, intrinsic=K,
+                           depth_range=torch.tensor([0.001, 10.0])))
+    Rast.calls.clear()
+    m = gm.GaussianMap(mapper_cfg(steps), "cpu")
+    m._means, m._scales, m._rotations = raw["means"].clone(), raw["scales"].clone(), raw["rotations"].clone()
+    m._opacities, m._harmonics = raw["opacities"].clone(), raw["harmonics"].clone()
+    m.view_scores, m.view_supports, m.view_means = torch.zeros(n), torch.zeros(n), torch.zeros(n, 3)
+    for f in frames:
+        m.training_data.append(f)
+        m.training_performance = torch.cat((m.training_performance, torch.tensor([10.0])), 0)
+    np.random.seed(7)
+    m.train()
+    torch.save(dict(n=n, h=h, w=w, steps=steps, cfg=json.loads(json.dumps(mapper_cfg(steps))), raw_init=raw, frames=frames,
+                    raw_final=dict(means=m._means.detach().clone(), scales=m._scales.detach().clone(),
+                                   rotations=m._rotations.detach().clone(), opacities=m._opacities.detach().clone(),
+                                   harmonics=m._harmonics.detach().clone()),
+                    training_performance=m.training_performance.clone(), view_supports=m.view_supports.clone(),
+                    view_scores=m.view_scores.clone(), view_means=m.view_means.clone(),
+                    rasterizer_calls=list(Rast.calls)), os.path.join(HERE, "train.pt"))
+
+    # ---------------------------------------------------------------- adam.pt
+    gen = torch.Generator().manual_seed(9)
+    shapes = [(300, 3), (300, 3), (300, 4), (300,), (300, 1, 3)]
+    lrs = [5e-4, 1e-2, 5e-4, 1e-2, 1e-4]
+    p0 = [torch.randn(*s, generator=gen) for s in shapes]
+    params = [torch.nn.Parameter(p.clone()) for p in p0]
+    opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(params, lrs)], eps=1e-15)
+    grads_all = []
+    for _ in range(3):
+        grads = [torch.randn(*s, generator=gen) for s in shapes]
+        grads[0][::2] = 0
+        grads_all.append(grads)
+        for p, g in zip(params, grads):
+            p.grad = g.clone()
+        opt.step()
+    torch.save(dict(lrs=lrs, eps=1e-15, p0=p0, grads=grads_all, p3=[p.detach().clone() for p in params]),
+               os.path.join(HERE, "adam.pt"))
+
+    # ---------------------------------------------------------------- oracle_*.pt
+    for tag, (n, h, w, view, mult, cfg) in dict(small=(64, 64, 64, 0, 6.0, (1, 1, 1, 0, 0)),
+                                                c1=(5000, 170, 300, 1, 2.0, (1, 1, 1, 1, 0))).items():
+        a, S = room_case(n, h, w, view=view, seed=view + 40, scale_mult=mult, config=cfg)
+        ins = oracle_inputs(a)
+        outs = rasterize(*ins, S)
+        gen = torch.Generator().manual_seed(3)
+        gr = [torch.randn(o.shape, generator=gen) for o in outs[:5]]
+        sum((o * g).sum() for o, g in zip(outs[:5], gr)).backward()
+        torch.save(dict(n=n, h=h, w=w, view=view, mult=mult, config=cfg, seed=view + 40,
+                        inputs=[t.detach().clone() for t in ins],
+                        outputs=[o.detach().clone() for o in outs], image_grads=gr,
+                        grads={i: ins[i].grad.clone() for i in (0, 1, 2, 4, 5, 6)}), os.path.join(HERE, f"oracle_{tag}.pt"))
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

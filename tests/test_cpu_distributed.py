@@ -1,0 +1,52 @@
+"""View-parallel data parallelism on CPU: world_size 2 over gloo reproduces the reference's
+single-process GaussianMap.train() capture (gradients all-reduced before a replicated Adam)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _worker(rank, world, port, ret):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_cpu_host_logic import _train_from_fixture
+        d = torch.load(os.path.join(GOLD, "train.pt"))
+        t = _train_from_fixture(d)
+        assert t.world == world and t.rank == rank
+        ret[rank] = dict(raw_final={k: getattr(t, k).clone() for k in d["raw_final"]},
+                         training_performance=t.training_performance.clone(), view_supports=t.view_supports.clone(),
+                         view_scores=t.view_scores.clone(), view_means=t.view_means.clone(), losses=list(t.last_losses))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_view_parallel_training_matches_reference_capture():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+        d = torch.load(os.path.join(GOLD, "train.pt"))
+        r0, r1 = ret[0], ret[1]
+        for k, ref in d["raw_final"].items():
+            assert torch.equal(r0["raw_final"][k], r1["raw_final"][k]), f"replicas diverged on {k}"
+            assert torch.allclose(r0["raw_final"][k], ref, rtol=2e-4, atol=2e-4), k
+        assert torch.allclose(r0["training_performance"], d["training_performance"], rtol=1e-3, atol=1e-5)
+        assert torch.equal(r0["view_supports"], d["view_supports"])
+        assert torch.allclose(r0["view_scores"], d["view_scores"], atol=1e-4)
+        assert r0["losses"] == r1["losses"]
