@@ -179,6 +179,43 @@ __device__ __forceinline__ void ags_for_each_tile(uint32_t cnt, uint32_t x0, uin
         for (uint32_t t = 0; t < cnt; ++t) f((y0 + t / wd) * tiles_x + x0 + t % wd, pa, pb);
 }
 
+// Transposed wave reduction of 16 per-lane values (gfx950 v_permlane32_swap / v_permlane16_swap):
+// each swap+add halves the lanes a value is spread over while packing two values into one
+// register, so 16 values cost 8+4 swap/add pairs + 4x4 in-row DPP adds (~43 VALU) instead of
+// 16 x 6 DPP adds + 16 read-backs.  On return every lane of row r (16 lanes) of q[k] holds the
+// wave total of value 4k + {0,2,1,3}[r]; `ags_reduce16_field(lane)` is that value's index
+// for the lanes with (lane & 15) < 4, which then own one total each.
+typedef unsigned int ags_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ags_swap32_add(float a, float b) {
+    const ags_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y); // lanes 0-31: a[l]+a[l+32]; lanes 32-63: b[l-32]+b[l]
+}
+__device__ __forceinline__ float ags_swap16_add(float a, float b) {
+    const ags_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y); // rows: a0+a1, b0+b1, a2+a3, b2+b3
+}
+__device__ __forceinline__ float ags_row_sum(float v) {
+    v += ags_dpp_f<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += ags_dpp_f<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += ags_dpp_f<0x141>(v); // row_half_mirror
+    v += ags_dpp_f<0x140>(v); // row_mirror
+    return v;
+}
+__device__ __forceinline__ int ags_reduce16_field(int lane) {
+    const int row = lane >> 4, k = lane & 15;
+    return 4 * k + ((row == 1) ? 2 : (row == 2) ? 1 : row);
+}
+// returns, for a lane with (lane&15) < 4, the wave total of value ags_reduce16_field(lane)
+__device__ __forceinline__ float ags_wave_reduce16(const float v[16], int lane) {
+    float r[8], q[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = ags_swap32_add(v[2 * i], v[2 * i + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = ags_row_sum(ags_swap16_add(r[2 * k], r[2 * k + 1]));
+    const int k = lane & 15;
+    return k == 0 ? q[0] : k == 1 ? q[1] : k == 2 ? q[2] : q[3];
+}
+
 // block -> tile map: block b runs on XCD b%8 (observed dispatch order); give every XCD one
 // contiguous run of row-major tiles so neighbouring tiles share that XCD's L2. Bijective.
 __device__ __forceinline__ int ags_xcd_remap(int b, int n) {

@@ -9,8 +9,9 @@
 //   * the four 16x4 strips keep their own reject: `__any` over the 64-bit ballot skips the
 //     accumulate (forward) or the whole gradient block (backward) when no lane takes the
 //     surfel, and `__all(done)` ends the tile early;
-//   * the backward reduces each surfel's 15 partial gradients over the wave with DPP adds
-//     and issues ONE 15-lane atomic per (surfel,tile) instead of 256 x 15 atomics.
+//   * the backward reduces each surfel's 15 partial gradients over the wave with a transposed
+//     permlane-swap/DPP reduction (ags_wave_reduce16) and issues ONE 15-lane atomic per
+//     (surfel,tile) instead of 256 x 15 atomics.
 // Blocks are mapped to tiles XCD-aware (ags_xcd_remap) so one XCD's L2 serves a contiguous
 // band of tiles.  Counterpart of renderCUDA fwd/bwd in SURVEY.md §2.3; arithmetic in
 // surfel_math.h.
@@ -24,6 +25,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
     uint32_t* __restrict__ n_contrib, float* __restrict__ importance, int* __restrict__ count, int num_tiles) {
     __shared__ AgsGeom sg[64];
     __shared__ uint32_t sid[64];
+    __shared__ uint32_t smask[64];
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
     const int lane = threadIdx.x;
@@ -31,6 +33,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
     const int py0 = ty * AGS_TILE + (lane >> 4);
     const float fpx = (float)px;
     const uint2 rg = ranges[tile];
+    const float bx0 = (float)(tx * AGS_TILE), by0 = (float)(ty * AGS_TILE);
     // four named accumulators (not an array): keeps every field in VGPRs
     AgsPix pix0, pix1, pix2, pix3;
     float mk0 = 1.f, mk1 = 1.f, mk2 = 1.f, mk3 = 1.f;
@@ -52,19 +55,31 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
         if (idx < rg.y) {
             const uint32_t gid = vals[(size_t)idx * id_stride];
             const float4* src = reinterpret_cast<const float4*>(geom + gid);
+            const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
             float4* dst = reinterpret_cast<float4*>(&sg[lane]);
-            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
             if (STATS) sid[lane] = gid;
+            // which of the tile's four 16x4 strips can this surfel reach at all? (one lane per surfel)
+            AgsGeom me;
+            me.mx = r0.x; me.my = r0.y; me.ca = r0.z; me.cb = r0.w; me.cc = r1.x; me.o = r1.y;
+            uint32_t m = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                m |= ags_reaches_box(me, bx0, bx0 + 15.f, by0 + 4.f * s, by0 + 4.f * s + 3.f) ? (1u << s) : 0u;
+            smask[lane] = m;
         }
         __syncthreads();
         const int cnt = (int)min(64u, rg.y - base);
         for (int k = 0; k < cnt; ++k) {
+            const uint32_t m = __builtin_amdgcn_readfirstlane(smask[k]); // wave-uniform
+            if (m == 0) continue;
             const AgsGeom g = sg[k];
-            float dx0, dy0, al0, dx1, dy1, al1, dx2, dy2, al2, dx3, dy3, al3;
-            const bool ok0 = ags_alpha(g, fpx, (float)(py0), dx0, dy0, al0) && !pix0.done;
-            const bool ok1 = ags_alpha(g, fpx, (float)(py0 + 4), dx1, dy1, al1) && !pix1.done;
-            const bool ok2 = ags_alpha(g, fpx, (float)(py0 + 8), dx2, dy2, al2) && !pix2.done;
-            const bool ok3 = ags_alpha(g, fpx, (float)(py0 + 12), dx3, dy3, al3) && !pix3.done;
+            float dx0 = 0, dy0 = 0, al0 = 0, dx1 = 0, dy1 = 0, al1 = 0, dx2 = 0, dy2 = 0, al2 = 0, dx3 = 0, dy3 = 0, al3 = 0;
+            bool ok0 = false, ok1 = false, ok2 = false, ok3 = false;
+            if (m & 1u) ok0 = ags_alpha(g, fpx, (float)(py0), dx0, dy0, al0) && !pix0.done;
+            if (m & 2u) ok1 = ags_alpha(g, fpx, (float)(py0 + 4), dx1, dy1, al1) && !pix1.done;
+            if (m & 4u) ok2 = ags_alpha(g, fpx, (float)(py0 + 8), dx2, dy2, al2) && !pix2.done;
+            if (m & 8u) ok3 = ags_alpha(g, fpx, (float)(py0 + 12), dx3, dy3, al3) && !pix3.done;
             if (!__any(ok0 | ok1 | ok2 | ok3)) continue;
             const uint32_t pos1 = base - rg.x + k + 1;
             float wsum = 0.f;
@@ -118,6 +133,7 @@ __global__ __launch_bounds__(64) void ags_k_render_bwd(
     AgsImageGrads dout, float* __restrict__ dgeom, int num_tiles) {
     __shared__ AgsGeom sg[64];
     __shared__ uint32_t sid[64];
+    __shared__ uint32_t smask[64];
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
     if (rg.y <= rg.x) return;
@@ -126,6 +142,7 @@ __global__ __launch_bounds__(64) void ags_k_render_bwd(
     const int px = tx * AGS_TILE + (lane & 15);
     const int py0 = ty * AGS_TILE + (lane >> 4);
     const float fpx = (float)px;
+    const float bx0 = (float)(tx * AGS_TILE), by0 = (float)(ty * AGS_TILE);
     const float bg[3] = {bgp[0], bgp[1], bgp[2]};
     const size_t HW = (size_t)F.H * F.W;
     AgsPixGrad pg[4];
@@ -152,27 +169,40 @@ __global__ __launch_bounds__(64) void ags_k_render_bwd(
     }
     const uint32_t maxlast = ags_wave_max_u32(mymax);
     if (maxlast == 0) return;
+    // lanes (lane&15) < 4 each own one field of the reduced gradient record (15 is padding)
+    const int my_field = ((lane & 15) < 4 && ags_reduce16_field(lane) < 15) ? ags_reduce16_field(lane) : -1;
     for (int r = (int)((maxlast - 1) >> 6); r >= 0; --r) {
         const uint32_t k0 = (uint32_t)r << 6;
         __syncthreads();
         if (k0 + lane < maxlast) {
             const uint32_t gid = vals[(size_t)(rg.x + k0 + lane) * id_stride];
             const float4* src = reinterpret_cast<const float4*>(geom + gid);
+            const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
             float4* dst = reinterpret_cast<float4*>(&sg[lane]);
-            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
             sid[lane] = gid;
+            AgsGeom me;
+            me.mx = r0.x; me.my = r0.y; me.ca = r0.z; me.cb = r0.w; me.cc = r1.x; me.o = r1.y;
+            uint32_t m = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                m |= ags_reaches_box(me, bx0, bx0 + 15.f, by0 + 4.f * s, by0 + 4.f * s + 3.f) ? (1u << s) : 0u;
+            smask[lane] = m;
         }
         __syncthreads();
         const int kend = (int)min(63u, maxlast - 1 - k0);
         for (int k = kend; k >= 0; --k) {
+            const uint32_t m = __builtin_amdgcn_readfirstlane(smask[k]); // wave-uniform strip mask
+            if (m == 0) continue;
             const AgsGeom g = sg[k];
             const uint32_t pos1 = k0 + k + 1;
-            float dx[4], dy[4], al[4];
-            bool ok[4];
+            float dx[4] = {0, 0, 0, 0}, dy[4] = {0, 0, 0, 0}, al[4] = {0, 0, 0, 0};
+            bool ok[4] = {false, false, false, false};
             bool any = false;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                ok[s] = ags_alpha(g, fpx, (float)(py0 + 4 * s), dx[s], dy[s], al[s]) && (pos1 <= pg[s].last);
+                if (m & (1u << s))
+                    ok[s] = ags_alpha(g, fpx, (float)(py0 + 4 * s), dx[s], dy[s], al[s]) && (pos1 <= pg[s].last);
                 any |= ok[s];
             }
             if (!__any(any)) continue;
@@ -183,13 +213,8 @@ __global__ __launch_bounds__(64) void ags_k_render_bwd(
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 if (ok[s]) ags_blend_bwd_apply(pg[s], g, dx[s], dy[s], al[s], acc);
-            float mine = 0.f;
-#pragma unroll
-            for (int j = 0; j < 15; ++j) {
-                const float t = ags_wave_sum(a[j]);
-                mine = (lane == j) ? t : mine;
-            }
-            if (lane < 15) unsafeAtomicAdd(dgeom + (size_t)sid[k] * 16 + lane, mine);
+            const float mine = ags_wave_reduce16(a, lane); // 16 lanes end up owning one total each
+            if (my_field >= 0) unsafeAtomicAdd(dgeom + (size_t)sid[k] * 16 + my_field, mine);
         }
     }
 }

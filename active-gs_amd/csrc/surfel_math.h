@@ -272,6 +272,33 @@ AGS_HD void ags_preprocess_bwd(const AgsFrame& F, const float* V, const float* P
 }
 
 // ---------------------------------------------------------------------------------
+// Conservative reach test used to skip work, never to change results: can ANY point of the
+// box [x0,x1]x[y0,y1] (pixel-centre extents) have alpha >= 1/255 for this surfel?
+// alpha >= 1/255  <=>  q(d) = ca dx^2 + 2 cb dx dy + cc dy^2 <= 2 ln(255 o).  The minimum of
+// the convex q over the box is 0 when the centre is inside, else it lies on a face nearest
+// to the centre.  A small margin absorbs rounding differences with the per-pixel test.
+AGS_HD bool ags_reaches_box(const AgsGeom& g, float x0, float x1, float y0, float y1) {
+    const float oo = 255.f * g.o;
+    if (!(oo >= 1.f)) return false;
+    const float tau = 2.f * logf(oo) * 1.0001f + 1e-3f;
+    const float ax0 = x0 - g.mx, ax1 = x1 - g.mx, ay0 = y0 - g.my, ay1 = y1 - g.my;
+    const bool inx = (ax0 <= 0.f) && (ax1 >= 0.f), iny = (ay0 <= 0.f) && (ay1 >= 0.f);
+    if (inx && iny) return true;
+    float best = 3.0e38f;
+    if (!inx) {
+        const float dx = ax0 > 0.f ? ax0 : ax1;
+        const float dy = fminf(fmaxf(-(g.cb / g.cc) * dx, ay0), ay1);
+        best = fminf(best, g.ca * dx * dx + 2.f * g.cb * dx * dy + g.cc * dy * dy);
+    }
+    if (!iny) {
+        const float dy = ay0 > 0.f ? ay0 : ay1;
+        const float dx = fminf(fmaxf(-(g.cb / g.ca) * dy, ax0), ax1);
+        best = fminf(best, g.ca * dx * dx + 2.f * g.cb * dx * dy + g.cc * dy * dy);
+    }
+    return best <= tau;
+}
+
+// ---------------------------------------------------------------------------------
 // Blend step, forward.  Per-pixel accumulator for one of the lane's pixels.
 struct AgsPix {
     float T;
