@@ -162,6 +162,7 @@ __device__ __forceinline__ uint32_t ags_wave_incl_scan_u32(uint32_t x) {
 // Visit every tile of a Gaussian's rect. Footprints above COOP tiles are walked by the whole
 // wave (lane-strided, coalesced side effects), small ones by their own lane.  `f(tile, a, b)`
 // gets the owner's two payload words.  Must be called by all 64 lanes (cnt = 0 when idle).
+// (used by the radix path, whose instance slots are ordered by Gaussian)
 template <typename Fn>
 __device__ __forceinline__ void ags_for_each_tile(uint32_t cnt, uint32_t x0, uint32_t y0, uint32_t wd,
                                                   uint32_t pa, uint32_t pb, int tiles_x, Fn&& f) {
@@ -177,6 +178,47 @@ __device__ __forceinline__ void ags_for_each_tile(uint32_t cnt, uint32_t x0, uin
     }
     if (cnt && cnt <= COOP)
         for (uint32_t t = 0; t < cnt; ++t) f((y0 + t / wd) * tiles_x + x0 + t % wd, pa, pb);
+}
+
+// Balanced form for the tile-sort path: the wave flattens the (surfel, candidate tile) pairs of
+// its 64 surfels into one index space (DPP prefix sum) and hands pair j to lane j%64, so a
+// surfel touching 400 tiles and one touching 2 cost the same per lane and every atomic in an
+// iteration is independent.  The owner of pair j is found by a 6-step binary search over the
+// exclusive prefix kept in LDS; the tile must pass the exact reach test (ags_reaches_box) -
+// tiles of the D3 rect that no pixel of the surfel can reach are never emitted (they would
+// contribute nothing: identical images, fewer instances to sort, gather and blend).
+struct AgsEmitRec { uint32_t excl, xy, wd, pa; float mx, my, ca, cb, cc, o; }; // per lane, in LDS
+template <typename Fn>
+__device__ __forceinline__ void ags_emit_tiles_balanced(AgsEmitRec* wave_lds, uint32_t cnt, uint32_t x0, uint32_t y0,
+                                                        uint32_t wd, uint32_t pa, const AgsGeom& g, int tiles_x,
+                                                        Fn&& f) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t incl = ags_wave_incl_scan_u32(cnt);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total == 0) return; // wave-uniform
+    AgsEmitRec me;
+    me.excl = incl - cnt; me.xy = x0 | (y0 << 16); me.wd = wd; me.pa = pa;
+    me.mx = g.mx; me.my = g.my; me.ca = g.ca; me.cb = g.cb; me.cc = g.cc; me.o = g.o;
+    wave_lds[lane] = me;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < total; base += 64) {
+        const uint32_t j = base + lane;
+        if (j < total) {
+            int lo = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (wave_lds[lo + step].excl <= j) lo += step; // largest lane with excl <= j
+            const AgsEmitRec r = wave_lds[lo];
+            const uint32_t t = j - r.excl;
+            const uint32_t tx = (r.xy & 0xFFFF) + t % r.wd, ty = (r.xy >> 16) + t / r.wd;
+            AgsGeom og;
+            og.mx = r.mx; og.my = r.my; og.ca = r.ca; og.cb = r.cb; og.cc = r.cc; og.o = r.o;
+            const float bx = (float)(tx * AGS_TILE), by = (float)(ty * AGS_TILE);
+            if (ags_reaches_box(og, bx, bx + (AGS_TILE - 1), by, by + (AGS_TILE - 1))) f(ty * tiles_x + tx, r.pa);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Transposed wave reduction of 16 per-lane values (gfx950 v_permlane32_swap / v_permlane16_swap):

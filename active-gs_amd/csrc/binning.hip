@@ -316,22 +316,32 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
     int n, int tiles_x, const uint32_t* __restrict__ tiles, const ushort4* __restrict__ rect,
     const AgsGeom* __restrict__ geom, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill,
     uint64_t* __restrict__ keys) {
+    __shared__ AgsEmitRec emit[AGS_PRE_THREADS];
+    __shared__ uint32_t depth_bits[AGS_PRE_THREADS];
     const int i = blockIdx.x * AGS_PRE_THREADS + threadIdx.x;
     const uint32_t cnt = (i < n) ? tiles[i] : 0u;
-    uint32_t x0 = 0, y0 = 0, wd = 1, db = 0;
+    uint32_t x0 = 0, y0 = 0, wd = 1;
+    AgsGeom g;
+    g.mx = g.my = g.ca = g.cb = g.cc = g.o = 0.f;
     if (cnt) {
         const ushort4 rc = rect[i];
         x0 = rc.x; y0 = rc.y; wd = (uint32_t)(rc.z - rc.x);
-        db = __float_as_uint(geom[i].dc);
+        const float4* src = reinterpret_cast<const float4*>(geom + i);
+        const float4 r0 = src[0], r1 = src[1];
+        g.mx = r0.x; g.my = r0.y; g.ca = r0.z; g.cb = r0.w; g.cc = r1.x; g.o = r1.y;
+        depth_bits[threadIdx.x] = __float_as_uint(r1.z);
     }
-    ags_for_each_tile(cnt, x0, y0, wd, db, (uint32_t)i, tiles_x, [&](uint32_t t, uint32_t depth_bits, uint32_t gid) {
+    // same predicate and same inputs as the counting pass in ags_k_preprocess<true>
+    ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, x0, y0, wd, (uint32_t)threadIdx.x, g, tiles_x,
+                            [&](uint32_t t, uint32_t owner_tid) {
         const uint2 rg = ranges[t];
         const uint32_t slot = rg.x + atomicAdd(&tile_fill[t], 1u);
-        if (slot < rg.y) keys[slot] = ((uint64_t)depth_bits << 32) | gid;
+        if (slot < rg.y)
+            keys[slot] = ((uint64_t)depth_bits[owner_tid] << 32) | (uint32_t)(blockIdx.x * AGS_PRE_THREADS + owner_tid);
     });
 }
 
-#define AGS_TSORT_LDS_KEYS 4096
+#define AGS_TSORT_LDS_KEYS 2048
 // ascending-only bitonic network (mirrored first sub-step), so indices >= K behave as +inf
 // padding without being stored: works for any K, in LDS or in global memory.
 template <typename Ptr>
@@ -365,6 +375,21 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort(const uint2* __restrict__
     if (K < 2) return;
     const int tid = threadIdx.x;
     uint64_t* g = keys + rg.x;
+    if (K <= 64) {
+        // one wave, no LDS, no barrier: keys are unique, so a key's rank is the number of smaller
+        // keys; every other key is broadcast through SGPRs (v_readlane)
+        if (tid >= 64) return;
+        const uint64_t mine = (tid < (int)K) ? g[tid] : ~0ull;
+        const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < K; ++j) {
+            const uint64_t other = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, j) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int)lo, j);
+            rank += (other < mine) ? 1u : 0u;
+        }
+        if (tid < (int)K) g[rank] = mine; // all loads happened before the first store (same wave)
+        return;
+    }
     if (K <= AGS_TSORT_LDS_KEYS) {
         for (uint32_t t = tid; t < K; t += 256) sk[t] = g[t];
         __syncthreads();

@@ -11,19 +11,21 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ status,
     uint32_t* __restrict__ tile_count) {
     __shared__ uint32_t wsum[AGS_PRE_THREADS / 64], wvis[AGS_PRE_THREADS / 64];
+    __shared__ AgsEmitRec emit[COUNT_TILES ? AGS_PRE_THREADS : 1];
     float V[16], P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
     const int i = blockIdx.x * AGS_PRE_THREADS + threadIdx.x;
     uint32_t cnt = 0, vis = 0;
     uint32_t rx0 = 0, ry0 = 0, rwd = 1;
+    AgsGeom g;
+    g.mx = g.my = g.ca = g.cb = g.cc = g.o = 0.f;
     if (i < in.n) {
         const float p[3] = {in.means3D[3 * i], in.means3D[3 * i + 1], in.means3D[3 * i + 2]};
         const float sc[3] = {in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]};
         const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
         const float q[4] = {q4.x, q4.y, q4.z, q4.w};
         const float col[3] = {in.colors[3 * i], in.colors[3 * i + 1], in.colors[3 * i + 2]};
-        AgsGeom g;
         int radius = 0, rc[4];
         if (ags_preprocess_fwd(F, V, P, p, sc, q, in.opacities[i], col, in.confidences[i], 0.f, 0.f, g, radius, rc)) {
             float4* dst = reinterpret_cast<float4*>(geom + i);
@@ -39,9 +41,9 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
         radii[i] = radius;
         tiles[i] = cnt;
     }
-    if (COUNT_TILES)  // tile-sort binning: how many surfels touch each tile
-        ags_for_each_tile(cnt, rx0, ry0, rwd, 0u, 0u, F.tiles_x,
-                          [&](uint32_t t, uint32_t, uint32_t) { atomicAdd(&tile_count[t], 1u); });
+    if (COUNT_TILES)  // tile-sort binning: how many surfels can reach each tile
+        ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, rx0, ry0, rwd, 0u, g, F.tiles_x,
+                                [&](uint32_t t, uint32_t) { atomicAdd(&tile_count[t], 1u); });
     const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { wsum[wave] = ws; wvis[wave] = wv; }

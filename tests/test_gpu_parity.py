@@ -170,7 +170,8 @@ def test_binning_modes_agree_bitwise_on_order(agslib):
         info = api.read_status(st)
         assert not info["overflow"]
         outs.append((st, info))
-    assert outs[0][1]["num_instances"] == outs[1][1]["num_instances"] > 0
+    # tile-sort mode also drops (surfel, tile) pairs no pixel can reach; radix keeps the D3 rect
+    assert 0 < outs[0][1]["num_instances"] <= outs[1][1]["num_instances"]
     for name in ("rgb", "normal", "depth", "opacity", "confidence", "radii"):
         assert torch.equal(getattr(outs[0][0], name), getattr(outs[1][0], name)), name
 
