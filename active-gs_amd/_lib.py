@@ -25,7 +25,8 @@ class AgsCamera(C.Structure):
 
 class AgsGaussians(C.Structure):
     _fields_ = [("n", C.c_int32), ("means3D", c_f32p), ("scales", c_f32p), ("rotations", c_f32p),
-                ("opacities", c_f32p), ("colors", c_f32p), ("confidences", c_f32p)]
+                ("opacities", c_f32p), ("colors", c_f32p), ("confidences", c_f32p), ("raw_params", C.c_int32),
+                ("scale_factor", C.c_float), ("max_scale", C.c_float)]
 
 
 class AgsImages(C.Structure):

@@ -71,7 +71,8 @@ int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* 
     char* base = (char*)ws->ptr;
     const AgsFrame F = ags_make_frame(cam);
     const AgsIdList vals_sorted = ags_sorted_ids(base, L, ws->binning_mode); // where the forward left them
-    if (hipMemsetAsync(base + L.dgeom, 0, (size_t)in->n * sizeof(AgsGeomGrad), s) != hipSuccess) return AGS_E_LAUNCH;
+    // dgeom needs no memset: ags_forward zeroed the records of the visible surfels and every
+    // ags_backward leaves them zeroed again
     { StageScope t(AGS_STAGE_RENDER_BWD, s); ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, s); }
     { StageScope t(AGS_STAGE_PREPROCESS_BWD, s); ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, s); }
     return ags_check_launch();

@@ -4,12 +4,27 @@
 // Counterpart of the preprocess / preprocess-backward stages listed in SURVEY.md §2.3.
 #include "ags_internal.h"
 
+// Activations of /root/reference/mapping/gaussian_map.py:529-549, applied in registers when the
+// caller hands over raw map parameters (AgsGaussians.raw_params).
+__device__ __forceinline__ void ags_activate_inplace(const AgsGaussians& in, float sc[3], float q[4], float& opacity,
+                                                     float raw_v[3], float& qinv) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        raw_v[k] = in.scale_factor * expf(sc[k]);
+        sc[k] = fminf(fmaxf(raw_v[k], 0.f), in.max_scale);
+    }
+    qinv = 1.0f / fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] *= qinv;
+    opacity = 1.0f / (1.0f + expf(-opacity));
+}
+
 template <bool COUNT_TILES>
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     AgsGeom* __restrict__ geom, uint32_t* __restrict__ tiles, ushort4* __restrict__ rect,
     int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ status,
-    uint32_t* __restrict__ tile_count) {
+    uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom) {
     __shared__ uint32_t wsum[AGS_PRE_THREADS / 64], wvis[AGS_PRE_THREADS / 64];
     __shared__ AgsEmitRec emit[COUNT_TILES ? AGS_PRE_THREADS : 1];
     float V[16], P[16];
@@ -22,17 +37,23 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     g.mx = g.my = g.ca = g.cb = g.cc = g.o = 0.f;
     if (i < in.n) {
         const float p[3] = {in.means3D[3 * i], in.means3D[3 * i + 1], in.means3D[3 * i + 2]};
-        const float sc[3] = {in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]};
+        float sc[3] = {in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]};
         const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
-        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        float opacity = in.opacities[i];
+        if (in.raw_params) { float rv[3], qi; ags_activate_inplace(in, sc, q, opacity, rv, qi); }
         const float col[3] = {in.colors[3 * i], in.colors[3 * i + 1], in.colors[3 * i + 2]};
         int radius = 0, rc[4];
-        if (ags_preprocess_fwd(F, V, P, p, sc, q, in.opacities[i], col, in.confidences[i], 0.f, 0.f, g, radius, rc)) {
+        if (ags_preprocess_fwd(F, V, P, p, sc, q, opacity, col, in.confidences[i], 0.f, 0.f, g, radius, rc)) {
             float4* dst = reinterpret_cast<float4*>(geom + i);
             dst[0] = make_float4(g.mx, g.my, g.ca, g.cb);
             dst[1] = make_float4(g.cc, g.o, g.dc, g.gx);
             dst[2] = make_float4(g.gy, g.r, g.g, g.b);
             dst[3] = make_float4(g.nx, g.ny, g.nz, g.conf);
+            // the gradient record the blend backward accumulates into starts at zero (no memset pass)
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            dgeom[4 * (size_t)i + 0] = z4; dgeom[4 * (size_t)i + 1] = z4;
+            dgeom[4 * (size_t)i + 2] = z4; dgeom[4 * (size_t)i + 3] = z4;
             rect[i] = make_ushort4((unsigned short)rc[0], (unsigned short)rc[1], (unsigned short)rc[2], (unsigned short)rc[3]);
             cnt = (uint32_t)((rc[2] - rc[0]) * (rc[3] - rc[1]));
             rx0 = (uint32_t)rc[0]; ry0 = (uint32_t)rc[1]; rwd = (uint32_t)(rc[2] - rc[0]);
@@ -59,7 +80,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
 
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
-    const int* __restrict__ radii, const AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out) {
+    const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out) {
     float V[16], P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
@@ -69,17 +90,31 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
     const bool vis = radii[i] > 0;
     if (vis) {
         const float p[3] = {in.means3D[3 * i], in.means3D[3 * i + 1], in.means3D[3 * i + 2]};
-        const float sc[3] = {in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]};
+        float sc[3] = {in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]};
         const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
-        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-        const float4* src = reinterpret_cast<const float4*>(dgeom + i);
+        float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        float opacity = in.opacities[i];
+        float raw_v[3] = {0, 0, 0}, qinv = 1.f;
+        if (in.raw_params) ags_activate_inplace(in, sc, q, opacity, raw_v, qinv);
+        float4* src = reinterpret_cast<float4*>(dgeom + i);
         const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+        // leave the record zeroed again: a second ags_backward on the same forward state is valid
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        src[0] = z4; src[1] = z4; src[2] = z4; src[3] = z4;
         AgsGeomGrad dg;
         dg.dmx = a.x; dg.dmy = a.y; dg.dca = a.z; dg.dcb = a.w;
         dg.dcc = b.x; dg.dop = b.y; dg.ddc = b.z; dg.dgx = b.w;
         dg.dgy = c.x; dg.dr = c.y; dg.dg = c.z; dg.db = c.w;
         dg.dnx = d.x; dg.dny = d.y; dg.dnz = d.z; dg.pad = 0.f;
-        ags_preprocess_bwd(F, V, P, p, sc, q, dg, dm, ds, dq, &dop, dcol, dm2);
+        ags_preprocess_bwd(F, V, P, p, sc, q, opacity, dg, dm, ds, dq, &dop, dcol, dm2);
+        if (in.raw_params) { // chain rule through clamp(exp), normalize, sigmoid
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ds[k] = (raw_v[k] >= 0.f && raw_v[k] <= in.max_scale) ? ds[k] * raw_v[k] : 0.f;
+            const float dot = q[0] * dq[0] + q[1] * dq[1] + q[2] * dq[2] + q[3] * dq[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dq[k] = (dq[k] - q[k] * dot) * qinv;
+            dop *= opacity * (1.f - opacity);
+        }
     } else if (out.accumulate) {
         return; // nothing to add
     }
@@ -113,16 +148,16 @@ void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGau
         hipLaunchKernelGGL(ags_k_preprocess<true>, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
                            cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
                            (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums),
-                           (uint32_t*)(ws + L.status), (uint32_t*)(ws + L.tile_count));
+                           (uint32_t*)(ws + L.status), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom));
     else
         hipLaunchKernelGGL(ags_k_preprocess<false>, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
                            cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
                            (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums),
-                           (uint32_t*)(ws + L.status), (uint32_t*)(ws + L.tile_count));
+                           (uint32_t*)(ws + L.status), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom));
 }
 
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
                                const AgsLayout& L, const int* radii, const AgsGaussianGrads& din, hipStream_t s) {
     hipLaunchKernelGGL(ags_k_preprocess_bwd, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
-                       cam.projmatrix, in, radii, (const AgsGeomGrad*)(ws + L.dgeom), din);
+                       cam.projmatrix, in, radii, (AgsGeomGrad*)(ws + L.dgeom), din);
 }

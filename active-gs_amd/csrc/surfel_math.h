@@ -38,7 +38,7 @@ struct AgsGeom {
 // Gradient record accumulated by the blend backward, 64 B, same field order idea.
 struct AgsGeomGrad {
     float dmx, dmy, dca, dcb;
-    float dcc, dop, ddc, dgx;
+    float dcc, dop, ddc, dgx; // dop = sum(alpha * dL/dalpha); divided by the opacity in ags_preprocess_bwd
     float dgy, dr, dg, db;
     float dnx, dny, dnz, pad;
 };
@@ -49,6 +49,14 @@ struct AgsFrame {
     float scale_mod;
     int perpix_depth, front_only;
 };
+
+AGS_HD float ags_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x); // v_rcp_f32, 1 ulp
+#else
+    return 1.0f / x;
+#endif
+}
 
 AGS_HD float ags_affine(const float* M, int j, float x, float y, float z) {
     // [x y z 1] * M, column j, as the fmaf chain the oracle reproduces bit for bit
@@ -170,13 +178,14 @@ AGS_HD bool ags_preprocess_fwd(const AgsFrame& F, const float* V, const float* P
 // Backward of the per-Gaussian stage (B2+B3 fused).  `dg` is what the blend
 // backward accumulated for this Gaussian.  Outputs are written (not accumulated).
 AGS_HD void ags_preprocess_bwd(const AgsFrame& F, const float* V, const float* P, const float p[3],
-                               const float sc[3], const float q[4], const AgsGeomGrad& dg,
+                               const float sc[3], const float q[4], float opacity, const AgsGeomGrad& dg,
                                float dmean[3], float dscale[3], float dquat[4], float* dopacity,
                                float dcolor[3], float dmean2d[2]) {
     AgsProj w;
     // caller guarantees the Gaussian was visible in the forward pass
     ags_project(F, V, P, p, sc, q, w);
-    *dopacity = dg.dop;
+    // the blend backward accumulates sum(alpha * dL/dalpha) = o * sum(G * dL/dalpha)
+    *dopacity = opacity > 0.f ? dg.dop / opacity : 0.f;
     dcolor[0] = dg.dr; dcolor[1] = dg.dg; dcolor[2] = dg.db;
     dmean2d[0] = dg.dmx; dmean2d[1] = dg.dmy;
 
@@ -380,13 +389,13 @@ AGS_HD void ags_pixgrad_init(AgsPixGrad& s, const float dC[3], const float dN[3]
 // One back-to-front step for a Gaussian whose alpha test passed at this pixel
 // (and pos1 <= s.last); accumulates the pixel's contribution into `acc`.
 AGS_HD void ags_blend_bwd_apply(AgsPixGrad& s, const AgsGeom& g, float dx, float dy, float alpha, AgsGeomGrad& acc) {
-    const float om = 1.f - alpha;
-    s.T = s.T / om; // transmittance in front of this Gaussian
+    const float iom = ags_rcp(1.f - alpha); // one reciprocal serves T/(1-a) and S/(1-a)
+    s.T = s.T * iom; // transmittance in front of this Gaussian
     const float w = alpha * s.T;
     const float dpix = g.dc + g.gx * dx + g.gy * dy;
     const float gsum = s.dC0 * g.r + s.dC1 * g.g + s.dC2 * g.b + s.dN0 * g.nx + s.dN1 * g.ny + s.dN2 * g.nz
                      + s.dDn * dpix + s.dCf * g.conf + s.dA;
-    const float dalpha = s.T * gsum - s.S / om;
+    const float dalpha = s.T * gsum - s.S * iom;
     s.S += w * gsum;
     acc.dr += w * s.dC0; acc.dg += w * s.dC1; acc.db += w * s.dC2;
     acc.dnx += w * s.dN0; acc.dny += w * s.dN1; acc.dnz += w * s.dN2;
@@ -394,8 +403,7 @@ AGS_HD void ags_blend_bwd_apply(AgsPixGrad& s, const AgsGeom& g, float dx, float
     acc.ddc += wd; acc.dgx += wd * dx; acc.dgy += wd * dy;
     float ddx = wd * g.gx, ddy = wd * g.gy; // through the per-pixel depth
     if (alpha < AGS_ALPHA_MAX) {            // clamp passes no gradient
-        const float G = alpha / g.o;        // exp(power)
-        acc.dop += G * dalpha;
+        acc.dop += alpha * dalpha;          // = o * G * dalpha; the caller divides the tile total by o once
         const float gp = alpha * dalpha;    // dL/dpower
         acc.dca += -0.5f * dx * dx * gp;
         acc.dcb += -dx * dy * gp;

@@ -55,6 +55,9 @@ class Gaussians:
     opacities: torch.Tensor
     colors: torch.Tensor
     confidences: torch.Tensor
+    raw_params: bool = False   # scales/rotations/opacities are raw map parameters (activated in-kernel)
+    scale_factor: float = 0.01
+    max_scale: float = 0.05
 
     @property
     def n(self) -> int:
@@ -62,7 +65,8 @@ class Gaussians:
 
     def c_struct(self) -> _lib.AgsGaussians:
         return _lib.AgsGaussians(self.n, ptr(self.means3D), ptr(self.scales), ptr(self.rotations),
-                                 ptr(self.opacities), ptr(self.colors), ptr(self.confidences))
+                                 ptr(self.opacities), ptr(self.colors), ptr(self.confidences), int(self.raw_params),
+                                 float(self.scale_factor), float(self.max_scale))
 
 
 @dataclass

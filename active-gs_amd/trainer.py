@@ -52,7 +52,8 @@ class SurfelTrainer:
     rotations (N,4), opacities (N), harmonics (N,1,3), confidences (N) on the GPU."""
 
     def __init__(self, raw: dict, lrs: Optional[dict] = None, scale_factor: float = 0.01, max_scale: float = 0.05,
-                 eps: float = 1e-15, process_group=None, binning_mode: int = api.BIN_TILE_SORT):
+                 eps: float = 1e-15, process_group=None, binning_mode: int = api.BIN_TILE_SORT,
+                 fused_activations: bool = True):
         from .optimizer import FusedAdam
         lrs = {**DEFAULT_LRS, **(lrs or {})}
         self.raw = {k: v.contiguous() for k, v in raw.items()}
@@ -72,6 +73,9 @@ class SurfelTrainer:
                                              lrs["harmonic"]], eps=eps)
         self.pg = process_group
         self.binning_mode = binning_mode
+        # True: the per-Gaussian kernels apply the activations and their chain rule in registers
+        # (AgsGaussians.raw_params); False: separate ags_activate / ags_activate_backward launches
+        self.fused_activations = fused_activations
         self._state = {}
 
     # -- pieces --------------------------------------------------------------------------
@@ -105,8 +109,15 @@ class SurfelTrainer:
         return torch.distributed.is_available() and torch.distributed.is_initialized() and \
             torch.distributed.get_world_size(self.pg) > 1
 
+    def gaussians(self) -> api.Gaussians:
+        if self.fused_activations:
+            return api.Gaussians(self.raw["means"], self.raw["scales"], self.raw["rotations"], self.raw["opacities"],
+                                 self.raw["harmonics"].view(self.n, 3), self.raw["confidences"], raw_params=True,
+                                 scale_factor=self.scale_factor, max_scale=self.max_scale)
+        return self.activate()
+
     def _local_pass(self, cams, image_grads, max_instances) -> None:
-        g = self.activate()
+        g = self.gaussians()
         for v, cam in enumerate(cams):
             st = self.state_for(cam.image_height, cam.image_width, max_instances)
             api.forward(cam, g, st)
@@ -114,7 +125,8 @@ class SurfelTrainer:
             api.backward(cam, g, st, *d, grads=self.slab.grads, accumulate=(v > 0))
         if len(cams) == 0:
             self.slab.flat.zero_()
-        self.activate_backward()
+        if not self.fused_activations:
+            self.activate_backward()
 
     def step(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int,
              world_views: Optional[int] = None, device_clock: bool = False) -> None:

@@ -109,7 +109,7 @@ def main():
     trainer = SurfelTrainer(raw, binning_mode=api.BIN_RADIX if args.binning == "radix" else api.BIN_TILE_SORT)
 
     # size the workspace from one probing forward (outside the timed region)
-    g = trainer.activate()
+    g = trainer.gaussians()
     probe = api.alloc_state(N_GAUSS, H, W, 16_000_000, dev)
     api.forward(cam, g, probe)
     info = api.read_status(probe)

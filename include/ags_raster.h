@@ -72,6 +72,13 @@ typedef struct AgsGaussians {
     const float* opacities;   /* (n)   */
     const float* colors;      /* (n,3) colors_precomp */
     const float* confidences; /* (n)   */
+    /* raw_params != 0: scales/rotations/opacities hold the RAW map parameters and the
+     * activations of gaussian_map.py:529-549 (clamp(scale_factor*exp(s),0,max_scale),
+     * normalize(q), sigmoid(o)) are applied inside the per-Gaussian kernels; ags_backward then
+     * returns gradients wrt the raw parameters. 0 (the drop-in module): activated values. */
+    int32_t raw_params;
+    float scale_factor;       /* 0.01 */
+    float max_scale;          /* 0.05 */
 } AgsGaussians;
 
 /* The five image outputs of the 8-tuple (operations.py:703). */

@@ -137,7 +137,7 @@ void emu_backward(int H, int W, float tanfovx, float tanfovy, float scale_mod, i
     for (int i = 0; i < N; ++i) {
         if (dgeom_out) std::memcpy(dgeom_out + 16 * i, &acc[i], 64);
         if (S.radius[i] > 0) {
-            ags_preprocess_bwd(S.F, V, P, means + 3 * i, scales + 3 * i, rots + 4 * i, acc[i], dmeans + 3 * i,
+            ags_preprocess_bwd(S.F, V, P, means + 3 * i, scales + 3 * i, rots + 4 * i, opac[i], acc[i], dmeans + 3 * i,
                                dscales + 3 * i, drots + 4 * i, dopac + i, dcolors + 3 * i, dmeans2d + 3 * i);
             dmeans2d[3 * i + 2] = 0.f;
         } else {

@@ -222,3 +222,32 @@ def test_graph_replay_matches_eager_steps(agslib):
         results.append([p.clone() for p in tr.params])
     for a, b in zip(*results):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_fused_activations_match_separate_kernels(agslib):
+    """raw_params mode (activations + chain rule inside the per-Gaussian kernels) == ags_activate
+    -> forward/backward on activated values -> ags_activate_backward."""
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.synthetic import make_room_scene
+    from active_gs_amd.trainer import SurfelTrainer
+    dev = torch.device("cuda:0")
+    _, S = room_case(6000, 136, 240, view=3, seed=3)
+    cam = api.Camera(S.image_height, S.image_width, S.tanfovx, S.tanfovy, S.viewmatrix.to(dev), S.projmatrix.to(dev),
+                     S.bg.to(dev))
+    gen = torch.Generator().manual_seed(4)
+    d = [(torch.randn(c, 136, 240, generator=gen) / (136 * 240)).to(dev) for c in (3, 3, 1)]
+    fn = lambda v, st: (d[0], d[1], d[2], None, None)
+    grads, params = [], []
+    for fused in (False, True):
+        raw = {k: v.to(dev) for k, v in make_room_scene(6000, seed=3).items()}
+        raw["scales"][:, :2] += 1.5   # some scales hit the 0.05 clamp
+        raw["rotations"] *= 1.7       # un-normalised raw quaternions
+        tr = SurfelTrainer(raw, fused_activations=fused)
+        tr.step([cam, cam], fn, 1 << 20)
+        torch.cuda.synchronize()
+        grads.append([g.clone() for g in tr.slab.as_list()])
+        params.append([p.clone() for p in tr.params])
+    for a, b in zip(grads[0], grads[1]):
+        assert (a - b).abs().sum() <= 1e-4 * a.abs().sum() + 1e-12
+    for a, b in zip(params[0], params[1]):
+        assert (a - b).abs().mean() < 1e-6
