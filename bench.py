@@ -27,11 +27,11 @@ def stage_bytes(N, V, I, P, T):
     """ALGORITHMIC bytes per launch of each stage: every logical
     array moved once."""
     return {
-        "preprocess": 60 * N + 8 * N + 72 * V,                 # inputs; radii+tiles; geom 64 + rect 8
-        "binning": 8 * N + 12 * I + 24 * I + 8 * I + 8 * T,    # scan r/w; dup write; sort r+w once; ranges
+        "preprocess": 60 * N + 8 * N + 136 * V,                # inputs; radii+tiles; geom 64 + rect 8 + zeroed dgeom 64
+        "binning": 8 * N + 12 * I + 24 * I + 8 * I + 8 * T,    # tile counts/scan; key write; sort r+w once; ranges
         "render_fwd": 8 * T + 68 * I + 44 * P,                  # ranges; id 4 + record 64; 9 ch + T + n_contrib
-        "render_bwd": 8 * T + 68 * I + 52 * P + 64 * N + 64 * V,  # + 9 grads, depth, opac, T, n; zero + accumulate dgeom
-        "preprocess_bwd": 44 * N + 64 * V + 68 * N,             # means/scales/rot/radii; dgeom; 5 grads (+means2D)
+        "render_bwd": 8 * T + 68 * I + 52 * P + 64 * V,         # + 9 grads, depth, opac, T, n; accumulate dgeom
+        "preprocess_bwd": 44 * N + 128 * V + 68 * N,            # means/scales/rot/radii; dgeom read + re-zero; 5 grads
     }
 
 
@@ -183,7 +183,7 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "pmc_hbm_bytes.json")
         if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get(dom)
+                traffic = json.load(open(pmc_path)).get(dom, {}).get("traffic")
             except Exception:
                 traffic = None
         ms_per_step = elapsed / args.steps * 1e3
