@@ -1,154 +1,176 @@
 // Per-tile alpha compositing, forward (F6) and backward (B1).
 //
-// Wave64-native shape, not a 16x16-thread CUDA block: ONE wavefront owns a 16x16 tile and
-// every lane owns four pixels (rows y0+{0,4,8,12}), so
-//   * a round stages 64 projected surfels (64 B each, one per lane) into 4 KiB of LDS and
-//     needs no cross-wave barrier;
-//   * each staged record is read from LDS once per wave (broadcast ds_read_b128) and
-//     serves four pixel evaluations — a quarter of the LDS traffic of a 256-thread tile;
-//   * the four 16x4 strips keep their own reject: `__any` over the 64-bit ballot skips the
-//     accumulate (forward) or the whole gradient block (backward) when no lane takes the
-//     surfel, and `__all(done)` ends the tile early;
+// Wave64-native shape, not a 16x16-thread CUDA block: a wavefront owns SLOTS of the four
+// 16x4-pixel strips of a 16x16 tile and every lane owns SLOTS pixels (one per strip), so
+//   * a round stages 64 projected surfels (64 B each, one per lane) into the wave's own
+//     4 KiB of LDS; a wave never waits for another wave (no workgroup barrier);
+//   * each staged record is read from LDS once per wave (broadcast ds_read_b128) and serves
+//     SLOTS pixel evaluations;
+//   * the staging lane of a surfel also computes which strips it can reach at all
+//     (ags_reaches_box, exact and conservative); the round's loop then walks only the set bits
+//     of the 64-bit ballot of "reaches one of my strips" (s_ff1), and evaluates only the
+//     reachable strips under scalar branches; `__any` skips the accumulate when no lane takes
+//     the surfel and `__all(done)` ends the wave early;
 //   * the backward reduces each surfel's 15 partial gradients over the wave with a transposed
 //     permlane-swap/DPP reduction (ags_wave_reduce16) and issues ONE 15-lane atomic per
-//     (surfel,tile) instead of 256 x 15 atomics.
+//     (surfel, wave) instead of 64 x SLOTS x 15 atomics.
+// SLOTS = 4 is one wave per tile; SLOTS = 2 / 1 split a tile over 2 / 4 waves (fewer VGPRs,
+// more waves in flight) and are chosen when the image has too few tiles to fill 1024 SIMDs.
 // Blocks are mapped to tiles XCD-aware (ags_xcd_remap) so one XCD's L2 serves a contiguous
 // band of tiles.  Counterpart of renderCUDA fwd/bwd in SURVEY.md §2.3; arithmetic in
 // surfel_math.h.
+#include <stdlib.h>
+
 #include "ags_internal.h"
 
-template <bool STATS>
-__global__ __launch_bounds__(64) void ags_k_render_fwd(
+struct AgsWaveStage {   // one per wave, in LDS
+    AgsGeom sg[64];
+    uint32_t sid[64];
+};
+
+// stage surfel `gid` from lane `lane` and return its 4-bit strip-reach mask for tile (bx0,by0)
+__device__ __forceinline__ uint32_t ags_stage_one(AgsWaveStage& st, int lane, const AgsGeom* __restrict__ geom,
+                                                  uint32_t gid, float bx0, float by0) {
+    const float4* src = reinterpret_cast<const float4*>(geom + gid);
+    const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+    float4* dst = reinterpret_cast<float4*>(&st.sg[lane]);
+    dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+    st.sid[lane] = gid;
+    AgsGeom me;
+    me.mx = r0.x; me.my = r0.y; me.ca = r0.z; me.cb = r0.w; me.cc = r1.x; me.o = r1.y;
+    uint32_t m = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        m |= ags_reaches_box(me, bx0, bx0 + 15.f, by0 + 4.f * s, by0 + 4.f * s + 3.f) ? (1u << s) : 0u;
+    return m;
+}
+
+__device__ __forceinline__ void ags_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int SLOTS, bool STATS>
+__global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     AgsFrame F, int normalize_depth, float weight_thres, const float* __restrict__ bgp,
     const float* __restrict__ mask, const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
     int id_stride, const AgsGeom* __restrict__ geom, AgsImages out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ importance, int* __restrict__ count, int num_tiles) {
-    __shared__ AgsGeom sg[64];
-    __shared__ uint32_t sid[64];
-    __shared__ uint32_t smask[64];
+    __shared__ AgsWaveStage stage[4 / SLOTS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    AgsWaveStage& st = stage[wave];
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
-    const int lane = threadIdx.x;
     const int px = tx * AGS_TILE + (lane & 15);
-    const int py0 = ty * AGS_TILE + (lane >> 4);
+    const int strip0 = wave * SLOTS;                       // first of this wave's strips
+    const int py0 = ty * AGS_TILE + strip0 * 4 + (lane >> 4);
     const float fpx = (float)px;
     const uint2 rg = ranges[tile];
     const float bx0 = (float)(tx * AGS_TILE), by0 = (float)(ty * AGS_TILE);
-    // four named accumulators (not an array): keeps every field in VGPRs
-    AgsPix pix0, pix1, pix2, pix3;
-    float mk0 = 1.f, mk1 = 1.f, mk2 = 1.f, mk3 = 1.f;
-#define AGS_SLOT_INIT(S, PIX, MK)                                                                   \
-    {                                                                                               \
-        const bool inside = (px < F.W) && (py0 + 4 * S < F.H);                                      \
-        ags_pix_init(PIX, inside);                                                                  \
-        if (STATS) {                                                                                \
-            MK = inside ? 1.f : 0.f;                                                                \
-            if (mask != nullptr && inside) MK = mask[(size_t)(py0 + 4 * S) * F.W + px] > 0.f ? 1.f : 0.f; \
-        }                                                                                           \
-    }
-    AGS_SLOT_INIT(0, pix0, mk0) AGS_SLOT_INIT(1, pix1, mk1) AGS_SLOT_INIT(2, pix2, mk2) AGS_SLOT_INIT(3, pix3, mk3)
-#undef AGS_SLOT_INIT
-    for (uint32_t base = rg.x; base < rg.y; base += 64) {
-        if (__all(pix0.done & pix1.done & pix2.done & pix3.done)) break;
-        __syncthreads();
-        const uint32_t idx = base + lane;
-        if (idx < rg.y) {
-            const uint32_t gid = vals[(size_t)idx * id_stride];
-            const float4* src = reinterpret_cast<const float4*>(geom + gid);
-            const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-            float4* dst = reinterpret_cast<float4*>(&sg[lane]);
-            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
-            if (STATS) sid[lane] = gid;
-            // which of the tile's four 16x4 strips can this surfel reach at all? (one lane per surfel)
-            AgsGeom me;
-            me.mx = r0.x; me.my = r0.y; me.ca = r0.z; me.cb = r0.w; me.cc = r1.x; me.o = r1.y;
-            uint32_t m = 0;
+    const uint32_t my_strips = ((1u << SLOTS) - 1u) << strip0;
+    AgsPix pix[SLOTS];
+    float mk[SLOTS];
+    int alldone = 1;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                m |= ags_reaches_box(me, bx0, bx0 + 15.f, by0 + 4.f * s, by0 + 4.f * s + 3.f) ? (1u << s) : 0u;
-            smask[lane] = m;
-        }
-        __syncthreads();
-        const int cnt = (int)min(64u, rg.y - base);
-        for (int k = 0; k < cnt; ++k) {
-            const uint32_t m = __builtin_amdgcn_readfirstlane(smask[k]); // wave-uniform
-            if (m == 0) continue;
-            const AgsGeom g = sg[k];
-            float dx0 = 0, dy0 = 0, al0 = 0, dx1 = 0, dy1 = 0, al1 = 0, dx2 = 0, dy2 = 0, al2 = 0, dx3 = 0, dy3 = 0, al3 = 0;
-            bool ok0 = false, ok1 = false, ok2 = false, ok3 = false;
-            if (m & 1u) ok0 = ags_alpha(g, fpx, (float)(py0), dx0, dy0, al0) && !pix0.done;
-            if (m & 2u) ok1 = ags_alpha(g, fpx, (float)(py0 + 4), dx1, dy1, al1) && !pix1.done;
-            if (m & 4u) ok2 = ags_alpha(g, fpx, (float)(py0 + 8), dx2, dy2, al2) && !pix2.done;
-            if (m & 8u) ok3 = ags_alpha(g, fpx, (float)(py0 + 12), dx3, dy3, al3) && !pix3.done;
-            if (!__any(ok0 | ok1 | ok2 | ok3)) continue;
+    for (int s = 0; s < SLOTS; ++s) {
+        const bool inside = (px < F.W) && (py0 + 4 * s < F.H);
+        ags_pix_init(pix[s], inside);
+        mk[s] = inside ? 1.f : 0.f;
+        if (STATS && mask != nullptr && inside) mk[s] = mask[(size_t)(py0 + 4 * s) * F.W + px] > 0.f ? 1.f : 0.f;
+        alldone &= pix[s].done;
+    }
+    for (uint32_t base = rg.x; base < rg.y; base += 64) {
+        if (__all(alldone)) break;
+        ags_wave_lds_sync();
+        const uint32_t idx = base + lane;
+        uint32_t m = 0;
+        if (idx < rg.y) m = ags_stage_one(st, lane, geom, vals[(size_t)idx * id_stride], bx0, by0);
+        ags_wave_lds_sync();
+        unsigned long long act = __ballot((m & my_strips) != 0u); // staged surfels that reach my strips
+        while (act) {
+            const int k = __ffsll((long long)act) - 1;
+            act &= act - 1;
+            const uint32_t mk_bits = ((uint32_t)__builtin_amdgcn_readlane((int)m, k)) >> strip0; // wave-uniform
+            const AgsGeom g = st.sg[k];
+            float dx[SLOTS], dy[SLOTS], al[SLOTS];
+            bool ok[SLOTS];
+            bool any = false;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                ok[s] = false; dx[s] = dy[s] = al[s] = 0.f;
+                if (mk_bits & (1u << s)) ok[s] = ags_alpha(g, fpx, (float)(py0 + 4 * s), dx[s], dy[s], al[s]) && !pix[s].done;
+                any |= ok[s];
+            }
+            if (!__any(any)) continue;
             const uint32_t pos1 = base - rg.x + k + 1;
             float wsum = 0.f;
             uint32_t wcnt = 0;
-#define AGS_SLOT_BLEND(OK, PIX, DX, DY, AL, MK)                                                     \
-    if (OK) {                                                                                       \
-        const float w = ags_blend_apply(PIX, g, DX, DY, AL, pos1);                                  \
-        if (STATS) { const float wm = w * MK; wsum += wm; wcnt += (wm > weight_thres) ? 1u : 0u; }  \
-    }
-            AGS_SLOT_BLEND(ok0, pix0, dx0, dy0, al0, mk0) AGS_SLOT_BLEND(ok1, pix1, dx1, dy1, al1, mk1)
-            AGS_SLOT_BLEND(ok2, pix2, dx2, dy2, al2, mk2) AGS_SLOT_BLEND(ok3, pix3, dx3, dy3, al3, mk3)
-#undef AGS_SLOT_BLEND
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                if (ok[s]) {
+                    const float w = ags_blend_apply(pix[s], g, dx[s], dy[s], al[s], pos1);
+                    if (STATS) { const float wm = w * mk[s]; wsum += wm; wcnt += (wm > weight_thres) ? 1u : 0u; }
+                }
+            }
             if (STATS) {
                 const float ts = ags_wave_sum(wsum);
                 const uint32_t tc = ags_wave_sum_u32(wcnt);
                 if (lane == 0 && ts > 0.f) {
-                    const uint32_t gid = sid[k];
+                    const uint32_t gid = st.sid[k];
                     atomicAdd(&importance[gid], ts);
                     if (tc) atomicAdd(&count[gid], (int)tc);
                 }
             }
         }
+        alldone = 1;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) alldone &= pix[s].done;
     }
     const float bg0 = bgp[0], bg1 = bgp[1], bg2 = bgp[2];
     const size_t HW = (size_t)F.H * F.W;
-#define AGS_SLOT_STORE(S, PIX)                                                                      \
-    {                                                                                               \
-        const int py = py0 + 4 * S;                                                                 \
-        if (px < F.W && py < F.H) {                                                                 \
-            const size_t o = (size_t)py * F.W + px;                                                 \
-            const float A = 1.f - PIX.T;                                                            \
-            out.rgb[o] = PIX.c0 + PIX.T * bg0; out.rgb[HW + o] = PIX.c1 + PIX.T * bg1;              \
-            out.rgb[2 * HW + o] = PIX.c2 + PIX.T * bg2;                                             \
-            out.normal[o] = PIX.n0; out.normal[HW + o] = PIX.n1; out.normal[2 * HW + o] = PIX.n2;   \
-            out.depth[o] = normalize_depth ? PIX.d / fmaxf(A, AGS_DEPTH_A_EPS) : PIX.d;             \
-            out.opacity[o] = A;                                                                     \
-            out.confidence[o] = PIX.cf;                                                             \
-            final_T[o] = PIX.T;                                                                     \
-            n_contrib[o] = PIX.last;                                                                \
-        }                                                                                           \
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int py = py0 + 4 * s;
+        if (px < F.W && py < F.H) {
+            const size_t o = (size_t)py * F.W + px;
+            const float T = pix[s].T, A = 1.f - T;
+            out.rgb[o] = pix[s].c0 + T * bg0; out.rgb[HW + o] = pix[s].c1 + T * bg1; out.rgb[2 * HW + o] = pix[s].c2 + T * bg2;
+            out.normal[o] = pix[s].n0; out.normal[HW + o] = pix[s].n1; out.normal[2 * HW + o] = pix[s].n2;
+            out.depth[o] = normalize_depth ? pix[s].d / fmaxf(A, AGS_DEPTH_A_EPS) : pix[s].d;
+            out.opacity[o] = A;
+            out.confidence[o] = pix[s].cf;
+            final_T[o] = T;
+            n_contrib[o] = pix[s].last;
+        }
     }
-    AGS_SLOT_STORE(0, pix0) AGS_SLOT_STORE(1, pix1) AGS_SLOT_STORE(2, pix2) AGS_SLOT_STORE(3, pix3)
-#undef AGS_SLOT_STORE
 }
 
-__global__ __launch_bounds__(64) void ags_k_render_bwd(
+template <int SLOTS>
+__global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_bwd(
     AgsFrame F, int normalize_depth, const float* __restrict__ bgp, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
-    const float* __restrict__ depth_out,
-    const float* __restrict__ opac_out, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    AgsImageGrads dout, float* __restrict__ dgeom, int num_tiles) {
-    __shared__ AgsGeom sg[64];
-    __shared__ uint32_t sid[64];
-    __shared__ uint32_t smask[64];
+    const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, AgsImageGrads dout, float* __restrict__ dgeom, int num_tiles) {
+    __shared__ AgsWaveStage stage[4 / SLOTS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    AgsWaveStage& st = stage[wave];
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
     if (rg.y <= rg.x) return;
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
-    const int lane = threadIdx.x;
     const int px = tx * AGS_TILE + (lane & 15);
-    const int py0 = ty * AGS_TILE + (lane >> 4);
+    const int strip0 = wave * SLOTS;
+    const int py0 = ty * AGS_TILE + strip0 * 4 + (lane >> 4);
     const float fpx = (float)px;
     const float bx0 = (float)(tx * AGS_TILE), by0 = (float)(ty * AGS_TILE);
+    const uint32_t my_strips = ((1u << SLOTS) - 1u) << strip0;
     const float bg[3] = {bgp[0], bgp[1], bgp[2]};
     const size_t HW = (size_t)F.H * F.W;
-    AgsPixGrad pg[4];
+    AgsPixGrad pg[SLOTS];
     uint32_t mymax = 0;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < SLOTS; ++s) {
         const int py = py0 + 4 * s;
         float dC[3] = {0, 0, 0}, dN[3] = {0, 0, 0}, dD = 0, dO = 0, dCf = 0, dep = 0, opa = 0, Tf = 1.f;
         uint32_t last = 0;
@@ -168,40 +190,29 @@ __global__ __launch_bounds__(64) void ags_k_render_bwd(
         mymax = max(mymax, last);
     }
     const uint32_t maxlast = ags_wave_max_u32(mymax);
-    if (maxlast == 0) return;
+    if (maxlast == 0) return; // wave-uniform; no workgroup barrier anywhere in this kernel
     // lanes (lane&15) < 4 each own one field of the reduced gradient record (15 is padding)
     const int my_field = ((lane & 15) < 4 && ags_reduce16_field(lane) < 15) ? ags_reduce16_field(lane) : -1;
     for (int r = (int)((maxlast - 1) >> 6); r >= 0; --r) {
         const uint32_t k0 = (uint32_t)r << 6;
-        __syncthreads();
-        if (k0 + lane < maxlast) {
-            const uint32_t gid = vals[(size_t)(rg.x + k0 + lane) * id_stride];
-            const float4* src = reinterpret_cast<const float4*>(geom + gid);
-            const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-            float4* dst = reinterpret_cast<float4*>(&sg[lane]);
-            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
-            sid[lane] = gid;
-            AgsGeom me;
-            me.mx = r0.x; me.my = r0.y; me.ca = r0.z; me.cb = r0.w; me.cc = r1.x; me.o = r1.y;
-            uint32_t m = 0;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                m |= ags_reaches_box(me, bx0, bx0 + 15.f, by0 + 4.f * s, by0 + 4.f * s + 3.f) ? (1u << s) : 0u;
-            smask[lane] = m;
-        }
-        __syncthreads();
-        const int kend = (int)min(63u, maxlast - 1 - k0);
-        for (int k = kend; k >= 0; --k) {
-            const uint32_t m = __builtin_amdgcn_readfirstlane(smask[k]); // wave-uniform strip mask
-            if (m == 0) continue;
-            const AgsGeom g = sg[k];
+        ags_wave_lds_sync();
+        uint32_t m = 0;
+        if (k0 + lane < maxlast) m = ags_stage_one(st, lane, geom, vals[(size_t)(rg.x + k0 + lane) * id_stride], bx0, by0);
+        ags_wave_lds_sync();
+        unsigned long long act = __ballot((m & my_strips) != 0u);
+        while (act) { // back to front: highest staged position first
+            const int k = 63 - __clzll((long long)act);
+            act &= ~(1ull << k);
+            const uint32_t mk_bits = ((uint32_t)__builtin_amdgcn_readlane((int)m, k)) >> strip0;
+            const AgsGeom g = st.sg[k];
             const uint32_t pos1 = k0 + k + 1;
-            float dx[4] = {0, 0, 0, 0}, dy[4] = {0, 0, 0, 0}, al[4] = {0, 0, 0, 0};
-            bool ok[4] = {false, false, false, false};
+            float dx[SLOTS], dy[SLOTS], al[SLOTS];
+            bool ok[SLOTS];
             bool any = false;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (m & (1u << s))
+            for (int s = 0; s < SLOTS; ++s) {
+                ok[s] = false; dx[s] = dy[s] = al[s] = 0.f;
+                if (mk_bits & (1u << s))
                     ok[s] = ags_alpha(g, fpx, (float)(py0 + 4 * s), dx[s], dy[s], al[s]) && (pos1 <= pg[s].last);
                 any |= ok[s];
             }
@@ -211,34 +222,64 @@ __global__ __launch_bounds__(64) void ags_k_render_bwd(
 #pragma unroll
             for (int j = 0; j < 16; ++j) a[j] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < SLOTS; ++s)
                 if (ok[s]) ags_blend_bwd_apply(pg[s], g, dx[s], dy[s], al[s], acc);
             const float mine = ags_wave_reduce16(a, lane); // 16 lanes end up owning one total each
-            if (my_field >= 0) unsafeAtomicAdd(dgeom + (size_t)sid[k] * 16 + my_field, mine);
+            if (my_field >= 0) unsafeAtomicAdd(dgeom + (size_t)st.sid[k] * 16 + my_field, mine);
         }
     }
 }
 
-void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
-                           AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, hipStream_t s) {
+// How many strips per wave: one wave per tile when the image has enough tiles to fill the
+// 1024 SIMDs several times over, otherwise split tiles over more waves.
+static int ags_pick_slots(int num_tiles) {
+    const char* e = getenv("AGS_RENDER_SLOTS");
+    if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) return e[0] - '0';
+    if (num_tiles >= 8192) return 4;
+    return 2;
+}
+
+template <int SLOTS>
+static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L, AgsIdList ids,
+                       const AgsImages& out, const AgsPerGaussian& pg, hipStream_t s) {
     const uint2* ranges = (const uint2*)(ws + L.ranges);
     const AgsGeom* geom = (const AgsGeom*)(ws + L.geom);
     float* fT = (float*)(ws + L.final_T);
     uint32_t* nc = (uint32_t*)(ws + L.n_contrib);
+    const dim3 block(64 * (4 / SLOTS));
     if (cam.want_stats)
-        hipLaunchKernelGGL(ags_k_render_fwd<true>, dim3(L.num_tiles), dim3(64), 0, s, F, cam.normalize_depth,
+        hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, true>), dim3(L.num_tiles), block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles);
     else
-        hipLaunchKernelGGL(ags_k_render_fwd<false>, dim3(L.num_tiles), dim3(64), 0, s, F, cam.normalize_depth,
+        hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, false>), dim3(L.num_tiles), block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles);
 }
 
+template <int SLOTS>
+static void launch_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L, AgsIdList ids,
+                       const AgsImages& fwd, const AgsImageGrads& dout, hipStream_t s) {
+    hipLaunchKernelGGL((ags_k_render_bwd<SLOTS>), dim3(L.num_tiles), dim3(64 * (4 / SLOTS)), 0, s, F,
+                       cam.normalize_depth, cam.bg, (const uint2*)(ws + L.ranges), ids.ids, ids.stride,
+                       (const AgsGeom*)(ws + L.geom), fwd.depth, fwd.opacity, (const float*)(ws + L.final_T),
+                       (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles);
+}
+
+void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
+                           AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, hipStream_t s) {
+    switch (ags_pick_slots(L.num_tiles)) {
+        case 1: launch_fwd<1>(F, cam, ws, L, ids, out, pg, s); break;
+        case 2: launch_fwd<2>(F, cam, ws, L, ids, out, pg, s); break;
+        default: launch_fwd<4>(F, cam, ws, L, ids, out, pg, s); break;
+    }
+}
+
 void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, hipStream_t s) {
-    hipLaunchKernelGGL(ags_k_render_bwd, dim3(L.num_tiles), dim3(64), 0, s, F, cam.normalize_depth, cam.bg,
-                       (const uint2*)(ws + L.ranges), ids.ids, ids.stride, (const AgsGeom*)(ws + L.geom), fwd.depth,
-                       fwd.opacity, (const float*)(ws + L.final_T), (const uint32_t*)(ws + L.n_contrib), dout,
-                       (float*)(ws + L.dgeom), L.num_tiles);
+    switch (ags_pick_slots(L.num_tiles)) {
+        case 1: launch_bwd<1>(F, cam, ws, L, ids, fwd, dout, s); break;
+        case 2: launch_bwd<2>(F, cam, ws, L, ids, fwd, dout, s); break;
+        default: launch_bwd<4>(F, cam, ws, L, ids, fwd, dout, s); break;
+    }
 }
