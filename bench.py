@@ -75,8 +75,8 @@ def cpu_baseline(raw_cpu, cam_cpu, budget_s=15.0, max_threads=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--binning", choices=["tile_sort", "radix"], default="tile_sort")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
@@ -136,6 +136,13 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    # bring the GPU to its sustained clock before the W warm-up steps (a step is ~0.2 ms:
+    # W of them alone finish before DVFS has settled)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.5:
+        for _ in range(20):
+            one_step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()

@@ -251,3 +251,66 @@ def test_fused_activations_match_separate_kernels(agslib):
         assert (a - b).abs().sum() <= 1e-4 * a.abs().sum() + 1e-12
     for a, b in zip(params[0], params[1]):
         assert (a - b).abs().mean() < 1e-6
+
+
+def _dense_patch_case(n=7000, h=128, w=128):
+    """Thousands of large, faint surfels stacked in front of the camera: every central tile
+    holds far more than 2048 keys (in-place global bitonic path of the tile sort), footprints
+    span > 32 tiles (wave-cooperative emission in the radix path), depths collide often."""
+    gen = torch.Generator().manual_seed(77)
+    means = torch.stack([(torch.rand(n, generator=gen) - 0.5) * 0.3, (torch.rand(n, generator=gen) - 0.5) * 0.3,
+                         0.5 + torch.rand(n, generator=gen) * 0.5], -1)
+    means[::50, 2] = 0.75                                    # exact depth ties
+    scales = torch.cat([0.02 + 0.03 * torch.rand(n, 2, generator=gen), torch.zeros(n, 1)], 1)
+    rots = torch.nn.functional.normalize(torch.tensor([1.0, 0, 0, 0]) + 0.2 * torch.randn(n, 4, generator=gen), dim=-1)
+    a = dict(means=means, scales=scales, rotations=rots, opacities=0.01 + 0.03 * torch.rand(n, generator=gen),
+             colors=torch.rand(n, 3, generator=gen), confidences=torch.rand(n, generator=gen))
+    from oracle.surfel_oracle import OracleSettings
+    near, far, t = 0.001, 10.0, 1.0
+    P = torch.zeros(4, 4)
+    P[0, 0] = 1 / t; P[1, 1] = 1 / t; P[3, 2] = 1; P[2, 2] = far / (far - near); P[2, 3] = -far * near / (far - near)
+    S = OracleSettings(h, w, t, t, torch.tensor([0.3, 0.2, 0.1, 0.0]), 1.0, torch.eye(4), (torch.eye(4) @ P.t()).contiguous(),
+                       campos=torch.zeros(3), config=torch.tensor([1.0, 1, 1, 0, 0]))
+    return a, S
+
+
+def test_overfull_tiles_and_huge_footprints(agslib):
+    from active_gs_amd import raster_api as api
+    from oracle.surfel_oracle import rasterize
+    dev = torch.device("cuda:0")
+    a, S = _dense_patch_case()
+    cam = api.Camera(S.image_height, S.image_width, S.tanfovx, S.tanfovy, S.viewmatrix.to(dev), S.projmatrix.to(dev),
+                     S.bg.to(dev))
+    g = api.Gaussians(*(a[k].to(dev).contiguous() for k in ("means", "scales", "rotations", "opacities", "colors",
+                                                              "confidences")))
+    gen = torch.Generator().manual_seed(5)
+    d = [torch.randn(c, S.image_height, S.image_width, generator=gen).to(dev) for c in (3, 3, 1, 1, 1)]
+    res = []
+    for mode in (api.BIN_TILE_SORT, api.BIN_RADIX):
+        st = api.alloc_state(g.n, S.image_height, S.image_width, 1 << 22, dev, mode)
+        api.forward(cam, g, st)
+        info = api.read_status(st)
+        assert not info["overflow"]
+        T = 64
+        rg = st.workspace[256 + 8192:256 + 8192 + T * 8].view(torch.int32).view(T, 2)
+        kmax = int((rg[:, 1] - rg[:, 0]).max())
+        assert kmax > 2048, kmax                         # the test really exercises the big-tile path
+        grads = api.backward(cam, g, st, *d)
+        torch.cuda.synchronize()
+        res.append((st, grads))
+    for name in ("rgb", "normal", "depth", "opacity", "confidence"):
+        assert torch.equal(getattr(res[0][0], name), getattr(res[1][0], name)), name
+    for name in ("means3D", "scales", "rotations", "opacities", "colors"):
+        x, y = getattr(res[0][1], name), getattr(res[1][1], name)
+        assert (x - y).abs().sum() <= 1e-3 * y.abs().sum()
+    ins = [a["means"].clone().requires_grad_(True), torch.zeros(g.n, 3), a["opacities"][:, None].clone().requires_grad_(True),
+           a["confidences"], a["colors"].clone().requires_grad_(True), a["scales"].clone().requires_grad_(True),
+           a["rotations"].clone().requires_grad_(True)]
+    ref = rasterize(*ins, S)
+    assert (res[0][0].rgb.cpu() - ref[0].detach()).abs().mean() < RGB_TOL
+    assert (res[0][0].opacity.cpu() - ref[3].detach()).abs().mean() < RGB_TOL
+    sum((o * x.cpu()).sum() for o, x in zip(ref[:5], d)).backward()
+    for name, i in (("means3D", 0), ("opacities", 2), ("colors", 4), ("scales", 5), ("rotations", 6)):
+        r = ins[i].grad.reshape(getattr(res[0][1], name).shape)
+        rel = (getattr(res[0][1], name).cpu() - r).abs().sum() / r.abs().sum()
+        assert rel < 2e-3, (name, float(rel))
