@@ -67,7 +67,7 @@ class AgsActivation(C.Structure):
                 ("raw_rotations", c_f32p), ("raw_opacities", c_f32p)]
 
 
-EXPORTS = ["ags_workspace_bytes", "ags_forward", "ags_backward", "ags_read_status", "ags_adam_step",
+EXPORTS = ["ags_workspace_bytes", "ags_workspace_init", "ags_forward", "ags_backward", "ags_read_status", "ags_adam_step",
            "ags_adam_step_device", "ags_activate", "ags_activate_backward", "ags_profile_enable", "ags_profile_read",
            "ags_error_string", "ags_version"]
 
@@ -91,6 +91,8 @@ def load() -> C.CDLL:
     lib = C.CDLL(path)
     lib.ags_workspace_bytes.restype = C.c_size_t
     lib.ags_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64]
+    lib.ags_workspace_init.restype = C.c_int
+    lib.ags_workspace_init.argtypes = [C.POINTER(AgsWorkspace), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.ags_forward.restype = C.c_int
     lib.ags_forward.argtypes = [C.POINTER(AgsCamera), C.POINTER(AgsGaussians), C.POINTER(AgsImages),
                                 C.POINTER(AgsPerGaussian), C.POINTER(AgsWorkspace), C.c_void_p]

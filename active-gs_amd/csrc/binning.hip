@@ -37,6 +37,8 @@ __global__ __launch_bounds__(1024) void ags_k_scan_blocks(uint32_t* __restrict__
         status[0] = total;
         status[1] = total < cap ? total : cap;
         status[2] = total > cap ? 1u : 0u;
+        status[3] = status[4]; // visible surfels counted by the preprocess kernel
+        status[4] = 0u;
     }
 }
 
@@ -309,6 +311,8 @@ __global__ __launch_bounds__(1024) void ags_k_scan_tiles(const uint32_t* __restr
         status[0] = total;
         status[1] = total < cap ? total : cap;
         status[2] = total > cap ? 1u : 0u;
+        status[3] = status[4];
+        status[4] = 0u;
     }
 }
 

@@ -28,6 +28,14 @@ size_t ags_workspace_bytes(int32_t n, int32_t h, int32_t w, int64_t max_instance
     return ags_make_layout(n, h, w, max_instances).total;
 }
 
+int ags_workspace_init(const AgsWorkspace* ws, int32_t n, int32_t h, int32_t w, ags_stream_t stream) {
+    if (!ws || !ws->ptr || n < 0 || h <= 0 || w <= 0 || ws->max_instances < 1) return AGS_E_INVALID;
+    const AgsLayout L = ags_make_layout(n, h, w, ws->max_instances);
+    if (ws->bytes < L.total) return AGS_E_WORKSPACE;
+    if (hipMemsetAsync((char*)ws->ptr + L.status, 0, L.clear_bytes, (hipStream_t)stream) != hipSuccess) return AGS_E_LAUNCH;
+    return AGS_OK;
+}
+
 int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* out,
                 const AgsPerGaussian* pg, const AgsWorkspace* ws, ags_stream_t stream) {
     if (!cam || !in || !out || !pg || !ws || !ws->ptr) return AGS_E_INVALID;
@@ -45,8 +53,10 @@ int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* o
     hipStream_t s = (hipStream_t)stream;
     char* base = (char*)ws->ptr;
     const AgsFrame F = ags_make_frame(cam);
-    if (hipMemsetAsync(base + L.status, 0, L.clear_bytes, s) != hipSuccess) return AGS_E_LAUNCH;
     const bool radix = ws->binning_mode == AGS_BIN_RADIX;
+    // tile-sort mode is self-cleaning (see ags_workspace_init); the radix path re-zeroes its digit
+    // totals and tile ranges every pass
+    if ((radix || in->n == 0) && hipMemsetAsync(base + L.status, 0, L.clear_bytes, s) != hipSuccess) return AGS_E_LAUNCH;
     if (in->n > 0) {
         { StageScope t(AGS_STAGE_PREPROCESS, s); ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, !radix, s); }
         { StageScope t(AGS_STAGE_BINNING, s);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
 #pragma unroll
         for (int k = 0; k < AGS_PRE_THREADS / 64; ++k) { a += wsum[k]; b += wvis[k]; }
         block_sums[blockIdx.x] = a;
-        if (b) atomicAdd(&status[3], b);
+        if (b) atomicAdd(&status[4], b); // visible-surfel accumulator, published + reset by the scan kernel
     }
 }
 

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     AgsFrame F, int normalize_depth, float weight_thres, const float* __restrict__ bgp,
     const float* __restrict__ mask, const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
     int id_stride, const AgsGeom* __restrict__ geom, AgsImages out, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float* __restrict__ importance, int* __restrict__ count, int num_tiles) {
+    uint32_t* __restrict__ n_contrib, float* __restrict__ importance, int* __restrict__ count, int num_tiles,
+    uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_fill) {
     __shared__ AgsWaveStage stage[4 / SLOTS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     AgsWaveStage& st = stage[wave];
@@ -69,6 +70,8 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     const uint2 rg = ranges[tile];
     const float bx0 = (float)(tx * AGS_TILE), by0 = (float)(ty * AGS_TILE);
     const uint32_t my_strips = ((1u << SLOTS) - 1u) << strip0;
+    // last consumer of this tile's binning counters: leave them zero for the next forward pass
+    if (threadIdx.x == 0) { tile_count[tile] = 0u; tile_fill[tile] = 0u; }
     AgsPix pix[SLOTS];
     float mk[SLOTS];
     int alldone = 1;
@@ -250,11 +253,13 @@ static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
     if (cam.want_stats)
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, true>), dim3(L.num_tiles), block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
-                           pg.importance, pg.count, L.num_tiles);
+                           pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
+                           (uint32_t*)(ws + L.tile_fill));
     else
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, false>), dim3(L.num_tiles), block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
-                           pg.importance, pg.count, L.num_tiles);
+                           pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
+                           (uint32_t*)(ws + L.tile_fill));
 }
 
 template <int SLOTS>

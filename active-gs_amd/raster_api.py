@@ -114,13 +114,16 @@ BIN_TILE_SORT, BIN_RADIX = 0, 1
 
 def alloc_state(n: int, h: int, w: int, max_instances: int, device, binning_mode: int = BIN_TILE_SORT) -> ForwardState:
     f = dict(device=device, dtype=torch.float32)
-    return ForwardState(
+    st = ForwardState(
         rgb=torch.empty(3, h, w, **f), normal=torch.empty(3, h, w, **f), depth=torch.empty(1, h, w, **f),
         opacity=torch.empty(1, h, w, **f), confidence=torch.empty(1, h, w, **f),
         importance=torch.zeros(n, **f), count=torch.zeros(n, device=device, dtype=torch.int32),
         radii=torch.empty(n, device=device, dtype=torch.int32),
         workspace=torch.empty(workspace_bytes(n, h, w, max_instances), device=device, dtype=torch.uint8),
         max_instances=int(max_instances), binning_mode=int(binning_mode))
+    ws = st.ws_struct()
+    _lib.check(_lib.load().ags_workspace_init(C.byref(ws), n, h, w, _stream()), "ags_workspace_init")
+    return st
 
 
 def forward(cam: Camera, g: Gaussians, state: ForwardState) -> ForwardState:

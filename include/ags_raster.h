@@ -140,7 +140,13 @@ typedef struct AgsStatus {
  * The forward pass leaves its state there; the backward pass of the same view reads it. */
 size_t ags_workspace_bytes(int32_t n, int32_t h, int32_t w, int64_t max_instances);
 
-/* Forward: cull+project, tile binning, radix sort, per-tile blend. */
+/* Must be called ONCE on a freshly allocated (or otherwise scribbled-on) workspace before its
+ * first ags_forward: clears the counters the forward pass relies on.  Every ags_forward leaves
+ * them clean again (each tile's workgroup resets its own counters), so there is no per-pass
+ * memset in the default binning mode. */
+int ags_workspace_init(const AgsWorkspace* ws, int32_t n, int32_t h, int32_t w, ags_stream_t stream);
+
+/* Forward: cull+project, tile binning, depth sort, per-tile blend. */
 int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* out,
                 const AgsPerGaussian* per_gaussian, const AgsWorkspace* ws, ags_stream_t stream);
 
