@@ -62,13 +62,19 @@ class AgsAdamTensors(C.Structure):
                 ("numel", C.c_int64 * 5), ("lr", C.c_float * 5)]
 
 
+class AgsLossConfig(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("fov_x", C.c_float), ("fov_y", C.c_float),
+                ("batch_total", C.c_int32), ("w_rgb", C.c_float), ("w_depth", C.c_float), ("w_cons", C.c_float),
+                ("w_tv", C.c_float), ("sigma", C.c_float)]
+
+
 class AgsActivation(C.Structure):
     _fields_ = [("n", C.c_int32), ("scale_factor", C.c_float), ("max_scale", C.c_float), ("raw_scales", c_f32p),
                 ("raw_rotations", c_f32p), ("raw_opacities", c_f32p)]
 
 
 EXPORTS = ["ags_workspace_bytes", "ags_workspace_init", "ags_forward", "ags_backward", "ags_read_status", "ags_adam_step",
-           "ags_adam_step_device", "ags_activate", "ags_activate_backward", "ags_profile_enable", "ags_profile_read",
+           "ags_adam_step_device", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_profile_enable", "ags_profile_read",
            "ags_error_string", "ags_version"]
 
 _lib = None
@@ -111,6 +117,11 @@ def load() -> C.CDLL:
     lib.ags_activate.argtypes = [C.POINTER(AgsActivation), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ags_activate_backward.restype = C.c_int
     lib.ags_activate_backward.argtypes = [C.POINTER(AgsActivation), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ags_loss_stage1.restype = C.c_int
+    lib.ags_loss_stage1.argtypes = [C.POINTER(AgsLossConfig), C.POINTER(AgsImages)] + [C.c_void_p] * 7 + [
+        C.c_int32, C.c_int32, C.c_void_p]
+    lib.ags_loss_stage2.restype = C.c_int
+    lib.ags_loss_stage2.argtypes = [C.POINTER(AgsLossConfig), C.POINTER(AgsImages)] + [C.c_void_p] * 6 + [C.c_void_p]
     lib.ags_profile_enable.restype = C.c_int
     lib.ags_profile_enable.argtypes = [C.c_int32]
     lib.ags_profile_read.restype = C.c_int

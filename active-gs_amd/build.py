@@ -14,8 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libags_raster.so")
-SOURCES = ["preprocess.hip", "binning.hip", "render.hip", "adam.hip", "capi.hip"]
+SOURCES = ["preprocess.hip", "binning.hip", "render.hip", "adam.hip", "loss.hip", "capi.hip"]
 HEADERS = ["ags_internal.h", "surfel_math.h", os.path.join("..", "..", "include", "ags_raster.h")]
+# loss.hip must reproduce exact cancellations of the reference's un-fused torch ops (see ags_point)
+EXTRA_FLAGS = {"loss.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]
 
@@ -46,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
@@ -54,7 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(r.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     tmp = LIB + ".tmp"
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp],

@@ -102,6 +102,11 @@ void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float ep
 void ags_launch_activate(const AgsActivation& a, float* scales, float* rotations, float* opacities, hipStream_t s);
 void ags_launch_activate_bwd(const AgsActivation& a, float* d_scales, float* d_rotations, float* d_opacities,
                              hipStream_t s);
+void ags_launch_loss_stage1(const AgsLossConfig& cfg, const AgsImages& img, const float* gt_rgb, const float* gt_depth,
+                            float* n_img, float* d_rgb, float* d_depth, int* msum, float* accum, int view,
+                            int first_view, hipStream_t s);
+void ags_launch_loss_stage2(const AgsLossConfig& cfg, const AgsImages& img, const float* n_img, const float* gt_depth,
+                            const int* msum, float* d_normal, float* d_depth, float* accum, hipStream_t s);
 int ags_sort_passes(int num_tiles);
 
 #if defined(__HIPCC__)

@@ -135,6 +135,31 @@ int ags_activate_backward(const AgsActivation* a, float* d_scales, float* d_rota
     return ags_check_launch();
 }
 
+static int ags_loss_check(const AgsLossConfig* c, const AgsImages* f) {
+    if (!c || !f || c->image_height <= 0 || c->image_width <= 0 || c->batch_total < 1 || !(c->sigma > 0.f)) return AGS_E_INVALID;
+    if (!f->rgb || !f->normal || !f->depth || !f->opacity) return AGS_E_INVALID;
+    return AGS_OK;
+}
+
+int ags_loss_stage1(const AgsLossConfig* cfg, const AgsImages* fwd, const float* gt_rgb, const float* gt_depth,
+                    float* n_img, float* d_rgb, float* d_depth, int32_t* msum, float* accum, int32_t view,
+                    int32_t first_view, ags_stream_t stream) {
+    if (ags_loss_check(cfg, fwd) != AGS_OK || !gt_rgb || !gt_depth || !n_img || !d_rgb || !d_depth || !msum || !accum ||
+        view < 0)
+        return AGS_E_INVALID;
+    ags_launch_loss_stage1(*cfg, *fwd, gt_rgb, gt_depth, n_img, d_rgb, d_depth, msum, accum, view, first_view,
+                           (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_loss_stage2(const AgsLossConfig* cfg, const AgsImages* fwd, const float* n_img, const float* gt_depth,
+                    const int32_t* msum, float* d_normal, float* d_depth, float* accum, ags_stream_t stream) {
+    if (ags_loss_check(cfg, fwd) != AGS_OK || !n_img || !gt_depth || !msum || !d_normal || !d_depth || !accum)
+        return AGS_E_INVALID;
+    ags_launch_loss_stage2(*cfg, *fwd, n_img, gt_depth, msum, d_normal, d_depth, accum, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
 int ags_profile_enable(int32_t slots) {
     if (slots < 0) return AGS_E_INVALID;
     for (int st = 0; st < AGS_NUM_STAGES; ++st) {

@@ -1,0 +1,205 @@
+// Fused loss head: facade post-processing + depth->normal + the four training losses, forward
+// and hand-derived backward, straight from the rasterizer's images to dL/d{rgb, normal, depth}.
+//
+// Replaces, per view, the torch ops of
+//   /root/reference/utils/operations.py:714-718   normal = normalize(normal)*(opacity>1e-2); d2n = depth2normal(...)
+//   /root/reference/utils/operations.py:172-219   depth2normal (4-neighbour cross products, replicate padding,
+//                                                 fov_x paired with H and fov_y with W — kept)
+//   /root/reference/mapping/gaussian_map.py:106-124 masked L1 rgb/depth, consistency, normal TV, weights 1/.8/.1/.1
+//   /root/reference/mapping/utils.py:14-62,120-121  cons_loss_fc, normal_tv_loss_fc/central_diff, l1_loss_fc_mask
+// including the reference's (B,H,W)x(B,1,H,W) broadcast in the consistency term: that term is
+//   sum_b' sum_p (1 - n_b'(p).d2n_b'(p)) * Msum(p) / (B*B*H*W),  Msum = sum over ALL views of (opacity>1e-3),
+// so stage 1 of every view of the batch runs (and Msum is all-reduced under view parallelism)
+// before stage 2 of any view.
+//   stage 1 (per pixel): n = normalised masked normal -> n image; direct L1 gradients d_rgb, d_depth;
+//                        Msum += visibility; loss / per-frame error sums
+//   stage 2 (per pixel): TV gradient wrt n(p) gathered from the 4 neighbours (each unordered pair counted
+//                        from both sides), consistency gradient, chain rule through the normalisation ->
+//                        d_normal; consistency gradient wrt d2n(p) through the cross products onto the
+//                        depths of p and its 4 neighbours (atomicAdd into d_depth)
+#include "ags_internal.h"
+
+struct AgsLossDev {
+    int H, W, B;
+    float fxq, fyq;          // H/(2 tan(fov_x/2)), W/(2 tan(fov_y/2))  (the reference's pairing)
+    float w_rgb, w_depth, w_cons, w_tv, inv_2sig2;
+};
+
+__device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
+__device__ __forceinline__ float3 operator-(float3 a, float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 operator+(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ float3 operator*(float3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+// back-projected point ray*d with ROUNDED products (no FMA contraction with a later subtraction): where
+// a replicated neighbour is the pixel itself, P(neighbour) - P(centre) must cancel to exactly 0 as it
+// does in the reference's torch ops, or the normalisation turns rounding residue into a unit vector
+__device__ __forceinline__ float3 ags_point(float3 ray, float d) {
+    return f3(__fmul_rn(ray.x, d), __fmul_rn(ray.y, d), __fmul_rn(ray.z, d));
+}
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float3 cross3(float3 a, float3 b) {
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = ags_wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[wave] = v;
+    __syncthreads();
+    const float t = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return t;
+}
+
+// accum layout (floats): [0] rgb L1 sum, [1] depth L1 sum, [2] cons sum, [3] tv sum (all views);
+//                        [4 + 2*view] rgb L1 sum of the view, [5 + 2*view] depth L1 sum of the view
+__global__ __launch_bounds__(256) void ags_k_loss_stage1(
+    AgsLossDev c, const float* __restrict__ rgb, const float* __restrict__ normal_raw,
+    const float* __restrict__ depth, const float* __restrict__ opacity, const float* __restrict__ gt_rgb,
+    const float* __restrict__ gt_depth, float* __restrict__ n_img, float* __restrict__ d_rgb,
+    float* __restrict__ d_depth, int* __restrict__ msum, float* __restrict__ accum, int view, int first_view) {
+    __shared__ float sh[4];
+    const int HW = c.H * c.W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float s_rgb = 0.f, s_dep = 0.f;
+    if (p < HW) {
+        const float o = opacity[p];
+        const float mvis = o > 1e-3f ? 1.f : 0.f, mn = o > 1e-2f ? 1.f : 0.f;
+        const float nx = normal_raw[p], ny = normal_raw[HW + p], nz = normal_raw[2 * HW + p];
+        const float inv = mn / fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-12f);
+        n_img[p] = nx * inv; n_img[HW + p] = ny * inv; n_img[2 * HW + p] = nz * inv;
+        const float k_rgb = c.w_rgb / ((float)c.B * 3.f * (float)HW);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float e = (rgb[ch * HW + p] - gt_rgb[ch * HW + p]) * mvis;
+            s_rgb += fabsf(e);
+            d_rgb[ch * HW + p] = (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * mvis * k_rgb;
+        }
+        const float dg = gt_depth[p];
+        const float md = dg > 0.f ? 1.f : 0.f;
+        const float e = (depth[p] - dg) * md;
+        s_dep = fabsf(e);
+        d_depth[p] = (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * md * (c.w_depth / ((float)c.B * (float)HW));
+        const int v = o > 1e-3f ? 1 : 0;
+        msum[p] = first_view ? v : msum[p] + v;
+    }
+    const float t_rgb = block_sum_256(s_rgb, sh), t_dep = block_sum_256(s_dep, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&accum[0], t_rgb); atomicAdd(&accum[1], t_dep);
+        atomicAdd(&accum[4 + 2 * view], t_rgb); atomicAdd(&accum[5 + 2 * view], t_dep);
+    }
+}
+
+__device__ __forceinline__ float3 load_n(const float* __restrict__ n_img, int HW, int q) {
+    return f3(n_img[q], n_img[HW + q], n_img[2 * HW + q]);
+}
+
+__global__ __launch_bounds__(256) void ags_k_loss_stage2(
+    AgsLossDev c, const float* __restrict__ depth, const float* __restrict__ opacity,
+    const float* __restrict__ normal_raw, const float* __restrict__ n_img, const float* __restrict__ gt_depth,
+    const int* __restrict__ msum, float* __restrict__ d_normal, float* __restrict__ d_depth,
+    float* __restrict__ accum) {
+    __shared__ float sh[4];
+    const int H = c.H, W = c.W, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float s_cons = 0.f, s_tv = 0.f;
+    if (p < HW) {
+        const int y = p / W, x = p - y * W;
+        const float3 n = load_n(n_img, HW, p);
+        const float dp = depth[p];
+        const float mdp = gt_depth[p] > 0.f ? 1.f : 0.f;
+        // ---------------- normal TV: gather over the (up to) 4 neighbours
+        float3 gn = f3(0.f, 0.f, 0.f);
+        const float k_tv = c.w_tv / ((float)c.B * 4.f * (float)HW);
+        const int qx[4] = {x + 1, x - 1, x, x};
+        const int qy[4] = {y, y, y + 1, y - 1};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            if (qx[d] < 0 || qx[d] >= W || qy[d] < 0 || qy[d] >= H) continue;
+            const int q = qy[d] * W + qx[d];
+            const float3 df = n - load_n(n_img, HW, q);
+            const float nd = dot3(df, df);
+            const float dd = dp - depth[q];
+            if (dd * dd <= 1e-4f) {
+                const float ex = __expf(-nd * c.inv_2sig2);
+                s_tv += ex * nd * mdp;                                   // this pixel's own term
+                const float mdq = gt_depth[q] > 0.f ? 1.f : 0.f;
+                const float fp = ex * (1.f - nd * c.inv_2sig2) * (mdp + mdq) * 2.f * k_tv; // both orientations of the pair
+                gn = gn + df * fp;
+            }
+        }
+        // ---------------- depth -> normal (replicate padding) and the consistency term
+        const float mn = opacity[p] > 1e-2f ? 1.f : 0.f;
+        const int yu = max(y - 1, 0), yb = min(y + 1, H - 1), xl = max(x - 1, 0), xr = min(x + 1, W - 1);
+        const int iu = yu * W + x, ib = yb * W + x, il = y * W + xl, ir = y * W + xr;
+        const float rx = ((float)x - 0.5f * (float)W) / c.fxq, ry = ((float)y - 0.5f * (float)H) / c.fyq;
+        const float rxl = ((float)xl - 0.5f * (float)W) / c.fxq, rxr = ((float)xr - 0.5f * (float)W) / c.fxq;
+        const float ryu = ((float)yu - 0.5f * (float)H) / c.fyq, ryb = ((float)yb - 0.5f * (float)H) / c.fyq;
+        const float du = depth[iu], db = depth[ib], dl = depth[il], dr = depth[ir];
+        const float Mu = opacity[iu] > 1e-2f ? 1.f : 0.f, Mb = opacity[ib] > 1e-2f ? 1.f : 0.f;
+        const float Ml = opacity[il] > 1e-2f ? 1.f : 0.f, Mr = opacity[ir] > 1e-2f ? 1.f : 0.f;
+        const float3 ray_c = f3(rx, ry, 1.f), ray_u = f3(rx, ryu, 1.f), ray_b = f3(rx, ryb, 1.f);
+        const float3 ray_l = f3(rxl, ry, 1.f), ray_r = f3(rxr, ry, 1.f);
+        const float3 pc = ags_point(ray_c, dp) * mn;
+        const float3 pu = (ags_point(ray_u, du) - pc) * Mu, pl = (ags_point(ray_l, dl) - pc) * Ml;
+        const float3 pb = (ags_point(ray_b, db) - pc) * Mb, pr = (ags_point(ray_r, dr) - pc) * Mr;
+        const float3 m = cross3(pu, pl) + cross3(pr, pu) + cross3(pb, pr) + cross3(pl, pb);
+        const float ml = fmaxf(sqrtf(dot3(m, m)), 1e-12f);
+        const float3 mh = m * (1.f / ml);
+        const float3 d2n = mh * mn;
+        const float ms = (float)msum[p];
+        const float k_c = c.w_cons / ((float)c.B * (float)c.B * (float)HW);
+        s_cons = (1.f - dot3(n, d2n)) * ms;
+        gn = gn + d2n * (-k_c * ms);
+        // chain rule through n = normalize(N) * mask
+        const float3 N = f3(normal_raw[p], normal_raw[HW + p], normal_raw[2 * HW + p]);
+        const float Nl = sqrtf(dot3(N, N));
+        float3 dN = f3(0.f, 0.f, 0.f);
+        if (mn > 0.f && Nl > 1e-12f) {
+            const float3 nh = N * (1.f / Nl);
+            dN = (gn - nh * dot3(nh, gn)) * (1.f / Nl);
+        }
+        d_normal[p] = dN.x; d_normal[HW + p] = dN.y; d_normal[2 * HW + p] = dN.z;
+        // consistency gradient wrt d2n(p) -> m -> the five depths
+        const float3 G = n * (-k_c * ms);
+        if (mn > 0.f && sqrtf(dot3(m, m)) > 1e-12f && ms > 0.f) {
+            const float3 Gm = (G - mh * dot3(mh, G)) * (1.f / ml);
+            const float3 gpu = cross3(pl, Gm) + cross3(Gm, pr);
+            const float3 gpl = cross3(Gm, pu) + cross3(pb, Gm);
+            const float3 gpr = cross3(pu, Gm) + cross3(Gm, pb);
+            const float3 gpb = cross3(pr, Gm) + cross3(Gm, pl);
+            const float3 gpc = (gpu * Mu + gpl * Ml + gpr * Mr + gpb * Mb) * -1.f;
+            atomicAdd(&d_depth[p], dot3(gpc, ray_c) * mn);
+            atomicAdd(&d_depth[iu], dot3(gpu, ray_u) * Mu);
+            atomicAdd(&d_depth[il], dot3(gpl, ray_l) * Ml);
+            atomicAdd(&d_depth[ir], dot3(gpr, ray_r) * Mr);
+            atomicAdd(&d_depth[ib], dot3(gpb, ray_b) * Mb);
+        }
+    }
+    const float t_c = block_sum_256(s_cons, sh), t_t = block_sum_256(s_tv, sh);
+    if (threadIdx.x == 0) { atomicAdd(&accum[2], t_c); atomicAdd(&accum[3], t_t); }
+}
+
+static AgsLossDev make_dev(const AgsLossConfig& cfg) {
+    AgsLossDev c;
+    c.H = cfg.image_height; c.W = cfg.image_width; c.B = cfg.batch_total;
+    c.fxq = (float)cfg.image_height / (2.0f * tanf(0.5f * cfg.fov_x));
+    c.fyq = (float)cfg.image_width / (2.0f * tanf(0.5f * cfg.fov_y));
+    c.w_rgb = cfg.w_rgb; c.w_depth = cfg.w_depth; c.w_cons = cfg.w_cons; c.w_tv = cfg.w_tv;
+    c.inv_2sig2 = 1.0f / (2.0f * cfg.sigma * cfg.sigma);
+    return c;
+}
+
+void ags_launch_loss_stage1(const AgsLossConfig& cfg, const AgsImages& img, const float* gt_rgb, const float* gt_depth,
+                            float* n_img, float* d_rgb, float* d_depth, int* msum, float* accum, int view,
+                            int first_view, hipStream_t s) {
+    const int HW = cfg.image_height * cfg.image_width;
+    hipLaunchKernelGGL(ags_k_loss_stage1, dim3((HW + 255) / 256), dim3(256), 0, s, make_dev(cfg), img.rgb, img.normal,
+                       img.depth, img.opacity, gt_rgb, gt_depth, n_img, d_rgb, d_depth, msum, accum, view, first_view);
+}
+
+void ags_launch_loss_stage2(const AgsLossConfig& cfg, const AgsImages& img, const float* n_img, const float* gt_depth,
+                            const int* msum, float* d_normal, float* d_depth, float* accum, hipStream_t s) {
+    const int HW = cfg.image_height * cfg.image_width;
+    hipLaunchKernelGGL(ags_k_loss_stage2, dim3((HW + 255) / 256), dim3(256), 0, s, make_dev(cfg), img.depth,
+                       img.opacity, img.normal, n_img, gt_depth, msum, d_normal, d_depth, accum);
+}

@@ -1,0 +1,68 @@
+"""Host binding of the fused loss head (C ABI ``ags_loss_stage1/2``): facade post-processing +
+depth->normal + the losses of /root/reference/mapping/gaussian_map.py:106-124, forward and
+backward, on the GPU.  See csrc/loss.hip."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import ptr
+from .raster_api import ForwardState
+
+
+@dataclass
+class LossBuffers:
+    """Per-view scratch: the post-processed normal image and the three image gradients."""
+    n_img: torch.Tensor
+    d_rgb: torch.Tensor
+    d_normal: torch.Tensor
+    d_depth: torch.Tensor
+
+
+class FusedLoss:
+    def __init__(self, h: int, w: int, fov_x: float, fov_y: float, batch_total: int, max_views: int, device,
+                 weights=(1.0, 0.8, 0.1, 0.1), sigma: float = 0.3):
+        self.h, self.w = h, w
+        self.cfg = _lib.AgsLossConfig(h, w, float(fov_x), float(fov_y), int(batch_total), *[float(x) for x in weights],
+                                      float(sigma))
+        self.msum = torch.zeros(h, w, dtype=torch.int32, device=device)
+        self.accum = torch.zeros(4 + 2 * max_views, dtype=torch.float32, device=device)
+        self.device = device
+
+    def set_batch_total(self, b: int) -> None:
+        self.cfg.batch_total = int(b)
+
+    def alloc_view(self) -> LossBuffers:
+        f = dict(device=self.device, dtype=torch.float32)
+        return LossBuffers(torch.empty(3, self.h, self.w, **f), torch.empty(3, self.h, self.w, **f),
+                           torch.empty(3, self.h, self.w, **f), torch.empty(1, self.h, self.w, **f))
+
+    def begin_step(self) -> None:
+        self.accum.zero_()
+
+    def stage1(self, st: ForwardState, gt_rgb, gt_depth, buf: LossBuffers, view: int, first_view: bool) -> None:
+        img = st.images_struct()
+        _lib.check(_lib.load().ags_loss_stage1(C.byref(self.cfg), C.byref(img), ptr(gt_rgb), ptr(gt_depth), ptr(buf.n_img),
+                                               ptr(buf.d_rgb), ptr(buf.d_depth), ptr(self.msum), ptr(self.accum),
+                                               int(view), int(first_view), torch.cuda.current_stream().cuda_stream),
+                   "ags_loss_stage1")
+
+    def stage2(self, st: ForwardState, gt_depth, buf: LossBuffers) -> None:
+        img = st.images_struct()
+        _lib.check(_lib.load().ags_loss_stage2(C.byref(self.cfg), C.byref(img), ptr(buf.n_img), ptr(gt_depth),
+                                               ptr(self.msum), ptr(buf.d_normal), ptr(buf.d_depth), ptr(self.accum),
+                                               torch.cuda.current_stream().cuda_stream), "ags_loss_stage2")
+
+    def total_loss(self) -> torch.Tensor:
+        c, a, hw = self.cfg, self.accum, float(self.h * self.w)
+        b = float(c.batch_total)
+        return (c.w_rgb * a[0] / (b * 3 * hw) + c.w_depth * a[1] / (b * hw) + c.w_cons * a[2] / (b * b * hw)
+                + c.w_tv * a[3] / (b * 4 * hw))
+
+    def per_frame_errors(self, n_views: int) -> torch.Tensor:
+        hw = float(self.h * self.w)
+        a = self.accum[4:4 + 2 * n_views].view(n_views, 2)
+        return a[:, 0] / (3 * hw) + a[:, 1] / hw

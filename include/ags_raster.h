@@ -198,6 +198,29 @@ int ags_activate(const AgsActivation* a, float* scales, float* rotations, float*
 int ags_activate_backward(const AgsActivation* a, float* d_scales, float* d_rotations,
                           float* d_opacities, ags_stream_t stream);
 
+/* Fused loss head: the facade's post-processing (operations.py:714-718,
+ * 172-219) and the loss of gaussian_map.py:106-124 / mapping/utils.py:14-62,120-121, forward and
+ * backward, from the images of ags_forward straight to the image gradients ags_backward takes.
+ * Per optimisation step: stage 1 for EVERY view of the batch (it also accumulates the
+ * visibility count `msum` the reference's broadcast in the consistency term needs; all-reduce
+ * msum across ranks under view parallelism), then per view stage 2 -> ags_backward.
+ * accum (floats, zeroed by the caller per step): [0] rgb-L1 sum, [1] depth-L1 sum, [2] consistency
+ * sum, [3] TV sum over all views; [4+2v], [5+2v] rgb / depth L1 sums of view v (per-frame error).
+ * total loss = w_rgb*a0/(B*3HW) + w_depth*a1/(B*HW) + w_cons*a2/(B*B*HW) + w_tv*a3/(B*4HW). */
+typedef struct AgsLossConfig {
+    int32_t image_height, image_width;
+    float fov_x, fov_y;    /* radians, as GaussianRenderer.fovs (operations.py:756-757) */
+    int32_t batch_total;   /* B: views in the batch over ALL ranks */
+    float w_rgb, w_depth, w_cons, w_tv; /* 1, 0.8, 0.1, 0.1 */
+    float sigma;           /* 0.3 */
+} AgsLossConfig;
+int ags_loss_stage1(const AgsLossConfig* cfg, const AgsImages* fwd, const float* gt_rgb, const float* gt_depth,
+                    float* n_img /* (3,H,W) */, float* d_rgb, float* d_depth, int32_t* msum /* (H,W) */,
+                    float* accum, int32_t view, int32_t first_view, ags_stream_t stream);
+int ags_loss_stage2(const AgsLossConfig* cfg, const AgsImages* fwd, const float* n_img, const float* gt_depth,
+                    const int32_t* msum, float* d_normal, float* d_depth /* += */, float* accum,
+                    ags_stream_t stream);
+
 /* Optional stage timing with library-owned hipEvents (process-global, for bench/profiling
  * only; off by default so the normal path records nothing).  `slots` event pairs are kept
  * per stage; each forward/backward call consumes one slot per stage it runs. */

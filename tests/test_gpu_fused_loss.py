@@ -1,0 +1,97 @@
+"""Fused loss head (csrc/loss.hip) vs torch autograd of the facade mirror, and the fully fused
+train loop vs the reference's GaussianMap.train() capture."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _scenes import room_case
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_fused_loss_matches_torch_autograd(agslib):
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.facade import depth_to_normal, training_losses
+    from active_gs_amd.fused_loss import FusedLoss
+    dev = torch.device("cuda:0")
+    n, h, w, B = 6000, 96, 128, 3
+    a, _ = room_case(n, h, w, view=0, seed=12, scale_mult=3.0)
+    a["opacities"] = a["opacities"] * 0.6   # leave holes: opacity crosses the 1e-2 / 1e-3 masks
+    g = api.Gaussians(*(a[k].to(dev).contiguous() for k in ("means", "scales", "rotations", "opacities", "colors",
+                                                              "confidences")))
+    states, fovs = [], None
+    for v in range(B):
+        _, S = room_case(16, h, w, view=v, seed=0)
+        cam = api.Camera(h, w, S.tanfovx, S.tanfovy, S.viewmatrix.to(dev), S.projmatrix.to(dev), S.bg.to(dev))
+        st = api.alloc_state(n, h, w, 1 << 21, dev)
+        api.forward(cam, g, st)
+        states.append(st)
+        fovs = (2 * np.arctan(S.tanfovx), 2 * np.arctan(S.tanfovy))
+    gen = torch.Generator().manual_seed(3)
+    gts = []
+    for st in states:
+        gt_rgb = (st.rgb.cpu() + 0.1 * torch.randn(3, h, w, generator=gen)).clamp(0, 1).to(dev)
+        gt_depth = (st.depth.cpu() * (1 + 0.05 * torch.randn(1, h, w, generator=gen))).to(dev)
+        gt_depth[:, :, : w // 5] = 0.0           # invalid depth region
+        gt_depth[:, h // 2, :] = -1.0
+        gts.append((gt_rgb, gt_depth))
+    # ---- torch reference on the same rasterizer outputs
+    leaves = [[getattr(st, k).clone().requires_grad_(True) for k in ("rgb", "normal", "depth")] for st in states]
+    fov_t = torch.tensor(fovs)
+    posts = []
+    for st, (rgb, nrm, dep) in zip(states, leaves):
+        mask = st.opacity > 1e-2
+        normal = torch.nn.functional.normalize(nrm, dim=0) * mask
+        posts.append((rgb, dep, normal, st.opacity, depth_to_normal(dep, mask, fov_t)))
+    stack = lambda k: torch.stack([p[k] for p in posts])
+    total, per_frame = training_losses(stack(0), stack(1), stack(2), stack(3), stack(4),
+                                       torch.stack([x[0] for x in gts]), torch.stack([x[1] for x in gts]))
+    total.backward()
+    # ---- fused kernels
+    fl = FusedLoss(h, w, fovs[0], fovs[1], B, 8, dev)
+    bufs = [fl.alloc_view() for _ in range(B)]
+    fl.begin_step()
+    for v, st in enumerate(states):
+        fl.stage1(st, gts[v][0], gts[v][1], bufs[v], v, v == 0)
+    for v, st in enumerate(states):
+        fl.stage2(st, gts[v][1], bufs[v])
+    torch.cuda.synchronize()
+    assert abs(float(fl.total_loss()) - float(total)) < 1e-5 * max(1.0, abs(float(total)))
+    assert torch.allclose(fl.per_frame_errors(B), per_frame, rtol=1e-4, atol=1e-6)
+    for v in range(B):
+        for name, ref, got in (("rgb", leaves[v][0].grad, bufs[v].d_rgb), ("normal", leaves[v][1].grad, bufs[v].d_normal),
+                               ("depth", leaves[v][2].grad, bufs[v].d_depth)):
+            denom = ref.abs().sum().item()
+            rel = (got - ref).abs().sum().item() / max(denom, 1e-12)
+            assert rel < 1e-3, (v, name, rel, denom)
+
+
+def test_fused_train_loop_matches_reference_train_capture(agslib):
+    from active_gs_amd.fused_map_trainer import FusedMapTrainer
+    dev = torch.device("cuda:0")
+    d = torch.load(os.path.join(GOLD, "train.pt"))
+    cfg = d["cfg"]
+    mine = dict(bound=tuple(cfg["bound"]), scale_factor=cfg["scale_factor"], optimization_steps=cfg["optimization_steps"],
+                prune_interval=cfg["prune_interval"], background=tuple(cfg["background"]),
+                batch_size=cfg["sampler"]["batch_size"], active_size=cfg["sampler"]["active_size"],
+                use_view_distribution=cfg["use_view_distribution"],
+                lrs=dict(mean=cfg["optimizer"]["mean_lr"], scale=cfg["optimizer"]["scale_lr"],
+                         rotation=cfg["optimizer"]["rotation_lr"], opacity=cfg["optimizer"]["opacity_lr"],
+                         harmonic=cfg["optimizer"]["harmonic_lr"]))
+    raw = {k: v.to(dev) for k, v in d["raw_init"].items()}
+    frames = [{k: v.to(dev) for k, v in f.items()} for f in d["frames"]]
+    t = FusedMapTrainer(raw, frames, mine)
+    np.random.seed(7)
+    t.train()
+    torch.cuda.synchronize()
+    for k, ref in d["raw_final"].items():
+        got, init = getattr(t, k).cpu(), d["raw_init"][k]
+        diff, travel = (got - ref).abs(), (ref - init).abs().mean()
+        assert diff.mean() < 2e-3 * travel, (k, float(diff.mean()), float(travel))
+        assert (diff > 1e-4).float().mean() < 5e-3, k
+    assert torch.allclose(t.training_performance.cpu(), d["training_performance"], rtol=1e-3, atol=1e-5)
+    assert (t.view_supports.cpu() != d["view_supports"]).float().mean() < 2e-3
+    assert len(t.last_losses) == d["steps"] and all(np.isfinite(t.last_losses))
