@@ -76,3 +76,57 @@ def test_two_ranks_equal_single_process_two_views(agslib, use_graph):
         for a, r, init in zip(ret[0], ref, [raw[k].cpu() for k in ("means", "scales", "rotations", "opacities", "harmonics")]):
             travel = (r - init).abs().mean()
             assert (a - r).abs().mean() < 5e-3 * travel + 1e-9     # Adam eps=1e-15: sign flips on ~0 gradients
+
+
+def _fused_cfg(d):
+    cfg = d["cfg"]
+    return dict(bound=tuple(cfg["bound"]), scale_factor=cfg["scale_factor"], optimization_steps=cfg["optimization_steps"],
+                prune_interval=cfg["prune_interval"], background=tuple(cfg["background"]),
+                batch_size=cfg["sampler"]["batch_size"], active_size=cfg["sampler"]["active_size"],
+                use_view_distribution=cfg["use_view_distribution"],
+                lrs=dict(mean=cfg["optimizer"]["mean_lr"], scale=cfg["optimizer"]["scale_lr"],
+                         rotation=cfg["optimizer"]["rotation_lr"], opacity=cfg["optimizer"]["opacity_lr"],
+                         harmonic=cfg["optimizer"]["harmonic_lr"]))
+
+
+def _fused_worker(rank, world, port, ret):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from active_gs_amd.fused_map_trainer import FusedMapTrainer
+        dev = torch.device("cuda:0")
+        d = torch.load(os.path.join(ROOT, "tests", "golden", "train.pt"))
+        raw = {k: v.to(dev) for k, v in d["raw_init"].items()}
+        frames = [{k: v.to(dev) for k, v in f.items()} for f in d["frames"]]
+        t = FusedMapTrainer(raw, frames, _fused_cfg(d))
+        assert t.world == world
+        np.random.seed(7)
+        t.train()
+        torch.cuda.synchronize()
+        ret[rank] = dict(params={k: getattr(t, k).cpu() for k in d["raw_final"]}, perf=t.training_performance.cpu(),
+                         supports=t.view_supports.cpu(), losses=list(t.last_losses))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_map_trainer_two_ranks_match_reference_capture(agslib):
+    """Fused loss + view-parallel DP: visibility-count, gradient and error collectives."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    d = torch.load(os.path.join(ROOT, "tests", "golden", "train.pt"))
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_fused_worker, args=(2, port, ret), nprocs=2, join=True)
+        r0, r1 = ret[0], ret[1]
+        for k, ref in d["raw_final"].items():
+            assert torch.equal(r0["params"][k], r1["params"][k]), k
+            diff, travel = (r0["params"][k] - ref).abs(), (ref - d["raw_init"][k]).abs().mean()
+            assert diff.mean() < 2e-3 * travel, (k, float(diff.mean()), float(travel))
+        assert torch.allclose(r0["perf"], d["training_performance"], rtol=1e-3, atol=1e-5)
+        assert (r0["supports"] != d["view_supports"]).float().mean() < 2e-3
+        assert r0["losses"] == r1["losses"]

@@ -59,7 +59,8 @@ def test_fused_loss_matches_torch_autograd(agslib):
     for v, st in enumerate(states):
         fl.stage2(st, gts[v][1], bufs[v])
     torch.cuda.synchronize()
-    assert abs(float(fl.total_loss()) - float(total)) < 1e-5 * max(1.0, abs(float(total)))
+    total_ref = float(total.detach())
+    assert abs(float(fl.total_loss()) - total_ref) < 1e-5 * max(1.0, abs(total_ref))
     assert torch.allclose(fl.per_frame_errors(B), per_frame, rtol=1e-4, atol=1e-6)
     for v in range(B):
         for name, ref, got in (("rgb", leaves[v][0].grad, bufs[v].d_rgb), ("normal", leaves[v][1].grad, bufs[v].d_normal),
