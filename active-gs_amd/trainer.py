@@ -154,12 +154,12 @@ class SurfelTrainer:
         g_local, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
             if dist_on:
-                with torch.cuda.graph(g_local, stream=side):
+                with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
                     self._local_pass(cams, image_grads, max_instances)
-                with torch.cuda.graph(g_opt, stream=side):
+                with torch.cuda.graph(g_opt, stream=side, capture_error_mode="thread_local"):
                     self.optim.step(self.slab.as_list(), device_clock=True)
             else:
-                with torch.cuda.graph(g_local, stream=side):
+                with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
                     self._local_pass(cams, image_grads, max_instances)
                     self.optim.step(self.slab.as_list(), device_clock=True)
         torch.cuda.current_stream().wait_stream(side)

@@ -130,7 +130,14 @@ def main():
     for _ in range(3):
         eager_step()  # creates every buffer before capture
     torch.cuda.synchronize()
-    one_step = eager_step if args.eager else trainer.capture([cam], grads_fn, cap)
+    launch_mode = "eager" if args.eager else "hipGraph replay"
+    one_step = eager_step
+    if not args.eager:
+        try:
+            one_step = trainer.capture([cam], grads_fn, cap)
+        except Exception as e:  # never lose the measurement to a capture problem
+            launch_mode = f"eager (graph capture failed: {type(e).__name__})"
+            torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
@@ -206,7 +213,7 @@ def main():
                        "gaussians": N_GAUSS, "image": [H, W], "views_per_gpu": 1, "visible": V,
                        "tile_instances": I, "parallelism": f"view-parallel dp{world}",
                        "overflow": bool(info["overflow"]), "binning": args.binning,
-                       "launch": "eager" if args.eager else "hipGraph replay",
+                       "launch": launch_mode,
                        "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                        "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -222,6 +229,7 @@ def main():
                                                              proj=cm["projmatrix"][0]))
         print(json.dumps(out))
     if world > 1:
+        torch.distributed.barrier()  # rank 0 may still be in the CPU-baseline leg; leave together
         torch.distributed.destroy_process_group()
 
 
