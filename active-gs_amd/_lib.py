@@ -44,7 +44,8 @@ class AgsImageGrads(C.Structure):
 
 class AgsGaussianGrads(C.Structure):
     _fields_ = [("d_means3D", c_f32p), ("d_scales", c_f32p), ("d_rotations", c_f32p), ("d_opacities", c_f32p),
-                ("d_colors", c_f32p), ("d_means2D", c_f32p), ("accumulate", C.c_int32)]
+                ("d_colors", c_f32p), ("d_means2D", c_f32p), ("accumulate", C.c_int32), ("adam_clock", C.c_void_p),
+                ("adam_lr", C.c_float * 5), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float)]
 
 
 class AgsWorkspace(C.Structure):
@@ -112,7 +113,7 @@ def load() -> C.CDLL:
     lib.ags_adam_step.argtypes = [C.POINTER(AgsAdamTensors), C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]
     lib.ags_adam_step_device.restype = C.c_int
     lib.ags_adam_step_device.argtypes = [C.POINTER(AgsAdamTensors), C.c_float, C.c_float, C.c_float, C.c_void_p,
-                                         C.c_void_p]
+                                         C.c_int32, C.c_void_p]
     lib.ags_activate.restype = C.c_int
     lib.ags_activate.argtypes = [C.POINTER(AgsActivation), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ags_activate_backward.restype = C.c_int

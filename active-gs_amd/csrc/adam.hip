@@ -16,19 +16,13 @@ struct AgsAdamArgs {
     float lr[5];
 };
 
-// Device-resident optimiser clock: { int step; float step_size[5]; float inv_sqrt_bc2; }.
-struct AgsAdamClock { int step; float step_size[5]; float inv_bc2_sqrt; float pad[9]; };
-
+// Device-resident optimiser clock AgsAdamClock { int step; float step_size[5]; float inv_sqrt_bc2; }
+// (ags_internal.h); advanced either by this 1-thread kernel or on the side of the step's last
+// ags_backward launch (AgsGaussianGrads.adam_clock).
 __global__ void ags_k_adam_tick(AgsAdamClock* c, float lr0, float lr1, float lr2, float lr3, float lr4,
                                 float beta1, float beta2, int host_step) {
-    // host_step > 0: the caller supplies the step; otherwise the device counter advances.
-    const int step = host_step > 0 ? host_step : c->step + 1;
-    c->step = step;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float lr[5] = {lr0, lr1, lr2, lr3, lr4};
-    for (int k = 0; k < 5; ++k) c->step_size[k] = (float)((double)lr[k] / bc1);
-    c->inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    ags_adam_tick(c, lr, beta1, beta2, host_step);
 }
 
 __global__ __launch_bounds__(256) void ags_k_adam(AgsAdamArgs a, AgsAdamClock host_clk,
@@ -52,7 +46,7 @@ __global__ __launch_bounds__(256) void ags_k_adam(AgsAdamArgs a, AgsAdamClock ho
 }
 
 void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, void* dev_state,
-                     hipStream_t s) {
+                     bool pre_ticked, hipStream_t s) {
     AgsAdamArgs a;
     long long run = 0;
     for (int k = 0; k < 5; ++k) {
@@ -64,7 +58,9 @@ void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float ep
     if (run <= 0) return;
     AgsAdamClock* clk = (AgsAdamClock*)dev_state;
     AgsAdamClock hc = {};
-    if (clk) {
+    if (clk && pre_ticked) {
+        // the clock was advanced by the step's last ags_backward launch
+    } else if (clk) {
         hipLaunchKernelGGL(ags_k_adam_tick, dim3(1), dim3(1), 0, s, clk, t.lr[0], t.lr[1], t.lr[2], t.lr[3], t.lr[4],
                            beta1, beta2, 0);
     } else { // host-side clock: scalars travel as kernel arguments

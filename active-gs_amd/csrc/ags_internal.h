@@ -98,7 +98,19 @@ void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
                                const AgsLayout& L, const int* radii, const AgsGaussianGrads& din, hipStream_t s);
 void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, void* dev_state,
-                     hipStream_t s);
+                     bool pre_ticked, hipStream_t s);
+// Device-resident optimiser clock shared by adam.hip and preprocess.hip
+struct AgsAdamClock { int step; float step_size[5]; float inv_bc2_sqrt; float pad[9]; };
+#if defined(__HIPCC__)
+__device__ __forceinline__ void ags_adam_tick(AgsAdamClock* c, const float lr[5], float beta1, float beta2, int host_step) {
+    const int step = host_step > 0 ? host_step : c->step + 1;
+    c->step = step;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    for (int k = 0; k < 5; ++k) c->step_size[k] = (float)((double)lr[k] / bc1);
+    c->inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+}
+#endif
 void ags_launch_activate(const AgsActivation& a, float* scales, float* rotations, float* opacities, hipStream_t s);
 void ags_launch_activate_bwd(const AgsActivation& a, float* d_scales, float* d_rotations, float* d_opacities,
                              hipStream_t s);

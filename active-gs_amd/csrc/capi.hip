@@ -107,14 +107,14 @@ static int ags_adam_check(const AgsAdamTensors* t) {
 
 int ags_adam_step(const AgsAdamTensors* t, float beta1, float beta2, float eps, int32_t step, ags_stream_t stream) {
     if (ags_adam_check(t) != AGS_OK || step < 1) return AGS_E_INVALID;
-    ags_launch_adam(*t, beta1, beta2, eps, step, nullptr, (hipStream_t)stream);
+    ags_launch_adam(*t, beta1, beta2, eps, step, nullptr, false, (hipStream_t)stream);
     return ags_check_launch();
 }
 
 int ags_adam_step_device(const AgsAdamTensors* t, float beta1, float beta2, float eps, void* state,
-                         ags_stream_t stream) {
+                         int32_t pre_ticked, ags_stream_t stream) {
     if (ags_adam_check(t) != AGS_OK || !state) return AGS_E_INVALID;
-    ags_launch_adam(*t, beta1, beta2, eps, 0, state, (hipStream_t)stream);
+    ags_launch_adam(*t, beta1, beta2, eps, 0, state, pre_ticked != 0, (hipStream_t)stream);
     return ags_check_launch();
 }
 

@@ -85,6 +85,9 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
     const int i = blockIdx.x * AGS_PRE_THREADS + threadIdx.x;
+    // side job of the step's last backward: advance the Adam device clock (this launch completes
+    // before the Adam kernel starts, so every Adam block sees the new scalars)
+    if (out.adam_clock && i == 0) ags_adam_tick((AgsAdamClock*)out.adam_clock, out.adam_lr, out.adam_beta1, out.adam_beta2, 0);
     if (i >= in.n) return;
     float dm[3] = {0, 0, 0}, ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0}, dm2[2] = {0, 0};
     const bool vis = radii[i] > 0;

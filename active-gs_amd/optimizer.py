@@ -32,9 +32,14 @@ class FusedAdam:
         # device-resident clock {int step; float step_size[5]; float inv_sqrt_bc2; ...} for graph replay
         self.device_clock = torch.zeros(16, device=params[0].device, dtype=torch.int32)
 
-    def step(self, grads: Sequence[torch.Tensor], device_clock: bool = False) -> None:
+    def tick_args(self):
+        """What ``raster_api.backward(adam_tick=...)`` needs to advance this optimizer's device clock."""
+        return (self.device_clock, self.lrs, self.betas[0], self.betas[1])
+
+    def step(self, grads: Sequence[torch.Tensor], device_clock: bool = False, pre_ticked: bool = False) -> None:
         """One Adam update. With ``device_clock=True`` the step counter lives on the GPU
-        (``ags_adam_step_device``), so the call can be captured in a hipGraph and replayed."""
+        (``ags_adam_step_device``), so the call can be captured in a hipGraph and replayed;
+        ``pre_ticked`` says the step's last backward launch already advanced that clock."""
         lib = _lib.load()
         if not device_clock:
             self.step_count += 1
@@ -55,7 +60,7 @@ class FusedAdam:
         stream = torch.cuda.current_stream().cuda_stream
         if device_clock:
             _lib.check(lib.ags_adam_step_device(C.byref(t), self.betas[0], self.betas[1], self.eps,
-                                                ptr(self.device_clock), stream), "ags_adam_step_device")
+                                                ptr(self.device_clock), int(pre_ticked), stream), "ags_adam_step_device")
         else:
             _lib.check(lib.ags_adam_step(C.byref(t), self.betas[0], self.betas[1], self.eps, self.step_count,
                                          stream), "ags_adam_step")

@@ -170,8 +170,9 @@ def alloc_grads(n: int, device, with_means2d: bool = False, zero: bool = False) 
 
 def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_normal=None, d_depth=None,
              d_opacity=None, d_confidence=None, grads: Optional[GaussianGrads] = None,
-             accumulate: bool = False) -> GaussianGrads:
-    """Enqueue the backward pass of the view held in ``state``. Asynchronous."""
+             accumulate: bool = False, adam_tick=None) -> GaussianGrads:
+    """Enqueue the backward pass of the view held in ``state``. Asynchronous.
+    ``adam_tick`` = (device_clock_tensor, lrs, beta1, beta2): also advance that Adam clock."""
     lib = _lib.load()
     if grads is None:
         grads = alloc_grads(g.n, g.means3D.device)
@@ -185,6 +186,12 @@ def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_norma
     dout = _lib.AgsImageGrads(ptr(d_rgb), ptr(d_normal), ptr(d_depth), ptr(d_opacity), ptr(d_confidence))
     din = _lib.AgsGaussianGrads(ptr(grads.means3D), ptr(grads.scales), ptr(grads.rotations), ptr(grads.opacities),
                                 ptr(grads.colors), ptr(grads.means2D), int(accumulate))
+    if adam_tick is not None:
+        clock, lrs, b1, b2 = adam_tick
+        din.adam_clock = ptr(clock)
+        for k in range(5):
+            din.adam_lr[k] = float(lrs[k])
+        din.adam_beta1, din.adam_beta2 = float(b1), float(b2)
     _lib.check(lib.ags_backward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(dout), C.byref(din),
                                 C.byref(ws), _stream()), "ags_backward")
     return grads

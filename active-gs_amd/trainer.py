@@ -116,17 +116,24 @@ class SurfelTrainer:
                                  scale_factor=self.scale_factor, max_scale=self.max_scale)
         return self.activate()
 
-    def _local_pass(self, cams, image_grads, max_instances) -> None:
+    def _local_pass(self, cams, image_grads, max_instances, tick: bool = False) -> bool:
+        """Forward+backward of this rank's views; with ``tick`` the last backward also advances
+        the Adam device clock. Returns whether the clock was advanced."""
         g = self.gaussians()
+        ticked = False
         for v, cam in enumerate(cams):
             st = self.state_for(cam.image_height, cam.image_width, max_instances)
             api.forward(cam, g, st)
             d = image_grads(v, st)
-            api.backward(cam, g, st, *d, grads=self.slab.grads, accumulate=(v > 0))
+            last = tick and v == len(cams) - 1
+            api.backward(cam, g, st, *d, grads=self.slab.grads, accumulate=(v > 0),
+                         adam_tick=self.optim.tick_args() if last else None)
+            ticked |= last
         if len(cams) == 0:
             self.slab.flat.zero_()
         if not self.fused_activations:
             self.activate_backward()
+        return ticked
 
     def step(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int,
              world_views: Optional[int] = None, device_clock: bool = False) -> None:
@@ -134,10 +141,10 @@ class SurfelTrainer:
         image gradients (d_rgb, d_normal, d_depth, d_opacity, d_confidence; None = zero)
         for that view, already divided by the GLOBAL number of views where the loss is a
         batch mean.  Asynchronous except for the collective."""
-        self._local_pass(cams, image_grads, max_instances)
+        ticked = self._local_pass(cams, image_grads, max_instances, tick=device_clock)
         if self._distributed():
             torch.distributed.all_reduce(self.slab.flat, group=self.pg)
-        self.optim.step(self.slab.as_list(), device_clock=device_clock)
+        self.optim.step(self.slab.as_list(), device_clock=device_clock, pre_ticked=ticked)
 
     def capture(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int) -> Callable:
         """Capture one optimisation step into hipGraphs and return a ``replay()`` callable.
@@ -155,13 +162,13 @@ class SurfelTrainer:
         with torch.cuda.stream(side):
             if dist_on:
                 with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
-                    self._local_pass(cams, image_grads, max_instances)
+                    ticked = self._local_pass(cams, image_grads, max_instances, tick=True)
                 with torch.cuda.graph(g_opt, stream=side, capture_error_mode="thread_local"):
-                    self.optim.step(self.slab.as_list(), device_clock=True)
+                    self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
             else:
                 with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
-                    self._local_pass(cams, image_grads, max_instances)
-                    self.optim.step(self.slab.as_list(), device_clock=True)
+                    ticked = self._local_pass(cams, image_grads, max_instances, tick=True)
+                    self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
         torch.cuda.current_stream().wait_stream(side)
 
         def replay():

@@ -116,6 +116,12 @@ typedef struct AgsGaussianGrads {
     float* d_colors;
     float* d_means2D;
     int32_t accumulate; /* 0: overwrite, 1: += (sum over views without an extra pass) */
+    /* Optional (NULL = off): an Adam device clock (see ags_adam_step_device) that this backward
+     * launch advances on the side - pass it with the LAST view of an optimisation step and call
+     * ags_adam_step_device(..., pre_ticked = 1): the step then needs no separate clock kernel. */
+    void* adam_clock;
+    float adam_lr[5];
+    float adam_beta1, adam_beta2;
 } AgsGaussianGrads;
 
 #define AGS_BIN_TILE_SORT 0 /* tile counting + bucket scatter + per-tile LDS bitonic sort (default) */
@@ -178,6 +184,7 @@ int ags_adam_step(const AgsAdamTensors* t, float beta1, float beta2, float eps, 
  * corrections on the device (in double), then runs the same update.  Capturing this call in
  * a hipGraph and replaying it k times performs Adam steps 1..k. */
 int ags_adam_step_device(const AgsAdamTensors* t, float beta1, float beta2, float eps, void* state,
+                         int32_t pre_ticked /* 1: ags_backward already advanced `state` for this step */,
                          ags_stream_t stream);
 
 /* Activations of /root/reference/mapping/gaussian_map.py:529-549 (get_scales / get_rotations /
