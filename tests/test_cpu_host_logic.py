@@ -130,3 +130,24 @@ def test_product_refuses_cpu_tensors(agslib):
     srcs = glob.glob(os.path.join(ROOT, "active-gs_amd", "*.py")) + glob.glob(os.path.join(ROOT, "diff_gaussian_rasterization_2d", "*.py"))
     for f in srcs:  # the product never imports the checker
         assert "oracle" not in open(f).read().replace("CPU oracle", "").replace("the oracle", ""), f
+
+
+def test_map_checkpoint_roundtrip_in_reference_schema(tmp_path):
+    """Keys / raw tensors of GaussianMap.save (gaussian_map.py:491-507) and a load round trip."""
+    from active_gs_amd.map_io import MAP_KEYS, load_map, save_map
+    from active_gs_amd.map_trainer import GaussianMapTrainer
+    d = torch.load(os.path.join(GOLD, "train.pt"))
+    t = GaussianMapTrainer(d["raw_init"], d["frames"], dict(bound=(0.001, 10.0)), rasterizer_module=_oracle_module,
+                           optimizer_factory=lambda p, lrs: _oracle_module.OracleAdam(p, lrs))
+    t.view_supports += 2.0
+    path = save_map(t, str(tmp_path), index=3)
+    assert path.endswith("map_3.th")
+    st = torch.load(path)
+    assert set(st.keys()) == set(MAP_KEYS)
+    assert st["harmonics"].shape == (d["n"], 1, 3) and st["scales"].shape == (d["n"], 3)
+    raw, cfg = load_map(path)
+    t2 = GaussianMapTrainer(raw, d["frames"], cfg, rasterizer_module=_oracle_module,
+                            optimizer_factory=lambda p, lrs: _oracle_module.OracleAdam(p, lrs))
+    for k in ("means", "scales", "rotations", "opacities", "harmonics", "view_supports", "view_scores", "view_means"):
+        assert torch.equal(getattr(t2, k), getattr(t, k)), k
+    assert t2.cfg["bound"] == (0.001, 10.0) and t2.cfg["scale_factor"] == 0.01
