@@ -314,3 +314,36 @@ def test_overfull_tiles_and_huge_footprints(agslib):
         r = ins[i].grad.reshape(getattr(res[0][1], name).shape)
         rel = (getattr(res[0][1], name).cpu() - r).abs().sum() / r.abs().sum()
         assert rel < 2e-3, (name, float(rel))
+
+
+def test_module_argument_variants(agslib):
+    """shs of degree 0, scale_modifier != 1, non-contiguous / strided inputs, opacities of exactly 0,
+    and an image smaller than one tile."""
+    from diff_gaussian_rasterization_2d import GaussianRasterizer
+    from oracle.surfel_oracle import OracleSettings, rasterize
+    dev = torch.device("cuda:0")
+    a, S = room_case(900, 10, 13, view=1, seed=9, scale_mult=6.0)          # 13x10 image: a single partial tile
+    S = OracleSettings(S.image_height, S.image_width, S.tanfovx, S.tanfovy, S.bg, 1.7, S.viewmatrix, S.projmatrix,
+                       campos=S.campos, config=S.config)
+    a["opacities"][::7] = 0.0
+    ins = oracle_inputs(a)
+    ref = rasterize(*ins, S)
+    (ref[0].sum() + 2 * ref[2].sum()).backward()
+    # strided views of larger buffers
+    big = lambda t: torch.cat([t, t], -1).to(dev)[..., : t.shape[-1]]
+    gin = [big(ins[0].detach()).requires_grad_(True), torch.zeros(900, 3, device=dev), ins[2].detach().to(dev).requires_grad_(True),
+           ins[3].to(dev), big(ins[4].detach()), big(ins[5].detach()).requires_grad_(True), ins[6].detach().to(dev).requires_grad_(True)]
+    assert not gin[0].is_contiguous()
+    out = GaussianRasterizer(product_settings(S, dev))(gin[0], gin[1], gin[2], gin[3], None, gin[4], gin[5], gin[6], None)
+    (out[0].sum() + 2 * out[2].sum()).backward()
+    assert (out[0].cpu() - ref[0].detach()).abs().mean() < RGB_TOL
+    assert (out[2].cpu() - ref[2].detach()).abs().mean() < 1e-3
+    for i in (0, 2, 5, 6):
+        r = ins[i].grad
+        assert (gin[i].grad.cpu() - r).abs().sum() <= GRAD_TOL * r.abs().sum() + 1e-9, i
+    assert torch.all(gin[2].grad.cpu()[::7] == 0)                           # o == 0 never contributes, no NaN
+    # SH degree 0: colour = max(C0*sh + 0.5, 0)
+    sh = ((ins[4].detach() - 0.5) / 0.28209479177387814)[:, None, :].to(dev)
+    out_sh = GaussianRasterizer(product_settings(S, dev))(gin[0].detach(), gin[1], gin[2].detach(), gin[3], sh, None,
+                                                          gin[5].detach(), gin[6].detach(), None)
+    assert (out_sh[0] - out[0].detach()).abs().max() < 1e-5
