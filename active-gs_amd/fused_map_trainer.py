@@ -21,11 +21,15 @@ from .trainer import GradSlab
 
 class FusedMapTrainer(GaussianMapTrainer):
     def __init__(self, raw: dict, frames: List[dict], cfg: Optional[dict] = None, process_group=None,
-                 binning_mode: int = api.BIN_TILE_SORT):
+                 binning_mode: int = api.BIN_TILE_SORT, use_graph: bool = True):
         super().__init__(raw, frames, cfg, process_group=process_group)
         if self.device.type != "cuda":
             raise RuntimeError("FusedMapTrainer needs GPU tensors: there is no CPU fallback")
         self.binning_mode = binning_mode
+        # hipGraph replay of the iteration (single rank): the launch sequence of an iteration is
+        # fixed for a given batch shape; what changes (which frames) is staged into static
+        # per-slot camera / ground-truth buffers by four index_select launches before the replay.
+        self.use_graph = use_graph
         self._cams = {}          # frame index -> (api.Camera, fov_x, fov_y)
         self._states = {}        # view slot -> ForwardState
         self._loss = None
@@ -124,4 +128,94 @@ class FusedMapTrainer(GaussianMapTrainer):
             raise RuntimeError("a view outgrew the rasterizer workspace during train(); call train() again "
                                "(the capacity has been raised)")
         self.last_losses = [float(x) for x in self.last_losses]
+        self.post_processing()
+
+    # ------------------------------------------------------------------ hipGraph iteration
+    def _graph_ok(self) -> bool:
+        if not self.use_graph or self.world > 1 or len(self.frames) == 0:
+            return False
+        shapes = {tuple(f["rgb"].shape) for f in self.frames}
+        tans = {(round(self._camera(i)[0].tanfovx, 7), round(self._camera(i)[0].tanfovy, 7)) for i in range(len(self.frames))}
+        return len(shapes) == 1 and len(tans) == 1   # scalars baked into the captured launches
+
+    def train_graph(self, steps: Optional[int] = None):
+        """Same iteration as ``train`` replayed from a hipGraph (single rank, frames of one shape
+        and one field of view).  Falls back to ``train`` when those conditions do not hold."""
+        if not self._graph_ok():
+            return self.train(steps)
+        lrs = self.cfg["lrs"]
+        for name in ("means", "scales", "rotations", "opacities", "harmonics"):
+            setattr(self, name, getattr(self, name).contiguous())
+        params = [self.means, self.scales, self.rotations, self.opacities, self.harmonics]
+        n = self.means.shape[0]
+        dev = self.device
+        optim = FusedAdam(params, [lrs["mean"], lrs["scale"], lrs["rotation"], lrs["opacity"], lrs["harmonic"]], eps=1e-15)
+        slab = GradSlab(n, dev)
+        sampler = WeightedFrameSampler(self.frames, self.cfg["batch_size"], self.cfg["active_size"])
+        K = len(self.frames)
+        h, w = self.frames[0]["rgb"].shape[-2:]
+        cam0, fx, fy = self._camera(0)
+        all_view = torch.stack([self._camera(i)[0].viewmatrix for i in range(K)])
+        all_proj = torch.stack([self._camera(i)[0].projmatrix for i in range(K)])
+        all_rgb = torch.stack([f["rgb"] for f in self.frames]).contiguous()
+        all_depth = torch.stack([f["depth"] for f in self.frames]).contiguous()
+        B = sampler.num_random + len(sampler.active_ids)
+        st_view = torch.empty(B, 4, 4, device=dev); st_proj = torch.empty(B, 4, 4, device=dev)
+        st_rgb = torch.empty(B, 3, h, w, device=dev); st_depth = torch.empty(B, 1, h, w, device=dev)
+        cams = [api.Camera(h, w, cam0.tanfovx, cam0.tanfovy, st_view[b], st_proj[b], self.background) for b in range(B)]
+        self._loss = FusedLoss(h, w, fx, fy, B, self.cfg["batch_size"], dev)
+        bufs = [self._loss.alloc_view() for _ in range(B)]
+        self._cap = max(self._cap, 1 << 16, 2 * n)
+        conf = self.confidences().contiguous()     # constant during train(): view stats change in post_processing
+        g = api.Gaussians(self.means, self.scales, self.rotations, self.opacities, self.harmonics.view(n, 3), conf,
+                          raw_params=True, scale_factor=self.cfg["scale_factor"], max_scale=0.05)
+
+        def stage(ids):
+            idx = torch.as_tensor(ids, device=dev, dtype=torch.long)
+            torch.index_select(all_view, 0, idx, out=st_view); torch.index_select(all_proj, 0, idx, out=st_proj)
+            torch.index_select(all_rgb, 0, idx, out=st_rgb); torch.index_select(all_depth, 0, idx, out=st_depth)
+
+        def iteration(tick: bool):
+            self._loss.begin_step()
+            for b in range(B):
+                st = self._state(b, n, h, w)
+                api.forward(cams[b], g, st)
+                self._loss.stage1(st, st_rgb[b], st_depth[b], bufs[b], b, b == 0)
+            for b in range(B):
+                st = self._states[b]
+                self._loss.stage2(st, st_depth[b], bufs[b])
+                api.backward(cams[b], g, st, bufs[b].d_rgb, bufs[b].d_normal, bufs[b].d_depth, None, None,
+                             grads=slab.grads, accumulate=(b > 0),
+                             adam_tick=optim.tick_args() if (tick and b == B - 1) else None)
+            optim.step(slab.as_list(), device_clock=True, pre_ticked=tick)
+
+        total = self.cfg["optimization_steps"] if steps is None else steps
+        self.last_losses = []
+        graph = None
+        for it in range(total):
+            _, _, _, _, ids = sampler.next_frames(self.training_performance)
+            stage(ids)
+            if it == 0:
+                while True:       # eager first iteration: sizes the workspaces, creates every buffer
+                    optim.device_clock.zero_()
+                    iteration(tick=True)
+                    if self._check_capacity(range(B)):
+                        break
+                    raise RuntimeError("workspace grown during the first iteration; call train_graph() again")
+            else:
+                if graph is None:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.stream(side):
+                        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                            iteration(tick=True)
+                    torch.cuda.current_stream().wait_stream(side)
+                graph.replay()
+            self.training_performance[torch.as_tensor(ids, device=dev)] = self._loss.per_frame_errors(B)
+            self.last_losses.append(self._loss.total_loss())
+        if not self._check_capacity(range(B)):
+            raise RuntimeError("a view outgrew the rasterizer workspace during train_graph(); call it again")
+        self.last_losses = [float(x) for x in self.last_losses]
+        self._graph = graph
         self.post_processing()

@@ -96,3 +96,32 @@ def test_fused_train_loop_matches_reference_train_capture(agslib):
     assert torch.allclose(t.training_performance.cpu(), d["training_performance"], rtol=1e-3, atol=1e-5)
     assert (t.view_supports.cpu() != d["view_supports"]).float().mean() < 2e-3
     assert len(t.last_losses) == d["steps"] and all(np.isfinite(t.last_losses))
+
+
+def test_graph_replayed_fused_iteration_equals_eager(agslib):
+    """train_graph() (first iteration eager, the rest replayed from one hipGraph, frames staged into
+    static buffers) lands on the same parameters as train()."""
+    from active_gs_amd.fused_map_trainer import FusedMapTrainer
+    dev = torch.device("cuda:0")
+    d = torch.load(os.path.join(GOLD, "train.pt"))
+    cfg = d["cfg"]
+    mine = dict(bound=tuple(cfg["bound"]), scale_factor=cfg["scale_factor"], optimization_steps=5,
+                prune_interval=1000, background=tuple(cfg["background"]), batch_size=3, active_size=2,
+                use_view_distribution=cfg["use_view_distribution"])
+    res = []
+    for graph in (False, True):
+        raw = {k: v.to(dev) for k, v in d["raw_init"].items()}
+        frames = [{k: v.to(dev) for k, v in f.items()} for f in d["frames"]]
+        t = FusedMapTrainer(raw, frames, mine)
+        np.random.seed(11)           # 4 frames, batch 3 = 2 newest + 1 error-weighted draw per iteration
+        (t.train_graph if graph else t.train)()
+        torch.cuda.synchronize()
+        if graph:
+            assert t._graph is not None
+        res.append(([getattr(t, k).clone() for k in ("means", "scales", "rotations", "opacities", "harmonics")],
+                    t.training_performance.clone(), list(t.last_losses)))
+    for a, b, init in zip(res[0][0], res[1][0], [d["raw_init"][k] for k in ("means", "scales", "rotations", "opacities", "harmonics")]):
+        travel = (a.cpu() - init).abs().mean()
+        assert (a - b).abs().mean() < 2e-3 * travel + 1e-9
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-3, atol=1e-5)
+    assert np.allclose(res[0][2], res[1][2], rtol=1e-4)
