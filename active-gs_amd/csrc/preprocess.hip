@@ -4,6 +4,47 @@
 // Counterpart of the preprocess / preprocess-backward stages listed in SURVEY.md §2.3.
 #include "ags_internal.h"
 
+// Coalesced access to the reference's (N,3) row-major arrays: the block's 256 rows are 3072
+// contiguous bytes, moved as 192 x 16-byte lane accesses and transposed through LDS (a stride-3
+// LDS access is conflict-free: 3 is coprime with the 32 banks), instead of three 12-byte-stride
+// dword accesses per lane.  `rows` = valid rows of this block; the ragged last block falls back
+// to dword accesses.
+__device__ __forceinline__ void ags_load_rows3(const float* __restrict__ base, int first_row, int rows, float* lds,
+                                               float out[3]) {
+    const int t = threadIdx.x;
+    const float* src = base + (size_t)first_row * 3;
+    if (rows == AGS_PRE_THREADS && ((uintptr_t)src & 15) == 0) { // block-uniform
+        if (t < 192) reinterpret_cast<float4*>(lds)[t] = reinterpret_cast<const float4*>(src)[t];
+    } else {
+        for (int k = t; k < rows * 3; k += AGS_PRE_THREADS) lds[k] = src[k];
+    }
+    __syncthreads();
+    out[0] = lds[3 * t]; out[1] = lds[3 * t + 1]; out[2] = lds[3 * t + 2];
+    __syncthreads();
+}
+
+template <bool ACCUMULATE>
+__device__ __forceinline__ void ags_store_rows3(float* __restrict__ base, int first_row, int rows, float* lds,
+                                                const float v[3]) {
+    const int t = threadIdx.x;
+    float* dst = base + (size_t)first_row * 3;
+    lds[3 * t] = v[0]; lds[3 * t + 1] = v[1]; lds[3 * t + 2] = v[2];
+    __syncthreads();
+    if (rows == AGS_PRE_THREADS && ((uintptr_t)dst & 15) == 0) {
+        if (t < 192) {
+            float4 x = reinterpret_cast<const float4*>(lds)[t];
+            if (ACCUMULATE) {
+                const float4 o = reinterpret_cast<const float4*>(dst)[t];
+                x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
+            }
+            reinterpret_cast<float4*>(dst)[t] = x;
+        }
+    } else {
+        for (int k = t; k < rows * 3; k += AGS_PRE_THREADS) dst[k] = ACCUMULATE ? dst[k] + lds[k] : lds[k];
+    }
+    __syncthreads();
+}
+
 // Activations of /root/reference/mapping/gaussian_map.py:529-549, applied in registers when the
 // caller hands over raw map parameters (AgsGaussians.raw_params).
 __device__ __forceinline__ void ags_activate_inplace(const AgsGaussians& in, float sc[3], float q[4], float& opacity,
@@ -27,22 +68,26 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom) {
     __shared__ uint32_t wsum[AGS_PRE_THREADS / 64], wvis[AGS_PRE_THREADS / 64];
     __shared__ AgsEmitRec emit[COUNT_TILES ? AGS_PRE_THREADS : 1];
+    __shared__ __attribute__((aligned(16))) float rows3[3 * AGS_PRE_THREADS];
     float V[16], P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
-    const int i = blockIdx.x * AGS_PRE_THREADS + threadIdx.x;
+    const int first = blockIdx.x * AGS_PRE_THREADS;
+    const int i = first + threadIdx.x;
+    const int rows = min(AGS_PRE_THREADS, in.n - first);
     uint32_t cnt = 0, vis = 0;
     uint32_t rx0 = 0, ry0 = 0, rwd = 1;
     AgsGeom g;
     g.mx = g.my = g.ca = g.cb = g.cc = g.o = 0.f;
+    float p[3], sc[3], col[3];
+    ags_load_rows3(in.means3D, first, rows, rows3, p);
+    ags_load_rows3(in.scales, first, rows, rows3, sc);
+    ags_load_rows3(in.colors, first, rows, rows3, col);
     if (i < in.n) {
-        const float p[3] = {in.means3D[3 * i], in.means3D[3 * i + 1], in.means3D[3 * i + 2]};
-        float sc[3] = {in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]};
         const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
         float q[4] = {q4.x, q4.y, q4.z, q4.w};
         float opacity = in.opacities[i];
         if (in.raw_params) { float rv[3], qi; ags_activate_inplace(in, sc, q, opacity, rv, qi); }
-        const float col[3] = {in.colors[3 * i], in.colors[3 * i + 1], in.colors[3 * i + 2]};
         int radius = 0, rc[4];
         if (ags_preprocess_fwd(F, V, P, p, sc, q, opacity, col, in.confidences[i], 0.f, 0.f, g, radius, rc)) {
             float4* dst = reinterpret_cast<float4*>(geom + i);
@@ -81,19 +126,26 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out) {
+    __shared__ __attribute__((aligned(16))) float rows3[3 * AGS_PRE_THREADS];
     float V[16], P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
-    const int i = blockIdx.x * AGS_PRE_THREADS + threadIdx.x;
+    const int first = blockIdx.x * AGS_PRE_THREADS;
+    const int i = first + threadIdx.x;
+    const int rows = min(AGS_PRE_THREADS, in.n - first);
     // side job of the step's last backward: advance the Adam device clock (this launch completes
     // before the Adam kernel starts, so every Adam block sees the new scalars)
     if (out.adam_clock && i == 0) ags_adam_tick((AgsAdamClock*)out.adam_clock, out.adam_lr, out.adam_beta1, out.adam_beta2, 0);
-    if (i >= in.n) return;
     float dm[3] = {0, 0, 0}, ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0}, dm2[2] = {0, 0};
-    const bool vis = radii[i] > 0;
+    const bool vis = (i < in.n) && radii[i] > 0;
+    // a block with no visible surfel has nothing to add (accumulate) / only zeros to write
+    const bool block_has_vis = __syncthreads_or(vis ? 1 : 0) != 0;
+    float p[3] = {0, 0, 0}, sc[3] = {0, 0, 0};
+    if (block_has_vis) {
+        ags_load_rows3(in.means3D, first, rows, rows3, p);
+        ags_load_rows3(in.scales, first, rows, rows3, sc);
+    }
     if (vis) {
-        const float p[3] = {in.means3D[3 * i], in.means3D[3 * i + 1], in.means3D[3 * i + 2]};
-        float sc[3] = {in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]};
         const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
         float q[4] = {q4.x, q4.y, q4.z, q4.w};
         float opacity = in.opacities[i];
@@ -118,30 +170,31 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
             for (int k = 0; k < 4; ++k) dq[k] = (dq[k] - q[k] * dot) * qinv;
             dop *= opacity * (1.f - opacity);
         }
-    } else if (out.accumulate) {
-        return; // nothing to add
     }
     if (out.accumulate) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            out.d_means3D[3 * i + k] += dm[k];
-            out.d_scales[3 * i + k] += ds[k];
-            out.d_colors[3 * i + k] += dcol[k];
+        if (!block_has_vis) return; // block-uniform
+        ags_store_rows3<true>(out.d_means3D, first, rows, rows3, dm);
+        ags_store_rows3<true>(out.d_scales, first, rows, rows3, ds);
+        ags_store_rows3<true>(out.d_colors, first, rows, rows3, dcol);
+        if (vis) {
+            float4* dr = reinterpret_cast<float4*>(out.d_rotations) + i;
+            const float4 o = *dr;
+            *dr = make_float4(o.x + dq[0], o.y + dq[1], o.z + dq[2], o.w + dq[3]);
+            out.d_opacities[i] += dop;
+            if (out.d_means2D) { out.d_means2D[3 * i] += dm2[0]; out.d_means2D[3 * i + 1] += dm2[1]; }
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out.d_rotations[4 * i + k] += dq[k];
-        out.d_opacities[i] += dop;
-        if (out.d_means2D) { out.d_means2D[3 * i] += dm2[0]; out.d_means2D[3 * i + 1] += dm2[1]; }
     } else {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            out.d_means3D[3 * i + k] = dm[k];
-            out.d_scales[3 * i + k] = ds[k];
-            out.d_colors[3 * i + k] = dcol[k];
+        ags_store_rows3<false>(out.d_means3D, first, rows, rows3, dm);
+        ags_store_rows3<false>(out.d_scales, first, rows, rows3, ds);
+        ags_store_rows3<false>(out.d_colors, first, rows, rows3, dcol);
+        if (i < in.n) {
+            reinterpret_cast<float4*>(out.d_rotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+            out.d_opacities[i] = dop;
         }
-        reinterpret_cast<float4*>(out.d_rotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
-        out.d_opacities[i] = dop;
-        if (out.d_means2D) { out.d_means2D[3 * i] = dm2[0]; out.d_means2D[3 * i + 1] = dm2[1]; out.d_means2D[3 * i + 2] = 0.f; }
+        if (out.d_means2D) {
+            const float m2[3] = {dm2[0], dm2[1], 0.f};
+            ags_store_rows3<false>(out.d_means2D, first, rows, rows3, m2);
+        }
     }
 }
 
