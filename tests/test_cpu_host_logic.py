@@ -151,3 +151,31 @@ def test_map_checkpoint_roundtrip_in_reference_schema(tmp_path):
     for k in ("means", "scales", "rotations", "opacities", "harmonics", "view_supports", "view_scores", "view_means"):
         assert torch.equal(getattr(t2, k), getattr(t, k)), k
     assert t2.cfg["bound"] == (0.001, 10.0) and t2.cfg["scale_factor"] == 0.01
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/ags_raster.h is the C ABI: it must compile as C (gcc, -std=c99 -pedantic) and the struct
+    layouts the ctypes binding assumes must match what a C compiler lays out."""
+    import subprocess
+    from active_gs_amd import _lib
+    src = tmp_path / "probe.c"
+    fields = {"AgsCamera": _lib.AgsCamera, "AgsGaussians": _lib.AgsGaussians, "AgsImages": _lib.AgsImages,
+              "AgsPerGaussian": _lib.AgsPerGaussian, "AgsImageGrads": _lib.AgsImageGrads,
+              "AgsGaussianGrads": _lib.AgsGaussianGrads, "AgsWorkspace": _lib.AgsWorkspace, "AgsStatus": _lib.AgsStatus,
+              "AgsAdamTensors": _lib.AgsAdamTensors, "AgsActivation": _lib.AgsActivation,
+              "AgsLossConfig": _lib.AgsLossConfig}
+    lines = ['#include "ags_raster.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
+    for name, cls in fields.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{name}.{fname} %zu\\n", offsetof({name}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe)])
+    out = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for name, cls in fields.items():
+        assert int(out[name]) == C.sizeof(cls), name
+        for fname, _ in cls._fields_:
+            assert int(out[f"{name}.{fname}"]) == getattr(cls, fname).offset, f"{name}.{fname}"
