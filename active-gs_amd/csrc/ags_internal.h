@@ -25,6 +25,7 @@ struct AgsLayout {
     size_t tiles;       // n * u32 tiles touched
     size_t rect;        // n * ushort4
     size_t block_sums;  // (ceil(n/256)+1) * u32
+    size_t block_vis;   // ceil(n/256) * u32 visible surfels per preprocess block
     size_t keys0, keys1;// cap * u64
     size_t vals0, vals1;// cap * u32
     size_t hist;        // 256 * nb_cap * u32
@@ -59,6 +60,7 @@ static inline AgsLayout ags_make_layout(int n, int h, int w, int64_t cap) {
     L.tiles = o; o += ags_align256((size_t)n * 4);
     L.rect = o; o += ags_align256((size_t)n * 8);
     L.block_sums = o; o += ags_align256((size_t)(L.n_blocks + 1) * 4);
+    L.block_vis = o; o += ags_align256((size_t)(L.n_blocks + 1) * 4);
     L.keys0 = o; o += ags_align256((size_t)L.cap * 8);
     L.keys1 = o; o += ags_align256((size_t)L.cap * 8);
     L.vals0 = o; o += ags_align256((size_t)L.cap * 4);

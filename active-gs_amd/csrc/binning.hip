@@ -11,11 +11,27 @@
 #include "ags_internal.h"
 
 // ------------------------------------------------------------------ F2: scan of block sums
+// number of visible surfels = sum of the per-block counts the preprocess kernel left
+__device__ __forceinline__ uint32_t ags_sum_block_vis(const uint32_t* __restrict__ block_vis, int nblk, uint32_t* sh16) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t v = 0;
+    for (int i = tid; i < nblk; i += 1024) v += block_vis[i];
+    v = ags_wave_sum_u32(v);
+    if (lane == 0) sh16[wave] = v;
+    __syncthreads();
+    uint32_t t = 0;
+    for (int k = 0; k < 16; ++k) t += sh16[k];
+    __syncthreads();
+    return t;
+}
+
 __global__ __launch_bounds__(1024) void ags_k_scan_blocks(uint32_t* __restrict__ block_sums, int nblk,
-                                                          uint32_t* __restrict__ status, uint32_t cap) {
+                                                          uint32_t* __restrict__ status, uint32_t cap,
+                                                          const uint32_t* __restrict__ block_vis) {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nvis = ags_sum_block_vis(block_vis, nblk, wtot);
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < nblk; base += 1024) {
@@ -37,8 +53,7 @@ __global__ __launch_bounds__(1024) void ags_k_scan_blocks(uint32_t* __restrict__
         status[0] = total;
         status[1] = total < cap ? total : cap;
         status[2] = total > cap ? 1u : 0u;
-        status[3] = status[4]; // visible surfels counted by the preprocess kernel
-        status[4] = 0u;
+        status[3] = nvis;
     }
 }
 
@@ -248,7 +263,8 @@ void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, con
     uint32_t* hist = (uint32_t*)(ws + L.hist);
     uint32_t* totals = (uint32_t*)(ws + L.totals);
     const uint32_t cap = (uint32_t)L.cap;
-    hipLaunchKernelGGL(ags_k_scan_blocks, dim3(1), dim3(1024), 0, s, bsum, L.n_blocks, status, cap);
+    hipLaunchKernelGGL(ags_k_scan_blocks, dim3(1), dim3(1024), 0, s, bsum, L.n_blocks, status, cap,
+                       (const uint32_t*)(ws + L.block_vis));
     hipLaunchKernelGGL(ags_k_duplicate, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, in.n, F.tiles_x,
                        (const uint32_t*)(ws + L.tiles), (const ushort4*)(ws + L.rect),
                        (const AgsGeom*)(ws + L.geom), bsum, keys[0], vals[0], cap);
@@ -283,10 +299,12 @@ void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, con
 // the atomics were served in: same per-tile order as the stable radix path.
 __global__ __launch_bounds__(1024) void ags_k_scan_tiles(const uint32_t* __restrict__ tile_count, int T,
                                                          uint2* __restrict__ ranges, uint32_t* __restrict__ status,
-                                                         uint32_t cap) {
+                                                         uint32_t cap, const uint32_t* __restrict__ block_vis,
+                                                         int nblk) {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nvis = ags_sum_block_vis(block_vis, nblk, wtot);
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < T; base += 1024) {
@@ -311,8 +329,7 @@ __global__ __launch_bounds__(1024) void ags_k_scan_tiles(const uint32_t* __restr
         status[0] = total;
         status[1] = total < cap ? total : cap;
         status[2] = total > cap ? 1u : 0u;
-        status[3] = status[4];
-        status[4] = 0u;
+        status[3] = nvis;
     }
 }
 
@@ -411,7 +428,7 @@ void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws
     uint2* ranges = (uint2*)(ws + L.ranges);
     uint64_t* keys = (uint64_t*)(ws + L.keys0);
     hipLaunchKernelGGL(ags_k_scan_tiles, dim3(1), dim3(1024), 0, s, (const uint32_t*)(ws + L.tile_count), L.num_tiles,
-                       ranges, status, (uint32_t)L.cap);
+                       ranges, status, (uint32_t)L.cap, (const uint32_t*)(ws + L.block_vis), L.n_blocks);
     hipLaunchKernelGGL(ags_k_bucket, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, in.n, F.tiles_x,
                        (const uint32_t*)(ws + L.tiles), (const ushort4*)(ws + L.rect), (const AgsGeom*)(ws + L.geom),
                        (const uint2*)ranges, (uint32_t*)(ws + L.tile_fill), keys);

@@ -136,7 +136,9 @@ int ags_activate_backward(const AgsActivation* a, float* d_scales, float* d_rota
 }
 
 static int ags_loss_check(const AgsLossConfig* c, const AgsImages* f) {
-    if (!c || !f || c->image_height <= 0 || c->image_width <= 0 || c->batch_total < 1 || !(c->sigma > 0.f)) return AGS_E_INVALID;
+    if (!c || !f || c->image_height <= 0 || c->image_width <= 0 || c->batch_total < 1 || !(c->sigma > 0.f) ||
+        c->accum_stride < 6)
+        return AGS_E_INVALID;
     if (!f->rgb || !f->normal || !f->depth || !f->opacity) return AGS_E_INVALID;
     return AGS_OK;
 }
@@ -145,7 +147,7 @@ int ags_loss_stage1(const AgsLossConfig* cfg, const AgsImages* fwd, const float*
                     float* n_img, float* d_rgb, float* d_depth, int32_t* msum, float* accum, int32_t view,
                     int32_t first_view, ags_stream_t stream) {
     if (ags_loss_check(cfg, fwd) != AGS_OK || !gt_rgb || !gt_depth || !n_img || !d_rgb || !d_depth || !msum || !accum ||
-        view < 0)
+        view < 0 || 5 + 2 * view >= cfg->accum_stride)
         return AGS_E_INVALID;
     ags_launch_loss_stage1(*cfg, *fwd, gt_rgb, gt_depth, n_img, d_rgb, d_depth, msum, accum, view, first_view,
                            (hipStream_t)stream);

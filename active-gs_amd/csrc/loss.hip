@@ -50,13 +50,16 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     return t;
 }
 
-// accum layout (floats): [0] rgb L1 sum, [1] depth L1 sum, [2] cons sum, [3] tv sum (all views);
+// accum layout (floats), AGS_LOSS_ACCUM_ROWS rows of `accum_stride` floats; a block adds into row
+// (blockIdx & 63) so the thousands of per-block atomics do not serialise on one word; the
+// reader sums the rows:  [0] rgb L1 sum, [1] depth L1 sum, [2] cons sum, [3] tv sum (all views);
 //                        [4 + 2*view] rgb L1 sum of the view, [5 + 2*view] depth L1 sum of the view
 __global__ __launch_bounds__(256) void ags_k_loss_stage1(
     AgsLossDev c, const float* __restrict__ rgb, const float* __restrict__ normal_raw,
     const float* __restrict__ depth, const float* __restrict__ opacity, const float* __restrict__ gt_rgb,
     const float* __restrict__ gt_depth, float* __restrict__ n_img, float* __restrict__ d_rgb,
-    float* __restrict__ d_depth, int* __restrict__ msum, float* __restrict__ accum, int view, int first_view) {
+    float* __restrict__ d_depth, int* __restrict__ msum, float* __restrict__ accum, int accum_stride, int view,
+    int first_view) {
     __shared__ float sh[4];
     const int HW = c.H * c.W;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -84,8 +87,9 @@ __global__ __launch_bounds__(256) void ags_k_loss_stage1(
     }
     const float t_rgb = block_sum_256(s_rgb, sh), t_dep = block_sum_256(s_dep, sh);
     if (threadIdx.x == 0) {
-        atomicAdd(&accum[0], t_rgb); atomicAdd(&accum[1], t_dep);
-        atomicAdd(&accum[4 + 2 * view], t_rgb); atomicAdd(&accum[5 + 2 * view], t_dep);
+        float* row = accum + (size_t)(blockIdx.x & (AGS_LOSS_ACCUM_ROWS - 1)) * accum_stride;
+        atomicAdd(&row[0], t_rgb); atomicAdd(&row[1], t_dep);
+        atomicAdd(&row[4 + 2 * view], t_rgb); atomicAdd(&row[5 + 2 * view], t_dep);
     }
 }
 
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void ags_k_loss_stage2(
     AgsLossDev c, const float* __restrict__ depth, const float* __restrict__ opacity,
     const float* __restrict__ normal_raw, const float* __restrict__ n_img, const float* __restrict__ gt_depth,
     const int* __restrict__ msum, float* __restrict__ d_normal, float* __restrict__ d_depth,
-    float* __restrict__ accum) {
+    float* __restrict__ accum, int accum_stride) {
     __shared__ float sh[4];
     const int H = c.H, W = c.W, HW = H * W;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -176,7 +180,10 @@ __global__ __launch_bounds__(256) void ags_k_loss_stage2(
         }
     }
     const float t_c = block_sum_256(s_cons, sh), t_t = block_sum_256(s_tv, sh);
-    if (threadIdx.x == 0) { atomicAdd(&accum[2], t_c); atomicAdd(&accum[3], t_t); }
+    if (threadIdx.x == 0) {
+        float* row = accum + (size_t)(blockIdx.x & (AGS_LOSS_ACCUM_ROWS - 1)) * accum_stride;
+        atomicAdd(&row[2], t_c); atomicAdd(&row[3], t_t);
+    }
 }
 
 static AgsLossDev make_dev(const AgsLossConfig& cfg) {
@@ -194,12 +201,13 @@ void ags_launch_loss_stage1(const AgsLossConfig& cfg, const AgsImages& img, cons
                             int first_view, hipStream_t s) {
     const int HW = cfg.image_height * cfg.image_width;
     hipLaunchKernelGGL(ags_k_loss_stage1, dim3((HW + 255) / 256), dim3(256), 0, s, make_dev(cfg), img.rgb, img.normal,
-                       img.depth, img.opacity, gt_rgb, gt_depth, n_img, d_rgb, d_depth, msum, accum, view, first_view);
+                       img.depth, img.opacity, gt_rgb, gt_depth, n_img, d_rgb, d_depth, msum, accum, cfg.accum_stride,
+                       view, first_view);
 }
 
 void ags_launch_loss_stage2(const AgsLossConfig& cfg, const AgsImages& img, const float* n_img, const float* gt_depth,
                             const int* msum, float* d_normal, float* d_depth, float* accum, hipStream_t s) {
     const int HW = cfg.image_height * cfg.image_width;
     hipLaunchKernelGGL(ags_k_loss_stage2, dim3((HW + 255) / 256), dim3(256), 0, s, make_dev(cfg), img.depth,
-                       img.opacity, img.normal, n_img, gt_depth, msum, d_normal, d_depth, accum);
+                       img.opacity, img.normal, n_img, gt_depth, msum, d_normal, d_depth, accum, cfg.accum_stride);
 }

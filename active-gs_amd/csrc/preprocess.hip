@@ -64,7 +64,7 @@ template <bool COUNT_TILES>
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     AgsGeom* __restrict__ geom, uint32_t* __restrict__ tiles, ushort4* __restrict__ rect,
-    int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ status,
+    int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_vis,
     uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom) {
     __shared__ uint32_t wsum[AGS_PRE_THREADS / 64], wvis[AGS_PRE_THREADS / 64];
     __shared__ AgsEmitRec emit[COUNT_TILES ? AGS_PRE_THREADS : 1];
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
 #pragma unroll
         for (int k = 0; k < AGS_PRE_THREADS / 64; ++k) { a += wsum[k]; b += wvis[k]; }
         block_sums[blockIdx.x] = a;
-        if (b) atomicAdd(&status[4], b); // visible-surfel accumulator, published + reset by the scan kernel
+        block_vis[blockIdx.x] = b;  // summed by the (single-workgroup) scan kernel: no fan-in atomics
     }
 }
 
@@ -204,12 +204,12 @@ void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGau
         hipLaunchKernelGGL(ags_k_preprocess<true>, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
                            cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
                            (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums),
-                           (uint32_t*)(ws + L.status), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom));
+                           (uint32_t*)(ws + L.block_vis), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom));
     else
         hipLaunchKernelGGL(ags_k_preprocess<false>, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
                            cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
                            (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums),
-                           (uint32_t*)(ws + L.status), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom));
+                           (uint32_t*)(ws + L.block_vis), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom));
 }
 
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,

@@ -26,10 +26,12 @@ class FusedLoss:
     def __init__(self, h: int, w: int, fov_x: float, fov_y: float, batch_total: int, max_views: int, device,
                  weights=(1.0, 0.8, 0.1, 0.1), sigma: float = 0.3):
         self.h, self.w = h, w
+        stride = 4 + 2 * max_views
         self.cfg = _lib.AgsLossConfig(h, w, float(fov_x), float(fov_y), int(batch_total), *[float(x) for x in weights],
-                                      float(sigma))
+                                      float(sigma), stride)
         self.msum = torch.zeros(h, w, dtype=torch.int32, device=device)
-        self.accum = torch.zeros(4 + 2 * max_views, dtype=torch.float32, device=device)
+        # 64 accumulator rows: workgroups spread their atomics over them, readers sum the rows
+        self.accum = torch.zeros(64, stride, dtype=torch.float32, device=device)
         self.device = device
 
     def set_batch_total(self, b: int) -> None:
@@ -57,12 +59,12 @@ class FusedLoss:
                                                torch.cuda.current_stream().cuda_stream), "ags_loss_stage2")
 
     def total_loss(self) -> torch.Tensor:
-        c, a, hw = self.cfg, self.accum, float(self.h * self.w)
+        c, a, hw = self.cfg, self.accum.sum(0), float(self.h * self.w)
         b = float(c.batch_total)
         return (c.w_rgb * a[0] / (b * 3 * hw) + c.w_depth * a[1] / (b * hw) + c.w_cons * a[2] / (b * b * hw)
                 + c.w_tv * a[3] / (b * 4 * hw))
 
     def per_frame_errors(self, n_views: int) -> torch.Tensor:
         hw = float(self.h * self.w)
-        a = self.accum[4:4 + 2 * n_views].view(n_views, 2)
+        a = self.accum.sum(0)[4:4 + 2 * n_views].view(n_views, 2)
         return a[:, 0] / (3 * hw) + a[:, 1] / hw

@@ -120,7 +120,7 @@ class FusedMapTrainer(GaussianMapTrainer):
                 slab.flat.zero_()
             if self.world > 1:
                 dist.all_reduce(slab.flat, group=self.pg)
-                dist.all_reduce(self._loss.accum, group=self.pg)
+                dist.all_reduce(self._loss.accum, group=self.pg)  # 64 x (4+2B) floats
             self.training_performance[torch.as_tensor(ids, device=self.device)] = self._loss.per_frame_errors(B)
             optim.step(slab.as_list())
             self.last_losses.append(self._loss.total_loss())

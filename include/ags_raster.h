@@ -211,15 +211,19 @@ int ags_activate_backward(const AgsActivation* a, float* d_scales, float* d_rota
  * Per optimisation step: stage 1 for EVERY view of the batch (it also accumulates the
  * visibility count `msum` the reference's broadcast in the consistency term needs; all-reduce
  * msum across ranks under view parallelism), then per view stage 2 -> ags_backward.
- * accum (floats, zeroed by the caller per step): [0] rgb-L1 sum, [1] depth-L1 sum, [2] consistency
- * sum, [3] TV sum over all views; [4+2v], [5+2v] rgb / depth L1 sums of view v (per-frame error).
+ * accum: AGS_LOSS_ACCUM_ROWS rows of `accum_stride` floats, zeroed by the caller per step; workgroups
+ * add into different rows (so their atomics do not serialise on one word) and the reader sums the
+ * rows. Per row: [0] rgb-L1 sum, [1] depth-L1 sum, [2] consistency sum, [3] TV sum over all views;
+ * [4+2v], [5+2v] rgb / depth L1 sums of view v (per-frame error).
  * total loss = w_rgb*a0/(B*3HW) + w_depth*a1/(B*HW) + w_cons*a2/(B*B*HW) + w_tv*a3/(B*4HW). */
+#define AGS_LOSS_ACCUM_ROWS 64
 typedef struct AgsLossConfig {
     int32_t image_height, image_width;
     float fov_x, fov_y;    /* radians, as GaussianRenderer.fovs (operations.py:756-757) */
     int32_t batch_total;   /* B: views in the batch over ALL ranks */
     float w_rgb, w_depth, w_cons, w_tv; /* 1, 0.8, 0.1, 0.1 */
     float sigma;           /* 0.3 */
+    int32_t accum_stride;  /* floats per accumulator row, >= 4 + 2 * (views in the batch) */
 } AgsLossConfig;
 int ags_loss_stage1(const AgsLossConfig* cfg, const AgsImages* fwd, const float* gt_rgb, const float* gt_depth,
                     float* n_img /* (3,H,W) */, float* d_rgb, float* d_depth, int32_t* msum /* (H,W) */,
