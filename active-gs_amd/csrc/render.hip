@@ -238,8 +238,9 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_bwd(
 static int ags_pick_slots(int num_tiles) {
     const char* e = getenv("AGS_RENDER_SLOTS");
     if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) return e[0] - '0';
-    if (num_tiles >= 8192) return 4;
-    return 2;
+    if (num_tiles >= 8192) return 4; // e.g. 2048x2048: one wave per tile already oversubscribes the SIMDs
+    if (num_tiles >= 2048) return 2; // e.g. 1200x680 (3225 tiles): measured best, DESIGN.md §9
+    return 1;                        // e.g. 512x512 (1024 tiles): four waves per tile
 }
 
 template <int SLOTS>
