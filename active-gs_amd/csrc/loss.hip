@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void ags_k_loss_stage1(
         s_dep = fabsf(e);
         d_depth[p] = (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * md * (c.w_depth / ((float)c.B * (float)HW));
         const int v = o > 1e-3f ? 1 : 0;
-        msum[p] = first_view ? v : msum[p] + v;
+        if (first_view < 0) { if (v) atomicAdd(&msum[p], 1); }   // concurrent views into a pre-zeroed count
+        else msum[p] = first_view ? v : msum[p] + v;
     }
     const float t_rgb = block_sum_256(s_rgb, sh), t_dep = block_sum_256(s_dep, sh);
     if (threadIdx.x == 0) {

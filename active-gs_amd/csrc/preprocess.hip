@@ -171,7 +171,20 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
             dop *= opacity * (1.f - opacity);
         }
     }
-    if (out.accumulate) {
+    if (out.accumulate == 2) { // concurrent views: only visible rows touch memory, atomically
+        if (vis) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                unsafeAtomicAdd(&out.d_means3D[3 * i + k], dm[k]);
+                unsafeAtomicAdd(&out.d_scales[3 * i + k], ds[k]);
+                unsafeAtomicAdd(&out.d_colors[3 * i + k], dcol[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) unsafeAtomicAdd(&out.d_rotations[4 * i + k], dq[k]);
+            unsafeAtomicAdd(&out.d_opacities[i], dop);
+            if (out.d_means2D) { unsafeAtomicAdd(&out.d_means2D[3 * i], dm2[0]); unsafeAtomicAdd(&out.d_means2D[3 * i + 1], dm2[1]); }
+        }
+    } else if (out.accumulate) {
         if (!block_has_vis) return; // block-uniform
         ags_store_rows3<true>(out.d_means3D, first, rows, rows3, dm);
         ags_store_rows3<true>(out.d_scales, first, rows, rows3, ds);

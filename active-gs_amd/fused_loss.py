@@ -45,18 +45,22 @@ class FusedLoss:
     def begin_step(self) -> None:
         self.accum.zero_()
 
-    def stage1(self, st: ForwardState, gt_rgb, gt_depth, buf: LossBuffers, view: int, first_view: bool) -> None:
+    def stage1(self, st: ForwardState, gt_rgb, gt_depth, buf: LossBuffers, view: int, first_view, stream=None) -> None:
+        """``first_view``: True / False for views processed one after another, -1 when views run
+        concurrently on several streams (``msum`` must have been zeroed)."""
         img = st.images_struct()
         _lib.check(_lib.load().ags_loss_stage1(C.byref(self.cfg), C.byref(img), ptr(gt_rgb), ptr(gt_depth), ptr(buf.n_img),
                                                ptr(buf.d_rgb), ptr(buf.d_depth), ptr(self.msum), ptr(self.accum),
-                                               int(view), int(first_view), torch.cuda.current_stream().cuda_stream),
+                                               int(view), int(first_view),
+                                               torch.cuda.current_stream().cuda_stream if stream is None else stream),
                    "ags_loss_stage1")
 
-    def stage2(self, st: ForwardState, gt_depth, buf: LossBuffers) -> None:
+    def stage2(self, st: ForwardState, gt_depth, buf: LossBuffers, stream=None) -> None:
         img = st.images_struct()
         _lib.check(_lib.load().ags_loss_stage2(C.byref(self.cfg), C.byref(img), ptr(buf.n_img), ptr(gt_depth),
                                                ptr(self.msum), ptr(buf.d_normal), ptr(buf.d_depth), ptr(self.accum),
-                                               torch.cuda.current_stream().cuda_stream), "ags_loss_stage2")
+                                               torch.cuda.current_stream().cuda_stream if stream is None else stream),
+                   "ags_loss_stage2")
 
     def total_loss(self) -> torch.Tensor:
         c, a, hw = self.cfg, self.accum.sum(0), float(self.h * self.w)

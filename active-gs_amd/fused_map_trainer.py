@@ -21,7 +21,7 @@ from .trainer import GradSlab
 
 class FusedMapTrainer(GaussianMapTrainer):
     def __init__(self, raw: dict, frames: List[dict], cfg: Optional[dict] = None, process_group=None,
-                 binning_mode: int = api.BIN_TILE_SORT, use_graph: bool = True):
+                 binning_mode: int = api.BIN_TILE_SORT, use_graph: bool = True, num_streams: int = 4):
         super().__init__(raw, frames, cfg, process_group=process_group)
         if self.device.type != "cuda":
             raise RuntimeError("FusedMapTrainer needs GPU tensors: there is no CPU fallback")
@@ -30,6 +30,12 @@ class FusedMapTrainer(GaussianMapTrainer):
         # fixed for a given batch shape; what changes (which frames) is staged into static
         # per-slot camera / ground-truth buffers by four index_select launches before the replay.
         self.use_graph = use_graph
+        # the views of an iteration are independent until the gradient sum: with num_streams > 1
+        # they run concurrently on that many HIP streams (a 512x512 view alone leaves most SIMDs
+        # idle), gradients and the visibility count are accumulated atomically, and the streams
+        # join before the collective / Adam.
+        self.num_streams = max(1, int(num_streams))
+        self._streams = None
         self._cams = {}          # frame index -> (api.Camera, fov_x, fov_y)
         self._states = {}        # view slot -> ForwardState
         self._loss = None
@@ -96,28 +102,59 @@ class FusedMapTrainer(GaussianMapTrainer):
             while len(self._loss_bufs) < len(mine):
                 self._loss_bufs.append(self._loss.alloc_view())
             g = self._gaussians()
+            S = min(self.num_streams, max(len(mine), 1))
+            if S > 1 and self._streams is None:
+                self._streams = [torch.cuda.Stream() for _ in range(self.num_streams)]
+            main = torch.cuda.current_stream()
+
+            main_h = main.cuda_stream
+            side_h = [s_.cuda_stream for s_ in self._streams] if S > 1 else []
+
+            def fan_out(fn):
+                """Run fn(slot, b, stream_handle) for this rank's views, round-robin over S streams that
+                first wait for the main stream and that the main stream then waits for.  The kernels
+                are enqueued through the C ABI with the raw stream handle (no torch stream switch)."""
+                if S == 1:
+                    for slot, b in enumerate(mine):
+                        fn(slot, b, main_h)
+                    return
+                for k in range(S):
+                    self._streams[k].wait_stream(main)
+                for slot, b in enumerate(mine):
+                    fn(slot, b, side_h[slot % S])
+                for k in range(S):
+                    main.wait_stream(self._streams[k])
+
+            def fwd_view(slot, b, sh):
+                cam, _, _ = self._camera(int(ids[b]))
+                st = self._state(slot, n, h, w)
+                api.forward(cam, g, st, stream=sh, checked=True)
+                f = self.frames[int(ids[b])]
+                self._loss.stage1(st, f["rgb"], f["depth"], self._loss_bufs[slot], b, -1 if S > 1 else slot == 0, sh)
+
+            def bwd_view(slot, b, sh):
+                cam, _, _ = self._camera(int(ids[b]))
+                st, buf = self._states[slot], self._loss_bufs[slot]
+                self._loss.stage2(st, self.frames[int(ids[b])]["depth"], buf, sh)
+                api.backward(cam, g, st, buf.d_rgb, buf.d_normal, buf.d_depth, None, None, grads=slab.grads,
+                             accumulate=2 if S > 1 else (slot > 0), stream=sh)
+
             while True:  # forward every local view; re-run the batch once if a workspace was too small
                 self._loss.begin_step()
-                for slot, b in enumerate(mine):
-                    cam, _, _ = self._camera(int(ids[b]))
-                    st = self._state(slot, n, h, w)
-                    api.forward(cam, g, st)
-                    f = self.frames[int(ids[b])]
-                    self._loss.stage1(st, f["rgb"], f["depth"], self._loss_bufs[slot], b, slot == 0)
+                if S > 1:
+                    self._loss.msum.zero_()
+                    for slot in range(len(mine)):   # allocate outside the side streams
+                        self._state(slot, n, h, w)
+                fan_out(fwd_view)
                 if it > 0 or self._check_capacity(range(len(mine))):
                     break
             if not mine:
                 self._loss.msum.zero_()
             if self.world > 1:
                 dist.all_reduce(self._loss.msum, group=self.pg)
-            for slot, b in enumerate(mine):
-                cam, _, _ = self._camera(int(ids[b]))
-                st, buf = self._states[slot], self._loss_bufs[slot]
-                self._loss.stage2(st, self.frames[int(ids[b])]["depth"], buf)
-                api.backward(cam, g, st, buf.d_rgb, buf.d_normal, buf.d_depth, None, None, grads=slab.grads,
-                             accumulate=(slot > 0))
-            if not mine:
+            if S > 1 or not mine:
                 slab.flat.zero_()
+            fan_out(bwd_view)
             if self.world > 1:
                 dist.all_reduce(slab.flat, group=self.pg)
                 dist.all_reduce(self._loss.accum, group=self.pg)  # 64 x (4+2B) floats
@@ -129,6 +166,26 @@ class FusedMapTrainer(GaussianMapTrainer):
                                "(the capacity has been raised)")
         self.last_losses = [float(x) for x in self.last_losses]
         self.post_processing()
+
+    def _render_counts(self, frame_ids, extr, intr, depth_gt, params, hw):
+        """Count render of post_processing straight through the C ABI (forward only, importance /
+        count enabled, front_only, render mask = valid ground-truth depth): no module, no autograd."""
+        n = self.means.shape[0]
+        h, w = hw
+        self._cap = max(self._cap, 1 << 16, 2 * n)
+        g = self._gaussians()
+        out = []
+        for k, fid in enumerate(frame_ids):
+            cam0, _, _ = self._camera(int(fid))
+            cam = api.Camera(h, w, cam0.tanfovx, cam0.tanfovy, cam0.viewmatrix, cam0.projmatrix, self.background,
+                             want_stats=True, front_only=True, render_mask=(depth_gt[k] > 0.0).float().contiguous())
+            while True:
+                st = self._state("count", n, h, w)
+                api.forward(cam, g, st)
+                if self._check_capacity(["count"]):
+                    break
+            out.append(st.count.clone())
+        return torch.stack(out)
 
     # ------------------------------------------------------------------ hipGraph iteration
     def _graph_ok(self) -> bool:

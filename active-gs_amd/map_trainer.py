@@ -156,9 +156,7 @@ class GaussianMapTrainer:
             mine = list(range(self.rank, len(use), self.world))
             n = self.means.shape[0]
             if mine:
-                counts = self._renderer(extr[mine], intr[mine], params, (h, w),
-                                        masks=(depth_gt[mine] > 0.0).float()).render_view_all(
-                    require_importance=True, front_only=True)[7]
+                counts = self._render_counts([use[m] for m in mine], extr[mine], intr[mine], depth_gt[mine], params, (h, w))
             else:
                 counts = torch.zeros(0, n, dtype=torch.int32, device=self.device)
             counts_sum = counts.sum(0).to(torch.int32)
@@ -181,6 +179,12 @@ class GaussianMapTrainer:
                 self.view_scores[seen] += ((1 - torch.clamp(dist / far, min=0, max=1)) * cos)[seen]
             if prune_now:
                 self.prune(~(counts_sum >= 1.0))
+
+    def _render_counts(self, frame_ids, extr, intr, depth_gt, params, hw):
+        """(len(frame_ids), N) int32: per view, pixels (with valid ground-truth depth) in which each
+        front-facing surfel has blend weight > weight_thres (gaussian_map.py:173-192)."""
+        return self._renderer(extr, intr, params, hw, masks=(depth_gt > 0.0).float()).render_view_all(
+            require_importance=True, front_only=True)[7]
 
     def prune(self, mask):
         mask = mask | (torch.sigmoid(self.opacities) < 0.1)

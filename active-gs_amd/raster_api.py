@@ -126,18 +126,22 @@ def alloc_state(n: int, h: int, w: int, max_instances: int, device, binning_mode
     return st
 
 
-def forward(cam: Camera, g: Gaussians, state: ForwardState) -> ForwardState:
-    """Enqueue one forward pass into ``state`` (see ``alloc_state``). Asynchronous."""
+def forward(cam: Camera, g: Gaussians, state: ForwardState, stream: Optional[int] = None, checked: bool = False
+            ) -> ForwardState:
+    """Enqueue one forward pass into ``state`` (see ``alloc_state``). Asynchronous.
+    ``stream``: raw HIP stream handle (default: torch's current stream); ``checked``: the caller
+    vouches for contiguous float32 GPU inputs (hot loops skip the per-call validation)."""
     lib = _lib.load()
-    for name in ("means3D", "scales", "rotations", "opacities", "colors", "confidences"):
-        _require_cuda(getattr(g, name), name)
+    if not checked:
+        for name in ("means3D", "scales", "rotations", "opacities", "colors", "confidences"):
+            _require_cuda(getattr(g, name), name)
     if cam.want_stats:
         state.importance.zero_()
         state.count.zero_()
     cs, gs = cam.c_struct(), g.c_struct()
     im, pg, ws = state.images_struct(), state.per_gaussian_struct(), state.ws_struct()
-    _lib.check(lib.ags_forward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(ws), _stream()),
-               "ags_forward")
+    _lib.check(lib.ags_forward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(ws),
+                               _stream() if stream is None else stream), "ags_forward")
     return state
 
 
@@ -170,7 +174,7 @@ def alloc_grads(n: int, device, with_means2d: bool = False, zero: bool = False) 
 
 def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_normal=None, d_depth=None,
              d_opacity=None, d_confidence=None, grads: Optional[GaussianGrads] = None,
-             accumulate: bool = False, adam_tick=None) -> GaussianGrads:
+             accumulate: bool = False, adam_tick=None, stream: Optional[int] = None) -> GaussianGrads:
     """Enqueue the backward pass of the view held in ``state``. Asynchronous.
     ``adam_tick`` = (device_clock_tensor, lrs, beta1, beta2): also advance that Adam clock."""
     lib = _lib.load()
@@ -185,7 +189,7 @@ def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_norma
     im, pg, ws = state.images_struct(), state.per_gaussian_struct(), state.ws_struct()
     dout = _lib.AgsImageGrads(ptr(d_rgb), ptr(d_normal), ptr(d_depth), ptr(d_opacity), ptr(d_confidence))
     din = _lib.AgsGaussianGrads(ptr(grads.means3D), ptr(grads.scales), ptr(grads.rotations), ptr(grads.opacities),
-                                ptr(grads.colors), ptr(grads.means2D), int(accumulate))
+                                ptr(grads.colors), ptr(grads.means2D), int(accumulate))  # 2 = atomic accumulate
     if adam_tick is not None:
         clock, lrs, b1, b2 = adam_tick
         din.adam_clock = ptr(clock)
@@ -193,5 +197,5 @@ def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_norma
             din.adam_lr[k] = float(lrs[k])
         din.adam_beta1, din.adam_beta2 = float(b1), float(b2)
     _lib.check(lib.ags_backward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(dout), C.byref(din),
-                                C.byref(ws), _stream()), "ags_backward")
+                                C.byref(ws), _stream() if stream is None else stream), "ags_backward")
     return grads

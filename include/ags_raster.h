@@ -115,7 +115,8 @@ typedef struct AgsGaussianGrads {
     float* d_opacities;
     float* d_colors;
     float* d_means2D;
-    int32_t accumulate; /* 0: overwrite, 1: += (sum over views without an extra pass) */
+    int32_t accumulate; /* 0: overwrite; 1: += (views one after another on a stream, no extra pass);
+                         * 2: atomic += into a pre-zeroed slab (views running concurrently on several streams) */
     /* Optional (NULL = off): an Adam device clock (see ags_adam_step_device) that this backward
      * launch advances on the side - pass it with the LAST view of an optimisation step and call
      * ags_adam_step_device(..., pre_ticked = 1): the step then needs no separate clock kernel. */
@@ -227,7 +228,9 @@ typedef struct AgsLossConfig {
 } AgsLossConfig;
 int ags_loss_stage1(const AgsLossConfig* cfg, const AgsImages* fwd, const float* gt_rgb, const float* gt_depth,
                     float* n_img /* (3,H,W) */, float* d_rgb, float* d_depth, int32_t* msum /* (H,W) */,
-                    float* accum, int32_t view, int32_t first_view, ags_stream_t stream);
+                    float* accum, int32_t view,
+                    int32_t first_view /* 1: msum = v; 0: msum += v; -1: atomic += into a zeroed msum (views on several streams) */,
+                    ags_stream_t stream);
 int ags_loss_stage2(const AgsLossConfig* cfg, const AgsImages* fwd, const float* n_img, const float* gt_depth,
                     const int32_t* msum, float* d_normal, float* d_depth /* += */, float* accum,
                     ags_stream_t stream);
