@@ -87,11 +87,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test-only hooks (tests/test_gpu_bench_multirank.py): several ranks on ONE GPU over gloo, to
+    # exercise the N>1 code path where only a single-GPU box is available
+    share_gpu = os.environ.get("AGS_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("AGS_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # nccl IS RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from active_gs_amd import _lib, raster_api as api
     from active_gs_amd.camera import camera_matrices

@@ -1,0 +1,29 @@
+"""bench.py's N>1 path end to end (process group, graph | all-reduce | graph step, barriers, max over
+ranks, one JSON line from rank 0) with two ranks sharing the single GPU over gloo."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_on_one_gpu(agslib):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, AGS_BENCH_SHARE_GPU="1", AGS_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
+           "--warmup", "3", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                  # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "view-parallel dp2" and not d["config"]["overflow"]
+    assert d["config"]["launch"].startswith("hipGraph")
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
