@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass, field
-from typing import Optional
+from typing import Optional, Sequence
 
 import torch
 
@@ -199,3 +199,51 @@ def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_norma
     _lib.check(lib.ags_backward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(dout), C.byref(din),
                                 C.byref(ws), _stream() if stream is None else stream), "ags_backward")
     return grads
+
+
+class StreamPool:
+    """A few HIP streams that fork from and join back into torch's current stream."""
+
+    def __init__(self, n: int = 4):
+        self.streams = [torch.cuda.Stream() for _ in range(max(1, n))]
+
+    def fork(self):
+        main = torch.cuda.current_stream()
+        for s in self.streams:
+            s.wait_stream(main)
+        return [s.cuda_stream for s in self.streams]
+
+    def join(self):
+        main = torch.cuda.current_stream()
+        for s in self.streams:
+            main.wait_stream(s)
+
+
+def forward_many(cams: Sequence[Camera], g: Gaussians, states: Sequence[ForwardState],
+                 pool: Optional[StreamPool] = None) -> None:
+    """Forward-only render of many (small) views, e.g. the ~100 candidate views at 128x128 of the
+    planners' utility pass (/root/reference/planning/confidence.py:24-46,
+    /root/reference/config/planner/confidence.yaml:9,15) or the K keyframes of the prune pass
+    (/root/reference/mapping/gaussian_map.py:149-192).  One view is far too small to fill the GPU
+    (64 tiles), so views are enqueued round-robin on the pool's streams and run concurrently; the
+    streams join torch's current stream before returning.  Asynchronous, no host sync."""
+    if len(cams) != len(states):
+        raise ValueError("one ForwardState per camera")
+    for name in ("means3D", "scales", "rotations", "opacities", "colors", "confidences"):
+        _require_cuda(getattr(g, name), name)
+    if pool is None or len(cams) < 2:
+        for cam, st in zip(cams, states):
+            forward(cam, g, st, checked=True)
+        return
+    for cam, st in zip(cams, states):   # stats buffers are zeroed on the main stream, before the fork
+        if cam.want_stats:
+            st.importance.zero_()
+            st.count.zero_()
+    handles = pool.fork()
+    lib = _lib.load()
+    for k, (cam, st) in enumerate(zip(cams, states)):
+        cs, gs = cam.c_struct(), g.c_struct()
+        im, pg, ws = st.images_struct(), st.per_gaussian_struct(), st.ws_struct()
+        _lib.check(lib.ags_forward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(ws),
+                                   handles[k % len(handles)]), "ags_forward")
+    pool.join()

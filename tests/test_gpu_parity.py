@@ -347,3 +347,33 @@ def test_module_argument_variants(agslib):
     out_sh = GaussianRasterizer(product_settings(S, dev))(gin[0].detach(), gin[1], gin[2].detach(), gin[3], sh, None,
                                                           gin[5].detach(), gin[6].detach(), None)
     assert (out_sh[0] - out[0].detach()).abs().max() < 1e-5
+
+
+def test_forward_many_streams_equal_sequential(agslib):
+    """Planner-style batch: many small forward-only views on a stream pool == one by one."""
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.camera import camera_matrices
+    from active_gs_amd.synthetic import activate, make_camera, make_room_scene
+    dev = torch.device("cuda:0")
+    n, h, w, V = 20000, 128, 128, 24
+    a = activate(make_room_scene(n, seed=5))
+    a["scales"] = a["scales"] * 2
+    g = api.Gaussians(*(a[k].to(dev).contiguous() for k in ("means", "scales", "rotations", "opacities", "colors",
+                                                              "confidences")))
+    cams = []
+    for v in range(V):
+        c2w, K = make_camera(v, h, w, focal_px=0.5 * 128 / 0.5773503)
+        cm = camera_matrices(c2w[None], K[None], 0.001, 10.0)
+        cams.append(api.Camera(h, w, cm["tanfov"][0, 0].item(), cm["tanfov"][0, 1].item(), cm["viewmatrix"][0].to(dev),
+                               cm["projmatrix"][0].to(dev), torch.zeros(4, device=dev), want_stats=(v % 2 == 0),
+                               front_only=(v % 3 == 0)))
+    seq = [api.alloc_state(n, h, w, 1 << 19, dev) for _ in range(V)]
+    par = [api.alloc_state(n, h, w, 1 << 19, dev) for _ in range(V)]
+    api.forward_many(cams, g, seq, None)
+    api.forward_many(cams, g, par, api.StreamPool(4))
+    torch.cuda.synchronize()
+    for s1, s2 in zip(seq, par):
+        assert not api.read_status(s2)["overflow"]
+        for name in ("rgb", "depth", "normal", "opacity", "confidence", "radii", "count"):
+            assert torch.equal(getattr(s1, name), getattr(s2, name)), name
+        assert torch.allclose(s1.importance, s2.importance, rtol=1e-4, atol=1e-6)
