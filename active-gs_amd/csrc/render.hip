@@ -15,7 +15,7 @@
 //     permlane-swap/DPP reduction (ags_wave_reduce16) and issues ONE 15-lane atomic per
 //     (surfel, wave) instead of 64 x SLOTS x 15 atomics.
 // SLOTS = 4 is one wave per tile; SLOTS = 2 / 1 split a tile over 2 / 4 waves (fewer VGPRs,
-// more waves in flight) and are chosen when the image has too few tiles to fill 1024 SIMDs.
+// more waves in flight).  Measured best: 2 from 2048 tiles up, 1 below (AGS_RENDER_SLOTS overrides).
 // Blocks are mapped to tiles XCD-aware (ags_xcd_remap) so one XCD's L2 serves a contiguous
 // band of tiles.  Counterpart of renderCUDA fwd/bwd in SURVEY.md §2.3; arithmetic in
 // surfel_math.h.
@@ -238,9 +238,10 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_bwd(
 static int ags_pick_slots(int num_tiles) {
     const char* e = getenv("AGS_RENDER_SLOTS");
     if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) return e[0] - '0';
-    if (num_tiles >= 8192) return 4; // e.g. 2048x2048: one wave per tile already oversubscribes the SIMDs
-    if (num_tiles >= 2048) return 2; // e.g. 1200x680 (3225 tiles): measured best, DESIGN.md §9
-    return 1;                        // e.g. 512x512 (1024 tiles): four waves per tile
+    // measured: two strips per wave wins from 1200x680 (3225 tiles) up to 2048x2048
+    // (16384 tiles, where one wave per tile is 13 % slower); small images want four waves per tile
+    if (num_tiles >= 2048) return 2;
+    return 1;                        // e.g. 512x512 (1024 tiles), 128x128 planner views
 }
 
 template <int SLOTS>
