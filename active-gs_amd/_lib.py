@@ -82,7 +82,8 @@ _lib = None
 
 
 def library_path() -> str:
-    return _build.LIB
+    # AGS_LIB_PATH: load an alternative build of the same library (kernel experiments)
+    return os.environ.get("AGS_LIB_PATH") or _build.LIB
 
 
 def load() -> C.CDLL:

@@ -17,7 +17,9 @@ LIB = os.path.join(LIBDIR, "libags_raster.so")
 SOURCES = ["preprocess.hip", "binning.hip", "render.hip", "adam.hip", "loss.hip", "capi.hip"]
 HEADERS = ["ags_internal.h", "surfel_math.h", os.path.join("..", "..", "include", "ags_raster.h")]
 # loss.hip must reproduce exact cancellations of the reference's un-fused torch ops (see ags_point)
-EXTRA_FLAGS = {"loss.hip": ["-ffp-contract=off"]}
+# render.hip: -fno-signed-zeros lets the compiler fold the `0 + x` of freshly zeroed accumulators
+# (-2.5 % step time); NaN / inf semantics are left alone.
+EXTRA_FLAGS = {"loss.hip": ["-ffp-contract=off"], "render.hip": ["-fno-signed-zeros"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]
 

@@ -149,8 +149,13 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     }
 }
 
+#ifdef AGS_BWD_WAVES   // experiment knob: force a register budget for N resident waves per SIMD
+#define AGS_BWD_ATTR __attribute__((amdgpu_waves_per_eu(AGS_BWD_WAVES, AGS_BWD_WAVES)))
+#else
+#define AGS_BWD_ATTR
+#endif
 template <int SLOTS>
-__global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_bwd(
+__global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bwd(
     AgsFrame F, int normalize_depth, const float* __restrict__ bgp, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
     const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
