@@ -111,8 +111,8 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
             uint32_t wcnt = 0;
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
-                if (ok[s]) {
-                    const float w = ags_blend_apply(pix[s], g, dx[s], dy[s], al[s], pos1);
+                if (__any(ok[s])) { // wave-uniform; lanes that do not take the surfel blend alpha = 0
+                    const float w = ags_blend_apply(pix[s], g, dx[s], dy[s], ok[s] ? al[s] : 0.f, pos1);
                     if (STATS) { const float wm = w * mk[s]; wsum += wm; wcnt += (wm > weight_thres) ? 1u : 0u; }
                 }
             }
@@ -231,7 +231,8 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
             for (int j = 0; j < 16; ++j) a[j] = 0.f;
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s)
-                if (ok[s]) ags_blend_bwd_apply(pg[s], g, dx[s], dy[s], al[s], acc);
+                if (__any(ok[s])) // wave-uniform branch; inactive lanes contribute with alpha = 0
+                    ags_blend_bwd_apply(pg[s], g, dx[s], dy[s], ok[s] ? al[s] : 0.f, acc);
             const float mine = ags_wave_reduce16(a, lane); // 16 lanes end up owning one total each
             if (my_field >= 0) unsafeAtomicAdd(dgeom + (size_t)st.sid[k] * 16 + my_field, mine);
         }

@@ -338,7 +338,8 @@ AGS_HD bool ags_alpha(const AgsGeom& g, float px, float py, float& dx, float& dy
 // Blend a Gaussian whose alpha test passed; returns weight w (0 when the pixel stops).
 // `pos1` = 1-based position in the tile list.
 AGS_HD float ags_blend_apply(AgsPix& s, const AgsGeom& g, float dx, float dy, float alpha, uint32_t pos1) {
-    // branchless on purpose: per-lane selects, and no conditional stores into `s`
+    // branchless on purpose: per-lane selects, and no conditional stores into `s`.  A lane that
+    // does not take the surfel may be passed alpha = 0: nothing changes for it.
     const float testT = s.T * (1.f - alpha);
     const bool stop = testT < AGS_T_EPS;
     const float w = stop ? 0.f : alpha * s.T;
@@ -347,7 +348,7 @@ AGS_HD float ags_blend_apply(AgsPix& s, const AgsGeom& g, float dx, float dy, fl
     s.d += w * (g.dc + g.gx * dx + g.gy * dy);
     s.cf += w * g.conf;
     s.T = stop ? s.T : testT;
-    s.last = stop ? s.last : pos1;
+    s.last = (stop || !(alpha > 0.f)) ? s.last : pos1;
     s.done = stop ? 1 : s.done;
     return w;
 }
@@ -389,6 +390,8 @@ AGS_HD void ags_pixgrad_init(AgsPixGrad& s, const float dC[3], const float dN[3]
 // One back-to-front step for a Gaussian whose alpha test passed at this pixel
 // (and pos1 <= s.last); accumulates the pixel's contribution into `acc`.
 AGS_HD void ags_blend_bwd_apply(AgsPixGrad& s, const AgsGeom& g, float dx, float dy, float alpha, AgsGeomGrad& acc) {
+    // branchless: a lane that does not take the surfel may be passed alpha = 0 (iom = 1, w = 0,
+    // every contribution vanishes, T and S are unchanged)
     const float iom = ags_rcp(1.f - alpha); // one reciprocal serves T/(1-a) and S/(1-a)
     s.T = s.T * iom; // transmittance in front of this Gaussian
     const float w = alpha * s.T;
@@ -401,16 +404,15 @@ AGS_HD void ags_blend_bwd_apply(AgsPixGrad& s, const AgsGeom& g, float dx, float
     acc.dnx += w * s.dN0; acc.dny += w * s.dN1; acc.dnz += w * s.dN2;
     const float wd = w * s.dDn;
     acc.ddc += wd; acc.dgx += wd * dx; acc.dgy += wd * dy;
-    float ddx = wd * g.gx, ddy = wd * g.gy; // through the per-pixel depth
-    if (alpha < AGS_ALPHA_MAX) {            // clamp passes no gradient
-        acc.dop += alpha * dalpha;          // = o * G * dalpha; the caller divides the tile total by o once
-        const float gp = alpha * dalpha;    // dL/dpower
-        acc.dca += -0.5f * dx * dx * gp;
-        acc.dcb += -dx * dy * gp;
-        acc.dcc += -0.5f * dy * dy * gp;
-        ddx += gp * (-g.ca * dx - g.cb * dy);
-        ddy += gp * (-g.cc * dy - g.cb * dx);
-    }
+    // the 0.99 clamp passes no gradient; gp = dL/dpower = o*G*dalpha = alpha*dalpha when unclamped.
+    // acc.dop collects alpha*dalpha = o * (G*dalpha); the per-Gaussian backward divides by o once.
+    const float gp = (alpha < AGS_ALPHA_MAX) ? alpha * dalpha : 0.f;
+    acc.dop += gp;
+    acc.dca += -0.5f * dx * dx * gp;
+    acc.dcb += -dx * dy * gp;
+    acc.dcc += -0.5f * dy * dy * gp;
+    const float ddx = wd * g.gx + gp * (-g.ca * dx - g.cb * dy); // through the per-pixel depth + the conic
+    const float ddy = wd * g.gy + gp * (-g.cc * dy - g.cb * dx);
     acc.dmx -= ddx; acc.dmy -= ddy; // dx = px - mx
 }
 
