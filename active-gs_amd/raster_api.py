@@ -8,7 +8,7 @@ drop-in ``diff_gaussian_rasterization_2d`` module.
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional, Sequence
 
 import torch

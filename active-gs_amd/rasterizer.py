@@ -10,7 +10,7 @@ The arithmetic runs in libags_raster.so (HIP, gfx950); there is no CPU fallback.
 """
 from __future__ import annotations
 
-from typing import NamedTuple, Optional
+from typing import NamedTuple
 
 import torch
 import torch.nn as nn

@@ -3,7 +3,6 @@ import ctypes
 import os
 import subprocess
 
-import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
