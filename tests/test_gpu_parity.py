@@ -377,3 +377,48 @@ def test_forward_many_streams_equal_sequential(agslib):
         for name in ("rgb", "depth", "normal", "opacity", "confidence", "radii", "count"):
             assert torch.equal(getattr(s1, name), getattr(s2, name)), name
         assert torch.allclose(s1.importance, s2.importance, rtol=1e-4, atol=1e-6)
+
+
+def test_alpha_clamp_near_plane_and_grazing_surfels(agslib):
+    """Branches a random room scene rarely reaches: o*G > 0.99 (clamped alpha, zero gradient through
+    the clamp), surfels on both sides of the z = 0.2 near cull, edge-on surfels (grazing clamp of the
+    depth slope, D5), a coloured background."""
+    from diff_gaussian_rasterization_2d import GaussianRasterizer
+    from oracle.surfel_oracle import OracleSettings, rasterize
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(31)
+    n, h, w = 1200, 96, 96
+    means = torch.stack([(torch.rand(n, generator=gen) - 0.5) * 1.6, (torch.rand(n, generator=gen) - 0.5) * 1.6,
+                         0.6 + torch.rand(n, generator=gen) * 1.5], -1)
+    means[:150, 2] = 0.15 + 0.1 * torch.rand(150, generator=gen)           # around the near cull
+    means[:150, :2] *= 0.1
+    scales = torch.cat([0.01 + 0.04 * torch.rand(n, 2, generator=gen), torch.zeros(n, 1)], 1)
+    q = torch.nn.functional.normalize(torch.tensor([1.0, 0, 0, 0]) + 0.3 * torch.randn(n, 4, generator=gen), dim=-1)
+    # edge-on: rotate 90 deg about x (normal ~ +-y), plus a tiny perturbation
+    s2 = 0.70710678
+    q[200:400] = torch.nn.functional.normalize(torch.tensor([s2, s2, 0, 0]) + 0.01 * torch.randn(200, 4, generator=gen), dim=-1)
+    opac = torch.ones(n)
+    opac[600:] = 0.3 + 0.7 * torch.rand(n - 600, generator=gen)
+    a = dict(means=means, scales=scales, rotations=q, opacities=opac, colors=torch.rand(n, 3, generator=gen),
+             confidences=torch.rand(n, generator=gen))
+    near, far, t = 0.001, 10.0, 0.8
+    P = torch.zeros(4, 4)
+    P[0, 0] = 1 / t; P[1, 1] = 1 / t; P[3, 2] = 1; P[2, 2] = far / (far - near); P[2, 3] = -far * near / (far - near)
+    S = OracleSettings(h, w, t, t, torch.tensor([0.9, 0.5, 0.1, 0.0]), 1.0, torch.eye(4), (torch.eye(4) @ P.t()).contiguous(),
+                       campos=torch.zeros(3), config=torch.tensor([1.0, 1, 1, 0, 0]))
+    ins = oracle_inputs(a)
+    ref = rasterize(*ins, S)
+    vis = ref[7] > 0
+    assert 0 < int(vis[:150].sum()) < 150                                   # some culled by z <= 0.2, some not
+    gen2 = torch.Generator().manual_seed(2)
+    gr = [torch.randn(o.shape, generator=gen2) for o in ref[:5]]
+    sum((o * g).sum() for o, g in zip(ref[:5], gr)).backward()
+    gin = [t_.detach().clone().to(dev).requires_grad_(t_.requires_grad) for t_ in ins]
+    out = GaussianRasterizer(product_settings(S, dev))(gin[0], gin[1], gin[2], gin[3], None, gin[4], gin[5], gin[6], None)
+    sum((o * g.to(dev)).sum() for o, g in zip(out[:5], gr)).backward()
+    torch.cuda.synchronize()
+    _check_images(ref, out)
+    assert (out[7].cpu() != ref[7]).float().mean().item() < 2e-3
+    _check_grads(ins, gin)
+    # the clamp really was active: many pixels carry alpha == 0.99 from an o = 1 surfel
+    assert float(out[3].detach().max()) > 0.98
