@@ -75,3 +75,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+
+
+DEMO_SRC = os.path.normpath(os.path.join(HERE, "..", "examples", "ags_cabi_demo.cpp"))
+DEMO_BIN = os.path.normpath(os.path.join(HERE, "..", "examples", "ags_cabi_demo"))
+
+
+def build_demo() -> str:
+    """Torch-free C++ user of the C ABI (examples/ags_cabi_demo.cpp), linked against the in-tree library."""
+    build()
+    if os.path.exists(DEMO_BIN) and os.path.getmtime(DEMO_BIN) >= max(os.path.getmtime(DEMO_SRC), os.path.getmtime(LIB)):
+        return DEMO_BIN
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.normpath(os.path.join(HERE, "..", "include")),
+           DEMO_SRC, "-L", LIBDIR, "-lags_raster", "-Wl,-rpath,$ORIGIN/../active-gs_amd/lib", "-o", DEMO_BIN]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on the C ABI demo:\n{r.stderr}")
+    return DEMO_BIN

@@ -27,3 +27,13 @@ def test_bench_two_ranks_on_one_gpu(agslib):
     assert d["config"]["parallelism"] == "view-parallel dp2" and not d["config"]["overflow"]
     assert d["config"]["launch"].startswith("hipGraph")
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def test_torch_free_cabi_demo(agslib):
+    """examples/ags_cabi_demo.cpp: the C ABI used from plain C++/HIP (hipMalloc'd buffers, the whole
+    step captured in a hipGraph and replayed) - no torch in the process."""
+    from active_gs_amd import build
+    exe = build.build_demo()
+    r = subprocess.run([exe, "30000", "50"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("OK") and "adam_steps=71" in r.stdout
