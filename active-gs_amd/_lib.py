@@ -33,8 +33,12 @@ class AgsImages(C.Structure):
     _fields_ = [("rgb", c_f32p), ("normal", c_f32p), ("depth", c_f32p), ("opacity", c_f32p), ("confidence", c_f32p)]
 
 
+class AgsRowSet(C.Structure):
+    _fields_ = [("member", C.c_void_p), ("rows", C.c_void_p), ("count", C.c_void_p)]
+
+
 class AgsPerGaussian(C.Structure):
-    _fields_ = [("importance", c_f32p), ("count", C.c_void_p), ("radii", C.c_void_p)]
+    _fields_ = [("importance", c_f32p), ("count", C.c_void_p), ("radii", C.c_void_p), ("touched", AgsRowSet)]
 
 
 class AgsImageGrads(C.Structure):
@@ -45,7 +49,8 @@ class AgsImageGrads(C.Structure):
 class AgsGaussianGrads(C.Structure):
     _fields_ = [("d_means3D", c_f32p), ("d_scales", c_f32p), ("d_rotations", c_f32p), ("d_opacities", c_f32p),
                 ("d_colors", c_f32p), ("d_means2D", c_f32p), ("accumulate", C.c_int32), ("adam_clock", C.c_void_p),
-                ("adam_lr", C.c_float * 5), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float)]
+                ("adam_lr", C.c_float * 5), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float),
+                ("touched", AgsRowSet), ("fused_adam", C.c_void_p), ("adam_eps", C.c_float)]
 
 
 class AgsWorkspace(C.Structure):
@@ -60,7 +65,7 @@ class AgsStatus(C.Structure):
 
 class AgsAdamTensors(C.Structure):
     _fields_ = [("param", c_f32p * 5), ("grad", c_f32p * 5), ("exp_avg", c_f32p * 5), ("exp_avg_sq", c_f32p * 5),
-                ("numel", C.c_int64 * 5), ("lr", C.c_float * 5)]
+                ("numel", C.c_int64 * 5), ("lr", C.c_float * 5), ("touched", AgsRowSet)]
 
 
 class AgsLossConfig(C.Structure):

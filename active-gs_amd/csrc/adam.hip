@@ -7,15 +7,6 @@
 // their moments and move, exactly like the dense torch update.
 #include "ags_internal.h"
 
-struct AgsAdamArgs {
-    float* p[5];
-    const float* g[5];
-    float* m[5];
-    float* v[5];
-    long long end[5]; // cumulative element counts
-    float lr[5];
-};
-
 // Device-resident optimiser clock AgsAdamClock { int step; float step_size[5]; float inv_sqrt_bc2; }
 // (ags_internal.h); advanced either by this 1-thread kernel or on the side of the step's last
 // ags_backward launch (AgsGaussianGrads.adam_clock).
@@ -45,16 +36,38 @@ __global__ __launch_bounds__(256) void ags_k_adam(AgsAdamArgs a, AgsAdamClock ho
     }
 }
 
+// Row-set form (AgsAdamTensors.touched): 16 lanes per member row, lane k < 14 owns one of the
+// row's 14 floats (means 0-2, scales 3-5, rotation 6-9, opacity 10, harmonics 11-13).  Rows
+// outside the set have g = m = v = 0, for which the dense update above is exactly 0.
+__global__ __launch_bounds__(256) void ags_k_adam_rows(AgsAdamArgs a, const AgsAdamClock* __restrict__ clk,
+                                                       AgsAdamClock host_clk, AgsRowSet touched, float beta1,
+                                                       float beta2, float eps) {
+    if (!clk) clk = &host_clk;
+    const float inv_bc2_sqrt = clk->inv_bc2_sqrt;
+    const int k = threadIdx.x & 15;
+    const int seg = (k >= 3) + (k >= 6) + (k >= 10) + (k >= 11);
+    const int width = seg == 2 ? 4 : (seg == 3 ? 1 : 3);
+    const int off = k - (seg == 0 ? 0 : seg == 1 ? 3 : seg == 2 ? 6 : seg == 3 ? 10 : 11);
+    const int count = *touched.count;
+    const int stride = gridDim.x * 16;
+    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < count; r += stride) {
+        if (k >= 14) continue;
+        const long long j = (long long)touched.rows[r] * width + off;
+        const float g = a.g[seg][j];
+        float m = a.m[seg][j], v = a.v[seg][j];
+        m = m + (1.f - beta1) * (g - m);
+        v = v * beta2 + (1.f - beta2) * g * g;
+        const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+        a.m[seg][j] = m;
+        a.v[seg][j] = v;
+        a.p[seg][j] -= clk->step_size[seg] * (m / denom);
+    }
+}
+
 void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, void* dev_state,
                      bool pre_ticked, hipStream_t s) {
-    AgsAdamArgs a;
-    long long run = 0;
-    for (int k = 0; k < 5; ++k) {
-        a.p[k] = t.param[k]; a.g[k] = t.grad[k]; a.m[k] = t.exp_avg[k]; a.v[k] = t.exp_avg_sq[k];
-        run += t.numel[k];
-        a.end[k] = run;
-        a.lr[k] = t.lr[k];
-    }
+    const AgsAdamArgs a = ags_adam_args(t);
+    const long long run = a.end[4];
     if (run <= 0) return;
     AgsAdamClock* clk = (AgsAdamClock*)dev_state;
     AgsAdamClock hc = {};
@@ -68,6 +81,13 @@ void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float ep
         hc.step = step;
         for (int k = 0; k < 5; ++k) hc.step_size[k] = (float)((double)t.lr[k] / bc1);
         hc.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    }
+    if (t.touched.rows) {
+        long long rb = (t.numel[3] + 15) / 16; // 16 rows per block
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(ags_k_adam_rows, dim3((unsigned)rb), dim3(256), 0, s, a, (const AgsAdamClock*)clk, hc,
+                           t.touched, beta1, beta2, eps);
+        return;
     }
     long long blocks = (run + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;

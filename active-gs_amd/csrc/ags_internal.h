@@ -84,25 +84,47 @@ static inline AgsFrame ags_make_frame(const AgsCamera* c) {
     return F;
 }
 
+// Device-resident optimiser clock shared by adam.hip, render.hip (tick) and preprocess.hip (fused step)
+struct AgsAdamClock { int step; float step_size[5]; float inv_bc2_sqrt; float pad[9]; };
+struct AgsAdamArgs {
+    float* p[5];
+    const float* g[5];
+    float* m[5];
+    float* v[5];
+    long long end[5]; // cumulative element counts
+    float lr[5];
+};
+// "advance this Adam clock on the side" request carried by a backward launch (clock == nullptr: off)
+struct AgsTick { AgsAdamClock* clock; float lr[5]; float beta1, beta2; };
+inline AgsAdamArgs ags_adam_args(const AgsAdamTensors& t) {
+    AgsAdamArgs a;
+    long long run = 0;
+    for (int k = 0; k < 5; ++k) {
+        a.p[k] = t.param[k]; a.g[k] = t.grad[k]; a.m[k] = t.exp_avg[k]; a.v[k] = t.exp_avg_sq[k];
+        run += t.numel[k];
+        a.end[k] = run;
+        a.lr[k] = t.lr[k];
+    }
+    return a;
+}
+
 // ---- launchers (one per translation unit; each enqueues on `s` and never synchronises)
 // `ids` + `id_stride`: sorted Gaussian ids per instance; stride 2 when they are the low
 // words of the 64-bit (depth|id) keys of the tile-sort mode.
 struct AgsIdList { const uint32_t* ids; int stride; };
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
-                           const AgsLayout& L, int* radii, bool count_tiles, hipStream_t s);
+                           const AgsLayout& L, int* radii, bool count_tiles, const AgsRowSet& touched, hipStream_t s);
 void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s);
 void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s);
 AgsIdList ags_sorted_ids(char* ws, const AgsLayout& L, int binning_mode);
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, hipStream_t s);
 void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
-                           AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, hipStream_t s);
+                           AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick, hipStream_t s);
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
                                const AgsLayout& L, const int* radii, const AgsGaussianGrads& din, hipStream_t s);
 void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, void* dev_state,
                      bool pre_ticked, hipStream_t s);
-// Device-resident optimiser clock shared by adam.hip and preprocess.hip
-struct AgsAdamClock { int step; float step_size[5]; float inv_bc2_sqrt; float pad[9]; };
 #if defined(__HIPCC__)
 __device__ __forceinline__ void ags_adam_tick(AgsAdamClock* c, const float lr[5], float beta1, float beta2, int host_step) {
     const int step = host_step > 0 ? host_step : c->step + 1;

@@ -58,13 +58,22 @@ int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* o
     // totals and tile ranges every pass
     if ((radix || in->n == 0) && hipMemsetAsync(base + L.status, 0, L.clear_bytes, s) != hipSuccess) return AGS_E_LAUNCH;
     if (in->n > 0) {
-        { StageScope t(AGS_STAGE_PREPROCESS, s); ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, !radix, s); }
+        { StageScope t(AGS_STAGE_PREPROCESS, s); ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, !radix, pg->touched, s); }
         { StageScope t(AGS_STAGE_BINNING, s);
           if (radix) ags_launch_binning(F, *in, base, L, s); else ags_launch_tile_binning(F, *in, base, L, s); }
     }
     { StageScope t(AGS_STAGE_RENDER_FWD, s);
       ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, s); }
     return ags_check_launch();
+}
+
+static int ags_adam_check(const AgsAdamTensors* t) {
+    if (!t) return AGS_E_INVALID;
+    for (int k = 0; k < 5; ++k) {
+        if (t->numel[k] < 0) return AGS_E_INVALID;
+        if (t->numel[k] > 0 && (!t->param[k] || !t->grad[k] || !t->exp_avg[k] || !t->exp_avg_sq[k])) return AGS_E_INVALID;
+    }
+    return AGS_OK;
 }
 
 int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* fwd,
@@ -83,7 +92,20 @@ int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* 
     const AgsIdList vals_sorted = ags_sorted_ids(base, L, ws->binning_mode); // where the forward left them
     // dgeom needs no memset: ags_forward zeroed the records of the visible surfels and every
     // ags_backward leaves them zeroed again
-    { StageScope t(AGS_STAGE_RENDER_BWD, s); ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, s); }
+    AgsTick tick = {};
+    if (din->adam_clock) {
+        tick.clock = (AgsAdamClock*)din->adam_clock;
+        for (int k = 0; k < 5; ++k) tick.lr[k] = din->adam_lr[k];
+        tick.beta1 = din->adam_beta1; tick.beta2 = din->adam_beta2;
+    }
+    if (din->fused_adam) {
+        if (!din->touched.rows || !din->touched.count || !din->adam_clock || din->accumulate == 2) return AGS_E_INVALID;
+        if (int e = ags_adam_check(din->fused_adam)) return e;
+        const int64_t* ne = din->fused_adam->numel; // the five map tensors: 3n, 3n, 4n, n, 3n
+        const int64_t n64 = in->n;
+        if (ne[0] != 3 * n64 || ne[1] != 3 * n64 || ne[2] != 4 * n64 || ne[3] != n64 || ne[4] != 3 * n64) return AGS_E_INVALID;
+    }
+    { StageScope t(AGS_STAGE_RENDER_BWD, s); ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, tick, s); }
     { StageScope t(AGS_STAGE_PREPROCESS_BWD, s); ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, s); }
     return ags_check_launch();
 }
@@ -93,15 +115,6 @@ int ags_read_status(const AgsWorkspace* ws, AgsStatus* host_out, ags_stream_t st
     hipStream_t s = (hipStream_t)stream;
     if (hipMemcpyAsync(host_out, ws->ptr, sizeof(AgsStatus), hipMemcpyDeviceToHost, s) != hipSuccess) return AGS_E_LAUNCH;
     if (hipStreamSynchronize(s) != hipSuccess) return AGS_E_LAUNCH;
-    return AGS_OK;
-}
-
-static int ags_adam_check(const AgsAdamTensors* t) {
-    if (!t) return AGS_E_INVALID;
-    for (int k = 0; k < 5; ++k) {
-        if (t->numel[k] < 0) return AGS_E_INVALID;
-        if (t->numel[k] > 0 && (!t->param[k] || !t->grad[k] || !t->exp_avg[k] || !t->exp_avg_sq[k])) return AGS_E_INVALID;
-    }
     return AGS_OK;
 }
 

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     AgsGeom* __restrict__ geom, uint32_t* __restrict__ tiles, ushort4* __restrict__ rect,
     int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_vis,
-    uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom) {
+    uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom, AgsRowSet touched) {
     __shared__ uint32_t wsum[AGS_PRE_THREADS / 64], wvis[AGS_PRE_THREADS / 64];
     __shared__ AgsEmitRec emit[COUNT_TILES ? AGS_PRE_THREADS : 1];
     __shared__ __attribute__((aligned(16))) float rows3[3 * AGS_PRE_THREADS];
@@ -107,6 +107,18 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
         radii[i] = radius;
         tiles[i] = cnt;
     }
+    if (touched.member) { // sticky row set of the optimisation loop: insert first-time-visible surfels
+        // (after the first few steps of a keyframe nothing is new and this is one sparse read)
+        const bool fresh = vis && touched.member[i] == 0 && atomicExch(&touched.member[i], 1) == 0;
+        const unsigned long long mask = __ballot(fresh);
+        if (mask) { // wave-uniform
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(touched.count, (int)__builtin_popcountll(mask));
+            base = __shfl(base, (int)__builtin_ctzll(mask));
+            if (fresh) touched.rows[base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = i;
+        }
+    }
     if (COUNT_TILES)  // tile-sort binning: how many surfels can reach each tile
         ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, rx0, ry0, rwd, 0u, g, F.tiles_x,
                                 [&](uint32_t t, uint32_t) { atomicAdd(&tile_count[t], 1u); });
@@ -133,9 +145,6 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
     const int first = blockIdx.x * AGS_PRE_THREADS;
     const int i = first + threadIdx.x;
     const int rows = min(AGS_PRE_THREADS, in.n - first);
-    // side job of the step's last backward: advance the Adam device clock (this launch completes
-    // before the Adam kernel starts, so every Adam block sees the new scalars)
-    if (out.adam_clock && i == 0) ags_adam_tick((AgsAdamClock*)out.adam_clock, out.adam_lr, out.adam_beta1, out.adam_beta2, 0);
     float dm[3] = {0, 0, 0}, ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0}, dm2[2] = {0, 0};
     const bool vis = (i < in.n) && radii[i] > 0;
     // a block with no visible surfel has nothing to add (accumulate) / only zeros to write
@@ -211,22 +220,194 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
     }
 }
 
+// Row-set form of the kernel above (AgsGaussianGrads.touched): one lane per MEMBER row instead of
+// one per map row.  At the headline view 6.7 % of the map is visible, so this reads and writes
+// ~13 k scattered rows instead of streaming all 200 k.
+//
+// FUSED_ADAM (AgsGaussianGrads.fused_adam): the row's 14 gradient values are final once this view
+// is added, so the same lane applies the Adam update to the row's parameters right here - no
+// second kernel and no gradient round trip.  The clock was advanced by the blend backward that
+// ran just before on this stream (AgsTick), so every lane reads finished scalars.
+#define AGS_ROWS_THREADS 64 // one wave per workgroup: the few member rows spread over all CUs
+template <bool FUSED_ADAM>
+__global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
+    AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
+    const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsAdamArgs adam) {
+    float V[16], P[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
+    __shared__ float adam_g[FUSED_ADAM ? AGS_ROWS_THREADS * 17 : 1]; // [row][14 gradients], stride 17: no bank conflicts
+    __shared__ int adam_row[FUSED_ADAM ? AGS_ROWS_THREADS : 1];
+    const int lane = threadIdx.x;
+    // This kernel is a short chain of dependent loads on few rows (latency, not bandwidth), so every
+    // load that can be issued early is: the first batch of row ids is fetched while the member count
+    // is still in flight (the list is zero-filled past `count`, so any slot holds a valid row), and
+    // a row's inputs are fetched together with its radius instead of behind the visibility test.
+    const int slot0 = min(blockIdx.x * AGS_ROWS_THREADS + lane, in.n - 1);
+    int i_next = out.touched.rows[slot0];
+    const int count = *out.touched.count;
+    for (int base = blockIdx.x * AGS_ROWS_THREADS; base < count; base += gridDim.x * AGS_ROWS_THREADS) { // wave-uniform
+        const bool valid = base + lane < count;
+        const int i = valid ? i_next : 0;
+        {
+            const int nb = base + gridDim.x * AGS_ROWS_THREADS;
+            if (nb < count) i_next = out.touched.rows[min(nb + lane, in.n - 1)];
+        }
+        const int rad = radii[i];
+        float p[3], sc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { p[k] = in.means3D[3 * i + k]; sc[k] = in.scales[3 * i + k]; }
+        const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
+        float opacity = in.opacities[i];
+        float4* src = reinterpret_cast<float4*>(dgeom + i);
+        const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+        const bool vis = valid && rad > 0;
+        float dm[3] = {0, 0, 0}, ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0}, dm2[2] = {0, 0};
+        if (vis) {
+            float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            float raw_v[3] = {0, 0, 0}, qinv = 1.f;
+            if (in.raw_params) ags_activate_inplace(in, sc, q, opacity, raw_v, qinv);
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            src[0] = z4; src[1] = z4; src[2] = z4; src[3] = z4;
+            AgsGeomGrad dg;
+            dg.dmx = a.x; dg.dmy = a.y; dg.dca = a.z; dg.dcb = a.w;
+            dg.dcc = b.x; dg.dop = b.y; dg.ddc = b.z; dg.dgx = b.w;
+            dg.dgy = c.x; dg.dr = c.y; dg.dg = c.z; dg.db = c.w;
+            dg.dnx = d.x; dg.dny = d.y; dg.dnz = d.z; dg.pad = 0.f;
+            ags_preprocess_bwd(F, V, P, p, sc, q, opacity, dg, dm, ds, dq, &dop, dcol, dm2);
+            if (in.raw_params) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ds[k] = (raw_v[k] >= 0.f && raw_v[k] <= in.max_scale) ? ds[k] * raw_v[k] : 0.f;
+                const float dot = q[0] * dq[0] + q[1] * dq[1] + q[2] * dq[2] + q[3] * dq[3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dq[k] = (dq[k] - q[k] * dot) * qinv;
+                dop *= opacity * (1.f - opacity);
+            }
+        }
+        if (out.accumulate == 2) {
+            if (vis) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    unsafeAtomicAdd(&out.d_means3D[3 * i + k], dm[k]);
+                    unsafeAtomicAdd(&out.d_scales[3 * i + k], ds[k]);
+                    unsafeAtomicAdd(&out.d_colors[3 * i + k], dcol[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) unsafeAtomicAdd(&out.d_rotations[4 * i + k], dq[k]);
+                unsafeAtomicAdd(&out.d_opacities[i], dop);
+                if (out.d_means2D) { unsafeAtomicAdd(&out.d_means2D[3 * i], dm2[0]); unsafeAtomicAdd(&out.d_means2D[3 * i + 1], dm2[1]); }
+            }
+        } else if (out.accumulate) {
+            if (vis || (FUSED_ADAM && valid)) { // the fused step needs the totals of rows this view does not show too
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    dm[k] += out.d_means3D[3 * i + k]; ds[k] += out.d_scales[3 * i + k]; dcol[k] += out.d_colors[3 * i + k];
+                }
+                float4* dr = reinterpret_cast<float4*>(out.d_rotations) + i;
+                const float4 o = *dr;
+                dq[0] += o.x; dq[1] += o.y; dq[2] += o.z; dq[3] += o.w;
+                dop += out.d_opacities[i];
+            }
+            if (vis) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    out.d_means3D[3 * i + k] = dm[k]; out.d_scales[3 * i + k] = ds[k]; out.d_colors[3 * i + k] = dcol[k];
+                }
+                reinterpret_cast<float4*>(out.d_rotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+                out.d_opacities[i] = dop;
+                if (out.d_means2D) { out.d_means2D[3 * i] += dm2[0]; out.d_means2D[3 * i + 1] += dm2[1]; }
+            }
+        } else if (valid) { // overwrite: member rows this view does not show get their zeros
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                out.d_means3D[3 * i + k] = dm[k]; out.d_scales[3 * i + k] = ds[k]; out.d_colors[3 * i + k] = dcol[k];
+            }
+            reinterpret_cast<float4*>(out.d_rotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+            out.d_opacities[i] = dop;
+            if (out.d_means2D) { out.d_means2D[3 * i] = dm2[0]; out.d_means2D[3 * i + 1] = dm2[1]; out.d_means2D[3 * i + 2] = 0.f; }
+        }
+        if (FUSED_ADAM) {
+            // regroup through LDS: 16 lanes per row, lane k < 14 owns one of the row's 14 floats
+            // (means 0-2, scales 3-5, rotation 6-9, opacity 10, harmonics 11-13), so each row's
+            // 3-4 consecutive floats of a tensor are one small coalesced access
+            float* gl = adam_g + lane * 17;
+            gl[0] = dm[0]; gl[1] = dm[1]; gl[2] = dm[2]; gl[3] = ds[0]; gl[4] = ds[1]; gl[5] = ds[2];
+            gl[6] = dq[0]; gl[7] = dq[1]; gl[8] = dq[2]; gl[9] = dq[3]; gl[10] = dop;
+            gl[11] = dcol[0]; gl[12] = dcol[1]; gl[13] = dcol[2];
+            adam_row[lane] = valid ? i : -1;
+            __syncthreads();
+            const AgsAdamClock* clk = (const AgsAdamClock*)out.adam_clock;
+            const float ib = clk->inv_bc2_sqrt, b1 = out.adam_beta1, b2 = out.adam_beta2, eps = out.adam_eps;
+            const int k = lane & 15;
+            const int seg = (k >= 3) + (k >= 6) + (k >= 10) + (k >= 11);
+            const int width = seg == 2 ? 4 : (seg == 3 ? 1 : 3);
+            const int off = k - (seg == 0 ? 0 : seg == 1 ? 3 : seg == 2 ? 6 : seg == 3 ? 10 : 11);
+            float* pp = seg == 0 ? adam.p[0] : seg == 1 ? adam.p[1] : seg == 2 ? adam.p[2] : seg == 3 ? adam.p[3] : adam.p[4];
+            float* pm = seg == 0 ? adam.m[0] : seg == 1 ? adam.m[1] : seg == 2 ? adam.m[2] : seg == 3 ? adam.m[3] : adam.m[4];
+            float* pv = seg == 0 ? adam.v[0] : seg == 1 ? adam.v[1] : seg == 2 ? adam.v[2] : seg == 3 ? adam.v[3] : adam.v[4];
+            const float step_size = clk->step_size[seg];
+            // two phases so that all 48 loads of the wave are in flight together (the stores of one
+            // row must not order the loads of the next)
+            constexpr int R = AGS_ROWS_THREADS / 4;
+            float mm[R], vv[R], pq[R], gg[R];
+            size_t jj[R];
+            bool on[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const int row = t * 4 + (lane >> 4);
+                const int i2 = adam_row[row];
+                on[t] = k < 14 && i2 >= 0;
+                jj[t] = on[t] ? (size_t)i2 * width + off : 0;
+                gg[t] = adam_g[row * 17 + k];
+            }
+#pragma unroll
+            for (int t = 0; t < R; ++t) { mm[t] = pm[jj[t]]; vv[t] = pv[jj[t]]; pq[t] = pp[jj[t]]; }
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const float m = mm[t] + (1.f - b1) * (gg[t] - mm[t]);
+                const float v = vv[t] * b2 + (1.f - b2) * gg[t] * gg[t];
+                const float denom = sqrtf(v) * ib + eps;
+                if (on[t]) {
+                    pm[jj[t]] = m;
+                    pv[jj[t]] = v;
+                    pp[jj[t]] = pq[t] - step_size * (m / denom);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
-                           const AgsLayout& L, int* radii, bool count_tiles, hipStream_t s) {
+                           const AgsLayout& L, int* radii, bool count_tiles, const AgsRowSet& touched, hipStream_t s) {
     if (count_tiles)
         hipLaunchKernelGGL(ags_k_preprocess<true>, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
                            cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
                            (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums),
-                           (uint32_t*)(ws + L.block_vis), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom));
+                           (uint32_t*)(ws + L.block_vis), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched);
     else
         hipLaunchKernelGGL(ags_k_preprocess<false>, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
                            cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
                            (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums),
-                           (uint32_t*)(ws + L.block_vis), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom));
+                           (uint32_t*)(ws + L.block_vis), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched);
 }
 
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
                                const AgsLayout& L, const int* radii, const AgsGaussianGrads& din, hipStream_t s) {
+    if (din.touched.rows) {
+        // the member count lives on the device: a fixed grid strides over the list
+        int blocks = (in.n + AGS_ROWS_THREADS - 1) / AGS_ROWS_THREADS;
+        if (blocks > 2048) blocks = 2048;
+        if (din.fused_adam)
+            hipLaunchKernelGGL(ags_k_preprocess_bwd_rows<true>, dim3(blocks), dim3(AGS_ROWS_THREADS), 0, s, F,
+                               cam.viewmatrix, cam.projmatrix, in, radii, (AgsGeomGrad*)(ws + L.dgeom), din,
+                               ags_adam_args(*din.fused_adam));
+        else
+            hipLaunchKernelGGL(ags_k_preprocess_bwd_rows<false>, dim3(blocks), dim3(AGS_ROWS_THREADS), 0, s, F,
+                               cam.viewmatrix, cam.projmatrix, in, radii, (AgsGeomGrad*)(ws + L.dgeom), din,
+                               AgsAdamArgs());
+        return;
+    }
     hipLaunchKernelGGL(ags_k_preprocess_bwd, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
                        cam.projmatrix, in, radii, (AgsGeomGrad*)(ws + L.dgeom), din);
 }

@@ -86,6 +86,10 @@ class FusedMapTrainer(GaussianMapTrainer):
         n = self.means.shape[0]
         optim = FusedAdam(params, [lrs["mean"], lrs["scale"], lrs["rotation"], lrs["opacity"], lrs["harmonic"]], eps=1e-15)
         slab = GradSlab(n, self.device)
+        # sticky set of the surfels this call's views have shown (single rank; see api.RowSet)
+        rows = api.RowSet(n, self.device) if self.world == 1 else None
+        optim.touched = rows
+        slab.flat.zero_()
         sampler = WeightedFrameSampler(self.frames, self.cfg["batch_size"], self.cfg["active_size"])
         self.last_losses = []
         self._cap = max(self._cap, 1 << 16, 2 * n)
@@ -128,7 +132,7 @@ class FusedMapTrainer(GaussianMapTrainer):
             def fwd_view(slot, b, sh):
                 cam, _, _ = self._camera(int(ids[b]))
                 st = self._state(slot, n, h, w)
-                api.forward(cam, g, st, stream=sh, checked=True)
+                api.forward(cam, g, st, stream=sh, checked=True, touched=rows)
                 f = self.frames[int(ids[b])]
                 self._loss.stage1(st, f["rgb"], f["depth"], self._loss_bufs[slot], b, -1 if S > 1 else slot == 0, sh)
 
@@ -137,7 +141,7 @@ class FusedMapTrainer(GaussianMapTrainer):
                 st, buf = self._states[slot], self._loss_bufs[slot]
                 self._loss.stage2(st, self.frames[int(ids[b])]["depth"], buf, sh)
                 api.backward(cam, g, st, buf.d_rgb, buf.d_normal, buf.d_depth, None, None, grads=slab.grads,
-                             accumulate=2 if S > 1 else (slot > 0), stream=sh)
+                             accumulate=2 if S > 1 else (slot > 0), stream=sh, touched=rows)
 
             while True:  # forward every local view; re-run the batch once if a workspace was too small
                 self._loss.begin_step()

@@ -31,18 +31,16 @@ class FusedAdam:
         self.step_count = 0
         # device-resident clock {int step; float step_size[5]; float inv_sqrt_bc2; ...} for graph replay
         self.device_clock = torch.zeros(16, device=params[0].device, dtype=torch.int32)
+        # optional raster_api.RowSet: update only the surfels this optimiser's views have shown
+        # (exact: the others have zero gradient and zero moments, so the dense update is 0)
+        self.touched = None
 
     def tick_args(self):
         """What ``raster_api.backward(adam_tick=...)`` needs to advance this optimizer's device clock."""
         return (self.device_clock, self.lrs, self.betas[0], self.betas[1])
 
-    def step(self, grads: Sequence[torch.Tensor], device_clock: bool = False, pre_ticked: bool = False) -> None:
-        """One Adam update. With ``device_clock=True`` the step counter lives on the GPU
-        (``ags_adam_step_device``), so the call can be captured in a hipGraph and replayed;
-        ``pre_ticked`` says the step's last backward launch already advanced that clock."""
-        lib = _lib.load()
-        if not device_clock:
-            self.step_count += 1
+    def tensors_struct(self, grads: Sequence[torch.Tensor]) -> "_lib.AgsAdamTensors":
+        """The C-ABI view of this optimiser (also what ``raster_api.backward(fused_adam=...)`` takes)."""
         t = _lib.AgsAdamTensors()
         for k in range(5):
             g = grads[k]
@@ -56,7 +54,19 @@ class FusedAdam:
             t.exp_avg_sq[k] = ptr(self.exp_avg_sq[k])
             t.numel[k] = self.params[k].numel()
             t.lr[k] = self.lrs[k]
+        if self.touched is not None:
+            t.touched = self.touched.c_struct()
         self._keep = grads
+        return t
+
+    def step(self, grads: Sequence[torch.Tensor], device_clock: bool = False, pre_ticked: bool = False) -> None:
+        """One Adam update. With ``device_clock=True`` the step counter lives on the GPU
+        (``ags_adam_step_device``), so the call can be captured in a hipGraph and replayed;
+        ``pre_ticked`` says the step's last backward launch already advanced that clock."""
+        lib = _lib.load()
+        if not device_clock:
+            self.step_count += 1
+        t = self.tensors_struct(grads)
         stream = torch.cuda.current_stream().cuda_stream
         if device_clock:
             _lib.check(lib.ags_adam_step_device(C.byref(t), self.betas[0], self.betas[1], self.eps,

@@ -69,6 +69,28 @@ class Gaussians:
                                  float(self.scale_factor), float(self.max_scale))
 
 
+class RowSet:
+    """Sticky set of surfels an optimisation loop has seen (``AgsRowSet`` in include/ags_raster.h):
+    ``forward`` inserts the visible ones, ``backward`` and the fused Adam then touch only member
+    rows.  ``reset()`` empties it - do that together with zeroing the gradient slab and the Adam
+    moments (the reference re-creates its optimiser per train() call, gaussian_map.py:259-292)."""
+
+    def __init__(self, n: int, device):
+        self.buf = torch.zeros(2 * n + 1, device=device, dtype=torch.int32)
+        self.n = n
+        self.member, self.rows, self.count = self.buf[:n], self.buf[n:2 * n], self.buf[2 * n:]
+
+    def reset(self) -> None:
+        self.buf.zero_()
+
+    def c_struct(self) -> _lib.AgsRowSet:
+        return _lib.AgsRowSet(ptr(self.member), ptr(self.rows), ptr(self.count))
+
+
+def _rowset_struct(rs) -> _lib.AgsRowSet:
+    return rs.c_struct() if rs is not None else _lib.AgsRowSet(None, None, None)
+
+
 @dataclass
 class ForwardState:
     rgb: torch.Tensor
@@ -86,8 +108,8 @@ class ForwardState:
     def images_struct(self) -> _lib.AgsImages:
         return _lib.AgsImages(ptr(self.rgb), ptr(self.normal), ptr(self.depth), ptr(self.opacity), ptr(self.confidence))
 
-    def per_gaussian_struct(self) -> _lib.AgsPerGaussian:
-        return _lib.AgsPerGaussian(ptr(self.importance), ptr(self.count), ptr(self.radii))
+    def per_gaussian_struct(self, touched=None) -> _lib.AgsPerGaussian:
+        return _lib.AgsPerGaussian(ptr(self.importance), ptr(self.count), ptr(self.radii), _rowset_struct(touched))
 
     def ws_struct(self) -> _lib.AgsWorkspace:
         return _lib.AgsWorkspace(ptr(self.workspace), self.workspace.numel(), self.max_instances,
@@ -126,9 +148,10 @@ def alloc_state(n: int, h: int, w: int, max_instances: int, device, binning_mode
     return st
 
 
-def forward(cam: Camera, g: Gaussians, state: ForwardState, stream: Optional[int] = None, checked: bool = False
-            ) -> ForwardState:
+def forward(cam: Camera, g: Gaussians, state: ForwardState, stream: Optional[int] = None, checked: bool = False,
+            touched: Optional[RowSet] = None) -> ForwardState:
     """Enqueue one forward pass into ``state`` (see ``alloc_state``). Asynchronous.
+    ``touched``: a ``RowSet`` the visible surfels are inserted into (training loops).
     ``stream``: raw HIP stream handle (default: torch's current stream); ``checked``: the caller
     vouches for contiguous float32 GPU inputs (hot loops skip the per-call validation)."""
     lib = _lib.load()
@@ -139,7 +162,7 @@ def forward(cam: Camera, g: Gaussians, state: ForwardState, stream: Optional[int
         state.importance.zero_()
         state.count.zero_()
     cs, gs = cam.c_struct(), g.c_struct()
-    im, pg, ws = state.images_struct(), state.per_gaussian_struct(), state.ws_struct()
+    im, pg, ws = state.images_struct(), state.per_gaussian_struct(touched), state.ws_struct()
     _lib.check(lib.ags_forward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(ws),
                                _stream() if stream is None else stream), "ags_forward")
     return state
@@ -174,9 +197,13 @@ def alloc_grads(n: int, device, with_means2d: bool = False, zero: bool = False) 
 
 def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_normal=None, d_depth=None,
              d_opacity=None, d_confidence=None, grads: Optional[GaussianGrads] = None,
-             accumulate: bool = False, adam_tick=None, stream: Optional[int] = None) -> GaussianGrads:
+             accumulate: bool = False, adam_tick=None, stream: Optional[int] = None,
+             touched: Optional[RowSet] = None, fused_adam=None) -> GaussianGrads:
     """Enqueue the backward pass of the view held in ``state``. Asynchronous.
-    ``adam_tick`` = (device_clock_tensor, lrs, beta1, beta2): also advance that Adam clock."""
+    ``adam_tick`` = (device_clock_tensor, lrs, beta1, beta2): also advance that Adam clock.
+    ``touched``: the ``RowSet`` given to this view's ``forward``: only its rows are written.
+    ``fused_adam`` = (AgsAdamTensors struct, eps): the launch also performs the optimiser step for
+    the member rows (last view of a single-GPU step; needs ``touched`` and ``adam_tick``)."""
     lib = _lib.load()
     if grads is None:
         grads = alloc_grads(g.n, g.means3D.device)
@@ -196,6 +223,11 @@ def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_norma
         for k in range(5):
             din.adam_lr[k] = float(lrs[k])
         din.adam_beta1, din.adam_beta2 = float(b1), float(b2)
+    din.touched = _rowset_struct(touched)
+    if fused_adam is not None:
+        tensors, eps = fused_adam
+        din.fused_adam = C.cast(C.pointer(tensors), C.c_void_p)
+        din.adam_eps = float(eps)
     _lib.check(lib.ags_backward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(dout), C.byref(din),
                                 C.byref(ws), _stream() if stream is None else stream), "ags_backward")
     return grads

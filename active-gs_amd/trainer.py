@@ -53,7 +53,7 @@ class SurfelTrainer:
 
     def __init__(self, raw: dict, lrs: Optional[dict] = None, scale_factor: float = 0.01, max_scale: float = 0.05,
                  eps: float = 1e-15, process_group=None, binning_mode: int = api.BIN_TILE_SORT,
-                 fused_activations: bool = True):
+                 fused_activations: bool = True, sparse_rows: bool = True):
         from .optimizer import FusedAdam
         lrs = {**DEFAULT_LRS, **(lrs or {})}
         self.raw = {k: v.contiguous() for k, v in raw.items()}
@@ -76,6 +76,14 @@ class SurfelTrainer:
         # True: the per-Gaussian kernels apply the activations and their chain rule in registers
         # (AgsGaussians.raw_params); False: separate ags_activate / ags_activate_backward launches
         self.fused_activations = fused_activations
+        # Sticky set of the surfels this optimiser's views have shown (api.RowSet): the per-Gaussian
+        # backward and Adam launch work for those rows only.  Lossless (untouched rows have zero
+        # gradient and zero moments -> a zero Adam update); single-rank only, because with data
+        # parallelism the all-reduced slab carries rows other ranks have seen.
+        self.rows = api.RowSet(self.n, dev) if (sparse_rows and not self._distributed()) else None
+        if self.rows is not None:
+            self.slab.flat.zero_()
+            self.optim.touched = self.rows
         self._state = {}
 
     # -- pieces --------------------------------------------------------------------------
@@ -116,19 +124,24 @@ class SurfelTrainer:
                                  scale_factor=self.scale_factor, max_scale=self.max_scale)
         return self.activate()
 
-    def _local_pass(self, cams, image_grads, max_instances, tick: bool = False) -> bool:
+    def _local_pass(self, cams, image_grads, max_instances, tick: bool = False, fuse_adam: bool = False) -> bool:
         """Forward+backward of this rank's views; with ``tick`` the last backward also advances
-        the Adam device clock. Returns whether the clock was advanced."""
+        the Adam device clock (returns whether it did); with ``fuse_adam`` that last backward
+        performs the optimiser step itself (``self.adam_fused`` says whether it did)."""
         g = self.gaussians()
         ticked = False
+        self.adam_fused = False
+        fuse_adam = fuse_adam and tick and self.rows is not None and self.fused_activations
         for v, cam in enumerate(cams):
             st = self.state_for(cam.image_height, cam.image_width, max_instances)
-            api.forward(cam, g, st)
+            api.forward(cam, g, st, touched=self.rows)
             d = image_grads(v, st)
             last = tick and v == len(cams) - 1
+            fused = (self.optim.tensors_struct(self.slab.as_list()), self.optim.eps) if (last and fuse_adam) else None
             api.backward(cam, g, st, *d, grads=self.slab.grads, accumulate=(v > 0),
-                         adam_tick=self.optim.tick_args() if last else None)
+                         adam_tick=self.optim.tick_args() if last else None, touched=self.rows, fused_adam=fused)
             ticked |= last
+            self.adam_fused |= fused is not None
         if len(cams) == 0:
             self.slab.flat.zero_()
         if not self.fused_activations:
@@ -141,10 +154,12 @@ class SurfelTrainer:
         image gradients (d_rgb, d_normal, d_depth, d_opacity, d_confidence; None = zero)
         for that view, already divided by the GLOBAL number of views where the loss is a
         batch mean.  Asynchronous except for the collective."""
-        ticked = self._local_pass(cams, image_grads, max_instances, tick=device_clock)
-        if self._distributed():
+        dist_on = self._distributed()
+        ticked = self._local_pass(cams, image_grads, max_instances, tick=device_clock, fuse_adam=not dist_on)
+        if dist_on:
             torch.distributed.all_reduce(self.slab.flat, group=self.pg)
-        self.optim.step(self.slab.as_list(), device_clock=device_clock, pre_ticked=ticked)
+        if not self.adam_fused:
+            self.optim.step(self.slab.as_list(), device_clock=device_clock, pre_ticked=ticked)
 
     def capture(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int) -> Callable:
         """Capture one optimisation step into hipGraphs and return a ``replay()`` callable.
@@ -167,8 +182,9 @@ class SurfelTrainer:
                     self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
             else:
                 with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
-                    ticked = self._local_pass(cams, image_grads, max_instances, tick=True)
-                    self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
+                    ticked = self._local_pass(cams, image_grads, max_instances, tick=True, fuse_adam=True)
+                    if not self.adam_fused:
+                        self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
         torch.cuda.current_stream().wait_stream(side)
 
         def replay():

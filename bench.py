@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--binning", choices=["tile_sort", "radix"], default="tile_sort")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
     args = ap.parse_args()
+    if os.environ.get("AGS_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack and exit after N s
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["AGS_BENCH_WATCHDOG"]), exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -90,12 +90,28 @@ typedef struct AgsImages {
     float* confidence; /* (1,H,W) */
 } AgsImages;
 
+/* Optional sticky row set (all NULL = off) for optimisation loops that see a small part of the
+ * map: the reference re-creates its optimiser for every train() call (gaussian_map.py:259-292),
+ * so a surfel that no view of the call has shown yet has gradient, exp_avg and exp_avg_sq all
+ * exactly zero and torch's dense Adam update moves it by exactly 0 - skipping it is lossless.
+ * ags_forward appends every surfel that passes the cull and is not yet a member (so the set
+ * only grows); ags_backward and ags_adam_step* then launch work for the listed rows only.
+ * The caller zero-fills member, rows and count, the gradient slab and the Adam moments together
+ * when it (re)creates the optimiser state.  Several views may insert concurrently from different
+ * streams (insertion is atomic). */
+typedef struct AgsRowSet {
+    int32_t* member; /* (n) 0 / 1 */
+    int32_t* rows;   /* (n) member rows in insertion order */
+    int32_t* count;  /* (1) number of member rows */
+} AgsRowSet;
+
 /* The three per-Gaussian outputs of the 8-tuple. importance/count are written only when
  * want_stats != 0 (they must be zero-filled by the caller before the call). */
 typedef struct AgsPerGaussian {
     float* importance; /* (n) */
     int32_t* count;    /* (n) */
     int32_t* radii;    /* (n) */
+    AgsRowSet touched; /* optional: ags_forward inserts the visible surfels */
 } AgsPerGaussian;
 
 /* Incoming image gradients of the backward pass (any may be NULL = zeros). */
@@ -106,6 +122,8 @@ typedef struct AgsImageGrads {
     const float* d_opacity;
     const float* d_confidence;
 } AgsImageGrads;
+
+struct AgsAdamTensors;
 
 /* Gradients wrt the tensor kwargs; d_means2D is (n,3) with z = 0 and may be NULL. */
 typedef struct AgsGaussianGrads {
@@ -123,6 +141,17 @@ typedef struct AgsGaussianGrads {
     void* adam_clock;
     float adam_lr[5];
     float adam_beta1, adam_beta2;
+    /* Optional: only the rows of this set are read or written (rows outside it keep whatever the
+     * slab holds - zeros, by the AgsRowSet contract).  Must contain every surfel the view shows,
+     * i.e. be the set that was passed to this view's ags_forward. */
+    AgsRowSet touched;
+    /* Optional (NULL = off): fold the optimiser step into this launch.  Give it with the LAST view
+     * of a single-GPU optimisation step, together with `touched` and `adam_clock`: after adding
+     * this view's gradients the per-Gaussian kernel applies ags_adam_step_device's update to every
+     * member row while its gradient is still in registers (fused_adam->grad is ignored, the slab
+     * above is still written).  Do not call ags_adam_step* for that step.  Not with accumulate 2. */
+    const struct AgsAdamTensors* fused_adam;
+    float adam_eps;
 } AgsGaussianGrads;
 
 #define AGS_BIN_TILE_SORT 0 /* tile counting + bucket scatter + per-tile LDS bitonic sort (default) */
@@ -175,6 +204,7 @@ typedef struct AgsAdamTensors {
     float* exp_avg_sq[5];
     int64_t numel[5];
     float lr[5];
+    AgsRowSet touched; /* optional: update the member rows only (exact, see AgsRowSet) */
 } AgsAdamTensors;
 int ags_adam_step(const AgsAdamTensors* t, float beta1, float beta2, float eps, int32_t step,
                   ags_stream_t stream);

@@ -14,11 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_two_ranks_on_one_gpu(agslib):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, AGS_BENCH_SHARE_GPU="1", AGS_BENCH_BACKEND="gloo")
+    env = dict(os.environ, AGS_BENCH_SHARE_GPU="1", AGS_BENCH_BACKEND="gloo", AGS_BENCH_WATCHDOG="180")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
            "--warmup", "3", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                  # exactly one JSON line, from rank 0

@@ -224,6 +224,66 @@ def test_graph_replay_matches_eager_steps(agslib):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
 
 
+def test_sparse_row_set_equals_dense_training(agslib):
+    """AgsRowSet: the per-Gaussian backward and Adam run over the sticky list of surfels the views
+    have shown.  Must equal the dense update (untouched rows have g = m = v = 0 -> zero update),
+    and the set must be exactly the union of the visible surfels, each listed once."""
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.synthetic import make_room_scene
+    from active_gs_amd.trainer import SurfelTrainer
+    dev = torch.device("cuda:0")
+    n, h, w = 9000, 136, 240
+    cams = []
+    for view in range(4):
+        _, S = room_case(n, h, w, view=view, seed=5)
+        cams.append(api.Camera(S.image_height, S.image_width, S.tanfovx, S.tanfovy, S.viewmatrix.to(dev),
+                               S.projmatrix.to(dev), S.bg.to(dev)))
+    gen = torch.Generator().manual_seed(6)
+    d = [(torch.randn(c, h, w, generator=gen) / (h * w)).to(dev) for c in (3, 3, 1)]
+    fn = lambda v, st: (d[0], d[1], d[2], None, None)
+    schedule = [[0], [1, 0], [2], [3, 1], [0, 2]]          # the set grows over the first four steps
+    out = {}
+    for sparse in (False, True):
+        raw = {k: v.to(dev) for k, v in make_room_scene(n, seed=5).items()}
+        init = [raw[k].clone() for k in ("means", "scales", "rotations", "opacities", "harmonics")]
+        tr = SurfelTrainer(raw, sparse_rows=sparse)
+        assert (tr.rows is not None) == sparse
+        seen = torch.zeros(n, dtype=torch.bool, device=dev)
+        for views in schedule:
+            tr.step([cams[v] for v in views], fn, 1 << 20, device_clock=True)
+            for v in views:   # radii of the last-rendered view only survive; re-render to collect the union
+                st = tr.state_for(h, w, 1 << 20)
+                api.forward(cams[v], tr.gaussians(), st)
+                seen |= st.radii > 0
+        torch.cuda.synchronize()
+        out[sparse] = dict(params=[p.clone() for p in tr.params], grads=[g.clone() for g in tr.slab.as_list()],
+                           m=[x.clone() for x in tr.optim.exp_avg], seen=seen, init=init, tr=tr)
+    # the blend backward sums with float atomics, so two runs differ in the last bits whatever the
+    # row-set setting; near-zero gradients then flip the sign-like eps=1e-15 Adam update of a few rows
+    for key in ("grads", "m"):
+        for a, b in zip(out[False][key], out[True][key]):
+            assert float((a - b).abs().sum()) <= 1e-3 * float(a.abs().sum()) + 1e-12, key
+    for a, b in zip(out[False]["params"], out[True]["params"]):
+        diff = (a - b).abs()
+        assert float(diff.mean()) < 2e-6 and float((diff > 1e-4).float().mean()) < 0.01
+    tr, seen = out[True]["tr"], out[True]["seen"]
+    count = int(tr.rows.count.item())
+    listed = tr.rows.rows[:count].long()
+    # parameters move between steps, so a surfel can enter/leave the frustum: the set holds at least
+    # everything visible at the final parameters that was visible when rendered, and nothing twice
+    assert listed.unique().numel() == count
+    member = tr.rows.member.bool()
+    assert torch.equal(torch.sort(listed).values, torch.nonzero(member).flatten())
+    assert 0 < count < n
+    untouched = ~member
+    for p, p0 in zip(out[True]["params"], out[True]["init"]):
+        assert torch.equal(p.reshape(n, -1)[untouched], p0.reshape(n, -1)[untouched])
+    for mom in tr.optim.exp_avg + tr.optim.exp_avg_sq:
+        assert float(mom.reshape(n, -1)[untouched].abs().max()) == 0.0
+    # every surfel seen at the final parameters of a replayed view belongs to the set
+    assert int((seen & ~member).sum()) <= int(0.002 * n)
+
+
 def test_fused_activations_match_separate_kernels(agslib):
     """raw_params mode (activations + chain rule inside the per-Gaussian kernels) == ags_activate
     -> forward/backward on activated values -> ags_activate_backward."""
