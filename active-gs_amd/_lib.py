@@ -79,8 +79,23 @@ class AgsActivation(C.Structure):
                 ("raw_rotations", c_f32p), ("raw_opacities", c_f32p)]
 
 
+class AgsKeyframe(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("rgb", c_f32p), ("depth", c_f32p),
+                ("intrinsic_inv", c_f32p), ("extrinsic", c_f32p)]
+
+
+class AgsDensifyPred(C.Structure):
+    _fields_ = [("rgb", c_f32p), ("depth", c_f32p), ("opacity", c_f32p)]
+
+
+class AgsCandidates(C.Structure):
+    _fields_ = [("means", c_f32p), ("rotations", c_f32p), ("harmonics", c_f32p), ("select", C.c_void_p)]
+
+
 EXPORTS = ["ags_workspace_bytes", "ags_workspace_init", "ags_forward", "ags_backward", "ags_read_status", "ags_adam_step",
-           "ags_adam_step_device", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_profile_enable", "ags_profile_read",
+           "ags_adam_step_device", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_smooth_depth", "ags_densify_candidates",
+           "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_compact_plan_bytes", "ags_compact_plan",
+           "ags_compact_rows", "ags_profile_enable", "ags_profile_read",
            "ags_error_string", "ags_version"]
 
 _lib = None
@@ -129,6 +144,24 @@ def load() -> C.CDLL:
         C.c_int32, C.c_int32, C.c_void_p]
     lib.ags_loss_stage2.restype = C.c_int
     lib.ags_loss_stage2.argtypes = [C.POINTER(AgsLossConfig), C.POINTER(AgsImages)] + [C.c_void_p] * 6 + [C.c_void_p]
+    lib.ags_smooth_depth.restype = C.c_int
+    lib.ags_smooth_depth.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float,
+                                     C.c_void_p]
+    lib.ags_densify_candidates.restype = C.c_int
+    lib.ags_densify_candidates.argtypes = [C.POINTER(AgsKeyframe), C.c_void_p, C.POINTER(AgsDensifyPred), C.c_float,
+                                           C.POINTER(AgsCandidates), C.c_void_p]
+    lib.ags_voxel_select_bytes.restype = C.c_size_t
+    lib.ags_voxel_select_bytes.argtypes = [C.c_int32]
+    lib.ags_voxel_select.restype = C.c_int
+    lib.ags_voxel_select.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.ags_prune_keep.restype = C.c_int
+    lib.ags_prune_keep.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    lib.ags_compact_plan_bytes.restype = C.c_size_t
+    lib.ags_compact_plan_bytes.argtypes = [C.c_int32]
+    lib.ags_compact_plan.restype = C.c_int
+    lib.ags_compact_plan.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.ags_compact_rows.restype = C.c_int
+    lib.ags_compact_rows.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ags_profile_enable.restype = C.c_int
     lib.ags_profile_enable.argtypes = [C.c_int32]
     lib.ags_profile_read.restype = C.c_int

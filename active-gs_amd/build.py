@@ -14,12 +14,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libags_raster.so")
-SOURCES = ["preprocess.hip", "binning.hip", "render.hip", "adam.hip", "loss.hip", "capi.hip"]
+SOURCES = ["preprocess.hip", "binning.hip", "render.hip", "adam.hip", "loss.hip", "densify.hip", "capi.hip"]
 HEADERS = ["ags_internal.h", "surfel_math.h", os.path.join("..", "..", "include", "ags_raster.h")]
 # loss.hip must reproduce exact cancellations of the reference's un-fused torch ops (see ags_point)
 # render.hip: -fno-signed-zeros lets the compiler fold the `0 + x` of freshly zeroed accumulators
 # (-2.5 % step time); NaN / inf semantics are left alone.
-EXTRA_FLAGS = {"loss.hip": ["-ffp-contract=off"], "render.hip": ["-fno-signed-zeros"]}
+# densify.hip: same reason as loss.hip - depth2normal relies on (p_neighbour - p_centre) being exactly
+# 0 at replicated borders, which an fma-contracted difference of products is not.
+EXTRA_FLAGS = {"loss.hip": ["-ffp-contract=off"], "densify.hip": ["-ffp-contract=off"],
+               "render.hip": ["-fno-signed-zeros"]}
 # -fno-slp-vectorize everywhere: hipcc's SLP pass packs pairs of scalar fp32 ops into v_pk_* at the
 # price of register-pair shuffles (25 % v_mov in render_bwd) and VGPRs; scalar code measured
 # faster in every kernel of this library (step -7.5 %).

@@ -144,6 +144,18 @@ void ags_launch_loss_stage1(const AgsLossConfig& cfg, const AgsImages& img, cons
 void ags_launch_loss_stage2(const AgsLossConfig& cfg, const AgsImages& img, const float* n_img, const float* gt_depth,
                             const int* msum, float* d_normal, float* d_depth, float* accum, hipStream_t s);
 int ags_sort_passes(int num_tiles);
+// densify.hip
+void ags_launch_bilateral(int h, int w, const float* depth, float* out, int d, float sigma_color, float sigma_space,
+                          hipStream_t s);
+void ags_launch_candidates(const AgsKeyframe& f, const float* depth_smooth, const AgsDensifyPred& pred,
+                           float error_thres, const AgsCandidates& out, hipStream_t s);
+size_t ags_voxel_bytes(int n);
+void ags_launch_voxel_select(int n, const float* points, int32_t* select, float voxel, void* ws, hipStream_t s);
+size_t ags_compact_bytes(int n);
+void ags_launch_compact_plan(int n, const int32_t* keep, int32_t* dst_index, int32_t* total, void* scratch, hipStream_t s);
+void ags_launch_compact_rows(int n, int width, const int32_t* dst_index, const float* src, float* dst, hipStream_t s);
+void ags_launch_prune_keep(int n, const float* prune_mask, const float* raw_opacities, float min_opacity, int32_t* keep,
+                           hipStream_t s);
 
 #if defined(__HIPCC__)
 // ---- wave64 helpers (gfx950): DPP reductions, no LDS, no ds_bpermute

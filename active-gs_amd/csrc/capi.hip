@@ -211,6 +211,65 @@ int ags_profile_read(int32_t stage, float* avg_ms, float* median_ms, int32_t* sa
     return AGS_OK;
 }
 
+int ags_smooth_depth(int32_t h, int32_t w, const float* depth, float* out, int32_t d, float sigma_color,
+                     float sigma_space, ags_stream_t stream) {
+    if (h <= 0 || w <= 0 || !depth || !out || d < 1 || !(sigma_color > 0.f) || !(sigma_space > 0.f)) return AGS_E_INVALID;
+    if (d / 2 >= h || d / 2 >= w || d > 31) return AGS_E_INVALID; // reflect-101 needs radius < size; LDS tile bound
+    ags_launch_bilateral(h, w, depth, out, d, sigma_color, sigma_space, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_densify_candidates(const AgsKeyframe* f, const float* depth_smooth, const AgsDensifyPred* pred,
+                           float error_thres, const AgsCandidates* out, ags_stream_t stream) {
+    if (!f || !depth_smooth || !pred || !out) return AGS_E_INVALID;
+    if (f->image_height <= 0 || f->image_width <= 0 || !f->rgb || !f->depth || !f->intrinsic_inv || !f->extrinsic)
+        return AGS_E_INVALID;
+    if (!out->means || !out->rotations || !out->harmonics || !out->select) return AGS_E_INVALID;
+    const int have = (pred->rgb != nullptr) + (pred->depth != nullptr) + (pred->opacity != nullptr);
+    if (have != 0 && have != 3) return AGS_E_INVALID;
+    ags_launch_candidates(*f, depth_smooth, *pred, error_thres, *out, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+size_t ags_voxel_select_bytes(int32_t n) { return ags_voxel_bytes(n < 0 ? 0 : n); }
+int ags_voxel_select(int32_t n, const float* points, int32_t* select, float voxel_size, void* ws, size_t ws_bytes,
+                     ags_stream_t stream) {
+    if (n < 0 || !(voxel_size > 0.f)) return AGS_E_INVALID;
+    if (n == 0) return AGS_OK;
+    if (!points || !select || !ws) return AGS_E_INVALID;
+    if (ws_bytes < ags_voxel_bytes(n)) return AGS_E_WORKSPACE;
+    ags_launch_voxel_select(n, points, select, voxel_size, ws, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_prune_keep(int32_t n, const float* prune_mask, const float* raw_opacities, float min_opacity, int32_t* keep,
+                   ags_stream_t stream) {
+    if (n < 0) return AGS_E_INVALID;
+    if (n == 0) return AGS_OK;
+    if (!raw_opacities || !keep) return AGS_E_INVALID;
+    ags_launch_prune_keep(n, prune_mask, raw_opacities, min_opacity, keep, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+size_t ags_compact_plan_bytes(int32_t n) { return ags_compact_bytes(n < 0 ? 0 : n); }
+int ags_compact_plan(int32_t n, const int32_t* keep, int32_t* dst_index, int32_t* total, void* scratch,
+                     size_t scratch_bytes, ags_stream_t stream) {
+    if (n < 0 || !total) return AGS_E_INVALID;
+    if (n == 0) return hipMemsetAsync(total, 0, 4, (hipStream_t)stream) == hipSuccess ? AGS_OK : AGS_E_LAUNCH;
+    if (!keep || !dst_index || !scratch) return AGS_E_INVALID;
+    if (scratch_bytes < ags_compact_bytes(n)) return AGS_E_WORKSPACE;
+    ags_launch_compact_plan(n, keep, dst_index, total, scratch, (hipStream_t)stream);
+    return ags_check_launch();
+}
+int ags_compact_rows(int32_t n, int32_t width, const int32_t* dst_index, const float* src, float* dst,
+                     ags_stream_t stream) {
+    if (n < 0 || width < 1) return AGS_E_INVALID;
+    if (n == 0) return AGS_OK;
+    if (!dst_index || !src || !dst) return AGS_E_INVALID;
+    ags_launch_compact_rows(n, width, dst_index, src, dst, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
 const char* ags_error_string(int code) {
     switch (code) {
         case AGS_OK: return "ok";

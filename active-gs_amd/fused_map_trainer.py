@@ -11,6 +11,7 @@ from typing import List, Optional
 
 import torch
 
+from . import densify
 from . import raster_api as api
 from .camera import camera_matrices
 from .fused_loss import FusedLoss
@@ -41,6 +42,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         self._loss = None
         self._loss_bufs = []
         self._cap = 0
+        self.is_init = len(frames) > 0 and self.means.shape[0] > 0   # gaussian_map.py:35,130
 
     # ---- cached per-frame camera (the intrinsics -> fov step needs host scalars once per frame)
     def _camera(self, idx: int):
@@ -190,6 +192,54 @@ class FusedMapTrainer(GaussianMapTrainer):
                     break
             out.append(st.count.clone())
         return torch.stack(out)
+
+    # ------------------------------------------------------------------ map growth / pruning
+    def _map_state(self) -> dict:
+        return {k: getattr(self, k) for k in densify.STATE_KEYS}
+
+    def _set_map_state(self, state: dict) -> None:
+        for k in densify.STATE_KEYS:
+            setattr(self, k, state[k])
+        self._states.clear()          # per-view workspaces are sized by the number of surfels
+
+    def add_gaussians(self, frame: dict) -> int:
+        """``GaussianMap.add_gaussians`` (gaussian_map.py:294-468): spawn surfels from a new RGB-D
+        keyframe where the map's own render is wrong / empty / occluding, one per 2 cm voxel, then
+        register the frame.  All per-pixel work and the compaction run in densify.hip.  Returns
+        the number of surfels added."""
+        frame = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in frame.items()}
+        pred = None
+        if self.is_init and self.means.shape[0] > 0:
+            h, w = frame["rgb"].shape[-2:]
+            n = self.means.shape[0]
+            cm = camera_matrices(frame["extrinsic"][None].float(), frame["intrinsic"][None].float(), *self.cfg["bound"])
+            tan = cm["tanfov"][0].cpu()
+            cam = api.Camera(h, w, float(tan[0]), float(tan[1]), cm["viewmatrix"][0].contiguous(),
+                             cm["projmatrix"][0].contiguous(), self.background)
+            self._cap = max(self._cap, 1 << 16, 2 * n)
+            g = self._gaussians()
+            while True:
+                st = self._state("densify", n, h, w)
+                api.forward(cam, g, st)
+                if self._check_capacity(["densify"]):
+                    break
+            pred = dict(rgb=st.rgb, depth=st.depth[0], opacity=st.opacity[0])
+        state, added = densify.add_gaussians(self._map_state(), frame, pred, self.cfg["error_thres"])
+        self._set_map_state(state)
+        self.frames.append(frame)
+        self.training_performance = torch.cat((self.training_performance, torch.tensor([10.0], device=self.device)), 0)
+        return added
+
+    def update(self, frame: dict, steps: Optional[int] = None) -> None:
+        """``GaussianMap.update`` (gaussian_map.py:62-64): grow the map from the keyframe, then train."""
+        self.add_gaussians(frame)
+        self.train(steps)
+        self.is_init = True
+
+    def prune(self, mask):
+        state, deleted = densify.prune(self._map_state(), mask)
+        self._set_map_state(state)
+        return deleted
 
     # ------------------------------------------------------------------ hipGraph iteration
     def _graph_ok(self) -> bool:

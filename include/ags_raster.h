@@ -265,6 +265,59 @@ int ags_loss_stage2(const AgsLossConfig* cfg, const AgsImages* fwd, const float*
                     const int32_t* msum, float* d_normal, float* d_depth /* += */, float* accum,
                     ags_stream_t stream);
 
+/* ---- Map growth and pruning (replaces the torch/cv2 code of GaussianMap.add_gaussians, cal_mask,
+ * prune and voxel_downsample: /root/reference/mapping/gaussian_map.py:234-246,294-489,
+ * /root/reference/utils/operations.py:161-169,603-625).  Same rules as everything above: device
+ * pointers owned by the caller, no allocation or synchronisation inside, stream-ordered. */
+
+/* get_smooth_depth (operations.py:161-169) = cv2.bilateralFilter(depth, d=15, sigma_color=0.5,
+ * sigma_space=20) with invalid (< 0) pixels entering as 0 and leaving as -1.  h, w > d/2. */
+int ags_smooth_depth(int32_t h, int32_t w, const float* depth, float* out, int32_t d, float sigma_color,
+                     float sigma_space, ags_stream_t stream);
+
+typedef struct AgsKeyframe {          /* dataframe of add_gaussians (gaussian_map.py:294-300) */
+    int32_t image_height, image_width;
+    const float* rgb;           /* (3,H,W) */
+    const float* depth;         /* (1,H,W) sensor depth; <= 0 = no measurement */
+    const float* intrinsic_inv; /* 9 floats, device: inverse of the NORMALISED 3x3 intrinsics */
+    const float* extrinsic;     /* 16 floats, device: camera-to-world, row-major */
+} AgsKeyframe;
+typedef struct AgsDensifyPred {       /* render of the current map at the keyframe; all NULL before the */
+    const float* rgb;                 /* map is initialised (cal_mask then selects every pixel)          */
+    const float* depth;
+    const float* opacity;
+} AgsDensifyPred;
+typedef struct AgsCandidates {        /* per pixel, P = H*W rows */
+    float* means;       /* (P,3) unprojected points */
+    float* rotations;   /* (P,4) wxyz from the depth-map normal (normal2rotation) */
+    float* harmonics;   /* (P,3) pixel colours */
+    int32_t* select;    /* (P) 1 = valid measurement that the map lacks (before the voxel filter) */
+} AgsCandidates;
+/* Everything add_gaussians derives per pixel (gaussian_map.py:301-400); depth_smooth from ags_smooth_depth. */
+int ags_densify_candidates(const AgsKeyframe* frame, const float* depth_smooth, const AgsDensifyPred* pred,
+                           float error_thres, const AgsCandidates* out, ags_stream_t stream);
+
+/* voxel_downsample (operations.py:603-625): among the rows with select != 0 keep one per occupied
+ * voxel - the highest row index (the reference picks a random one; see oracle/densify_oracle.py) -
+ * and clear the others.  `ws`: ags_voxel_select_bytes(n) bytes of scratch. */
+size_t ags_voxel_select_bytes(int32_t n);
+int ags_voxel_select(int32_t n, const float* points, int32_t* select, float voxel_size, void* ws, size_t ws_bytes,
+                     ags_stream_t stream);
+
+/* prune's rule (gaussian_map.py:234-236): keep[i] = !(prune_mask[i] != 0 || sigmoid(raw_opacities[i]) < min_opacity);
+ * prune_mask may be NULL. */
+int ags_prune_keep(int32_t n, const float* prune_mask, const float* raw_opacities, float min_opacity, int32_t* keep,
+                   ags_stream_t stream);
+
+/* Stable stream compaction (torch boolean indexing / torch.cat of the selected rows):
+ * plan:  dst_index[i] = number of kept rows before i, or -1; *total (device) = kept rows.
+ * rows:  dst[dst_index[i]*width + c] = src[i*width + c] for one (n,width) float array. */
+size_t ags_compact_plan_bytes(int32_t n);
+int ags_compact_plan(int32_t n, const int32_t* keep, int32_t* dst_index, int32_t* total, void* scratch,
+                     size_t scratch_bytes, ags_stream_t stream);
+int ags_compact_rows(int32_t n, int32_t width, const int32_t* dst_index, const float* src, float* dst,
+                     ags_stream_t stream);
+
 /* Optional stage timing with library-owned hipEvents (process-global, for bench/profiling
  * only; off by default so the normal path records nothing).  `slots` event pairs are kept
  * per stage; each forward/backward call consumes one slot per stage it runs. */

@@ -11,6 +11,11 @@ the module name ``diff_gaussian_rasterization_2d`` and records
   adam.pt       torch.optim.Adam (eps 1e-15, 5 groups) for 3 steps incl. zero-gradient rows
   oracle_*.pt   oracle forward/backward vectors on seeded scenes (detects oracle drift and is
                 the fixed target of the GPU parity tests)
+  densify.pt    GaussianMap.add_gaussians on a first keyframe (no map yet: every valid pixel is a
+                candidate) and on a second one (candidates from the error mask of a render of the
+                map), then GaussianMap.prune.  cv2 is absent, so cv2.bilateralFilter is served by
+                oracle/densify_oracle.py's restatement; torch.randperm is the identity during
+                voxel_downsample (see that file's header).
 Only tensors (inputs and expected outputs) are stored; no reference source text.
 """
 import json
@@ -157,6 +162,62 @@ def main():
                     training_performance=m.training_performance.clone(), view_supports=m.view_supports.clone(),
                     view_scores=m.view_scores.clone(), view_means=m.view_means.clone(),
                     rasterizer_calls=list(Rast.calls)), os.path.join(HERE, "train.pt"))
+
+    # ---------------------------------------------------------------- densify.pt
+    from oracle import densify_oracle as dor
+    ops.cv2.bilateralFilter = lambda img, d, sc, ss: dor.bilateral_filter(img, d, sc, ss)
+    h, w = 64, 96
+    gen = torch.Generator().manual_seed(31)
+    dframes = []
+    for v in range(2):
+        c2w, K = make_camera(v + 5, h, w)
+        with torch.no_grad():
+            rr = ops.GaussianRenderer(c2w[None], K[None], (ga["means"], gt_raw["harmonics"], ga["opacities"],
+                                                           ga["confidences"], ga["scales"], ga["rotations"]),
+                                      torch.zeros(4), (0.001, 10.0), (h, w), "cpu").render_view_all()
+        depth = rr[1][0].clone()
+        depth[0, 5:12, 7:20] = 0.0       # holes: not valid, but not "invalid" for the smoothing either
+        depth[0, 40:47, 60:70] = -1.0    # sensor-invalid
+        depth += 0.002 * torch.randn(depth.shape, generator=gen) * (depth > 0)
+        dframes.append(dict(rgb=rr[0][0].clone(), depth=depth, extrinsic=c2w, intrinsic=K,
+                            depth_range=torch.tensor([0.001, 10.0])))
+    m = gm.GaussianMap(mapper_cfg(2), "cpu")
+    captured = {}
+    orig_cal_mask = m.cal_mask
+
+    def cal_mask_rec(rgb_gt, depth_gt, pred):
+        captured["pred"] = None if pred is None else {k: v.detach().clone() for k, v in pred.items()}
+        return orig_cal_mask(rgb_gt, depth_gt, pred)
+    m.cal_mask = cal_mask_rec
+    real_randperm = torch.randperm
+    snaps = []
+
+    def snap():
+        return dict(means=m._means.detach().clone(), scales=m._scales.detach().clone(),
+                    rotations=m._rotations.detach().clone(), opacities=m._opacities.detach().clone(),
+                    harmonics=m._harmonics.detach().clone(), view_scores=m.view_scores.clone(),
+                    view_supports=m.view_supports.clone(), view_means=m.view_means.clone())
+    torch.randperm = lambda n, device=None: torch.arange(n)
+    try:
+        m.add_gaussians(dframes[0])
+        snaps.append(dict(state=snap(), pred=captured["pred"]))
+        # make the map differ from the second frame so that the error mask is non-trivial
+        with torch.no_grad():
+            m._opacities += 2.0 * torch.randn(m._opacities.shape, generator=gen)
+            m._harmonics += 0.4 * torch.randn(m._harmonics.shape, generator=gen)
+            m._scales[:, :2] += 0.5
+        m.is_init = True
+        before = snap()
+        m.add_gaussians(dframes[1])
+        snaps.append(dict(before=before, state=snap(), pred=captured["pred"]))
+    finally:
+        torch.randperm = real_randperm
+    pm = torch.zeros(m._means.shape[0])
+    pm[::7] = 1.0
+    before_prune = snap()
+    m.prune(pm.clone())
+    torch.save(dict(h=h, w=w, frames=dframes, error_thres=0.25, first=snaps[0], second=snaps[1],
+                    prune_mask=pm, before_prune=before_prune, after_prune=snap()), os.path.join(HERE, "densify.pt"))
 
     # ---------------------------------------------------------------- adam.pt
     gen = torch.Generator().manual_seed(9)

@@ -101,3 +101,64 @@ def test_product_math_header_matches_oracle(tag):
         ref = d["grads"][i].reshape(g[n].shape)
         rel = (ref - g[n]).abs().sum() / ref.abs().sum().clamp_min(1e-12)
         assert rel < 1e-3, (n, float(rel))
+
+
+# ---------------------------------------------------------------------------------------------
+# map growth / pruning oracle (oracle/densify_oracle.py) against the reference's own
+# GaussianMap.add_gaussians / prune outputs (tests/golden/densify.pt, make_golden.py)
+def _empty_state():
+    z = torch.zeros
+    return dict(means=z(0, 3), scales=z(0, 3), rotations=z(0, 4), opacities=z(0), harmonics=z(0, 1, 3),
+                view_scores=z(0), view_supports=z(0), view_means=z(0, 3))
+
+
+def _same_state(a, b, rot_tol=5e-4):
+    for k in b:
+        assert a[k].shape == b[k].shape, k
+        tol = rot_tol if k == "rotations" else 1e-6
+        assert float((a[k] - b[k]).abs().max()) <= tol if a[k].numel() else True, k
+
+
+def test_densify_oracle_matches_reference_add_gaussians_and_prune():
+    from oracle import densify_oracle as dor
+    g = torch.load(os.path.join(GOLD, "densify.pt"))
+    first = dor.add_gaussians(_empty_state(), g["frames"][0], None, g["error_thres"])
+    assert first["means"].shape[0] == g["first"]["state"]["means"].shape[0] > 1000
+    _same_state(first, g["first"]["state"])
+    pred = g["second"]["pred"]
+    p2 = dict(rgb=pred["rgb"][0], depth=pred["depth"][0], opacity=pred["opacity"][0])
+    second = dor.add_gaussians(g["second"]["before"], g["frames"][1], p2, g["error_thres"])
+    n0 = g["second"]["before"]["means"].shape[0]
+    assert n0 < second["means"].shape[0] == g["second"]["state"]["means"].shape[0] < n0 + g["h"] * g["w"]
+    _same_state(second, g["second"]["state"])
+    pruned = dor.prune(g["before_prune"], g["prune_mask"])
+    _same_state(pruned, g["after_prune"], rot_tol=0.0)
+
+
+def test_densify_oracle_voxel_rule_and_bilateral_properties():
+    import numpy as np
+    from oracle import densify_oracle as dor
+    gen = torch.Generator().manual_seed(0)
+    pts = torch.rand(5000, 3, generator=gen) * 0.2                      # 10^3 voxels of 2 cm: many collisions
+    sel = torch.rand(5000, generator=gen) > 0.3
+    keep = dor.voxel_select_last(pts, sel)
+    keys = dor.voxel_keys(pts)
+    assert not bool((keep & ~sel).any())
+    kept_keys = {tuple(k.tolist()) for k in keys[keep]}
+    assert len(kept_keys) == int(keep.sum()) == len({tuple(k.tolist()) for k in keys[sel]})
+    for i in torch.nonzero(keep).flatten()[:50]:                        # the kept point is the last of its voxel
+        same = (keys == keys[i]).all(1) & sel
+        assert int(torch.nonzero(same).max()) == int(i)
+    # bilateral: constants are fixed points, output stays within the local range, invalid -> -1
+    img = np.full((40, 50), 2.5, np.float32)
+    assert np.allclose(dor.bilateral_filter(img), 2.5)
+    rng = np.random.default_rng(1)
+    img = (2.0 + 0.01 * rng.standard_normal((40, 50))).astype(np.float32)
+    img[:, 25:] += 3.0                                                  # a depth edge >> sigma_color survives
+    out = dor.bilateral_filter(img)
+    assert out.min() >= img.min() - 1e-6 and out.max() <= img.max() + 1e-6
+    assert abs(out[:, :25].mean() - 2.0) < 1e-2 and abs(out[:, 25:].mean() - 5.0) < 1e-2
+    assert out[:, :25].std() < 0.5 * img[:, :25].std()
+    d = img.copy(); d[3:6, 4:9] = -1.0
+    sm = dor.smooth_depth(d)
+    assert np.all(sm[3:6, 4:9] == -1.0) and np.all(sm[d >= 0] >= 0)
