@@ -16,6 +16,8 @@ the module name ``diff_gaussian_rasterization_2d`` and records
                 map), then GaussianMap.prune.  cv2 is absent, so cv2.bilateralFilter is served by
                 oracle/densify_oracle.py's restatement; torch.randperm is the identity during
                 voxel_downsample (see that file's header).
+  mapper_loop.pt  GaussianMap.update() x 4 keyframes from an empty map (grow, train, prune): sizes
+                and per-frame errors after every keyframe, final parameters.
 Only tensors (inputs and expected outputs) are stored; no reference source text.
 """
 import json
@@ -218,6 +220,31 @@ def main():
     m.prune(pm.clone())
     torch.save(dict(h=h, w=w, frames=dframes, error_thres=0.25, first=snaps[0], second=snaps[1],
                     prune_mask=pm, before_prune=before_prune, after_prune=snap()), os.path.join(HERE, "densify.pt"))
+
+    # ---------------------------------------------------------------- mapper_loop.pt
+    # GaussianMap.update() (= add_gaussians + train + post_processing) for four keyframes from an
+    # empty map, prune every 2nd keyframe: the "full mapper loop" configuration in miniature.
+    loop_cfg = mapper_cfg(4)
+    loop_cfg["prune_interval"] = 2
+    loop_cfg["sampler"] = AttrDict(sampler_type="weighted", batch_size=4, active_size=2)
+    m = gm.GaussianMap(loop_cfg, "cpu")
+    torch.randperm = lambda n, device=None: torch.arange(n)
+    np.random.seed(11)
+    history = []
+    try:
+        for k in range(4):
+            n_before = m._means.shape[0]
+            m.update(dict(dframes[k % 2]))
+            history.append(dict(n_before=n_before, n_after=m._means.shape[0],
+                                training_performance=m.training_performance.clone(),
+                                opacity_mean=float(torch.sigmoid(m._opacities.detach()).mean()),
+                                supports=m.view_supports.clone(), scores_mean=float(m.view_scores.mean())))
+    finally:
+        torch.randperm = real_randperm
+    torch.save(dict(frames=dframes, cfg=json.loads(json.dumps(loop_cfg)), seed=11, history=history,
+                    final=dict(means=m._means.detach().clone(), opacities=m._opacities.detach().clone(),
+                               harmonics=m._harmonics.detach().clone(), scales=m._scales.detach().clone())),
+               os.path.join(HERE, "mapper_loop.pt"))
 
     # ---------------------------------------------------------------- adam.pt
     gen = torch.Generator().manual_seed(9)
