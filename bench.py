@@ -23,15 +23,22 @@ H, W = 680, 1200
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def stage_bytes(N, V, I, P, T):
+def stage_bytes(N, V, I, P, T, rows=None):
     """ALGORITHMIC bytes per launch of each stage: every logical
-    array moved once."""
+    array moved once.  ``rows``: member rows of the sticky row set when the per-Gaussian backward
+    runs in its row-set form with the Adam step fused in (single rank), else None."""
+    if rows is not None:
+        # per member row: id 4 + radius 4 + params 44 + gradient record read 64 / re-zeroed 64 (visible
+        # rows) + gradient row 56 + Adam m, v read+write 224 + parameters written 56
+        pbwd = 8 * rows + 128 * V + (44 + 56 + 224 + 56) * rows
+    else:
+        pbwd = 44 * N + 128 * V + 68 * N                       # means/scales/rot/radii; dgeom read + re-zero; 5 grads
     return {
         "preprocess": 60 * N + 8 * N + 136 * V,                # inputs; radii+tiles; geom 64 + rect 8 + zeroed dgeom 64
         "binning": 8 * N + 12 * I + 24 * I + 8 * I + 8 * T,    # tile counts/scan; key write; sort r+w once; ranges
         "render_fwd": 8 * T + 68 * I + 44 * P,                  # ranges; id 4 + record 64; 9 ch + T + n_contrib
         "render_bwd": 8 * T + 68 * I + 52 * P + 64 * V,         # + 9 grads, depth, opac, T, n; accumulate dgeom
-        "preprocess_bwd": 44 * N + 128 * V + 68 * N,            # means/scales/rot/radii; dgeom read + re-zero; 5 grads
+        "preprocess_bwd": pbwd,
     }
 
 
@@ -201,7 +208,8 @@ def main():
 
     if rank == 0:
         T = ((H + 15) // 16) * ((W + 15) // 16)
-        sb = stage_bytes(N_GAUSS, V, I, P, T)
+        rows = int(trainer.rows.count.item()) if getattr(trainer, "rows", None) is not None else None
+        sb = stage_bytes(N_GAUSS, V, I, P, T, rows)
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         ach = sb[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         traffic = None
@@ -220,11 +228,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "office0 stand-in (seeded box room), 200k surfels, 1200x680, 1 view per GPU, "
-                                   "step = activations + fwd + bwd + grad all-reduce (N>1) + fused Adam",
+                                   "step = activations + fwd + bwd + grad all-reduce (N>1) + Adam",
                        "gaussians": N_GAUSS, "image": [H, W], "views_per_gpu": 1, "visible": V,
                        "tile_instances": I, "parallelism": f"view-parallel dp{world}",
                        "overflow": bool(info["overflow"]), "binning": args.binning,
                        "launch": launch_mode,
+                       "optimizer": ("row-set Adam fused into the per-Gaussian backward (exact: untouched rows "
+                                     f"have zero gradient and moments), {rows} member rows") if rows is not None
+                                    else "dense fused Adam kernel after the gradient all-reduce",
                        "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                        "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

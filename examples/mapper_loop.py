@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Configuration 3 of BASELINE.json in one script: the full mapper loop (grow from each new
+RGB-D keyframe, train, post-process / prune) for 500 optimisation iterations on one MI355X.
+
+Mirrors how /root/reference/main.py drives ``GaussianMap.update`` (mapping/gaussian_map.py:62-64)
+with the values of config/mapper/incremental.yaml (10 iterations per keyframe, batch 8 + 3 active
+frames, prune every 5th keyframe) and the simulator's 512x512 frames (config/simulator/habitat.yaml).
+Replica is not available offline, so the keyframes are rendered from a dense ground-truth surfel
+room (the office0 stand-in of active_gs_amd.synthetic) with this library's own rasterizer.
+Prints one JSON line with the time split between growth, training and post-processing.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--keyframes", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=10, help="optimisation iterations per keyframe")
+    ap.add_argument("--size", type=int, nargs=2, default=[512, 512], metavar=("H", "W"))
+    ap.add_argument("--gt-surfels", type=int, default=400_000)
+    ap.add_argument("--streams", type=int, default=4)
+    args = ap.parse_args()
+
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.camera import camera_matrices
+    from active_gs_amd.fused_map_trainer import FusedMapTrainer
+    from active_gs_amd.synthetic import activate, make_camera, make_room_scene
+
+    dev = torch.device("cuda:0")
+    h, w = args.size
+    gt = {k: v.to(dev) for k, v in make_room_scene(args.gt_surfels, seed=0).items()}
+    gt["scales"][:, :2] += 0.6                       # dense coverage: the ground truth is a closed room
+    gt["opacities"] += 4.0
+    a = activate(gt)
+    g = api.Gaussians(a["means"], a["scales"], a["rotations"], a["opacities"], gt["harmonics"].view(-1, 3).contiguous(),
+                      a["confidences"])
+    st = api.alloc_state(args.gt_surfels, h, w, 1 << 24, dev)
+    frames = []
+    for v in range(args.keyframes):
+        c2w, K = make_camera(v, h, w)
+        cm = camera_matrices(c2w[None].to(dev), K[None].to(dev), 0.001, 10.0)
+        tan = cm["tanfov"][0].cpu()
+        cam = api.Camera(h, w, float(tan[0]), float(tan[1]), cm["viewmatrix"][0].contiguous(),
+                         cm["projmatrix"][0].contiguous(), torch.zeros(4, device=dev))
+        api.forward(cam, g, st)
+        assert not api.read_status(st)["overflow"]
+        depth = torch.where(st.opacity > 0.5, st.depth, torch.zeros_like(st.depth))
+        frames.append(dict(rgb=st.rgb.clone().clamp(0, 1), depth=depth.clone(), extrinsic=c2w.to(dev),
+                           intrinsic=K.to(dev), depth_range=torch.tensor([0.001, 10.0], device=dev)))
+    z = lambda *s: torch.zeros(*s, device=dev)
+    raw = dict(means=z(0, 3), scales=z(0, 3), rotations=z(0, 4), opacities=z(0), harmonics=z(0, 1, 3))
+    np.random.seed(0)
+    tr = FusedMapTrainer(raw, [], dict(optimization_steps=args.steps), use_graph=False, num_streams=args.streams)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+
+    t_grow = t_train = 0.0
+    sizes, added = [], []
+    t_all0 = time.perf_counter()
+    for k, f in enumerate(frames):
+        n_add, dt = timed(lambda: tr.add_gaussians(f))
+        t_grow += dt
+        added.append(n_add)
+        _, dt = timed(lambda: tr.train())             # includes post_processing (confidence update, prune)
+        t_train += dt
+        tr.is_init = True
+        sizes.append(tr.means.shape[0])
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t_all0
+    iters = args.keyframes * args.steps
+    print(json.dumps(dict(
+        workload=f"mapper loop: {args.keyframes} keyframes x {args.steps} iterations @{h}x{w}, batch 8 + 3 active, "
+                 f"prune every 5th keyframe, from an empty map",
+        iterations=iters, seconds=round(t_all, 3), ms_per_iteration_incl_growth=round(1e3 * t_all / iters, 3),
+        grow_ms_per_keyframe=round(1e3 * t_grow / args.keyframes, 3),
+        train_ms_per_keyframe=round(1e3 * t_train / args.keyframes, 3),
+        final_surfels=sizes[-1], surfels_after_10=sizes[min(9, len(sizes) - 1)],
+        added_first=added[0], added_last=added[-1],
+        mean_frame_error=round(float(tr.training_performance.mean()), 5), last_loss=round(tr.last_losses[-1], 5))))
+
+
+if __name__ == "__main__":
+    main()
