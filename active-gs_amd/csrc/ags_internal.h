@@ -246,6 +246,9 @@ __device__ __forceinline__ void ags_emit_tiles_balanced(AgsEmitRec* wave_lds, ui
                                                         uint32_t wd, uint32_t pa, const AgsGeom& g, int tiles_x,
                                                         Fn&& f) {
     const int lane = threadIdx.x & 63;
+#ifdef AGS_EXP_NO_EMIT
+    if (cnt != 0xFFFFFFFFu) return;
+#endif
     const uint32_t incl = ags_wave_incl_scan_u32(cnt);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (total == 0) return; // wave-uniform

@@ -418,9 +418,13 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
         uint32_t b, e;
         if (SCAN) { b = pre[t]; e = pre[t + 1]; e = e < cap ? e : cap; }
         else { const uint2 rg = ranges[t]; b = rg.x; e = rg.y; }
+#ifdef AGS_EXP_BUCKET_NOATOMIC
+        if (b + t == 0xFFFFFFFFu) keys[0] = e;
+#else
         const uint32_t slot = b + atomicAdd(&tile_fill[t], 1u);
         if (slot < e)
             keys[slot] = ((uint64_t)depth_bits[owner_tid] << 32) | (uint32_t)(blockIdx.x * AGS_PRE_THREADS + owner_tid);
+#endif
     });
 }
 

@@ -121,7 +121,13 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     }
     if (COUNT_TILES)  // tile-sort binning: how many surfels can reach each tile
         ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, rx0, ry0, rwd, 0u, g, F.tiles_x,
-                                [&](uint32_t t, uint32_t) { atomicAdd(&tile_count[t], 1u); });
+                                [&](uint32_t t, uint32_t) {
+#ifdef AGS_EXP_PRE_NOCOUNT
+                                    if (t == 0xFFFFFFFFu) tile_count[0] = 1;
+#else
+                                    atomicAdd(&tile_count[t], 1u);
+#endif
+                                });
     const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { wsum[wave] = ws; wvis[wave] = wv; }
