@@ -161,7 +161,7 @@ class SurfelTrainer:
         if not self.adam_fused:
             self.optim.step(self.slab.as_list(), device_clock=device_clock, pre_ticked=ticked)
 
-    def capture(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int) -> Callable:
+    def capture(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int, repeat: int = 1) -> Callable:
         """Capture one optimisation step into hipGraphs and return a ``replay()`` callable.
 
         The library never allocates or synchronises and every per-view input that changes
@@ -169,8 +169,12 @@ class SurfelTrainer:
         parameters), so a step is a fixed launch sequence: new views are rendered by copying
         their matrices into the captured ``Camera`` tensors before ``replay()``.  With more
         than one rank the all-reduce stays outside the graphs (graph | collective | graph).
-        Call after at least one eager ``step`` so every buffer exists."""
+        Call after at least one eager ``step`` so every buffer exists.  ``repeat`` > 1 (single rank)
+        records that many consecutive optimisation steps in ONE graph, so a replay pays the
+        graph-launch latency once per ``repeat`` steps; ``replay.steps`` says how many steps a call
+        performs."""
         dist_on = self._distributed()
+        repeat = 1 if dist_on else max(1, int(repeat))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         g_local, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -182,9 +186,10 @@ class SurfelTrainer:
                     self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
             else:
                 with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
-                    ticked = self._local_pass(cams, image_grads, max_instances, tick=True, fuse_adam=True)
-                    if not self.adam_fused:
-                        self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
+                    for _ in range(repeat):
+                        ticked = self._local_pass(cams, image_grads, max_instances, tick=True, fuse_adam=True)
+                        if not self.adam_fused:
+                            self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
         torch.cuda.current_stream().wait_stream(side)
 
         def replay():
@@ -194,4 +199,5 @@ class SurfelTrainer:
                 g_opt.replay()
 
         self._graphs = (g_local, g_opt)
+        replay.steps = repeat
         return replay

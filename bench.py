@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--binning", choices=["tile_sort", "radix"], default="tile_sort")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
+    ap.add_argument("--graph-steps", type=int, default=int(os.environ.get("AGS_BENCH_GRAPH_STEPS", "10")),
+                    help="optimisation steps recorded per hipGraph (single GPU); K steps = K/this replays")
     args = ap.parse_args()
     if os.environ.get("AGS_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack and exit after N s
         import faulthandler
@@ -150,12 +152,27 @@ def main():
     torch.cuda.synchronize()
     launch_mode = "eager" if args.eager else "hipGraph replay"
     one_step = eager_step
+    many_steps, per_replay = None, 1
     if not args.eager:
         try:
             one_step = trainer.capture([cam], grads_fn, cap)
+            if args.graph_steps > 1 and world == 1:
+                many_steps = trainer.capture([cam], grads_fn, cap, repeat=args.graph_steps)
+                per_replay = many_steps.steps
+                launch_mode = f"hipGraph replay, {per_replay} steps per graph"
         except Exception as e:  # never lose the measurement to a capture problem
             launch_mode = f"eager (graph capture failed: {type(e).__name__})"
+            many_steps, per_replay = None, 1
             torch.cuda.synchronize()
+
+    def run_steps(k):
+        """exactly k optimisation steps"""
+        if many_steps is not None:
+            for _ in range(k // per_replay):
+                many_steps()
+            k = k % per_replay
+        for _ in range(k):
+            one_step()
 
     def barrier():
         if world > 1:
@@ -168,14 +185,12 @@ def main():
         for _ in range(20):
             one_step()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        one_step()
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    run_steps(args.steps)
     enqueue_s = time.perf_counter() - t0
     torch.cuda.synchronize()
     barrier()
