@@ -28,9 +28,11 @@ struct AgsWaveStage {   // one per wave, in LDS
     uint32_t sid[64];
 };
 
-// stage surfel `gid` from lane `lane` and return its 4-bit strip-reach mask for tile (bx0,by0)
+// stage surfel `gid` from lane `lane` and return its strip-reach mask for tile (bx0,by0): bit s is
+// set when the surfel can reach strip s; only this wave's SLOTS strips (from strip0) are tested
+template <int SLOTS>
 __device__ __forceinline__ uint32_t ags_stage_one(AgsWaveStage& st, int lane, const AgsGeom* __restrict__ geom,
-                                                  uint32_t gid, float bx0, float by0) {
+                                                  uint32_t gid, float bx0, float by0, int strip0) {
     const float4* src = reinterpret_cast<const float4*>(geom + gid);
     const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
     float4* dst = reinterpret_cast<float4*>(&st.sg[lane]);
@@ -40,8 +42,10 @@ __device__ __forceinline__ uint32_t ags_stage_one(AgsWaveStage& st, int lane, co
     me.mx = r0.x; me.my = r0.y; me.ca = r0.z; me.cb = r0.w; me.cc = r1.x; me.o = r1.y;
     uint32_t m = 0;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int k = 0; k < SLOTS; ++k) {
+        const int s = strip0 + k;
         m |= ags_reaches_box(me, bx0, bx0 + 15.f, by0 + 4.f * s, by0 + 4.f * s + 3.f) ? (1u << s) : 0u;
+    }
     return m;
 }
 
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
         ags_wave_lds_sync();
         const uint32_t idx = base + lane;
         uint32_t m = 0;
-        if (idx < rg.y) m = ags_stage_one(st, lane, geom, vals[(size_t)idx * id_stride], bx0, by0);
+        if (idx < rg.y) m = ags_stage_one<SLOTS>(st, lane, geom, vals[(size_t)idx * id_stride], bx0, by0, strip0);
         ags_wave_lds_sync();
         unsigned long long act = __ballot((m & my_strips) != 0u); // staged surfels that reach my strips
         while (act) {
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
         const uint32_t k0 = (uint32_t)r << 6;
         ags_wave_lds_sync();
         uint32_t m = 0;
-        if (k0 + lane < maxlast) m = ags_stage_one(st, lane, geom, vals[(size_t)(rg.x + k0 + lane) * id_stride], bx0, by0);
+        if (k0 + lane < maxlast) m = ags_stage_one<SLOTS>(st, lane, geom, vals[(size_t)(rg.x + k0 + lane) * id_stride], bx0, by0, strip0);
         ags_wave_lds_sync();
         unsigned long long act = __ballot((m & my_strips) != 0u);
         while (act) { // back to front: highest staged position first

@@ -14,11 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_two_ranks_on_one_gpu(agslib):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, AGS_BENCH_SHARE_GPU="1", AGS_BENCH_BACKEND="gloo", AGS_BENCH_WATCHDOG="180")
+    env = dict(os.environ, AGS_BENCH_SHARE_GPU="1", AGS_BENCH_BACKEND="gloo", AGS_BENCH_WATCHDOG="240")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
            "--warmup", "3", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=480)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                  # exactly one JSON line, from rank 0
@@ -34,6 +34,6 @@ def test_torch_free_cabi_demo(agslib):
     step captured in a hipGraph and replayed) - no torch in the process."""
     from active_gs_amd import build
     exe = build.build_demo()
-    r = subprocess.run([exe, "30000", "50"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, "30000", "50"], capture_output=True, text=True, timeout=480)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("OK") and "adam_steps=71" in r.stdout
