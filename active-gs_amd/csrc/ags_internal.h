@@ -277,6 +277,65 @@ __device__ __forceinline__ void ags_emit_tiles_balanced(AgsEmitRec* wave_lds, ui
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- per-tile sort of the (depth_bits << 32 | id) keys of the tile-sort binning mode.
+// ascending-only bitonic network (mirrored first sub-step), so indices >= K behave as +inf
+// padding without being stored: works for any K, in LDS or in global memory.
+template <int NT, typename Ptr>
+__device__ __forceinline__ void ags_bitonic(Ptr a, uint32_t K, int tid) {
+    uint32_t Kp = 1;
+    while (Kp < K) Kp <<= 1;
+    const uint32_t half = Kp >> 1;
+    for (uint32_t k = 2; k <= Kp; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t t = tid; t < half; t += NT) {
+            const uint32_t blk = t / hk, off = t % hk;
+            const uint32_t i = blk * k + off, l = blk * k + (k - 1 - off);
+            if (l < K) { const uint64_t x = a[i], y = a[l]; if (x > y) { a[i] = y; a[l] = x; } }
+        }
+        __syncthreads();
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < half; t += NT) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;
+                if (l < K) { const uint64_t x = a[i], y = a[l]; if (x > y) { a[i] = y; a[l] = x; } }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Sorts g[0..K) in place with the NT threads of one workgroup (K is workgroup-uniform) and ends
+// with a workgroup barrier, after which every wave of the workgroup sees the sorted keys (a
+// workgroup's waves share their CU's L1).
+//   K <= 64:        ONE wave, no LDS: keys are unique, so a key's rank is the number of smaller keys;
+//                   every other key is broadcast through SGPRs (v_readlane)
+//   K <= LDS_KEYS:  bitonic network in LDS
+//   larger:         the same network on the (L2-resident) global slice
+template <int NT, int LDS_KEYS>
+__device__ __forceinline__ void ags_sort_tile_keys(uint64_t* g, uint32_t K, uint64_t* sk, int tid) {
+    if (K < 2) return;
+    if (K <= 64) {
+        if (tid < 64) {
+            const uint64_t mine = (tid < (int)K) ? g[tid] : ~0ull;
+            const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < K; ++j) {
+                const uint64_t other = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, j) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readlane((int)lo, j);
+                rank += (other < mine) ? 1u : 0u;
+            }
+            if (tid < (int)K) g[rank] = mine; // all loads happened before the first store (same wave)
+        }
+    } else if (K <= (uint32_t)LDS_KEYS) {
+        for (uint32_t t = tid; t < K; t += NT) sk[t] = g[t];
+        __syncthreads();
+        ags_bitonic<NT>(sk, K, tid);
+        for (uint32_t t = tid; t < K; t += NT) g[t] = sk[t];
+    } else {
+        ags_bitonic<NT>((volatile uint64_t*)g, K, tid);
+    }
+    __syncthreads();
+}
+
 // Transposed wave reduction of 16 per-lane values (gfx950 v_permlane32_swap / v_permlane16_swap):
 // each swap+add halves the lanes a value is spread over while packing two values into one
 // register, so 16 values cost 8+4 swap/add pairs + 4x4 in-row DPP adds (~43 VALU) instead of

@@ -428,65 +428,16 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
     });
 }
 
+// The per-tile sort (ags_sort_tile_keys, ags_internal.h) as its own launch: one 256-thread workgroup
+// per tile, 16 KiB of LDS.  Running it at the head of the tile's render workgroup instead was
+// measured: +1 % at C2, but -7 % / -19 % on the 1.5 M / 5 M-surfel configurations, where most tiles
+// hold more than 64 keys and would sort with half the threads and a quarter of the LDS.
 #define AGS_TSORT_LDS_KEYS 2048
-// ascending-only bitonic network (mirrored first sub-step), so indices >= K behave as +inf
-// padding without being stored: works for any K, in LDS or in global memory.
-template <typename Ptr>
-__device__ __forceinline__ void ags_bitonic_256(Ptr a, uint32_t K, int tid) {
-    uint32_t Kp = 1;
-    while (Kp < K) Kp <<= 1;
-    const uint32_t half = Kp >> 1;
-    for (uint32_t k = 2; k <= Kp; k <<= 1) {
-        const uint32_t hk = k >> 1;
-        for (uint32_t t = tid; t < half; t += 256) {
-            const uint32_t blk = t / hk, off = t % hk;
-            const uint32_t i = blk * k + off, l = blk * k + (k - 1 - off);
-            if (l < K) { const uint64_t x = a[i], y = a[l]; if (x > y) { a[i] = y; a[l] = x; } }
-        }
-        __syncthreads();
-        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < half; t += 256) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;
-                if (l < K) { const uint64_t x = a[i], y = a[l]; if (x > y) { a[i] = y; a[l] = x; } }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void ags_k_tile_sort(const uint2* __restrict__ ranges, uint64_t* keys, int num_tiles) {
     __shared__ uint64_t sk[AGS_TSORT_LDS_KEYS];
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
-    const uint32_t K = rg.y - rg.x;
-    if (K < 2) return;
-    const int tid = threadIdx.x;
-    uint64_t* g = keys + rg.x;
-    if (K <= 64) {
-        // one wave, no LDS, no barrier: keys are unique, so a key's rank is the number of smaller
-        // keys; every other key is broadcast through SGPRs (v_readlane)
-        if (tid >= 64) return;
-        const uint64_t mine = (tid < (int)K) ? g[tid] : ~0ull;
-        const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < K; ++j) {
-            const uint64_t other = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, j) << 32) |
-                                   (uint32_t)__builtin_amdgcn_readlane((int)lo, j);
-            rank += (other < mine) ? 1u : 0u;
-        }
-        if (tid < (int)K) g[rank] = mine; // all loads happened before the first store (same wave)
-        return;
-    }
-    if (K <= AGS_TSORT_LDS_KEYS) {
-        for (uint32_t t = tid; t < K; t += 256) sk[t] = g[t];
-        __syncthreads();
-        ags_bitonic_256(sk, K, tid);
-        for (uint32_t t = tid; t < K; t += 256) g[t] = sk[t];
-    } else {
-        // rare: one tile holds more keys than the LDS stage; same network on the (L2-resident)
-        // global slice. __syncthreads() orders a workgroup's global accesses on its own CU.
-        ags_bitonic_256((volatile uint64_t*)g, K, tid);
-    }
+    ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS>(keys + rg.x, rg.y - rg.x, sk, threadIdx.x);
 }
 
 void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s) {
