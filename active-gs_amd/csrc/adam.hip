@@ -84,7 +84,7 @@ void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float ep
     }
     if (t.touched.rows) {
         long long rb = (t.numel[3] + 15) / 16; // 16 rows per block
-        if (rb > 2048) rb = 2048;
+        if (rb > 16384) rb = 16384;
         hipLaunchKernelGGL(ags_k_adam_rows, dim3((unsigned)rb), dim3(256), 0, s, a, (const AgsAdamClock*)clk, hc,
                            t.touched, beta1, beta2, eps);
         return;

@@ -403,7 +403,7 @@ void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const Ag
     if (din.touched.rows) {
         // the member count lives on the device: a fixed grid strides over the list
         int blocks = (in.n + AGS_ROWS_THREADS - 1) / AGS_ROWS_THREADS;
-        if (blocks > 2048) blocks = 2048;
+        if (blocks > 16384) blocks = 16384; // fixed grid (the member count lives on the device): idle blocks exit at once
         if (din.fused_adam)
             hipLaunchKernelGGL(ags_k_preprocess_bwd_rows<true>, dim3(blocks), dim3(AGS_ROWS_THREADS), 0, s, F,
                                cam.viewmatrix, cam.projmatrix, in, radii, (AgsGeomGrad*)(ws + L.dgeom), din,
