@@ -52,7 +52,11 @@ struct AgsFrame {
 
 AGS_HD float ags_rcp(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rcpf(x); // v_rcp_f32, 1 ulp
+    float r = __builtin_amdgcn_rcpf(x); // v_rcp_f32, 1 ulp
+    // opaque to the optimiser: otherwise a later `-(..) * r` is rewritten as a SECOND quarter-rate
+    // v_rcp_f32 of the negated argument instead of a free neg modifier on the multiply
+    asm("" : "+v"(r));
+    return r;
 #else
     return 1.0f / x;
 #endif
