@@ -86,6 +86,18 @@ class SurfelTrainer:
             self.optim.touched = self.rows
         self._state = {}
 
+    def reset_optimizer(self) -> None:
+        """What the reference does at the start of every ``train()`` call (``init_training``,
+        gaussian_map.py:259-292): a fresh Adam.  Moments, step counter, gradient slab and the sticky
+        row set are cleared together (the row set's losslessness rests on exactly that)."""
+        for t in self.optim.exp_avg + self.optim.exp_avg_sq:
+            t.zero_()
+        self.optim.step_count = 0
+        self.optim.device_clock.zero_()
+        self.slab.flat.zero_()
+        if self.rows is not None:
+            self.rows.reset()
+
     # -- pieces --------------------------------------------------------------------------
     def _act_struct(self) -> _lib.AgsActivation:
         return _lib.AgsActivation(self.n, self.scale_factor, self.max_scale, ptr(self.raw["scales"]),

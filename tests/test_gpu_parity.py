@@ -284,6 +284,38 @@ def test_sparse_row_set_equals_dense_training(agslib):
     assert int((seen & ~member).sum()) <= int(0.002 * n)
 
 
+def test_reset_optimizer_restarts_adam_and_row_set(agslib):
+    """SurfelTrainer.reset_optimizer() == a fresh trainer on the current parameters (the reference
+    re-creates Adam per train() call); a captured graph keeps working across the reset."""
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.synthetic import make_room_scene
+    from active_gs_amd.trainer import SurfelTrainer
+    dev = torch.device("cuda:0")
+    n, h, w = 5000, 136, 240
+    _, S = room_case(n, h, w, view=1, seed=7)
+    cam = api.Camera(S.image_height, S.image_width, S.tanfovx, S.tanfovy, S.viewmatrix.to(dev), S.projmatrix.to(dev),
+                     S.bg.to(dev))
+    gen = torch.Generator().manual_seed(8)
+    d = [(torch.randn(c, h, w, generator=gen) / (h * w)).to(dev) for c in (3, 3, 1)]
+    fn = lambda v, st: (d[0], d[1], d[2], None, None)
+    raw = {k: v.to(dev) for k, v in make_room_scene(n, seed=7).items()}
+    a = SurfelTrainer(raw)
+    for _ in range(3):
+        a.step([cam], fn, 1 << 20, device_clock=True)
+    replay = a.capture([cam], fn, 1 << 20)
+    a.reset_optimizer()
+    assert int(a.rows.count.item()) == 0 and int(a.optim.device_clock[0].item()) == 0
+    b = SurfelTrainer({k: v.clone() for k, v in a.raw.items()})       # fresh optimiser, same parameters
+    for _ in range(2):
+        replay()
+        b.step([cam], fn, 1 << 20, device_clock=True)
+    torch.cuda.synchronize()
+    assert int(a.optim.device_clock[0].item()) == 2 and int(a.rows.count.item()) == int(b.rows.count.item()) > 0
+    for x, y in zip(a.params, b.params):
+        diff = (x - y).abs()
+        assert float(diff.mean()) < 2e-6 and float((diff > 1e-4).float().mean()) < 0.01
+
+
 def test_fused_activations_match_separate_kernels(agslib):
     """raw_params mode (activations + chain rule inside the per-Gaussian kernels) == ags_activate
     -> forward/backward on activated values -> ags_activate_backward."""
