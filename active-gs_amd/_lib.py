@@ -92,7 +92,8 @@ class AgsCandidates(C.Structure):
     _fields_ = [("means", c_f32p), ("rotations", c_f32p), ("harmonics", c_f32p), ("select", C.c_void_p)]
 
 
-EXPORTS = ["ags_workspace_bytes", "ags_workspace_init", "ags_forward", "ags_backward", "ags_read_status", "ags_adam_step",
+EXPORTS = ["ags_workspace_bytes", "ags_workspace_init", "ags_forward", "ags_forward_batch",
+           "ags_forward_batch_workspace_bytes", "ags_backward", "ags_read_status", "ags_adam_step",
            "ags_adam_step_device", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_smooth_depth", "ags_densify_candidates",
            "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_compact_plan_bytes", "ags_compact_plan",
            "ags_compact_rows", "ags_profile_enable", "ags_profile_read",
@@ -117,6 +118,15 @@ def load() -> C.CDLL:
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the rasterizer.")
     lib = C.CDLL(path)
+    if os.environ.get("AGS_LIB_ALLOW_MISSING"):   # kernel archaeology only: A/B an OLD build of the library
+        class _Partial:
+            def __init__(self, inner): self._inner = inner
+            def __getattr__(self, name):
+                try:
+                    return getattr(self._inner, name)
+                except AttributeError:
+                    return C.CFUNCTYPE(C.c_int)(lambda *a: -1)
+        lib = _Partial(lib)
     lib.ags_workspace_bytes.restype = C.c_size_t
     lib.ags_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64]
     lib.ags_workspace_init.restype = C.c_int
@@ -124,6 +134,11 @@ def load() -> C.CDLL:
     lib.ags_forward.restype = C.c_int
     lib.ags_forward.argtypes = [C.POINTER(AgsCamera), C.POINTER(AgsGaussians), C.POINTER(AgsImages),
                                 C.POINTER(AgsPerGaussian), C.POINTER(AgsWorkspace), C.c_void_p]
+    lib.ags_forward_batch.restype = C.c_int
+    lib.ags_forward_batch.argtypes = [C.POINTER(AgsCamera), C.c_int32, C.POINTER(AgsGaussians), C.POINTER(AgsImages),
+                                      C.POINTER(AgsPerGaussian), C.POINTER(AgsWorkspace), C.c_void_p]
+    lib.ags_forward_batch_workspace_bytes.restype = C.c_size_t
+    lib.ags_forward_batch_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64]
     lib.ags_backward.restype = C.c_int
     lib.ags_backward.argtypes = [C.POINTER(AgsCamera), C.POINTER(AgsGaussians), C.POINTER(AgsImages),
                                  C.POINTER(AgsPerGaussian), C.POINTER(AgsImageGrads), C.POINTER(AgsGaussianGrads),

@@ -108,17 +108,30 @@ inline AgsAdamArgs ags_adam_args(const AgsAdamTensors& t) {
     return a;
 }
 
+// Batched forward (ags_forward_batch): blockIdx.y selects the view; every per-view pointer moves by
+// these strides (all zero-cost for the single-view launches, which pass gridDim.y == 1).
+struct AgsViewStride {
+    long long ws;   // bytes between two views' workspaces
+    long long px;   // pixels per image plane (H*W): images / masks of consecutive views are contiguous
+    long long n;    // Gaussians: per-Gaussian outputs (radii, importance, count) of consecutive views
+    int views;      // gridDim.y
+};
+#define AGS_WS_SHIFT(ptr, off) ptr = reinterpret_cast<decltype(ptr)>(reinterpret_cast<uintptr_t>(ptr) + (off))
+
 // ---- launchers (one per translation unit; each enqueues on `s` and never synchronises)
 // `ids` + `id_stride`: sorted Gaussian ids per instance; stride 2 when they are the low
 // words of the 64-bit (depth|id) keys of the tile-sort mode.
 struct AgsIdList { const uint32_t* ids; int stride; };
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
-                           const AgsLayout& L, int* radii, bool count_tiles, const AgsRowSet& touched, hipStream_t s);
+                           const AgsLayout& L, int* radii, bool count_tiles, const AgsRowSet& touched,
+                           const AgsViewStride& vs, hipStream_t s);
 void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s);
-void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s);
+void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L,
+                             const AgsViewStride& vs, hipStream_t s);
 AgsIdList ags_sorted_ids(char* ws, const AgsLayout& L, int binning_mode);
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
-                           AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, hipStream_t s);
+                           AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs,
+                           hipStream_t s);
 void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick, hipStream_t s);
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
@@ -303,13 +316,28 @@ __device__ __forceinline__ void ags_bitonic(Ptr a, uint32_t K, int tid) {
     }
 }
 
+// Steps j = j0, j0/2, ..., 1 of the network on one LDS-resident chunk (the "finish" of a stage whose
+// wide steps ran in global memory); `base` = global index of the chunk's first key.
+template <int NT>
+__device__ __forceinline__ void ags_bitonic_finish_lds(uint64_t* sk, uint32_t n, uint32_t j0, int tid) {
+    for (uint32_t j = j0; j > 0; j >>= 1) {
+        for (uint32_t t = tid; t < (n + 1) / 2 + j; t += NT) {
+            const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;
+            if (l < n) { const uint64_t x = sk[i], y = sk[l]; if (x > y) { sk[i] = y; sk[l] = x; } }
+        }
+        __syncthreads();
+    }
+}
+
 // Sorts g[0..K) in place with the NT threads of one workgroup (K is workgroup-uniform) and ends
 // with a workgroup barrier, after which every wave of the workgroup sees the sorted keys (a
 // workgroup's waves share their CU's L1).
 //   K <= 64:        ONE wave, no LDS: keys are unique, so a key's rank is the number of smaller keys;
 //                   every other key is broadcast through SGPRs (v_readlane)
 //   K <= LDS_KEYS:  bitonic network in LDS
-//   larger:         the same network on the (L2-resident) global slice
+//   larger:         chunks of LDS_KEYS are sorted in LDS, then only the steps whose partners are
+//                   >= LDS_KEYS apart run on the (L2-resident) global slice and every stage is finished
+//                   chunk by chunk in LDS again: 3 global passes for 8192 keys instead of 91
 template <int NT, int LDS_KEYS>
 __device__ __forceinline__ void ags_sort_tile_keys(uint64_t* g, uint32_t K, uint64_t* sk, int tid) {
     if (K < 2) return;
@@ -331,7 +359,45 @@ __device__ __forceinline__ void ags_sort_tile_keys(uint64_t* g, uint32_t K, uint
         ags_bitonic<NT>(sk, K, tid);
         for (uint32_t t = tid; t < K; t += NT) g[t] = sk[t];
     } else {
-        ags_bitonic<NT>((volatile uint64_t*)g, K, tid);
+        constexpr uint32_t C = LDS_KEYS; // power of two
+        // phase 1: every chunk sorted ascending on its own
+        for (uint32_t c0 = 0; c0 < K; c0 += C) {
+            const uint32_t n = (K - c0 < C) ? K - c0 : C;
+            for (uint32_t t = tid; t < n; t += NT) sk[t] = g[c0 + t];
+            __syncthreads();
+            ags_bitonic<NT>(sk, n, tid);
+            for (uint32_t t = tid; t < n; t += NT) g[c0 + t] = sk[t];
+            __syncthreads();
+        }
+        // phase 2: merge stages k = 2C, 4C, ...: wide steps in global memory, the rest per chunk in LDS
+        volatile uint64_t* a = (volatile uint64_t*)g;
+        uint32_t Kp = 1;
+        while (Kp < K) Kp <<= 1;
+        const uint32_t half = Kp >> 1;
+        for (uint32_t k = 2 * C; k <= Kp; k <<= 1) {
+            const uint32_t hk = k >> 1;
+            for (uint32_t t = tid; t < half; t += NT) { // mirrored first step of the stage
+                const uint32_t blk = t / hk, off = t % hk;
+                const uint32_t i = blk * k + off, l = blk * k + (k - 1 - off);
+                if (l < K) { const uint64_t x = a[i], y = a[l]; if (x > y) { a[i] = y; a[l] = x; } }
+            }
+            __syncthreads();
+            for (uint32_t j = k >> 2; j >= C; j >>= 1) {
+                for (uint32_t t = tid; t < half; t += NT) {
+                    const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;
+                    if (l < K) { const uint64_t x = a[i], y = a[l]; if (x > y) { a[i] = y; a[l] = x; } }
+                }
+                __syncthreads();
+            }
+            for (uint32_t c0 = 0; c0 < K; c0 += C) {
+                const uint32_t n = (K - c0 < C) ? K - c0 : C;
+                for (uint32_t t = tid; t < n; t += NT) sk[t] = g[c0 + t];
+                __syncthreads();
+                ags_bitonic_finish_lds<NT>(sk, n, C >> 1, tid);
+                for (uint32_t t = tid; t < n; t += NT) g[c0 + t] = sk[t];
+                __syncthreads();
+            }
+        }
     }
     __syncthreads();
 }

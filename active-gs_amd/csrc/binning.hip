@@ -300,7 +300,11 @@ void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, con
 __global__ __launch_bounds__(1024) void ags_k_scan_tiles(const uint32_t* __restrict__ tile_count, int T,
                                                          uint2* __restrict__ ranges, uint32_t* __restrict__ status,
                                                          uint32_t cap, const uint32_t* __restrict__ block_vis,
-                                                         int nblk) {
+                                                         int nblk, AgsViewStride vs) {
+    if (vs.views > 1) {
+        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
+        AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(status, wo); AGS_WS_SHIFT(block_vis, wo);
+    }
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -344,7 +348,13 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
     int n, int tiles_x, const uint32_t* __restrict__ tiles, const ushort4* __restrict__ rect,
     const AgsGeom* __restrict__ geom, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill,
     uint64_t* __restrict__ keys, const uint32_t* __restrict__ tile_count, int T, uint32_t cap,
-    uint32_t* __restrict__ status, const uint32_t* __restrict__ block_vis, int nblk) {
+    uint32_t* __restrict__ status, const uint32_t* __restrict__ block_vis, int nblk, AgsViewStride vs) {
+    if (vs.views > 1) {
+        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
+        AGS_WS_SHIFT(tiles, wo); AGS_WS_SHIFT(rect, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(ranges, wo);
+        AGS_WS_SHIFT(tile_fill, wo); AGS_WS_SHIFT(keys, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(status, wo);
+        AGS_WS_SHIFT(block_vis, wo);
+    }
     __shared__ AgsEmitRec emit[AGS_PRE_THREADS];
     __shared__ uint32_t depth_bits[AGS_PRE_THREADS];
     __shared__ uint32_t pre[SCAN ? AGS_BUCKET_SCAN_TILES + 1 : 1]; // pre[t] = instances of tiles < t
@@ -433,14 +443,20 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
 // measured: +1 % at C2, but -7 % / -19 % on the 1.5 M / 5 M-surfel configurations, where most tiles
 // hold more than 64 keys and would sort with half the threads and a quarter of the LDS.
 #define AGS_TSORT_LDS_KEYS 2048
-__global__ __launch_bounds__(256) void ags_k_tile_sort(const uint2* __restrict__ ranges, uint64_t* keys, int num_tiles) {
+__global__ __launch_bounds__(256) void ags_k_tile_sort(const uint2* __restrict__ ranges, uint64_t* keys, int num_tiles,
+                                                       AgsViewStride vs) {
+    if (vs.views > 1) {
+        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
+        AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(keys, wo);
+    }
     __shared__ uint64_t sk[AGS_TSORT_LDS_KEYS];
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
     ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS>(keys + rg.x, rg.y - rg.x, sk, threadIdx.x);
 }
 
-void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s) {
+void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L,
+                             const AgsViewStride& vs, hipStream_t s) {
     uint32_t* status = (uint32_t*)(ws + L.status);
     uint2* ranges = (uint2*)(ws + L.ranges);
     uint64_t* keys = (uint64_t*)(ws + L.keys0);
@@ -448,17 +464,18 @@ void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws
     const uint32_t* block_vis = (const uint32_t*)(ws + L.block_vis);
     static const bool no_fuse = getenv("AGS_BUCKET_NO_SCAN") != nullptr; // experiment knob
     if (L.num_tiles <= AGS_BUCKET_SCAN_TILES && !no_fuse) {
-        hipLaunchKernelGGL(ags_k_bucket<true>, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, in.n, F.tiles_x,
+        hipLaunchKernelGGL(ags_k_bucket<true>, dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, in.n, F.tiles_x,
                            (const uint32_t*)(ws + L.tiles), (const ushort4*)(ws + L.rect), (const AgsGeom*)(ws + L.geom),
                            ranges, (uint32_t*)(ws + L.tile_fill), keys, tile_count, L.num_tiles, (uint32_t)L.cap, status,
-                           block_vis, L.n_blocks);
+                           block_vis, L.n_blocks, vs);
     } else {
-        hipLaunchKernelGGL(ags_k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_count, L.num_tiles, ranges, status,
-                           (uint32_t)L.cap, block_vis, L.n_blocks);
-        hipLaunchKernelGGL(ags_k_bucket<false>, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, in.n, F.tiles_x,
+        hipLaunchKernelGGL(ags_k_scan_tiles, dim3(1, vs.views), dim3(1024), 0, s, tile_count, L.num_tiles, ranges, status,
+                           (uint32_t)L.cap, block_vis, L.n_blocks, vs);
+        hipLaunchKernelGGL(ags_k_bucket<false>, dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, in.n, F.tiles_x,
                            (const uint32_t*)(ws + L.tiles), (const ushort4*)(ws + L.rect), (const AgsGeom*)(ws + L.geom),
                            ranges, (uint32_t*)(ws + L.tile_fill), keys, tile_count, L.num_tiles, (uint32_t)L.cap, status,
-                           block_vis, L.n_blocks);
+                           block_vis, L.n_blocks, vs);
     }
-    hipLaunchKernelGGL(ags_k_tile_sort, dim3(L.num_tiles), dim3(256), 0, s, (const uint2*)ranges, keys, L.num_tiles);
+    hipLaunchKernelGGL(ags_k_tile_sort, dim3(L.num_tiles, vs.views), dim3(256), 0, s, (const uint2*)ranges, keys,
+                       L.num_tiles, vs);
 }

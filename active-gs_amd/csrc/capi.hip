@@ -36,6 +36,8 @@ int ags_workspace_init(const AgsWorkspace* ws, int32_t n, int32_t h, int32_t w, 
     return AGS_OK;
 }
 
+static const AgsViewStride kOneView = {0, 0, 0, 1};
+
 int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* out,
                 const AgsPerGaussian* pg, const AgsWorkspace* ws, ags_stream_t stream) {
     if (!cam || !in || !out || !pg || !ws || !ws->ptr) return AGS_E_INVALID;
@@ -58,12 +60,40 @@ int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* o
     // totals and tile ranges every pass
     if ((radix || in->n == 0) && hipMemsetAsync(base + L.status, 0, L.clear_bytes, s) != hipSuccess) return AGS_E_LAUNCH;
     if (in->n > 0) {
-        { StageScope t(AGS_STAGE_PREPROCESS, s); ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, !radix, pg->touched, s); }
+        { StageScope t(AGS_STAGE_PREPROCESS, s); ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, !radix, pg->touched, kOneView, s); }
         { StageScope t(AGS_STAGE_BINNING, s);
-          if (radix) ags_launch_binning(F, *in, base, L, s); else ags_launch_tile_binning(F, *in, base, L, s); }
+          if (radix) ags_launch_binning(F, *in, base, L, s); else ags_launch_tile_binning(F, *in, base, L, kOneView, s); }
     }
     { StageScope t(AGS_STAGE_RENDER_FWD, s);
-      ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, s); }
+      ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, kOneView, s); }
+    return ags_check_launch();
+}
+
+size_t ags_forward_batch_workspace_bytes(int32_t views, int32_t n, int32_t h, int32_t w, int64_t max_instances) {
+    if (views < 1 || n < 0 || h <= 0 || w <= 0) return 0;
+    return (size_t)views * ags_make_layout(n, h, w, max_instances).total;
+}
+
+int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* in, const AgsImages* out,
+                      const AgsPerGaussian* pg, const AgsWorkspace* ws, ags_stream_t stream) {
+    if (!cam || !in || !out || !pg || !ws || !ws->ptr || views < 1 || views > 65535) return AGS_E_INVALID;
+    if (in->n <= 0 || cam->image_height <= 0 || cam->image_width <= 0) return AGS_E_INVALID;
+    if (!cam->viewmatrix || !cam->projmatrix || !cam->bg || !pg->radii) return AGS_E_INVALID;
+    if (!out->rgb || !out->normal || !out->depth || !out->opacity || !out->confidence) return AGS_E_INVALID;
+    if (cam->want_stats && (!pg->importance || !pg->count)) return AGS_E_INVALID;
+    if (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences) return AGS_E_INVALID;
+    if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll) return AGS_E_INVALID;
+    if (ws->binning_mode != AGS_BIN_TILE_SORT || pg->touched.member) return AGS_E_INVALID;
+    const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
+    if (ws->bytes < (size_t)views * L.total) return AGS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* base = (char*)ws->ptr;
+    const AgsFrame F = ags_make_frame(cam);
+    AgsViewStride vs;
+    vs.ws = (long long)L.total; vs.px = (long long)cam->image_height * cam->image_width; vs.n = in->n; vs.views = views;
+    ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, true, pg->touched, vs, s);
+    ags_launch_tile_binning(F, *in, base, L, vs, s);
+    ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, vs, s);
     return ags_check_launch();
 }
 

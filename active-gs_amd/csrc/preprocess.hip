@@ -65,7 +65,14 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     AgsGeom* __restrict__ geom, uint32_t* __restrict__ tiles, ushort4* __restrict__ rect,
     int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_vis,
-    uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom, AgsRowSet touched) {
+    uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom, AgsRowSet touched, AgsViewStride vs) {
+    if (vs.views > 1) { // batched forward: this workgroup's view
+        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
+        Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
+        radii += (size_t)blockIdx.y * (size_t)vs.n;
+        AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(tiles, wo); AGS_WS_SHIFT(rect, wo); AGS_WS_SHIFT(block_sums, wo);
+        AGS_WS_SHIFT(block_vis, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(dgeom, wo);
+    }
     __shared__ uint32_t wsum[AGS_PRE_THREADS / 64], wvis[AGS_PRE_THREADS / 64];
     __shared__ AgsEmitRec emit[COUNT_TILES ? AGS_PRE_THREADS : 1];
     __shared__ __attribute__((aligned(16))) float rows3[3 * AGS_PRE_THREADS];
@@ -385,17 +392,18 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
 }
 
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
-                           const AgsLayout& L, int* radii, bool count_tiles, const AgsRowSet& touched, hipStream_t s) {
+                           const AgsLayout& L, int* radii, bool count_tiles, const AgsRowSet& touched,
+                           const AgsViewStride& vs, hipStream_t s) {
     if (count_tiles)
-        hipLaunchKernelGGL(ags_k_preprocess<true>, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
+        hipLaunchKernelGGL(ags_k_preprocess<true>, dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
                            cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
                            (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums),
-                           (uint32_t*)(ws + L.block_vis), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched);
+                           (uint32_t*)(ws + L.block_vis), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched, vs);
     else
-        hipLaunchKernelGGL(ags_k_preprocess<false>, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
+        hipLaunchKernelGGL(ags_k_preprocess<false>, dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
                            cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
                            (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums),
-                           (uint32_t*)(ws + L.block_vis), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched);
+                           (uint32_t*)(ws + L.block_vis), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched, vs);
 }
 
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,

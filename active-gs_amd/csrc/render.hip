@@ -61,7 +61,15 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     const float* __restrict__ mask, const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
     int id_stride, const AgsGeom* __restrict__ geom, AgsImages out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ importance, int* __restrict__ count, int num_tiles,
-    uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_fill) {
+    uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_fill, AgsViewStride vs) {
+    if (vs.views > 1) { // batched forward: this workgroup's view
+        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws, po = (size_t)blockIdx.y * (size_t)vs.px;
+        AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(vals, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(final_T, wo);
+        AGS_WS_SHIFT(n_contrib, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(tile_fill, wo);
+        if (mask) mask += po;
+        out.rgb += 3 * po; out.normal += 3 * po; out.depth += po; out.opacity += po; out.confidence += po;
+        if (STATS) { importance += (size_t)blockIdx.y * (size_t)vs.n; count += (size_t)blockIdx.y * (size_t)vs.n; }
+    }
     __shared__ AgsWaveStage stage[4 / SLOTS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     AgsWaveStage& st = stage[wave];
@@ -260,22 +268,22 @@ static int ags_pick_slots(int num_tiles) {
 
 template <int SLOTS>
 static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L, AgsIdList ids,
-                       const AgsImages& out, const AgsPerGaussian& pg, hipStream_t s) {
+                       const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs, hipStream_t s) {
     const uint2* ranges = (const uint2*)(ws + L.ranges);
     const AgsGeom* geom = (const AgsGeom*)(ws + L.geom);
     float* fT = (float*)(ws + L.final_T);
     uint32_t* nc = (uint32_t*)(ws + L.n_contrib);
     const dim3 block(64 * (4 / SLOTS));
     if (cam.want_stats)
-        hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, true>), dim3(L.num_tiles), block, 0, s, F, cam.normalize_depth,
+        hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, true>), dim3(L.num_tiles, vs.views), block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
-                           (uint32_t*)(ws + L.tile_fill));
+                           (uint32_t*)(ws + L.tile_fill), vs);
     else
-        hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, false>), dim3(L.num_tiles), block, 0, s, F, cam.normalize_depth,
+        hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, false>), dim3(L.num_tiles, vs.views), block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
-                           (uint32_t*)(ws + L.tile_fill));
+                           (uint32_t*)(ws + L.tile_fill), vs);
 }
 
 template <int SLOTS>
@@ -288,11 +296,13 @@ static void launch_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
 }
 
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
-                           AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, hipStream_t s) {
-    switch (ags_pick_slots(L.num_tiles)) {
-        case 1: launch_fwd<1>(F, cam, ws, L, ids, out, pg, s); break;
-        case 2: launch_fwd<2>(F, cam, ws, L, ids, out, pg, s); break;
-        default: launch_fwd<4>(F, cam, ws, L, ids, out, pg, s); break;
+                           AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs,
+                           hipStream_t s) {
+    // strips per wave by the number of tiles in flight: a batch of views fills the GPU like one big image
+    switch (ags_pick_slots(L.num_tiles * vs.views)) {
+        case 1: launch_fwd<1>(F, cam, ws, L, ids, out, pg, vs, s); break;
+        case 2: launch_fwd<2>(F, cam, ws, L, ids, out, pg, vs, s); break;
+        default: launch_fwd<4>(F, cam, ws, L, ids, out, pg, vs, s); break;
     }
 }
 

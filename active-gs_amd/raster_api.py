@@ -279,3 +279,96 @@ def forward_many(cams: Sequence[Camera], g: Gaussians, states: Sequence[ForwardS
         _lib.check(lib.ags_forward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(ws),
                                    handles[k % len(handles)]), "ags_forward")
     pool.join()
+
+
+class ViewBatch:
+    """``V`` forward-only views of one size and field of view rendered by ONE set of launches
+    (``ags_forward_batch``: blockIdx.y = view).
+
+    The planners' utility pass renders ~100 candidate views at 128x128 per planning step
+    (/root/reference/planning/confidence.py:24-46) and the prune pass renders every keyframe
+    (/root/reference/mapping/gaussian_map.py:149-192).  One such view is 64 tiles - it cannot fill
+    256 CUs, and 600 separate launches are host-bound besides; a batch is one big grid.
+    Outputs are batched tensors (``rgb`` (V,3,H,W), ``depth`` (V,1,H,W), ..., ``count`` (V,n));
+    ``states[v]`` is a per-view ``ForwardState`` of slices of them.  ``mode="streams"`` keeps the
+    older path (per-view launches on a stream pool, replayed from a hipGraph) for comparison."""
+
+    def __init__(self, g: Gaussians, num_views: int, height: int, width: int, tanfovx: float, tanfovy: float,
+                 bg: torch.Tensor, max_instances: int, num_streams: int = 8, want_stats: bool = False,
+                 front_only: bool = False, render_masks: Optional[torch.Tensor] = None,
+                 binning_mode: int = BIN_TILE_SORT, mode: str = "batched"):
+        for name in ("means3D", "scales", "rotations", "opacities", "colors", "confidences"):
+            _require_cuda(getattr(g, name), name)
+        if mode not in ("batched", "streams"):
+            raise ValueError("mode is 'batched' or 'streams'")
+        dev = g.means3D.device
+        V, n, h, w = int(num_views), g.n, int(height), int(width)
+        self.g, self.num_views, self.mode, self.want_stats = g, V, mode, want_stats
+        self.viewmats = torch.zeros(V, 4, 4, device=dev)
+        self.projmats = torch.zeros(V, 4, 4, device=dev)
+        self.masks = None if render_masks is None else render_masks.to(dev).float().reshape(V, h, w).contiguous()
+        f = dict(device=dev, dtype=torch.float32)
+        self.rgb, self.normal = torch.empty(V, 3, h, w, **f), torch.empty(V, 3, h, w, **f)
+        self.depth, self.opacity, self.confidence = (torch.empty(V, 1, h, w, **f) for _ in range(3))
+        self.importance = torch.zeros(V, n, **f)
+        self.count = torch.zeros(V, n, device=dev, dtype=torch.int32)
+        self.radii = torch.empty(V, n, device=dev, dtype=torch.int32)
+        per = workspace_bytes(n, h, w, max_instances)
+        self.workspace = torch.empty(V * per, device=dev, dtype=torch.uint8)
+        self.states = [ForwardState(self.rgb[v], self.normal[v], self.depth[v], self.opacity[v], self.confidence[v],
+                                    self.importance[v], self.count[v], self.radii[v],
+                                    self.workspace[v * per:(v + 1) * per], int(max_instances), int(binning_mode))
+                       for v in range(V)]
+        lib = _lib.load()
+        for st in self.states:
+            ws = st.ws_struct()
+            _lib.check(lib.ags_workspace_init(C.byref(ws), n, h, w, _stream()), "ags_workspace_init")
+        self.cam = Camera(h, w, tanfovx, tanfovy, self.viewmats, self.projmats, bg, want_stats=want_stats,
+                          front_only=front_only, render_mask=self.masks)
+        self.cams = [Camera(h, w, tanfovx, tanfovy, self.viewmats[v], self.projmats[v], bg, want_stats=want_stats,
+                            front_only=front_only, render_mask=None if self.masks is None else self.masks[v])
+                     for v in range(V)]
+        self.pool = StreamPool(min(num_streams, max(1, V))) if mode == "streams" else None
+        self._graph = None
+
+    def _enqueue_batched(self) -> None:
+        lib = _lib.load()
+        if self.want_stats:
+            self.importance.zero_()
+            self.count.zero_()
+        cs, gs = self.cam.c_struct(), self.g.c_struct()
+        im = _lib.AgsImages(ptr(self.rgb), ptr(self.normal), ptr(self.depth), ptr(self.opacity), ptr(self.confidence))
+        pg = _lib.AgsPerGaussian(ptr(self.importance), ptr(self.count), ptr(self.radii), _rowset_struct(None))
+        ws = _lib.AgsWorkspace(ptr(self.workspace), self.workspace.numel(), self.states[0].max_instances,
+                               self.states[0].binning_mode)
+        _lib.check(lib.ags_forward_batch(C.byref(cs), self.num_views, C.byref(gs), C.byref(im), C.byref(pg),
+                                         C.byref(ws), _stream()), "ags_forward_batch")
+
+    def render(self, viewmats: torch.Tensor, projmats: torch.Tensor, use_graph: bool = True):
+        """Render the ``V`` poses (``(V,4,4)`` view and view-projection matrices, row-vector
+        convention as everywhere).  Asynchronous; returns the per-view ``ForwardState`` list."""
+        self.viewmats.copy_(viewmats.reshape(self.num_views, 4, 4), non_blocking=True)
+        self.projmats.copy_(projmats.reshape(self.num_views, 4, 4), non_blocking=True)
+        if self.mode == "batched":
+            self._enqueue_batched()
+            return self.states
+        if not use_graph:
+            forward_many(self.cams, self.g, self.states, self.pool)
+            return self.states
+        if self._graph is None:
+            forward_many(self.cams, self.g, self.states, self.pool)   # warm-up outside capture
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                    forward_many(self.cams, self.g, self.states, self.pool)
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = graph
+        self._graph.replay()
+        return self.states
+
+    def overflowed(self) -> bool:
+        """Blocking: did any view need more tile instances than ``max_instances``?"""
+        return any(read_status(st)["overflow"] for st in self.states)

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""The planners' utility render (/root/reference/planning/confidence.py:24-46,
+config/planner/confidence.yaml: ~100 candidate views at 128x128) four ways: through the facade +
+one by one through the C ABI, concurrently on HIP streams (forward_many), the same replayed from one
+hipGraph, and as ONE batched set of launches (ViewBatch -> ags_forward_batch).  Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.camera import camera_matrices
+    from active_gs_amd.synthetic import activate, make_camera, make_room_scene
+    dev = torch.device("cuda:0")
+    n, h, w, V = 200_000, 128, 128, 100
+    a = activate(make_room_scene(n, seed=0))
+    g = api.Gaussians(*(a[k].to(dev).contiguous() for k in ("means", "scales", "rotations", "opacities", "colors",
+                                                              "confidences")))
+    c2w, K = zip(*[make_camera(v, h, w) for v in range(V)])
+    cm = camera_matrices(torch.stack(c2w).to(dev), torch.stack(K).to(dev), 0.001, 10.0)
+    tan = cm["tanfov"][0].cpu()
+    bg = torch.zeros(4, device=dev)
+    vm, pm = cm["viewmatrix"].contiguous(), cm["projmatrix"].contiguous()
+    cams = [api.Camera(h, w, float(tan[0]), float(tan[1]), vm[v], pm[v], bg) for v in range(V)]
+    cap = 1 << 19
+    states = [api.alloc_state(n, h, w, cap, dev) for _ in range(V)]
+
+    def timed(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    t_seq = timed(lambda: api.forward_many(cams, g, states, None))
+    t_streams = timed(lambda: api.forward_many(cams, g, states, api.StreamPool(8)))
+    batch = api.ViewBatch(g, V, h, w, float(tan[0]), float(tan[1]), bg, cap, num_streams=8, mode="streams")
+    t_graph = round(timed(lambda: batch.render(vm, pm)), 2)
+    batch = api.ViewBatch(g, V, h, w, float(tan[0]), float(tan[1]), bg, cap)
+    t_batched = round(timed(lambda: batch.render(vm, pm)), 2)
+    assert not batch.overflowed()
+    diff = max(float((a_.rgb - b_.rgb).abs().max()) for a_, b_ in zip(states, batch.states))
+    print(json.dumps(dict(workload=f"{V} candidate views @{h}x{w}, {n} surfels, forward only",
+                          ms_one_by_one=round(t_seq, 2), ms_streams8=round(t_streams, 2), ms_streams8_graph_replay=t_graph,
+                          ms_one_batched_launch=t_batched,
+                          max_abs_rgb_difference_batched_vs_single=diff)))
+
+
+if __name__ == "__main__":
+    main()

@@ -186,6 +186,20 @@ int ags_workspace_init(const AgsWorkspace* ws, int32_t n, int32_t h, int32_t w, 
 int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* out,
                 const AgsPerGaussian* per_gaussian, const AgsWorkspace* ws, ags_stream_t stream);
 
+/* Forward-only render of `views` views of ONE size and field of view in a single set of launches
+ * (blockIdx.y = view): the planners' utility pass (~100 candidate views at 128x128,
+ * /root/reference/planning/confidence.py:24-46) and the prune pass over all keyframes
+ * (/root/reference/mapping/gaussian_map.py:149-192).  One small view cannot fill the GPU; a batch can.
+ *   cam:  the common fields; viewmatrix / projmatrix point at (views,16) floats, render_mask (if any)
+ *         at (views,H,W);
+ *   out:  pointers to (views,C,H,W) image batches; per_gaussian: (views,n) batches;
+ *   ws:   `views` consecutive workspaces of ags_workspace_bytes(n,h,w,max_instances) each, every one
+ *         initialised with ags_workspace_init; view v's status block is at ptr + v * that size.
+ * Tile-sort binning only. */
+size_t ags_forward_batch_workspace_bytes(int32_t views, int32_t n, int32_t h, int32_t w, int64_t max_instances);
+int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* in, const AgsImages* out,
+                      const AgsPerGaussian* per_gaussian, const AgsWorkspace* ws, ags_stream_t stream);
+
 /* Backward of the same view; `fwd` are the images ags_forward wrote. */
 int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* fwd,
                  const AgsPerGaussian* per_gaussian, const AgsImageGrads* dout,

@@ -471,6 +471,40 @@ def test_forward_many_streams_equal_sequential(agslib):
         assert torch.allclose(s1.importance, s2.importance, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode", ["batched", "streams"])
+def test_view_batch_equals_sequential(agslib, mode):
+    """ViewBatch: many small forward-only views in ONE set of launches (blockIdx.y = view), or
+    replayed from a hipGraph over a stream pool == the same views rendered one after another;
+    poses can change between calls."""
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.synthetic import activate, make_room_scene
+    dev = torch.device("cuda:0")
+    n, h, w, V = 20000, 128, 128, 12
+    a = activate(make_room_scene(n, seed=9))
+    g = api.Gaussians(*(a[k].to(dev).contiguous() for k in ("means", "scales", "rotations", "opacities", "colors",
+                                                              "confidences")))
+    S = [room_case(16, h, w, view=v, seed=9)[1] for v in range(2 * V)]
+    bg = S[0].bg.to(dev)
+    batch = api.ViewBatch(g, V, h, w, S[0].tanfovx, S[0].tanfovy, bg, 1 << 18, num_streams=4, want_stats=True,
+                          mode=mode)
+    for rnd in range(2):                                  # second round: new poses through the same graph
+        sel = S[rnd * V:(rnd + 1) * V]
+        vm = torch.stack([s.viewmatrix for s in sel]).to(dev)
+        pm = torch.stack([s.projmatrix for s in sel]).to(dev)
+        states = batch.render(vm, pm)
+        torch.cuda.synchronize()
+        assert not batch.overflowed()
+        got = [(st.rgb.clone(), st.depth.clone(), st.count.clone(), st.radii.clone()) for st in states]
+        for v, s in enumerate(sel):
+            cam = api.Camera(h, w, s.tanfovx, s.tanfovy, s.viewmatrix.to(dev), s.projmatrix.to(dev), bg, want_stats=True)
+            ref = api.alloc_state(n, h, w, 1 << 18, dev)
+            api.forward(cam, g, ref)
+            torch.cuda.synchronize()
+            assert torch.equal(ref.rgb, got[v][0]) and torch.equal(ref.depth, got[v][1])
+            assert torch.equal(ref.count, got[v][2]) and torch.equal(ref.radii, got[v][3])
+        assert float(got[0][0].abs().sum()) > 0
+
+
 def test_alpha_clamp_near_plane_and_grazing_surfels(agslib):
     """Branches a random room scene rarely reaches: o*G > 0.99 (clamped alpha, zero gradient through
     the clamp), surfels on both sides of the z = 0.2 near cull, edge-on surfels (grazing clamp of the
