@@ -118,15 +118,6 @@ def load() -> C.CDLL:
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the rasterizer.")
     lib = C.CDLL(path)
-    if os.environ.get("AGS_LIB_ALLOW_MISSING"):   # kernel archaeology only: A/B an OLD build of the library
-        class _Partial:
-            def __init__(self, inner): self._inner = inner
-            def __getattr__(self, name):
-                try:
-                    return getattr(self._inner, name)
-                except AttributeError:
-                    return C.CFUNCTYPE(C.c_int)(lambda *a: -1)
-        lib = _Partial(lib)
     lib.ags_workspace_bytes.restype = C.c_size_t
     lib.ags_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64]
     lib.ags_workspace_init.restype = C.c_int
