@@ -71,7 +71,7 @@ class AgsAdamTensors(C.Structure):
 class AgsLossConfig(C.Structure):
     _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("fov_x", C.c_float), ("fov_y", C.c_float),
                 ("batch_total", C.c_int32), ("w_rgb", C.c_float), ("w_depth", C.c_float), ("w_cons", C.c_float),
-                ("w_tv", C.c_float), ("sigma", C.c_float), ("accum_stride", C.c_int32)]
+                ("w_tv", C.c_float), ("sigma", C.c_float), ("accum_stride", C.c_int32), ("num_views", C.c_int32)]
 
 
 class AgsActivation(C.Structure):
@@ -93,7 +93,7 @@ class AgsCandidates(C.Structure):
 
 
 EXPORTS = ["ags_workspace_bytes", "ags_workspace_init", "ags_forward", "ags_forward_batch",
-           "ags_forward_batch_workspace_bytes", "ags_backward", "ags_read_status", "ags_adam_step",
+           "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_read_status", "ags_adam_step",
            "ags_adam_step_device", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_smooth_depth", "ags_densify_candidates",
            "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_compact_plan_bytes", "ags_compact_plan",
            "ags_compact_rows", "ags_profile_enable", "ags_profile_read",
@@ -134,6 +134,10 @@ def load() -> C.CDLL:
     lib.ags_backward.argtypes = [C.POINTER(AgsCamera), C.POINTER(AgsGaussians), C.POINTER(AgsImages),
                                  C.POINTER(AgsPerGaussian), C.POINTER(AgsImageGrads), C.POINTER(AgsGaussianGrads),
                                  C.POINTER(AgsWorkspace), C.c_void_p]
+    lib.ags_backward_batch.restype = C.c_int
+    lib.ags_backward_batch.argtypes = [C.POINTER(AgsCamera), C.c_int32, C.POINTER(AgsGaussians), C.POINTER(AgsImages),
+                                       C.POINTER(AgsPerGaussian), C.POINTER(AgsImageGrads), C.POINTER(AgsGaussianGrads),
+                                       C.POINTER(AgsWorkspace), C.c_void_p]
     lib.ags_read_status.restype = C.c_int
     lib.ags_read_status.argtypes = [C.POINTER(AgsWorkspace), C.POINTER(AgsStatus), C.c_void_p]
     lib.ags_adam_step.restype = C.c_int

@@ -133,9 +133,11 @@ void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
                            AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs,
                            hipStream_t s);
 void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
-                           AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick, hipStream_t s);
+                           AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick,
+                           const AgsViewStride& vs, hipStream_t s);
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
-                               const AgsLayout& L, const int* radii, const AgsGaussianGrads& din, hipStream_t s);
+                               const AgsLayout& L, const int* radii, const AgsGaussianGrads& din,
+                               const AgsViewStride& vs, hipStream_t s);
 void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, void* dev_state,
                      bool pre_ticked, hipStream_t s);
 #if defined(__HIPCC__)

@@ -83,7 +83,7 @@ int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* i
     if (cam->want_stats && (!pg->importance || !pg->count)) return AGS_E_INVALID;
     if (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences) return AGS_E_INVALID;
     if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll) return AGS_E_INVALID;
-    if (ws->binning_mode != AGS_BIN_TILE_SORT || pg->touched.member) return AGS_E_INVALID;
+    if (ws->binning_mode != AGS_BIN_TILE_SORT) return AGS_E_INVALID;
     const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
     if (ws->bytes < (size_t)views * L.total) return AGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -135,8 +135,34 @@ int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* 
         const int64_t n64 = in->n;
         if (ne[0] != 3 * n64 || ne[1] != 3 * n64 || ne[2] != 4 * n64 || ne[3] != n64 || ne[4] != 3 * n64) return AGS_E_INVALID;
     }
-    { StageScope t(AGS_STAGE_RENDER_BWD, s); ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, tick, s); }
-    { StageScope t(AGS_STAGE_PREPROCESS_BWD, s); ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, s); }
+    { StageScope t(AGS_STAGE_RENDER_BWD, s); ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, tick, kOneView, s); }
+    { StageScope t(AGS_STAGE_PREPROCESS_BWD, s); ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, kOneView, s); }
+    return ags_check_launch();
+}
+
+int ags_backward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* in, const AgsImages* fwd,
+                       const AgsPerGaussian* pg, const AgsImageGrads* dout, const AgsGaussianGrads* din,
+                       const AgsWorkspace* ws, ags_stream_t stream) {
+    if (!cam || !in || !fwd || !pg || !dout || !din || !ws || !ws->ptr || views < 1 || views > 65535) return AGS_E_INVALID;
+    if (in->n <= 0 || !pg->radii || !fwd->depth || !fwd->opacity) return AGS_E_INVALID;
+    if (!din->d_means3D || !din->d_scales || !din->d_rotations || !din->d_opacities || !din->d_colors) return AGS_E_INVALID;
+    if (din->accumulate != 2 || din->fused_adam) return AGS_E_INVALID; // views sum with atomics into a pre-zeroed slab
+    if (ws->binning_mode != AGS_BIN_TILE_SORT) return AGS_E_INVALID;
+    const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
+    if (ws->bytes < (size_t)views * L.total) return AGS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* base = (char*)ws->ptr;
+    const AgsFrame F = ags_make_frame(cam);
+    AgsViewStride vs;
+    vs.ws = (long long)L.total; vs.px = (long long)cam->image_height * cam->image_width; vs.n = in->n; vs.views = views;
+    AgsTick tick = {};
+    if (din->adam_clock) {
+        tick.clock = (AgsAdamClock*)din->adam_clock;
+        for (int k = 0; k < 5; ++k) tick.lr[k] = din->adam_lr[k];
+        tick.beta1 = din->adam_beta1; tick.beta2 = din->adam_beta2;
+    }
+    ags_launch_render_bwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *fwd, *dout, tick, vs, s);
+    ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, vs, s);
     return ags_check_launch();
 }
 
@@ -190,7 +216,8 @@ int ags_loss_stage1(const AgsLossConfig* cfg, const AgsImages* fwd, const float*
                     float* n_img, float* d_rgb, float* d_depth, int32_t* msum, float* accum, int32_t view,
                     int32_t first_view, ags_stream_t stream) {
     if (ags_loss_check(cfg, fwd) != AGS_OK || !gt_rgb || !gt_depth || !n_img || !d_rgb || !d_depth || !msum || !accum ||
-        view < 0 || 5 + 2 * view >= cfg->accum_stride)
+        view < 0 || 5 + 2 * (view + (cfg->num_views > 1 ? cfg->num_views - 1 : 0)) >= cfg->accum_stride ||
+        cfg->num_views < 0 || cfg->num_views > 65535 || (cfg->num_views > 1 && first_view >= 0))
         return AGS_E_INVALID;
     ags_launch_loss_stage1(*cfg, *fwd, gt_rgb, gt_depth, n_img, d_rgb, d_depth, msum, accum, view, first_view,
                            (hipStream_t)stream);

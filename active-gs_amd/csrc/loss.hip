@@ -62,6 +62,12 @@ __global__ __launch_bounds__(256) void ags_k_loss_stage1(
     int first_view) {
     __shared__ float sh[4];
     const int HW = c.H * c.W;
+    if (gridDim.y > 1) { // batched: blockIdx.y = view of the batch, image batches are contiguous
+        const size_t po = (size_t)blockIdx.y * (size_t)HW;
+        rgb += 3 * po; normal_raw += 3 * po; depth += po; opacity += po; gt_rgb += 3 * po; gt_depth += po;
+        n_img += 3 * po; d_rgb += 3 * po; d_depth += po;
+        view += blockIdx.y;
+    }
     const int p = blockIdx.x * 256 + threadIdx.x;
     float s_rgb = 0.f, s_dep = 0.f;
     if (p < HW) {
@@ -105,6 +111,11 @@ __global__ __launch_bounds__(256) void ags_k_loss_stage2(
     float* __restrict__ accum, int accum_stride) {
     __shared__ float sh[4];
     const int H = c.H, W = c.W, HW = H * W;
+    if (gridDim.y > 1) {
+        const size_t po = (size_t)blockIdx.y * (size_t)HW;
+        depth += po; opacity += po; normal_raw += 3 * po; n_img += 3 * po; gt_depth += po;
+        d_normal += 3 * po; d_depth += po;
+    }
     const int p = blockIdx.x * 256 + threadIdx.x;
     float s_cons = 0.f, s_tv = 0.f;
     if (p < HW) {
@@ -201,7 +212,8 @@ void ags_launch_loss_stage1(const AgsLossConfig& cfg, const AgsImages& img, cons
                             float* n_img, float* d_rgb, float* d_depth, int* msum, float* accum, int view,
                             int first_view, hipStream_t s) {
     const int HW = cfg.image_height * cfg.image_width;
-    hipLaunchKernelGGL(ags_k_loss_stage1, dim3((HW + 255) / 256), dim3(256), 0, s, make_dev(cfg), img.rgb, img.normal,
+    const int views = cfg.num_views > 1 ? cfg.num_views : 1;
+    hipLaunchKernelGGL(ags_k_loss_stage1, dim3((HW + 255) / 256, views), dim3(256), 0, s, make_dev(cfg), img.rgb, img.normal,
                        img.depth, img.opacity, gt_rgb, gt_depth, n_img, d_rgb, d_depth, msum, accum, cfg.accum_stride,
                        view, first_view);
 }
@@ -209,6 +221,7 @@ void ags_launch_loss_stage1(const AgsLossConfig& cfg, const AgsImages& img, cons
 void ags_launch_loss_stage2(const AgsLossConfig& cfg, const AgsImages& img, const float* n_img, const float* gt_depth,
                             const int* msum, float* d_normal, float* d_depth, float* accum, hipStream_t s) {
     const int HW = cfg.image_height * cfg.image_width;
-    hipLaunchKernelGGL(ags_k_loss_stage2, dim3((HW + 255) / 256), dim3(256), 0, s, make_dev(cfg), img.depth,
+    const int views = cfg.num_views > 1 ? cfg.num_views : 1;
+    hipLaunchKernelGGL(ags_k_loss_stage2, dim3((HW + 255) / 256, views), dim3(256), 0, s, make_dev(cfg), img.depth,
                        img.opacity, img.normal, n_img, gt_depth, msum, d_normal, d_depth, accum, cfg.accum_stride);
 }

@@ -150,7 +150,12 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
 
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
-    const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out) {
+    const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsViewStride vs) {
+    if (vs.views > 1) { // batched backward (accumulate == 2): this workgroup's view
+        Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
+        radii += (size_t)blockIdx.y * (size_t)vs.n;
+        AGS_WS_SHIFT(dgeom, (size_t)blockIdx.y * (size_t)vs.ws);
+    }
     __shared__ __attribute__((aligned(16))) float rows3[3 * AGS_PRE_THREADS];
     float V[16], P[16];
 #pragma unroll
@@ -245,7 +250,13 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
 template <bool FUSED_ADAM>
 __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
-    const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsAdamArgs adam) {
+    const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsAdamArgs adam,
+    AgsViewStride vs) {
+    if (vs.views > 1) {
+        Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
+        radii += (size_t)blockIdx.y * (size_t)vs.n;
+        AGS_WS_SHIFT(dgeom, (size_t)blockIdx.y * (size_t)vs.ws);
+    }
     float V[16], P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
@@ -407,7 +418,8 @@ void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGau
 }
 
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
-                               const AgsLayout& L, const int* radii, const AgsGaussianGrads& din, hipStream_t s) {
+                               const AgsLayout& L, const int* radii, const AgsGaussianGrads& din,
+                               const AgsViewStride& vs, hipStream_t s) {
     if (din.touched.rows) {
         // the member count lives on the device: a fixed grid strides over the list
         int blocks = (in.n + AGS_ROWS_THREADS - 1) / AGS_ROWS_THREADS;
@@ -415,13 +427,13 @@ void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const Ag
         if (din.fused_adam)
             hipLaunchKernelGGL(ags_k_preprocess_bwd_rows<true>, dim3(blocks), dim3(AGS_ROWS_THREADS), 0, s, F,
                                cam.viewmatrix, cam.projmatrix, in, radii, (AgsGeomGrad*)(ws + L.dgeom), din,
-                               ags_adam_args(*din.fused_adam));
+                               ags_adam_args(*din.fused_adam), vs);
         else
-            hipLaunchKernelGGL(ags_k_preprocess_bwd_rows<false>, dim3(blocks), dim3(AGS_ROWS_THREADS), 0, s, F,
+            hipLaunchKernelGGL(ags_k_preprocess_bwd_rows<false>, dim3(blocks, vs.views), dim3(AGS_ROWS_THREADS), 0, s, F,
                                cam.viewmatrix, cam.projmatrix, in, radii, (AgsGeomGrad*)(ws + L.dgeom), din,
-                               AgsAdamArgs());
+                               AgsAdamArgs(), vs);
         return;
     }
-    hipLaunchKernelGGL(ags_k_preprocess_bwd, dim3(L.n_blocks), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
-                       cam.projmatrix, in, radii, (AgsGeomGrad*)(ws + L.dgeom), din);
+    hipLaunchKernelGGL(ags_k_preprocess_bwd, dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
+                       cam.projmatrix, in, radii, (AgsGeomGrad*)(ws + L.dgeom), din, vs);
 }

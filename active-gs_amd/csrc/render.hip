@@ -172,13 +172,24 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
     const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
     const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, AgsImageGrads dout, float* __restrict__ dgeom, int num_tiles,
-    AgsTick tick) {
+    AgsTick tick, AgsViewStride vs) {
+    if (vs.views > 1) { // batched backward: this workgroup's view
+        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws, po = (size_t)blockIdx.y * (size_t)vs.px;
+        AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(vals, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(final_T, wo);
+        AGS_WS_SHIFT(n_contrib, wo); AGS_WS_SHIFT(dgeom, wo);
+        depth_out += po; opac_out += po;
+        if (dout.d_rgb) dout.d_rgb += 3 * po;
+        if (dout.d_normal) dout.d_normal += 3 * po;
+        if (dout.d_depth) dout.d_depth += po;
+        if (dout.d_opacity) dout.d_opacity += po;
+        if (dout.d_confidence) dout.d_confidence += po;
+    }
     __shared__ AgsWaveStage stage[4 / SLOTS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     AgsWaveStage& st = stage[wave];
     // side job of a step's last backward: advance the Adam device clock.  Nothing in this launch
     // reads it; the per-Gaussian kernel that follows (fused step) or ags_adam_step_device does.
-    if (tick.clock && blockIdx.x == 0 && threadIdx.x == 0) ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2, 0);
+    if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2, 0);
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
     if (rg.y <= rg.x) return;
@@ -288,11 +299,12 @@ static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
 
 template <int SLOTS>
 static void launch_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L, AgsIdList ids,
-                       const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick, hipStream_t s) {
-    hipLaunchKernelGGL((ags_k_render_bwd<SLOTS>), dim3(L.num_tiles), dim3(64 * (4 / SLOTS)), 0, s, F,
+                       const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick, const AgsViewStride& vs,
+                       hipStream_t s) {
+    hipLaunchKernelGGL((ags_k_render_bwd<SLOTS>), dim3(L.num_tiles, vs.views), dim3(64 * (4 / SLOTS)), 0, s, F,
                        cam.normalize_depth, cam.bg, (const uint2*)(ws + L.ranges), ids.ids, ids.stride,
                        (const AgsGeom*)(ws + L.geom), fwd.depth, fwd.opacity, (const float*)(ws + L.final_T),
-                       (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick);
+                       (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick, vs);
 }
 
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
@@ -308,10 +320,10 @@ void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
 
 void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick,
-                           hipStream_t s) {
-    switch (ags_pick_slots(L.num_tiles)) {
-        case 1: launch_bwd<1>(F, cam, ws, L, ids, fwd, dout, tick, s); break;
-        case 2: launch_bwd<2>(F, cam, ws, L, ids, fwd, dout, tick, s); break;
-        default: launch_bwd<4>(F, cam, ws, L, ids, fwd, dout, tick, s); break;
+                           const AgsViewStride& vs, hipStream_t s) {
+    switch (ags_pick_slots(L.num_tiles * vs.views)) {
+        case 1: launch_bwd<1>(F, cam, ws, L, ids, fwd, dout, tick, vs, s); break;
+        case 2: launch_bwd<2>(F, cam, ws, L, ids, fwd, dout, tick, vs, s); break;
+        default: launch_bwd<4>(F, cam, ws, L, ids, fwd, dout, tick, vs, s); break;
     }
 }

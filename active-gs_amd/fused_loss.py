@@ -28,7 +28,7 @@ class FusedLoss:
         self.h, self.w = h, w
         stride = 4 + 2 * max_views
         self.cfg = _lib.AgsLossConfig(h, w, float(fov_x), float(fov_y), int(batch_total), *[float(x) for x in weights],
-                                      float(sigma), stride)
+                                      float(sigma), stride, 0)
         self.msum = torch.zeros(h, w, dtype=torch.int32, device=device)
         # 64 accumulator rows: workgroups spread their atomics over them, readers sum the rows
         self.accum = torch.zeros(64, stride, dtype=torch.float32, device=device)
@@ -61,6 +61,32 @@ class FusedLoss:
                                                ptr(self.msum), ptr(buf.d_normal), ptr(buf.d_depth), ptr(self.accum),
                                                torch.cuda.current_stream().cuda_stream if stream is None else stream),
                    "ags_loss_stage2")
+
+    # ---- all views of the batch in one launch each (blockIdx.y = view)
+    def alloc_batch(self, views: int) -> LossBuffers:
+        f = dict(device=self.device, dtype=torch.float32)
+        return LossBuffers(torch.empty(views, 3, self.h, self.w, **f), torch.empty(views, 3, self.h, self.w, **f),
+                           torch.empty(views, 3, self.h, self.w, **f), torch.empty(views, 1, self.h, self.w, **f))
+
+    def stage1_batch(self, images: "_lib.AgsImages", gt_rgb, gt_depth, buf: LossBuffers, views: int) -> None:
+        """``images``: AgsImages of (views,C,H,W) batches; ``msum`` must be zero (atomic counting)."""
+        self.cfg.num_views = int(views)
+        try:
+            _lib.check(_lib.load().ags_loss_stage1(C.byref(self.cfg), C.byref(images), ptr(gt_rgb), ptr(gt_depth),
+                                                   ptr(buf.n_img), ptr(buf.d_rgb), ptr(buf.d_depth), ptr(self.msum),
+                                                   ptr(self.accum), 0, -1, torch.cuda.current_stream().cuda_stream),
+                       "ags_loss_stage1")
+        finally:
+            self.cfg.num_views = 0
+
+    def stage2_batch(self, images: "_lib.AgsImages", gt_depth, buf: LossBuffers, views: int) -> None:
+        self.cfg.num_views = int(views)
+        try:
+            _lib.check(_lib.load().ags_loss_stage2(C.byref(self.cfg), C.byref(images), ptr(buf.n_img), ptr(gt_depth),
+                                                   ptr(self.msum), ptr(buf.d_normal), ptr(buf.d_depth), ptr(self.accum),
+                                                   torch.cuda.current_stream().cuda_stream), "ags_loss_stage2")
+        finally:
+            self.cfg.num_views = 0
 
     def total_loss(self) -> torch.Tensor:
         c, a, hw = self.cfg, self.accum.sum(0), float(self.h * self.w)

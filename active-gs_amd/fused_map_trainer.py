@@ -22,8 +22,13 @@ from .trainer import GradSlab
 
 class FusedMapTrainer(GaussianMapTrainer):
     def __init__(self, raw: dict, frames: List[dict], cfg: Optional[dict] = None, process_group=None,
-                 binning_mode: int = api.BIN_TILE_SORT, use_graph: bool = True, num_streams: int = 4):
+                 binning_mode: int = api.BIN_TILE_SORT, use_graph: bool = True, num_streams: int = 4,
+                 batched: bool = True):
         super().__init__(raw, frames, cfg, process_group=process_group)
+        # single rank, frames of one size and field of view: all views of an iteration go through ONE
+        # set of launches (ags_forward_batch / ags_backward_batch, loss stages with blockIdx.y = view)
+        self.batched = batched
+        self.graph_min_steps = 50   # train_batched replays a hipGraph only for calls at least this long
         if self.device.type != "cuda":
             raise RuntimeError("FusedMapTrainer needs GPU tensors: there is no CPU fallback")
         self.binning_mode = binning_mode
@@ -80,6 +85,8 @@ class FusedMapTrainer(GaussianMapTrainer):
         return True
 
     def train(self, steps: Optional[int] = None):
+        if self.batched and self._uniform_frames():
+            return self.train_batched(steps)
         dist = torch.distributed
         lrs = self.cfg["lrs"]
         for name in ("means", "scales", "rotations", "opacities", "harmonics"):
@@ -241,13 +248,121 @@ class FusedMapTrainer(GaussianMapTrainer):
         self._set_map_state(state)
         return deleted
 
-    # ------------------------------------------------------------------ hipGraph iteration
-    def _graph_ok(self) -> bool:
-        if not self.use_graph or self.world > 1 or len(self.frames) == 0:
+    # ------------------------------------------------------------------ batched iteration
+    def _uniform_frames(self) -> bool:
+        if self.world > 1 or len(self.frames) == 0 or self.means.shape[0] == 0:
             return False
         shapes = {tuple(f["rgb"].shape) for f in self.frames}
         tans = {(round(self._camera(i)[0].tanfovx, 7), round(self._camera(i)[0].tanfovy, 7)) for i in range(len(self.frames))}
-        return len(shapes) == 1 and len(tans) == 1   # scalars baked into the captured launches
+        return len(shapes) == 1 and len(tans) == 1   # one AgsFrame for the whole batch
+
+    def train_batched(self, steps: Optional[int] = None):
+        """``train`` with the B views of an iteration in ONE set of launches: 4 forward kernels, 2 loss
+        kernels, 2 backward kernels and the row-set Adam per ITERATION instead of per view (a 512x512
+        view is 1024 tiles - a quarter of what the GPU holds).  The sampled frames' poses and
+        ground truth are staged into the batch's buffers with four index_select launches."""
+        lrs = self.cfg["lrs"]
+        for name in ("means", "scales", "rotations", "opacities", "harmonics"):
+            setattr(self, name, getattr(self, name).contiguous())
+        params = [self.means, self.scales, self.rotations, self.opacities, self.harmonics]
+        n, dev = self.means.shape[0], self.device
+        optim = FusedAdam(params, [lrs["mean"], lrs["scale"], lrs["rotation"], lrs["opacity"], lrs["harmonic"]], eps=1e-15)
+        slab = GradSlab(n, dev)
+        rows = api.RowSet(n, dev)
+        optim.touched = rows
+        sampler = WeightedFrameSampler(self.frames, self.cfg["batch_size"], self.cfg["active_size"])
+        K = len(self.frames)
+        h, w = self.frames[0]["rgb"].shape[-2:]
+        cam0, fx, fy = self._camera(0)
+        all_view = torch.stack([self._camera(i)[0].viewmatrix for i in range(K)])
+        all_proj = torch.stack([self._camera(i)[0].projmatrix for i in range(K)])
+        all_rgb = torch.stack([f["rgb"] for f in self.frames]).contiguous()
+        all_depth = torch.stack([f["depth"] for f in self.frames]).contiguous()
+        Bmax = self.cfg["batch_size"] + self.cfg["active_size"]
+        self._cap = max(self._cap, 1 << 16, 2 * n)
+        g = self._gaussians()
+        self._loss = FusedLoss(h, w, fx, fy, Bmax, Bmax, dev)
+        self._loss_bufs = []
+        gt_rgb = torch.empty(Bmax, 3, h, w, device=dev)
+        gt_depth = torch.empty(Bmax, 1, h, w, device=dev)
+        bufs = self._loss.alloc_batch(Bmax)
+        total = self.cfg["optimization_steps"] if steps is None else steps
+        losses = torch.zeros(max(total, 1), device=dev)
+        loss_now = torch.zeros((), device=dev)
+        state = dict(batch=None, idx=None, B=0)
+
+        def iteration():
+            """everything of one optimisation step that runs on the GPU; inputs: state['idx'] (device)"""
+            batch, idx, B = state["batch"], state["idx"], state["B"]
+            torch.index_select(all_view, 0, idx, out=batch.viewmats[:B])
+            torch.index_select(all_proj, 0, idx, out=batch.projmats[:B])
+            torch.index_select(all_rgb, 0, idx, out=gt_rgb[:B])
+            torch.index_select(all_depth, 0, idx, out=gt_depth[:B])
+            batch.forward(B, touched=rows)
+            images = batch._structs()[0]
+            self._loss.begin_step()
+            self._loss.msum.zero_()
+            self._loss.stage1_batch(images, gt_rgb, gt_depth, bufs, B)
+            self._loss.stage2_batch(images, gt_depth, bufs, B)
+            slab.flat.zero_()
+            batch.backward(B, bufs.d_rgb, bufs.d_normal, bufs.d_depth, slab.grads, touched=rows,
+                           adam_tick=optim.tick_args())
+            self.training_performance.index_copy_(0, idx, self._loss.per_frame_errors(B))
+            optim.step(slab.as_list(), device_clock=True, pre_ticked=True)
+            loss_now.copy_(self._loss.total_loss())
+
+        def fits() -> bool:
+            """forward-only probe of the staged batch: were the per-view workspaces large enough?"""
+            batch, idx, B = state["batch"], state["idx"], state["B"]
+            torch.index_select(all_view, 0, idx, out=batch.viewmats[:B])
+            torch.index_select(all_proj, 0, idx, out=batch.projmats[:B])
+            batch.forward(B)
+            need = max(api.read_status(batch.states[b])["num_instances"] for b in range(B))
+            if need <= self._cap:
+                return True
+            self._cap = int(need * 1.5) + 4096
+            return False
+
+        graph = None
+        for it in range(total):
+            _, _, _, _, ids = sampler.next_frames(self.training_performance)   # host read of the errors
+            B = len(ids)
+            self._loss.set_batch_total(B)
+            if state["idx"] is None or B != state["B"]:
+                state["idx"], state["B"], graph = torch.empty(B, device=dev, dtype=torch.long), B, None
+            state["idx"].copy_(torch.as_tensor(ids, dtype=torch.long))
+            if graph is not None:
+                graph.replay()
+            else:
+                while state["batch"] is None or (it == 0 and not fits()):
+                    state["batch"] = api.ViewBatch(g, Bmax, h, w, cam0.tanfovx, cam0.tanfovy, self.background,
+                                                   self._cap, binning_mode=self.binning_mode)
+                iteration()
+                if self.use_graph and total >= self.graph_min_steps and it + 1 < total:
+                    # for a given batch size the iteration is a fixed launch sequence: record it once
+                    # (capture costs a few ms: it pays for long train() calls, not for the mapper's 10)
+                    torch.cuda.synchronize()
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.stream(side):
+                        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                            iteration()
+                    torch.cuda.current_stream().wait_stream(side)
+            losses[it].copy_(loss_now)
+        batch = state["batch"]
+        if batch is not None and any(api.read_status(batch.states[b])["overflow"] for b in range(state["B"])):
+            self._cap = int(self._cap * 2)
+            raise RuntimeError("a view outgrew the rasterizer workspace during train(); call train() again "
+                               "(the capacity has been raised)")
+        self.last_losses = [float(x) for x in losses[:total].cpu()]
+        self.post_processing()
+
+    # ------------------------------------------------------------------ hipGraph iteration
+    def _graph_ok(self) -> bool:
+        if not self.use_graph:
+            return False
+        return self._uniform_frames()
 
     def train_graph(self, steps: Optional[int] = None):
         """Same iteration as ``train`` replayed from a hipGraph (single rank, frames of one shape

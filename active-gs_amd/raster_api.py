@@ -331,18 +331,48 @@ class ViewBatch:
         self.pool = StreamPool(min(num_streams, max(1, V))) if mode == "streams" else None
         self._graph = None
 
-    def _enqueue_batched(self) -> None:
+    def _structs(self, touched=None):
+        im = _lib.AgsImages(ptr(self.rgb), ptr(self.normal), ptr(self.depth), ptr(self.opacity), ptr(self.confidence))
+        pg = _lib.AgsPerGaussian(ptr(self.importance), ptr(self.count), ptr(self.radii), _rowset_struct(touched))
+        ws = _lib.AgsWorkspace(ptr(self.workspace), self.workspace.numel(), self.states[0].max_instances,
+                               self.states[0].binning_mode)
+        return im, pg, ws
+
+    def _enqueue_batched(self, views: Optional[int] = None, touched: Optional[RowSet] = None) -> None:
         lib = _lib.load()
         if self.want_stats:
             self.importance.zero_()
             self.count.zero_()
         cs, gs = self.cam.c_struct(), self.g.c_struct()
-        im = _lib.AgsImages(ptr(self.rgb), ptr(self.normal), ptr(self.depth), ptr(self.opacity), ptr(self.confidence))
-        pg = _lib.AgsPerGaussian(ptr(self.importance), ptr(self.count), ptr(self.radii), _rowset_struct(None))
-        ws = _lib.AgsWorkspace(ptr(self.workspace), self.workspace.numel(), self.states[0].max_instances,
-                               self.states[0].binning_mode)
-        _lib.check(lib.ags_forward_batch(C.byref(cs), self.num_views, C.byref(gs), C.byref(im), C.byref(pg),
-                                         C.byref(ws), _stream()), "ags_forward_batch")
+        im, pg, ws = self._structs(touched)
+        _lib.check(lib.ags_forward_batch(C.byref(cs), self.num_views if views is None else int(views), C.byref(gs),
+                                         C.byref(im), C.byref(pg), C.byref(ws), _stream()), "ags_forward_batch")
+
+    def forward(self, views: Optional[int] = None, touched: Optional[RowSet] = None) -> None:
+        """Render the first ``views`` poses currently held in ``viewmats`` / ``projmats`` (training
+        loops stage them with one index_select); ``touched``: see ``forward``."""
+        self._enqueue_batched(views, touched)
+
+    def backward(self, views: int, d_rgb, d_normal, d_depth, grads: "GaussianGrads", touched: Optional[RowSet] = None,
+                 adam_tick=None) -> None:
+        """Backward of the first ``views`` views of the last ``forward``: image-gradient batches
+        ``(views,C,H,W)`` (None = zeros), gradients of all views SUMMED atomically into the pre-zeroed
+        ``grads``."""
+        lib = _lib.load()
+        cs, gs = self.cam.c_struct(), self.g.c_struct()
+        im, pg, ws = self._structs()
+        dout = _lib.AgsImageGrads(ptr(d_rgb), ptr(d_normal), ptr(d_depth), None, None)
+        din = _lib.AgsGaussianGrads(ptr(grads.means3D), ptr(grads.scales), ptr(grads.rotations), ptr(grads.opacities),
+                                    ptr(grads.colors), ptr(grads.means2D), 2)
+        if adam_tick is not None:
+            clock, lrs, b1, b2 = adam_tick
+            din.adam_clock = ptr(clock)
+            for k in range(5):
+                din.adam_lr[k] = float(lrs[k])
+            din.adam_beta1, din.adam_beta2 = float(b1), float(b2)
+        din.touched = _rowset_struct(touched)
+        _lib.check(lib.ags_backward_batch(C.byref(cs), int(views), C.byref(gs), C.byref(im), C.byref(pg), C.byref(dout),
+                                          C.byref(din), C.byref(ws), _stream()), "ags_backward_batch")
 
     def render(self, viewmats: torch.Tensor, projmats: torch.Tensor, use_graph: bool = True):
         """Render the ``V`` poses (``(V,4,4)`` view and view-projection matrices, row-vector

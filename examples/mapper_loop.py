@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--size", type=int, nargs=2, default=[512, 512], metavar=("H", "W"))
     ap.add_argument("--gt-surfels", type=int, default=400_000)
     ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--no-graph", action="store_true", help="launch every iteration eagerly instead of replaying it")
+    ap.add_argument("--per-view", action="store_true", help="per-view launches on HIP streams instead of one batch")
     args = ap.parse_args()
 
     from active_gs_amd import raster_api as api
@@ -59,7 +61,8 @@ def main():
     z = lambda *s: torch.zeros(*s, device=dev)
     raw = dict(means=z(0, 3), scales=z(0, 3), rotations=z(0, 4), opacities=z(0), harmonics=z(0, 1, 3))
     np.random.seed(0)
-    tr = FusedMapTrainer(raw, [], dict(optimization_steps=args.steps), use_graph=False, num_streams=args.streams)
+    tr = FusedMapTrainer(raw, [], dict(optimization_steps=args.steps), use_graph=not args.no_graph,
+                         num_streams=args.streams, batched=not args.per_view)
 
     def timed(fn):
         torch.cuda.synchronize()

@@ -200,6 +200,14 @@ size_t ags_forward_batch_workspace_bytes(int32_t views, int32_t n, int32_t h, in
 int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* in, const AgsImages* out,
                       const AgsPerGaussian* per_gaussian, const AgsWorkspace* ws, ags_stream_t stream);
 
+/* Backward of the views of an ags_forward_batch (same argument conventions: batched `fwd` images,
+ * batched image gradients, `views` consecutive workspaces).  The views' gradients are SUMMED into
+ * the single gradient slab `din` with atomics: din->accumulate must be 2 (pre-zeroed slab) and
+ * din->fused_adam NULL; din->touched / adam_clock work as in ags_backward. */
+int ags_backward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* in, const AgsImages* fwd,
+                       const AgsPerGaussian* per_gaussian, const AgsImageGrads* dout, const AgsGaussianGrads* din,
+                       const AgsWorkspace* ws, ags_stream_t stream);
+
 /* Backward of the same view; `fwd` are the images ags_forward wrote. */
 int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* fwd,
                  const AgsPerGaussian* per_gaussian, const AgsImageGrads* dout,
@@ -269,6 +277,9 @@ typedef struct AgsLossConfig {
     float w_rgb, w_depth, w_cons, w_tv; /* 1, 0.8, 0.1, 0.1 */
     float sigma;           /* 0.3 */
     int32_t accum_stride;  /* floats per accumulator row, >= 4 + 2 * (views in the batch) */
+    int32_t num_views;     /* 0 / 1: one view per call.  > 1: the call handles that many views at once
+                            * (blockIdx.y): every image argument points at a contiguous (views,C,H,W) batch,
+                            * `view` is the index of the first one, and stage 1 needs first_view = -1. */
 } AgsLossConfig;
 int ags_loss_stage1(const AgsLossConfig* cfg, const AgsImages* fwd, const float* gt_rgb, const float* gt_depth,
                     float* n_img /* (3,H,W) */, float* d_rgb, float* d_depth, int32_t* msum /* (H,W) */,

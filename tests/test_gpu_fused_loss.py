@@ -125,3 +125,33 @@ def test_graph_replayed_fused_iteration_equals_eager(agslib):
         assert (a - b).abs().mean() < 2e-3 * travel + 1e-9
     assert torch.allclose(res[0][1], res[1][1], rtol=1e-3, atol=1e-5)
     assert np.allclose(res[0][2], res[1][2], rtol=1e-4)
+
+
+def test_batched_iteration_equals_per_view_and_replays_from_a_graph(agslib):
+    """train_batched() (all views of an iteration in one set of launches; optionally the iteration
+    replayed from a hipGraph) lands where the per-view train() lands."""
+    from active_gs_amd.fused_map_trainer import FusedMapTrainer
+    dev = torch.device("cuda:0")
+    d = torch.load(os.path.join(GOLD, "train.pt"))
+    cfg = d["cfg"]
+    mine = dict(bound=tuple(cfg["bound"]), scale_factor=cfg["scale_factor"], optimization_steps=5,
+                prune_interval=1000, background=tuple(cfg["background"]), batch_size=3, active_size=2,
+                use_view_distribution=cfg["use_view_distribution"])
+    res = []
+    for variant in ("per_view", "batched", "batched_graph"):
+        raw = {k: v.to(dev) for k, v in d["raw_init"].items()}
+        frames = [{k: v.to(dev) for k, v in f.items()} for f in d["frames"]]
+        t = FusedMapTrainer(raw, frames, mine, batched=variant != "per_view", num_streams=1)
+        t.graph_min_steps = 0 if variant == "batched_graph" else 10 ** 9
+        np.random.seed(11)
+        t.train()
+        torch.cuda.synchronize()
+        res.append(([getattr(t, k).clone() for k in ("means", "scales", "rotations", "opacities", "harmonics")],
+                    t.training_performance.clone(), list(t.last_losses)))
+    init = [d["raw_init"][k] for k in ("means", "scales", "rotations", "opacities", "harmonics")]
+    for other in res[1:]:
+        for a, b, i0 in zip(res[0][0], other[0], init):
+            travel = (a.cpu() - i0).abs().mean()
+            assert (a - b).abs().mean() < 2e-3 * travel + 1e-9
+        assert torch.allclose(res[0][1], other[1], rtol=1e-3, atol=1e-5)
+        assert np.allclose(res[0][2], other[2], rtol=1e-4)
