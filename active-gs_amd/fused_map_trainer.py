@@ -187,6 +187,21 @@ class FusedMapTrainer(GaussianMapTrainer):
         h, w = hw
         self._cap = max(self._cap, 1 << 16, 2 * n)
         g = self._gaussians()
+        if len(frame_ids) > 1 and self._uniform_frames():
+            # the prune pass over all keyframes: one batched set of launches, one status read
+            cam0, _, _ = self._camera(int(frame_ids[0]))
+            vm = torch.stack([self._camera(int(f))[0].viewmatrix for f in frame_ids])
+            pm = torch.stack([self._camera(int(f))[0].projmatrix for f in frame_ids])
+            masks = (depth_gt > 0.0).float().reshape(len(frame_ids), h, w)
+            while True:
+                batch = api.ViewBatch(g, len(frame_ids), h, w, cam0.tanfovx, cam0.tanfovy, self.background, self._cap,
+                                      want_stats=True, front_only=True, render_masks=masks,
+                                      binning_mode=self.binning_mode)
+                batch.render(vm, pm)
+                need = int(batch.statuses()[:, 0].max())
+                if need <= self._cap:
+                    return batch.count.clone()
+                self._cap = int(need * 1.5) + 4096
         out = []
         for k, fid in enumerate(frame_ids):
             cam0, _, _ = self._camera(int(fid))
@@ -317,7 +332,7 @@ class FusedMapTrainer(GaussianMapTrainer):
             torch.index_select(all_view, 0, idx, out=batch.viewmats[:B])
             torch.index_select(all_proj, 0, idx, out=batch.projmats[:B])
             batch.forward(B)
-            need = max(api.read_status(batch.states[b])["num_instances"] for b in range(B))
+            need = int(batch.statuses(B)[:, 0].max())
             if need <= self._cap:
                 return True
             self._cap = int(need * 1.5) + 4096
@@ -351,7 +366,7 @@ class FusedMapTrainer(GaussianMapTrainer):
                     torch.cuda.current_stream().wait_stream(side)
             losses[it].copy_(loss_now)
         batch = state["batch"]
-        if batch is not None and any(api.read_status(batch.states[b])["overflow"] for b in range(state["B"])):
+        if batch is not None and batch.overflowed(state["B"]):
             self._cap = int(self._cap * 2)
             raise RuntimeError("a view outgrew the rasterizer workspace during train(); call train() again "
                                "(the capacity has been raised)")

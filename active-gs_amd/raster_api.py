@@ -323,8 +323,9 @@ class ViewBatch:
         for st in self.states:
             ws = st.ws_struct()
             _lib.check(lib.ags_workspace_init(C.byref(ws), n, h, w, _stream()), "ags_workspace_init")
-        self.cam = Camera(h, w, tanfovx, tanfovy, self.viewmats, self.projmats, bg, want_stats=want_stats,
-                          front_only=front_only, render_mask=self.masks)
+        # the batch entry point offsets these per view: base pointers = view 0
+        self.cam = Camera(h, w, tanfovx, tanfovy, self.viewmats[0], self.projmats[0], bg, want_stats=want_stats,
+                          front_only=front_only, render_mask=None if self.masks is None else self.masks[0])
         self.cams = [Camera(h, w, tanfovx, tanfovy, self.viewmats[v], self.projmats[v], bg, want_stats=want_stats,
                             front_only=front_only, render_mask=None if self.masks is None else self.masks[v])
                      for v in range(V)]
@@ -399,6 +400,14 @@ class ViewBatch:
         self._graph.replay()
         return self.states
 
-    def overflowed(self) -> bool:
+    def statuses(self, views: Optional[int] = None) -> torch.Tensor:
+        """Blocking: the first four words of every view's status block in ONE transfer ->
+        (views, 4) int64 on the host: instances needed, instances sorted, overflow flag, visible."""
+        V = self.num_views if views is None else int(views)
+        per = self.workspace.numel() // self.num_views
+        words = self.workspace.view(self.num_views, per)[:V, :16].contiguous().view(torch.int32).view(V, 4)
+        return (words.cpu().to(torch.int64)) & 0xFFFFFFFF
+
+    def overflowed(self, views: Optional[int] = None) -> bool:
         """Blocking: did any view need more tile instances than ``max_instances``?"""
-        return any(read_status(st)["overflow"] for st in self.states)
+        return bool(self.statuses(views)[:, 2].any())
