@@ -548,3 +548,44 @@ def test_alpha_clamp_near_plane_and_grazing_surfels(agslib):
     _check_grads(ins, gin)
     # the clamp really was active: many pixels carry alpha == 0.99 from an o = 1 surfel
     assert float(out[3].detach().max()) > 0.98
+
+
+@pytest.mark.parametrize("use_rows", [False, True])
+def test_batched_backward_equals_sum_of_per_view_backwards(agslib, use_rows):
+    """ags_backward_batch (views summed atomically into one slab; dense or row-set form of the
+    per-Gaussian stage) == per-view ags_backward accumulated one after another."""
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.synthetic import activate, make_room_scene
+    dev = torch.device("cuda:0")
+    n, h, w, V = 12000, 136, 240, 5
+    a = activate(make_room_scene(n, seed=12))
+    g = api.Gaussians(*(a[k].to(dev).contiguous() for k in ("means", "scales", "rotations", "opacities", "colors",
+                                                              "confidences")))
+    S = [room_case(16, h, w, view=v, seed=12)[1] for v in range(V)]
+    bg = S[0].bg.to(dev)
+    gen = torch.Generator().manual_seed(13)
+    d_rgb = (torch.randn(V, 3, h, w, generator=gen) / (h * w)).to(dev)
+    d_nrm = (torch.randn(V, 3, h, w, generator=gen) / (h * w)).to(dev)
+    d_dep = (torch.randn(V, 1, h, w, generator=gen) / (h * w)).to(dev)
+    # reference: one view after another
+    ref = api.alloc_grads(n, dev, zero=True)
+    for v, s in enumerate(S):
+        cam = api.Camera(h, w, s.tanfovx, s.tanfovy, s.viewmatrix.to(dev), s.projmatrix.to(dev), bg)
+        st = api.alloc_state(n, h, w, 1 << 19, dev)
+        api.forward(cam, g, st)
+        api.backward(cam, g, st, d_rgb[v], d_nrm[v], d_dep[v], None, None, grads=ref, accumulate=True)
+    batch = api.ViewBatch(g, V, h, w, S[0].tanfovx, S[0].tanfovy, bg, 1 << 19)
+    batch.viewmats.copy_(torch.stack([s.viewmatrix for s in S]).to(dev))
+    batch.projmats.copy_(torch.stack([s.projmatrix for s in S]).to(dev))
+    rows = api.RowSet(n, dev) if use_rows else None
+    batch.forward(V, touched=rows)
+    out = api.alloc_grads(n, dev, zero=True)
+    batch.backward(V, d_rgb, d_nrm, d_dep, out, touched=rows)
+    torch.cuda.synchronize()
+    assert not batch.overflowed()
+    for name in ("means3D", "scales", "rotations", "opacities", "colors"):
+        x, y = getattr(out, name), getattr(ref, name)
+        assert float(y.abs().sum()) > 0
+        assert float((x - y).abs().sum()) <= 1e-4 * float(y.abs().sum()), name
+    if use_rows:
+        assert int(rows.count.item()) == int((batch.radii > 0).any(0).sum())
