@@ -28,6 +28,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         # single rank, frames of one size and field of view: all views of an iteration go through ONE
         # set of launches (ags_forward_batch / ags_backward_batch, loss stages with blockIdx.y = view)
         self.batched = batched
+        self._batched_cache = None
         self.graph_min_steps = 50   # train_batched replays a hipGraph only for calls at least this long
         if self.device.type != "cuda":
             raise RuntimeError("FusedMapTrainer needs GPU tensors: there is no CPU fallback")
@@ -53,16 +54,20 @@ class FusedMapTrainer(GaussianMapTrainer):
     def _camera(self, idx: int):
         c = self._cams.get(idx)
         if c is None:
-            f = self.frames[idx]
-            h, w = f["rgb"].shape[-2:]
-            cm = camera_matrices(f["extrinsic"][None].float(), f["intrinsic"][None].float(), *self.cfg["bound"])
-            tan = cm["tanfov"][0].cpu()
-            cam = api.Camera(h, w, float(tan[0]), float(tan[1]), cm["viewmatrix"][0].contiguous(),
-                             cm["projmatrix"][0].contiguous(), self.background)
-            fov = (2.0 * torch.atan(tan)).tolist()
-            c = (cam, fov[0], fov[1])
+            c = self._make_camera(self.frames[idx])
             self._cams[idx] = c
         return c
+
+    def _make_camera(self, f: dict):
+        """(api.Camera, fov_x, fov_y) of a frame.  The 4x4 / 3x3 algebra runs on the HOST (one small
+        read of the pose, two small uploads): on the GPU it is a dozen tiny launches and an inverse."""
+        h, w = f["rgb"].shape[-2:]
+        cm = camera_matrices(f["extrinsic"][None].float().cpu(), f["intrinsic"][None].float().cpu(), *self.cfg["bound"])
+        tan = cm["tanfov"][0]
+        cam = api.Camera(h, w, float(tan[0]), float(tan[1]), cm["viewmatrix"][0].contiguous().to(self.device),
+                         cm["projmatrix"][0].contiguous().to(self.device), self.background)
+        fov = (2.0 * torch.atan(tan)).tolist()
+        return (cam, fov[0], fov[1])
 
     def _state(self, slot: int, n: int, h: int, w: int) -> api.ForwardState:
         st = self._states.get(slot)
@@ -234,10 +239,9 @@ class FusedMapTrainer(GaussianMapTrainer):
         if self.is_init and self.means.shape[0] > 0:
             h, w = frame["rgb"].shape[-2:]
             n = self.means.shape[0]
-            cm = camera_matrices(frame["extrinsic"][None].float(), frame["intrinsic"][None].float(), *self.cfg["bound"])
-            tan = cm["tanfov"][0].cpu()
-            cam = api.Camera(h, w, float(tan[0]), float(tan[1]), cm["viewmatrix"][0].contiguous(),
-                             cm["projmatrix"][0].contiguous(), self.background)
+            made = self._make_camera(frame)
+            self._cams[len(self.frames)] = made          # the frame is registered below under this index
+            cam = made[0]
             self._cap = max(self._cap, 1 << 16, 2 * n)
             g = self._gaussians()
             while True:
@@ -296,15 +300,26 @@ class FusedMapTrainer(GaussianMapTrainer):
         Bmax = self.cfg["batch_size"] + self.cfg["active_size"]
         self._cap = max(self._cap, 1 << 16, 2 * n)
         g = self._gaussians()
-        self._loss = FusedLoss(h, w, fx, fy, Bmax, Bmax, dev)
+        # buffers that do not depend on the map size live across train() calls; the ViewBatch is
+        # allocated with head-room for a growing map and re-bound (bind) while the map fits
+        key = (h, w, Bmax, round(fx, 7), round(fy, 7))
+        keep = self._batched_cache if self._batched_cache and self._batched_cache["key"] == key else None
+        if keep is None:
+            loss = FusedLoss(h, w, fx, fy, Bmax, Bmax, dev)
+            keep = dict(key=key, loss=loss, gt_rgb=torch.empty(Bmax, 3, h, w, device=dev),
+                        gt_depth=torch.empty(Bmax, 1, h, w, device=dev), bufs=loss.alloc_batch(Bmax), batch=None)
+            self._batched_cache = keep
+        self._loss, gt_rgb, gt_depth, bufs = keep["loss"], keep["gt_rgb"], keep["gt_depth"], keep["bufs"]
         self._loss_bufs = []
-        gt_rgb = torch.empty(Bmax, 3, h, w, device=dev)
-        gt_depth = torch.empty(Bmax, 1, h, w, device=dev)
-        bufs = self._loss.alloc_batch(Bmax)
         total = self.cfg["optimization_steps"] if steps is None else steps
         losses = torch.zeros(max(total, 1), device=dev)
         loss_now = torch.zeros((), device=dev)
         state = dict(batch=None, idx=None, B=0)
+        cached = keep["batch"]
+        if cached is not None and cached.capacity_n >= n and cached.max_instances >= self._cap:
+            cached.bind(g)
+            state["batch"] = cached
+            self._cap = cached.max_instances
 
         def iteration():
             """everything of one optimisation step that runs on the GPU; inputs: state['idx'] (device)"""
@@ -350,8 +365,12 @@ class FusedMapTrainer(GaussianMapTrainer):
                 graph.replay()
             else:
                 while state["batch"] is None or (it == 0 and not fits()):
-                    state["batch"] = api.ViewBatch(g, Bmax, h, w, cam0.tanfovx, cam0.tanfovy, self.background,
-                                                   self._cap, binning_mode=self.binning_mode)
+                    keep["batch"] = None               # release the old buffers before the larger ones are made
+                    ncap = int(n * 1.3) + 4096
+                    self._cap = max(self._cap, 2 * ncap)
+                    state["batch"] = keep["batch"] = api.ViewBatch(
+                        g, Bmax, h, w, cam0.tanfovx, cam0.tanfovy, self.background, self._cap,
+                        binning_mode=self.binning_mode, capacity_n=ncap)
                 iteration()
                 if self.use_graph and total >= self.graph_min_steps and it + 1 < total:
                     # for a given batch size the iteration is a fixed launch sequence: record it once

@@ -296,47 +296,63 @@ class ViewBatch:
     def __init__(self, g: Gaussians, num_views: int, height: int, width: int, tanfovx: float, tanfovy: float,
                  bg: torch.Tensor, max_instances: int, num_streams: int = 8, want_stats: bool = False,
                  front_only: bool = False, render_masks: Optional[torch.Tensor] = None,
-                 binning_mode: int = BIN_TILE_SORT, mode: str = "batched"):
-        for name in ("means3D", "scales", "rotations", "opacities", "colors", "confidences"):
-            _require_cuda(getattr(g, name), name)
+                 binning_mode: int = BIN_TILE_SORT, mode: str = "batched", capacity_n: Optional[int] = None):
         if mode not in ("batched", "streams"):
             raise ValueError("mode is 'batched' or 'streams'")
         dev = g.means3D.device
-        V, n, h, w = int(num_views), g.n, int(height), int(width)
-        self.g, self.num_views, self.mode, self.want_stats = g, V, mode, want_stats
+        V, h, w = int(num_views), int(height), int(width)
+        ncap = max(int(capacity_n or 0), g.n)          # buffers sized for maps of up to this many surfels
+        self.num_views, self.mode, self.want_stats = V, mode, want_stats
+        self.capacity_n, self.max_instances, self.binning_mode = ncap, int(max_instances), int(binning_mode)
+        self._hw = (h, w)
         self.viewmats = torch.zeros(V, 4, 4, device=dev)
         self.projmats = torch.zeros(V, 4, 4, device=dev)
         self.masks = None if render_masks is None else render_masks.to(dev).float().reshape(V, h, w).contiguous()
         f = dict(device=dev, dtype=torch.float32)
         self.rgb, self.normal = torch.empty(V, 3, h, w, **f), torch.empty(V, 3, h, w, **f)
         self.depth, self.opacity, self.confidence = (torch.empty(V, 1, h, w, **f) for _ in range(3))
-        self.importance = torch.zeros(V, n, **f)
-        self.count = torch.zeros(V, n, device=dev, dtype=torch.int32)
-        self.radii = torch.empty(V, n, device=dev, dtype=torch.int32)
-        per = workspace_bytes(n, h, w, max_instances)
-        self.workspace = torch.empty(V * per, device=dev, dtype=torch.uint8)
-        self.states = [ForwardState(self.rgb[v], self.normal[v], self.depth[v], self.opacity[v], self.confidence[v],
-                                    self.importance[v], self.count[v], self.radii[v],
-                                    self.workspace[v * per:(v + 1) * per], int(max_instances), int(binning_mode))
-                       for v in range(V)]
-        lib = _lib.load()
-        for st in self.states:
-            ws = st.ws_struct()
-            _lib.check(lib.ags_workspace_init(C.byref(ws), n, h, w, _stream()), "ags_workspace_init")
-        # the batch entry point offsets these per view: base pointers = view 0
+        self._importance = torch.zeros(V * ncap, **f)
+        self._count = torch.zeros(V * ncap, device=dev, dtype=torch.int32)
+        self._radii = torch.empty(V * ncap, device=dev, dtype=torch.int32)
+        self.workspace = torch.empty(V * workspace_bytes(ncap, h, w, max_instances), device=dev, dtype=torch.uint8)
+        self._graph = None
+        self.bind(g)
         self.cam = Camera(h, w, tanfovx, tanfovy, self.viewmats[0], self.projmats[0], bg, want_stats=want_stats,
                           front_only=front_only, render_mask=None if self.masks is None else self.masks[0])
         self.cams = [Camera(h, w, tanfovx, tanfovy, self.viewmats[v], self.projmats[v], bg, want_stats=want_stats,
                             front_only=front_only, render_mask=None if self.masks is None else self.masks[v])
                      for v in range(V)]
         self.pool = StreamPool(min(num_streams, max(1, V))) if mode == "streams" else None
-        self._graph = None
+
+    def bind(self, g: Gaussians) -> None:
+        """(Re)attach a map of ``g.n <= capacity_n`` surfels: the per-view workspaces are laid out for
+        that size inside the allocated buffers and re-initialised.  Lets a training loop whose map grows
+        every keyframe keep one allocation."""
+        if g.n > self.capacity_n:
+            raise ValueError("map larger than this ViewBatch's capacity_n")
+        for name in ("means3D", "scales", "rotations", "opacities", "colors", "confidences"):
+            _require_cuda(getattr(g, name), name)
+        V, n, (h, w) = self.num_views, g.n, self._hw
+        self.g = g
+        self._graph = None                     # a recorded replay (mode "streams") points at the old layout
+        per = workspace_bytes(n, h, w, self.max_instances)
+        self._per = per
+        self.importance = self._importance[:V * n].view(V, n)
+        self.count = self._count[:V * n].view(V, n)
+        self.radii = self._radii[:V * n].view(V, n)
+        self.states = [ForwardState(self.rgb[v], self.normal[v], self.depth[v], self.opacity[v], self.confidence[v],
+                                    self.importance[v], self.count[v], self.radii[v],
+                                    self.workspace[v * per:(v + 1) * per], self.max_instances, self.binning_mode)
+                       for v in range(V)]
+        lib = _lib.load()
+        for st in self.states:
+            ws = st.ws_struct()
+            _lib.check(lib.ags_workspace_init(C.byref(ws), n, h, w, _stream()), "ags_workspace_init")
 
     def _structs(self, touched=None):
         im = _lib.AgsImages(ptr(self.rgb), ptr(self.normal), ptr(self.depth), ptr(self.opacity), ptr(self.confidence))
         pg = _lib.AgsPerGaussian(ptr(self.importance), ptr(self.count), ptr(self.radii), _rowset_struct(touched))
-        ws = _lib.AgsWorkspace(ptr(self.workspace), self.workspace.numel(), self.states[0].max_instances,
-                               self.states[0].binning_mode)
+        ws = _lib.AgsWorkspace(ptr(self.workspace), self.workspace.numel(), self.max_instances, self.binning_mode)
         return im, pg, ws
 
     def _enqueue_batched(self, views: Optional[int] = None, touched: Optional[RowSet] = None) -> None:
@@ -404,8 +420,8 @@ class ViewBatch:
         """Blocking: the first four words of every view's status block in ONE transfer ->
         (views, 4) int64 on the host: instances needed, instances sorted, overflow flag, visible."""
         V = self.num_views if views is None else int(views)
-        per = self.workspace.numel() // self.num_views
-        words = self.workspace.view(self.num_views, per)[:V, :16].contiguous().view(torch.int32).view(V, 4)
+        per = self._per
+        words = self.workspace[:self.num_views * per].view(self.num_views, per)[:V, :16].contiguous().view(torch.int32).view(V, 4)
         return (words.cpu().to(torch.int64)) & 0xFFFFFFFF
 
     def overflowed(self, views: Optional[int] = None) -> bool:
