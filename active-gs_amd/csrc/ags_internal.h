@@ -256,6 +256,46 @@ __device__ __forceinline__ void ags_for_each_tile(uint32_t cnt, uint32_t x0, uin
 // tiles of the D3 rect that no pixel of the surfel can reach are never emitted (they would
 // contribute nothing: identical images, fewer instances to sort, gather and blend).
 struct AgsEmitRec { uint32_t excl, xy, wd, pa; float mx, my, ca, cb, cc, o; }; // per lane, in LDS
+
+// counter[t] += 1 for every `active` lane, returning the lane's old value (its slot).
+// AGG = false: one atomic per lane.  AGG = true (images of few tiles, where a wave's 64 emissions hit
+// a handful of counters and same-address atomics serialise in L2): lanes that hit the SAME counter
+// are grouped first - up to AGS_AGG_ROUNDS groups per call, found with readlane + ballot, no memory
+// traffic - then every group leader issues ONE atomic for the whole group (all leaders in the same
+// instruction: a single round trip), and members take base + rank.  RETURN = false drops the result
+// (counting pass: fire and forget).  Must be called by all lanes of the wave.
+#define AGS_AGG_ROUNDS 6
+#define AGS_AGG_MAX_TILES 256
+template <bool AGG, bool RETURN>
+__device__ __forceinline__ uint32_t ags_wave_agg_inc(uint32_t* __restrict__ counter, uint32_t t, bool active) {
+    if (!AGG) {
+        uint32_t slot = 0;
+        if (active) { if (RETURN) slot = atomicAdd(&counter[t], 1u); else atomicAdd(&counter[t], 1u); }
+        return slot;
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned long long rem = __ballot(active);
+    int leader_of = lane;
+    uint32_t rank = 0, size = active ? 1u : 0u;
+#pragma unroll 1
+    for (int round = 0; round < AGS_AGG_ROUNDS && rem; ++round) {
+        const int leader = __ffsll((long long)rem) - 1;
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);
+        const unsigned long long m = __ballot(active && t == t0) & rem;
+        if ((m >> lane) & 1ull) {
+            leader_of = leader;
+            rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            size = lane == leader ? (uint32_t)__builtin_popcountll(m) : 0u;
+        }
+        rem &= ~m;
+    }
+    uint32_t base = 0;
+    if (size) { if (RETURN) base = atomicAdd(&counter[t], size); else atomicAdd(&counter[t], size); }
+    if (!RETURN) return 0;
+    base = (uint32_t)__shfl((int)base, leader_of);
+    return base + rank;
+}
+
 template <typename Fn>
 __device__ __forceinline__ void ags_emit_tiles_balanced(AgsEmitRec* wave_lds, uint32_t cnt, uint32_t x0, uint32_t y0,
                                                         uint32_t wd, uint32_t pa, const AgsGeom& g, int tiles_x,
@@ -275,6 +315,8 @@ __device__ __forceinline__ void ags_emit_tiles_balanced(AgsEmitRec* wave_lds, ui
     __builtin_amdgcn_wave_barrier();
     for (uint32_t base = 0; base < total; base += 64) {
         const uint32_t j = base + lane;
+        bool hit = false;
+        uint32_t tile = 0, owner = 0;
         if (j < total) {
             int lo = 0;
 #pragma unroll
@@ -286,8 +328,10 @@ __device__ __forceinline__ void ags_emit_tiles_balanced(AgsEmitRec* wave_lds, ui
             AgsGeom og;
             og.mx = r.mx; og.my = r.my; og.ca = r.ca; og.cb = r.cb; og.cc = r.cc; og.o = r.o;
             const float bx = (float)(tx * AGS_TILE), by = (float)(ty * AGS_TILE);
-            if (ags_reaches_box(og, bx, bx + (AGS_TILE - 1), by, by + (AGS_TILE - 1))) f(ty * tiles_x + tx, r.pa);
+            hit = ags_reaches_box(og, bx, bx + (AGS_TILE - 1), by, by + (AGS_TILE - 1));
+            tile = ty * tiles_x + tx; owner = r.pa;
         }
+        f(hit, tile, owner); // called by the whole wave (wave-uniform control flow): see ags_wave_agg_inc
     }
     __builtin_amdgcn_wave_barrier();
 }

@@ -424,16 +424,20 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
     }
     // same predicate and same inputs as the counting pass in ags_k_preprocess<true>
     ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, x0, y0, wd, (uint32_t)threadIdx.x, g, tiles_x,
-                            [&](uint32_t t, uint32_t owner_tid) {
-        uint32_t b, e;
-        if (SCAN) { b = pre[t]; e = pre[t + 1]; e = e < cap ? e : cap; }
-        else { const uint2 rg = ranges[t]; b = rg.x; e = rg.y; }
+                            [&](bool hit, uint32_t t, uint32_t owner_tid) {
 #ifdef AGS_EXP_BUCKET_NOATOMIC
-        if (b + t == 0xFFFFFFFFu) keys[0] = e;
+        if (hit && t == 0xFFFFFFFFu) keys[0] = 1;
 #else
-        const uint32_t slot = b + atomicAdd(&tile_fill[t], 1u);
-        if (slot < e)
-            keys[slot] = ((uint64_t)depth_bits[owner_tid] << 32) | (uint32_t)(blockIdx.x * AGS_PRE_THREADS + owner_tid);
+        const uint32_t got = (T <= AGS_AGG_MAX_TILES) ? ags_wave_agg_inc<true, true>(tile_fill, t, hit)
+                                                      : ags_wave_agg_inc<false, true>(tile_fill, t, hit);
+        if (hit) {
+            uint32_t b, e;
+            if (SCAN) { b = pre[t]; e = pre[t + 1]; e = e < cap ? e : cap; }
+            else { const uint2 rg = ranges[t]; b = rg.x; e = rg.y; }
+            const uint32_t slot = b + got;
+            if (slot < e)
+                keys[slot] = ((uint64_t)depth_bits[owner_tid] << 32) | (uint32_t)(blockIdx.x * AGS_PRE_THREADS + owner_tid);
+        }
 #endif
     });
 }

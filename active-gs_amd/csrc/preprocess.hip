@@ -128,11 +128,12 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     }
     if (COUNT_TILES)  // tile-sort binning: how many surfels can reach each tile
         ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, rx0, ry0, rwd, 0u, g, F.tiles_x,
-                                [&](uint32_t t, uint32_t) {
+                                [&](bool hit, uint32_t t, uint32_t) {
 #ifdef AGS_EXP_PRE_NOCOUNT
-                                    if (t == 0xFFFFFFFFu) tile_count[0] = 1;
+                                    if (hit && t == 0xFFFFFFFFu) tile_count[0] = 1;
 #else
-                                    atomicAdd(&tile_count[t], 1u);
+                                    if (F.tiles_x * F.tiles_y <= AGS_AGG_MAX_TILES) ags_wave_agg_inc<true, false>(tile_count, t, hit);
+                                    else ags_wave_agg_inc<false, false>(tile_count, t, hit);
 #endif
                                 });
     const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
