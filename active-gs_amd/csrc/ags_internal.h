@@ -116,7 +116,10 @@ struct AgsViewStride {
     long long n;    // Gaussians: per-Gaussian outputs (radii, importance, count) of consecutive views
     int views;      // gridDim.y
 };
-#define AGS_WS_SHIFT(ptr, off) ptr = reinterpret_cast<decltype(ptr)>(reinterpret_cast<uintptr_t>(ptr) + (off))
+// pointer arithmetic, NOT an integer round trip: an inttoptr would lose the pointer's global address
+// space (flat_load / flat_store instead of global_*, and the uniform `ranges[tile]` reads stop being
+// scalar loads - measured +1.3 us on a 5 us kernel)
+#define AGS_WS_SHIFT(ptr, off) ptr = (decltype(ptr))((char*)(ptr) + (off))
 
 // ---- launchers (one per translation unit; each enqueues on `s` and never synchronises)
 // `ids` + `id_stride`: sorted Gaussian ids per instance; stride 2 when they are the low
@@ -384,10 +387,11 @@ __device__ __forceinline__ void ags_bitonic_finish_lds(uint64_t* sk, uint32_t n,
 //   larger:         chunks of LDS_KEYS are sorted in LDS, then only the steps whose partners are
 //                   >= LDS_KEYS apart run on the (L2-resident) global slice and every stage is finished
 //                   chunk by chunk in LDS again: 3 global passes for 8192 keys instead of 91
-template <int NT, int LDS_KEYS>
+template <int NT, int LDS_KEYS, bool BARRIER_AT_END = true>
 __device__ __forceinline__ void ags_sort_tile_keys(uint64_t* g, uint32_t K, uint64_t* sk, int tid) {
     if (K < 2) return;
     if (K <= 64) {
+        if (!BARRIER_AT_END && tid >= 64) return; // stand-alone sort kernel: the other waves are done
         if (tid < 64) {
             const uint64_t mine = (tid < (int)K) ? g[tid] : ~0ull;
             const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
@@ -445,7 +449,7 @@ __device__ __forceinline__ void ags_sort_tile_keys(uint64_t* g, uint32_t K, uint
             }
         }
     }
-    __syncthreads();
+    if (BARRIER_AT_END) __syncthreads();
 }
 
 // Transposed wave reduction of 16 per-lane values (gfx950 v_permlane32_swap / v_permlane16_swap):

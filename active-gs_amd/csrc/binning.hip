@@ -301,7 +301,7 @@ __global__ __launch_bounds__(1024) void ags_k_scan_tiles(const uint32_t* __restr
                                                          uint2* __restrict__ ranges, uint32_t* __restrict__ status,
                                                          uint32_t cap, const uint32_t* __restrict__ block_vis,
                                                          int nblk, AgsViewStride vs) {
-    if (vs.views > 1) {
+    { // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
         AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(status, wo); AGS_WS_SHIFT(block_vis, wo);
     }
@@ -343,13 +343,13 @@ __global__ __launch_bounds__(1024) void ags_k_scan_tiles(const uint32_t* __restr
 // one kernel and one dependency edge less per forward (-5 us at 1200x680).  Workgroup 0 publishes
 // the ranges and the status block for the kernels that follow.
 #define AGS_BUCKET_SCAN_TILES 4096
-template <bool SCAN>
+template <bool SCAN, bool AGG>
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
     int n, int tiles_x, const uint32_t* __restrict__ tiles, const ushort4* __restrict__ rect,
     const AgsGeom* __restrict__ geom, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill,
     uint64_t* __restrict__ keys, const uint32_t* __restrict__ tile_count, int T, uint32_t cap,
     uint32_t* __restrict__ status, const uint32_t* __restrict__ block_vis, int nblk, AgsViewStride vs) {
-    if (vs.views > 1) {
+    { // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
         AGS_WS_SHIFT(tiles, wo); AGS_WS_SHIFT(rect, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(ranges, wo);
         AGS_WS_SHIFT(tile_fill, wo); AGS_WS_SHIFT(keys, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(status, wo);
@@ -428,8 +428,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
 #ifdef AGS_EXP_BUCKET_NOATOMIC
         if (hit && t == 0xFFFFFFFFu) keys[0] = 1;
 #else
-        const uint32_t got = (T <= AGS_AGG_MAX_TILES) ? ags_wave_agg_inc<true, true>(tile_fill, t, hit)
-                                                      : ags_wave_agg_inc<false, true>(tile_fill, t, hit);
+        const uint32_t got = ags_wave_agg_inc<AGG, true>(tile_fill, t, hit);
         if (hit) {
             uint32_t b, e;
             if (SCAN) { b = pre[t]; e = pre[t + 1]; e = e < cap ? e : cap; }
@@ -449,14 +448,14 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
 #define AGS_TSORT_LDS_KEYS 2048
 __global__ __launch_bounds__(256) void ags_k_tile_sort(const uint2* __restrict__ ranges, uint64_t* keys, int num_tiles,
                                                        AgsViewStride vs) {
-    if (vs.views > 1) {
+    { // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(keys, wo);
     }
     __shared__ uint64_t sk[AGS_TSORT_LDS_KEYS];
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
-    ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS>(keys + rg.x, rg.y - rg.x, sk, threadIdx.x);
+    ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS, false>(keys + rg.x, rg.y - rg.x, sk, threadIdx.x);
 }
 
 void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L,
@@ -468,17 +467,17 @@ void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws
     const uint32_t* block_vis = (const uint32_t*)(ws + L.block_vis);
     static const bool no_fuse = getenv("AGS_BUCKET_NO_SCAN") != nullptr; // experiment knob
     if (L.num_tiles <= AGS_BUCKET_SCAN_TILES && !no_fuse) {
-        hipLaunchKernelGGL(ags_k_bucket<true>, dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, in.n, F.tiles_x,
-                           (const uint32_t*)(ws + L.tiles), (const ushort4*)(ws + L.rect), (const AgsGeom*)(ws + L.geom),
-                           ranges, (uint32_t*)(ws + L.tile_fill), keys, tile_count, L.num_tiles, (uint32_t)L.cap, status,
-                           block_vis, L.n_blocks, vs);
+#define AGS_LAUNCH_BUCKET(SCAN, AGG)                                                                                     \
+    hipLaunchKernelGGL((ags_k_bucket<SCAN, AGG>), dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, in.n, F.tiles_x, \
+                       (const uint32_t*)(ws + L.tiles), (const ushort4*)(ws + L.rect), (const AgsGeom*)(ws + L.geom),       \
+                       ranges, (uint32_t*)(ws + L.tile_fill), keys, tile_count, L.num_tiles, (uint32_t)L.cap, status,       \
+                       block_vis, L.n_blocks, vs)
+        if (L.num_tiles <= AGS_AGG_MAX_TILES) AGS_LAUNCH_BUCKET(true, true); else AGS_LAUNCH_BUCKET(true, false);
     } else {
         hipLaunchKernelGGL(ags_k_scan_tiles, dim3(1, vs.views), dim3(1024), 0, s, tile_count, L.num_tiles, ranges, status,
                            (uint32_t)L.cap, block_vis, L.n_blocks, vs);
-        hipLaunchKernelGGL(ags_k_bucket<false>, dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, in.n, F.tiles_x,
-                           (const uint32_t*)(ws + L.tiles), (const ushort4*)(ws + L.rect), (const AgsGeom*)(ws + L.geom),
-                           ranges, (uint32_t*)(ws + L.tile_fill), keys, tile_count, L.num_tiles, (uint32_t)L.cap, status,
-                           block_vis, L.n_blocks, vs);
+        AGS_LAUNCH_BUCKET(false, false);
+#undef AGS_LAUNCH_BUCKET
     }
     hipLaunchKernelGGL(ags_k_tile_sort, dim3(L.num_tiles, vs.views), dim3(256), 0, s, (const uint2*)ranges, keys,
                        L.num_tiles, vs);

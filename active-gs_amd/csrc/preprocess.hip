@@ -60,13 +60,13 @@ __device__ __forceinline__ void ags_activate_inplace(const AgsGaussians& in, flo
     opacity = 1.0f / (1.0f + expf(-opacity));
 }
 
-template <bool COUNT_TILES>
+template <bool COUNT_TILES, bool AGG>
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     AgsGeom* __restrict__ geom, uint32_t* __restrict__ tiles, ushort4* __restrict__ rect,
     int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_vis,
     uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom, AgsRowSet touched, AgsViewStride vs) {
-    if (vs.views > 1) { // batched forward: this workgroup's view
+    { // batched forward: this workgroup's view // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
         Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
         radii += (size_t)blockIdx.y * (size_t)vs.n;
@@ -132,8 +132,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
 #ifdef AGS_EXP_PRE_NOCOUNT
                                     if (hit && t == 0xFFFFFFFFu) tile_count[0] = 1;
 #else
-                                    if (F.tiles_x * F.tiles_y <= AGS_AGG_MAX_TILES) ags_wave_agg_inc<true, false>(tile_count, t, hit);
-                                    else ags_wave_agg_inc<false, false>(tile_count, t, hit);
+                                    ags_wave_agg_inc<AGG, false>(tile_count, t, hit);
 #endif
                                 });
     const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
@@ -152,7 +151,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsViewStride vs) {
-    if (vs.views > 1) { // batched backward (accumulate == 2): this workgroup's view
+    { // batched backward (accumulate == 2): this workgroup's view // (offsets are 0 for a single view)
         Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
         radii += (size_t)blockIdx.y * (size_t)vs.n;
         AGS_WS_SHIFT(dgeom, (size_t)blockIdx.y * (size_t)vs.ws);
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsAdamArgs adam,
     AgsViewStride vs) {
-    if (vs.views > 1) {
+    { // (offsets are 0 for a single view)
         Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
         radii += (size_t)blockIdx.y * (size_t)vs.n;
         AGS_WS_SHIFT(dgeom, (size_t)blockIdx.y * (size_t)vs.ws);
@@ -406,16 +405,15 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
                            const AgsLayout& L, int* radii, bool count_tiles, const AgsRowSet& touched,
                            const AgsViewStride& vs, hipStream_t s) {
-    if (count_tiles)
-        hipLaunchKernelGGL(ags_k_preprocess<true>, dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
-                           cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
-                           (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums),
-                           (uint32_t*)(ws + L.block_vis), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched, vs);
-    else
-        hipLaunchKernelGGL(ags_k_preprocess<false>, dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix,
-                           cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),
-                           (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums),
-                           (uint32_t*)(ws + L.block_vis), (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched, vs);
+#define AGS_LAUNCH_PRE(COUNT, AGG)                                                                                       \
+    hipLaunchKernelGGL((ags_k_preprocess<COUNT, AGG>), dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, F,         \
+                       cam.viewmatrix, cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),             \
+                       (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.block_vis),      \
+                       (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched, vs)
+    if (!count_tiles) AGS_LAUNCH_PRE(false, false);
+    else if (L.num_tiles <= AGS_AGG_MAX_TILES) AGS_LAUNCH_PRE(true, true);
+    else AGS_LAUNCH_PRE(true, false);
+#undef AGS_LAUNCH_PRE
 }
 
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     int id_stride, const AgsGeom* __restrict__ geom, AgsImages out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ importance, int* __restrict__ count, int num_tiles,
     uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_fill, AgsViewStride vs) {
-    if (vs.views > 1) { // batched forward: this workgroup's view
+    { // batched forward: this workgroup's view // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws, po = (size_t)blockIdx.y * (size_t)vs.px;
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(vals, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(final_T, wo);
         AGS_WS_SHIFT(n_contrib, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(tile_fill, wo);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
     const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, AgsImageGrads dout, float* __restrict__ dgeom, int num_tiles,
     AgsTick tick, AgsViewStride vs) {
-    if (vs.views > 1) { // batched backward: this workgroup's view
+    { // batched backward: this workgroup's view // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws, po = (size_t)blockIdx.y * (size_t)vs.px;
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(vals, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(final_T, wo);
         AGS_WS_SHIFT(n_contrib, wo); AGS_WS_SHIFT(dgeom, wo);
