@@ -65,7 +65,7 @@ class AgsStatus(C.Structure):
 
 class AgsAdamTensors(C.Structure):
     _fields_ = [("param", c_f32p * 5), ("grad", c_f32p * 5), ("exp_avg", c_f32p * 5), ("exp_avg_sq", c_f32p * 5),
-                ("numel", C.c_int64 * 5), ("lr", C.c_float * 5), ("touched", AgsRowSet)]
+                ("numel", C.c_int64 * 5), ("lr", C.c_float * 5), ("touched", AgsRowSet), ("zero_grad", C.c_int32)]
 
 
 class AgsLossConfig(C.Structure):
@@ -94,7 +94,7 @@ class AgsCandidates(C.Structure):
 
 EXPORTS = ["ags_workspace_bytes", "ags_workspace_init", "ags_forward", "ags_forward_batch",
            "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_read_status", "ags_adam_step",
-           "ags_adam_step_device", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_smooth_depth", "ags_densify_candidates",
+           "ags_adam_step_device", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_smooth_depth", "ags_densify_candidates",
            "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_compact_plan_bytes", "ags_compact_plan",
            "ags_compact_rows", "ags_profile_enable", "ags_profile_read",
            "ags_error_string", "ags_version"]
@@ -154,6 +154,11 @@ def load() -> C.CDLL:
         C.c_int32, C.c_int32, C.c_void_p]
     lib.ags_loss_stage2.restype = C.c_int
     lib.ags_loss_stage2.argtypes = [C.POINTER(AgsLossConfig), C.POINTER(AgsImages)] + [C.c_void_p] * 6 + [C.c_void_p]
+    lib.ags_stage_frames.restype = C.c_int
+    lib.ags_stage_frames.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 10 + [C.c_void_p]
+    lib.ags_loss_finish.restype = C.c_int
+    lib.ags_loss_finish.argtypes = [C.POINTER(AgsLossConfig), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]
     lib.ags_smooth_depth.restype = C.c_int
     lib.ags_smooth_depth.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float,
                                      C.c_void_p]

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void ags_k_adam(AgsAdamArgs a, AgsAdamClock ho
 // outside the set have g = m = v = 0, for which the dense update above is exactly 0.
 __global__ __launch_bounds__(256) void ags_k_adam_rows(AgsAdamArgs a, const AgsAdamClock* __restrict__ clk,
                                                        AgsAdamClock host_clk, AgsRowSet touched, float beta1,
-                                                       float beta2, float eps) {
+                                                       float beta2, float eps, int zero_grad) {
     if (!clk) clk = &host_clk;
     const float inv_bc2_sqrt = clk->inv_bc2_sqrt;
     const int k = threadIdx.x & 15;
@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void ags_k_adam_rows(AgsAdamArgs a, const AgsA
         a.m[seg][j] = m;
         a.v[seg][j] = v;
         a.p[seg][j] -= clk->step_size[seg] * (m / denom);
+        if (zero_grad) const_cast<float*>(a.g[seg])[j] = 0.f; // consumed: the slab is clean for the next step
     }
 }
 
@@ -86,7 +87,7 @@ void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float ep
         long long rb = (t.numel[3] + 15) / 16; // 16 rows per block
         if (rb > 16384) rb = 16384;
         hipLaunchKernelGGL(ags_k_adam_rows, dim3((unsigned)rb), dim3(256), 0, s, a, (const AgsAdamClock*)clk, hc,
-                           t.touched, beta1, beta2, eps);
+                           t.touched, beta1, beta2, eps, t.zero_grad);
         return;
     }
     long long blocks = (run + 255) / 256;

@@ -161,6 +161,11 @@ void ags_launch_loss_stage1(const AgsLossConfig& cfg, const AgsImages& img, cons
                             int first_view, hipStream_t s);
 void ags_launch_loss_stage2(const AgsLossConfig& cfg, const AgsImages& img, const float* n_img, const float* gt_depth,
                             const int* msum, float* d_normal, float* d_depth, float* accum, hipStream_t s);
+void ags_launch_stage_frames(int views, int hw, const long long* frame_index, const float* all_view, const float* all_proj,
+                             const float* all_rgb, const float* all_depth, float* dst_view, float* dst_proj,
+                             float* dst_rgb, float* dst_depth, int* msum, hipStream_t s);
+void ags_launch_loss_finish(const AgsLossConfig& cfg, float* accum, int views, const long long* frame_index,
+                            float* frame_error, float* total_loss, hipStream_t s);
 int ags_sort_passes(int num_tiles);
 // densify.hip
 void ags_launch_bilateral(int h, int w, const float* depth, float* out, int d, float sigma_color, float sigma_space,

@@ -232,6 +232,26 @@ int ags_loss_stage2(const AgsLossConfig* cfg, const AgsImages* fwd, const float*
     return ags_check_launch();
 }
 
+int ags_stage_frames(int32_t views, int32_t h, int32_t w, const int64_t* frame_index, const float* all_view,
+                     const float* all_proj, const float* all_rgb, const float* all_depth, float* dst_view, float* dst_proj,
+                     float* dst_rgb, float* dst_depth, int32_t* msum, ags_stream_t stream) {
+    if (views < 1 || views > 65535 || h <= 0 || w <= 0 || ((long long)h * w) % 4 != 0) return AGS_E_INVALID;
+    if (!frame_index || !all_view || !all_proj || !all_rgb || !all_depth || !dst_view || !dst_proj || !dst_rgb || !dst_depth)
+        return AGS_E_INVALID;
+    ags_launch_stage_frames(views, h * w, (const long long*)frame_index, all_view, all_proj, all_rgb, all_depth, dst_view,
+                            dst_proj, dst_rgb, dst_depth, msum, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_loss_finish(const AgsLossConfig* cfg, float* accum, int32_t views, const int64_t* frame_index,
+                    float* frame_error, float* total_loss, ags_stream_t stream) {
+    if (!cfg || !accum || views < 0 || cfg->accum_stride < 4 + 2 * views || cfg->accum_stride > 256 ||
+        cfg->batch_total < 1 || cfg->image_height <= 0 || cfg->image_width <= 0)
+        return AGS_E_INVALID;
+    ags_launch_loss_finish(*cfg, accum, views, (const long long*)frame_index, frame_error, total_loss, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
 int ags_profile_enable(int32_t slots) {
     if (slots < 0) return AGS_E_INVALID;
     for (int st = 0; st < AGS_NUM_STAGES; ++st) {

@@ -198,6 +198,55 @@ __global__ __launch_bounds__(256) void ags_k_loss_stage2(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two helpers that keep a batched training iteration down to a handful of launches (the host of the
+// GPU box needs 20-40 us per torch op; an iteration used to issue ~35 of them):
+//   ags_k_stage_frames: gathers the sampled frames' poses and ground truth into the batch buffers
+//                       (replaces four index_select launches) and zeroes the visibility count
+//   ags_k_loss_finish:  sums the 64 accumulator rows, writes the per-frame errors
+//                       (track_performance, gaussian_map.py:132-139) and the total loss, and leaves
+//                       the accumulators zeroed for the next iteration
+__global__ __launch_bounds__(256) void ags_k_stage_frames(
+    int HW, const long long* __restrict__ frame_index, const float* __restrict__ all_view,
+    const float* __restrict__ all_proj, const float* __restrict__ all_rgb, const float* __restrict__ all_depth,
+    float* __restrict__ dst_view, float* __restrict__ dst_proj, float* __restrict__ dst_rgb,
+    float* __restrict__ dst_depth, int* __restrict__ msum) {
+    const int v = blockIdx.y;
+    const size_t f = (size_t)frame_index[v];
+    const int q = blockIdx.x * 256 + threadIdx.x;          // float4 index within a plane
+    const int HW4 = HW >> 2;                                 // HW is a multiple of 4 (checked by the caller)
+    if (q < HW4) {
+        const float4* r = reinterpret_cast<const float4*>(all_rgb + f * 3 * (size_t)HW);
+        float4* o = reinterpret_cast<float4*>(dst_rgb + (size_t)v * 3 * (size_t)HW);
+        o[q] = r[q]; o[HW4 + q] = r[HW4 + q]; o[2 * HW4 + q] = r[2 * HW4 + q];
+        reinterpret_cast<float4*>(dst_depth + (size_t)v * HW)[q] = reinterpret_cast<const float4*>(all_depth + f * (size_t)HW)[q];
+        if (v == 0 && msum) reinterpret_cast<int4*>(msum)[q] = make_int4(0, 0, 0, 0);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 32) {
+        const int k = threadIdx.x & 15;
+        if (threadIdx.x < 16) dst_view[v * 16 + k] = all_view[f * 16 + k];
+        else dst_proj[v * 16 + k] = all_proj[f * 16 + k];
+    }
+}
+
+__global__ __launch_bounds__(256) void ags_k_loss_finish(AgsLossDev c, float* __restrict__ accum, int accum_stride,
+                                                         int views, const long long* __restrict__ frame_index,
+                                                         float* __restrict__ frame_error, float* __restrict__ total_loss) {
+    __shared__ float sums[256];
+    const int t = threadIdx.x;
+    float s = 0.f;
+    if (t < accum_stride) {
+        for (int r = 0; r < AGS_LOSS_ACCUM_ROWS; ++r) { s += accum[(size_t)r * accum_stride + t]; accum[(size_t)r * accum_stride + t] = 0.f; }
+    }
+    sums[t] = s;
+    __syncthreads();
+    const float hw = (float)c.H * (float)c.W, b = (float)c.B;
+    if (t < views && frame_error) frame_error[frame_index ? frame_index[t] : t] = sums[4 + 2 * t] / (3.f * hw) + sums[5 + 2 * t] / hw;
+    if (t == 0 && total_loss)
+        *total_loss = c.w_rgb * sums[0] / (b * 3.f * hw) + c.w_depth * sums[1] / (b * hw) + c.w_cons * sums[2] / (b * b * hw) +
+                      c.w_tv * sums[3] / (b * 4.f * hw);
+}
+
 static AgsLossDev make_dev(const AgsLossConfig& cfg) {
     AgsLossDev c;
     c.H = cfg.image_height; c.W = cfg.image_width; c.B = cfg.batch_total;
@@ -224,4 +273,17 @@ void ags_launch_loss_stage2(const AgsLossConfig& cfg, const AgsImages& img, cons
     const int views = cfg.num_views > 1 ? cfg.num_views : 1;
     hipLaunchKernelGGL(ags_k_loss_stage2, dim3((HW + 255) / 256, views), dim3(256), 0, s, make_dev(cfg), img.depth,
                        img.opacity, img.normal, n_img, gt_depth, msum, d_normal, d_depth, accum, cfg.accum_stride);
+}
+
+void ags_launch_stage_frames(int views, int hw, const long long* frame_index, const float* all_view, const float* all_proj,
+                             const float* all_rgb, const float* all_depth, float* dst_view, float* dst_proj,
+                             float* dst_rgb, float* dst_depth, int* msum, hipStream_t s) {
+    hipLaunchKernelGGL(ags_k_stage_frames, dim3(((hw >> 2) + 255) / 256, views), dim3(256), 0, s, hw, frame_index, all_view,
+                       all_proj, all_rgb, all_depth, dst_view, dst_proj, dst_rgb, dst_depth, msum);
+}
+
+void ags_launch_loss_finish(const AgsLossConfig& cfg, float* accum, int views, const long long* frame_index,
+                            float* frame_error, float* total_loss, hipStream_t s) {
+    hipLaunchKernelGGL(ags_k_loss_finish, dim3(1), dim3(256), 0, s, make_dev(cfg), accum, cfg.accum_stride, views,
+                       frame_index, frame_error, total_loss);
 }

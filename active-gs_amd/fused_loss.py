@@ -88,6 +88,21 @@ class FusedLoss:
         finally:
             self.cfg.num_views = 0
 
+    def stage_frames(self, views: int, frame_index, all_view, all_proj, all_rgb, all_depth, dst_view, dst_proj,
+                     dst_rgb, dst_depth) -> None:
+        """Gather the sampled frames into the batch buffers and zero ``msum`` - one launch."""
+        _lib.check(_lib.load().ags_stage_frames(int(views), self.h, self.w, ptr(frame_index), ptr(all_view), ptr(all_proj),
+                                                ptr(all_rgb), ptr(all_depth), ptr(dst_view), ptr(dst_proj), ptr(dst_rgb),
+                                                ptr(dst_depth), ptr(self.msum), torch.cuda.current_stream().cuda_stream),
+                   "ags_stage_frames")
+
+    def finish(self, views: int, frame_index, frame_error, total_loss) -> None:
+        """Per-frame errors -> ``frame_error[frame_index]``, total loss -> ``total_loss`` (a 0-d / 1-element
+        tensor), accumulators zeroed - one launch instead of per_frame_errors + total_loss + begin_step."""
+        _lib.check(_lib.load().ags_loss_finish(C.byref(self.cfg), ptr(self.accum), int(views), ptr(frame_index),
+                                               ptr(frame_error), ptr(total_loss),
+                                               torch.cuda.current_stream().cuda_stream), "ags_loss_finish")
+
     def total_loss(self) -> torch.Tensor:
         c, a, hw = self.cfg, self.accum.sum(0), float(self.h * self.w)
         b = float(c.batch_total)

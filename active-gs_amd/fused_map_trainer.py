@@ -321,25 +321,30 @@ class FusedMapTrainer(GaussianMapTrainer):
             state["batch"] = cached
             self._cap = cached.max_instances
 
-        def iteration():
-            """everything of one optimisation step that runs on the GPU; inputs: state['idx'] (device)"""
+        optim.zero_grad = True          # the row-set Adam leaves the slab clean for the next iteration
+        fast_stage = (h * w) % 4 == 0
+
+        def iteration(loss_out):
+            """everything of one optimisation step that runs on the GPU (11 launches); inputs:
+            state['idx'] (device), output: per-frame errors and the loss value"""
             batch, idx, B = state["batch"], state["idx"], state["B"]
-            torch.index_select(all_view, 0, idx, out=batch.viewmats[:B])
-            torch.index_select(all_proj, 0, idx, out=batch.projmats[:B])
-            torch.index_select(all_rgb, 0, idx, out=gt_rgb[:B])
-            torch.index_select(all_depth, 0, idx, out=gt_depth[:B])
+            if fast_stage:
+                self._loss.stage_frames(B, idx, all_view, all_proj, all_rgb, all_depth, batch.viewmats, batch.projmats,
+                                        gt_rgb, gt_depth)
+            else:
+                torch.index_select(all_view, 0, idx, out=batch.viewmats[:B])
+                torch.index_select(all_proj, 0, idx, out=batch.projmats[:B])
+                torch.index_select(all_rgb, 0, idx, out=gt_rgb[:B])
+                torch.index_select(all_depth, 0, idx, out=gt_depth[:B])
+                self._loss.msum.zero_()
             batch.forward(B, touched=rows)
             images = batch._structs()[0]
-            self._loss.begin_step()
-            self._loss.msum.zero_()
             self._loss.stage1_batch(images, gt_rgb, gt_depth, bufs, B)
             self._loss.stage2_batch(images, gt_depth, bufs, B)
-            slab.flat.zero_()
             batch.backward(B, bufs.d_rgb, bufs.d_normal, bufs.d_depth, slab.grads, touched=rows,
                            adam_tick=optim.tick_args())
-            self.training_performance.index_copy_(0, idx, self._loss.per_frame_errors(B))
             optim.step(slab.as_list(), device_clock=True, pre_ticked=True)
-            loss_now.copy_(self._loss.total_loss())
+            self._loss.finish(B, idx, self.training_performance, loss_out)
 
         def fits() -> bool:
             """forward-only probe of the staged batch: were the per-view workspaces large enough?"""
@@ -354,6 +359,7 @@ class FusedMapTrainer(GaussianMapTrainer):
             return False
 
         graph = None
+        self._loss.accum.zero_()           # from here on ags_loss_finish leaves it zeroed
         for it in range(total):
             _, _, _, _, ids = sampler.next_frames(self.training_performance)   # host read of the errors
             B = len(ids)
@@ -371,7 +377,7 @@ class FusedMapTrainer(GaussianMapTrainer):
                     state["batch"] = keep["batch"] = api.ViewBatch(
                         g, Bmax, h, w, cam0.tanfovx, cam0.tanfovy, self.background, self._cap,
                         binning_mode=self.binning_mode, capacity_n=ncap)
-                iteration()
+                iteration(losses[it:it + 1])
                 if self.use_graph and total >= self.graph_min_steps and it + 1 < total:
                     # for a given batch size the iteration is a fixed launch sequence: record it once
                     # (capture costs a few ms: it pays for long train() calls, not for the mapper's 10)
@@ -381,8 +387,9 @@ class FusedMapTrainer(GaussianMapTrainer):
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.stream(side):
                         with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-                            iteration()
+                            iteration(loss_now)
                     torch.cuda.current_stream().wait_stream(side)
+                continue
             losses[it].copy_(loss_now)
         batch = state["batch"]
         if batch is not None and batch.overflowed(state["B"]):

@@ -173,10 +173,13 @@ class GaussianMapTrainer:
                 to_cam = extr[-1:, :3, 3] - self.means
                 dist = torch.linalg.norm(to_cam, dim=1)
                 to_cam = to_cam / dist.unsqueeze(-1)
-                self.view_means[seen] += (to_cam[seen] - self.view_means[seen]) / self.view_supports[seen].unsqueeze(-1)
+                # masked updates written with where(): boolean indexing would cost a host sync (nonzero) each
+                step = (to_cam - self.view_means) / self.view_supports.clamp(min=1.0).unsqueeze(-1)
+                self.view_means = torch.where(seen.unsqueeze(-1), self.view_means + step, self.view_means)
                 cos = torch.clamp(torch.sum(normals * to_cam, 1), min=0, max=1)
                 far = self.frames[-1]["depth_range"][1]
-                self.view_scores[seen] += ((1 - torch.clamp(dist / far, min=0, max=1)) * cos)[seen]
+                gain = (1 - torch.clamp(dist / far, min=0, max=1)) * cos
+                self.view_scores = self.view_scores + torch.where(seen, gain, torch.zeros_like(gain))
             if prune_now:
                 self.prune(~(counts_sum >= 1.0))
 

@@ -34,6 +34,8 @@ class FusedAdam:
         # optional raster_api.RowSet: update only the surfels this optimiser's views have shown
         # (exact: the others have zero gradient and zero moments, so the dense update is 0)
         self.touched = None
+        # with ``touched``: gradient rows are zeroed as they are consumed (slabs the views add into atomically)
+        self.zero_grad = False
 
     def tick_args(self):
         """What ``raster_api.backward(adam_tick=...)`` needs to advance this optimizer's device clock."""
@@ -56,6 +58,7 @@ class FusedAdam:
             t.lr[k] = self.lrs[k]
         if self.touched is not None:
             t.touched = self.touched.c_struct()
+            t.zero_grad = int(self.zero_grad)
         self._keep = grads
         return t
 

@@ -227,6 +227,8 @@ typedef struct AgsAdamTensors {
     int64_t numel[5];
     float lr[5];
     AgsRowSet touched; /* optional: update the member rows only (exact, see AgsRowSet) */
+    int32_t zero_grad; /* with `touched`: write 0 over every gradient row once it is consumed, so that a slab the
+                        * views accumulate into atomically (accumulate = 2) needs no memset per step */
 } AgsAdamTensors;
 int ags_adam_step(const AgsAdamTensors* t, float beta1, float beta2, float eps, int32_t step,
                   ags_stream_t stream);
@@ -342,6 +344,21 @@ int ags_compact_plan(int32_t n, const int32_t* keep, int32_t* dst_index, int32_t
                      size_t scratch_bytes, ags_stream_t stream);
 int ags_compact_rows(int32_t n, int32_t width, const int32_t* dst_index, const float* src, float* dst,
                      ags_stream_t stream);
+
+/* Two helpers that keep a batched training iteration to a handful of launches:
+ * ags_stage_frames gathers the sampled frames (frame_index: `views` int64 indices, device) of the
+ * stacked keyframe arrays all_view / all_proj (K,16), all_rgb (K,3,H,W), all_depth (K,1,H,W) into the
+ * batch buffers dst_* (what four index_select calls would do) and, if msum != NULL, zeroes that (H,W)
+ * visibility count; H*W must be a multiple of 4.
+ * ags_loss_finish sums the accumulator rows of the loss stages, writes
+ * frame_error[frame_index[v]] = mean rgb L1 + mean depth L1 of view v (track_performance,
+ * gaussian_map.py:132-139; frame_index NULL: frame_error[v]) and *total_loss, and zeroes the
+ * accumulators for the next iteration.  frame_error / total_loss may be NULL. */
+int ags_stage_frames(int32_t views, int32_t h, int32_t w, const int64_t* frame_index, const float* all_view,
+                     const float* all_proj, const float* all_rgb, const float* all_depth, float* dst_view, float* dst_proj,
+                     float* dst_rgb, float* dst_depth, int32_t* msum, ags_stream_t stream);
+int ags_loss_finish(const AgsLossConfig* cfg, float* accum, int32_t views, const int64_t* frame_index,
+                    float* frame_error, float* total_loss, ags_stream_t stream);
 
 /* Optional stage timing with library-owned hipEvents (process-global, for bench/profiling
  * only; off by default so the normal path records nothing).  `slots` event pairs are kept
