@@ -19,20 +19,37 @@ __global__ void ags_k_adam_tick(AgsAdamClock* c, float lr0, float lr1, float lr2
 __global__ __launch_bounds__(256) void ags_k_adam(AgsAdamArgs a, AgsAdamClock host_clk,
                                                   const AgsAdamClock* __restrict__ dev_clk, float beta1,
                                                   float beta2, float eps, long long total) {
-    const AgsAdamClock* clk = dev_clk ? dev_clk : &host_clk; // wave-uniform
-    const float inv_bc2_sqrt = clk->inv_bc2_sqrt;
+    // the step's scalars, from the device clock (global loads) or the by-value host copy - not through
+    // one pointer to either, which would be a flat access per use
+    float ss[5], inv_bc2_sqrt;
+    if (dev_clk) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) ss[k] = dev_clk->step_size[k];
+        inv_bc2_sqrt = dev_clk->inv_bc2_sqrt;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) ss[k] = host_clk.step_size[k];
+        inv_bc2_sqrt = host_clk.inv_bc2_sqrt;
+    }
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        int seg = (i >= a.end[0]) + (i >= a.end[1]) + (i >= a.end[2]) + (i >= a.end[3]);
+        const int seg = (i >= a.end[0]) + (i >= a.end[1]) + (i >= a.end[2]) + (i >= a.end[3]);
         const long long j = i - (seg ? a.end[seg - 1] : 0);
-        const float g = a.g[seg][j];
-        float m = a.m[seg][j], v = a.v[seg][j];
+        // the four arrays of the element's tensor, selected with conditional moves: indexing the
+        // kernel-argument pointer arrays with a runtime `seg` would make these flat_* accesses
+        const float* pg = seg == 0 ? a.g[0] : seg == 1 ? a.g[1] : seg == 2 ? a.g[2] : seg == 3 ? a.g[3] : a.g[4];
+        float* pm = seg == 0 ? a.m[0] : seg == 1 ? a.m[1] : seg == 2 ? a.m[2] : seg == 3 ? a.m[3] : a.m[4];
+        float* pv = seg == 0 ? a.v[0] : seg == 1 ? a.v[1] : seg == 2 ? a.v[2] : seg == 3 ? a.v[3] : a.v[4];
+        float* pp = seg == 0 ? a.p[0] : seg == 1 ? a.p[1] : seg == 2 ? a.p[2] : seg == 3 ? a.p[3] : a.p[4];
+        const float g = pg[j];
+        float m = pm[j], v = pv[j];
         m = m + (1.f - beta1) * (g - m);                 // exp_avg.lerp_(grad, 1-beta1)
         v = v * beta2 + (1.f - beta2) * g * g;           // mul_(beta2).addcmul_(g, g, 1-beta2)
         const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
-        a.m[seg][j] = m;
-        a.v[seg][j] = v;
-        a.p[seg][j] -= clk->step_size[seg] * (m / denom); // addcdiv_(m, denom, -step_size)
+        pm[j] = m;
+        pv[j] = v;
+        const float step_size = seg == 0 ? ss[0] : seg == 1 ? ss[1] : seg == 2 ? ss[2] : seg == 3 ? ss[3] : ss[4];
+        pp[j] -= step_size * (m / denom); // addcdiv_(m, denom, -step_size)
     }
 }
 
@@ -42,26 +59,39 @@ __global__ __launch_bounds__(256) void ags_k_adam(AgsAdamArgs a, AgsAdamClock ho
 __global__ __launch_bounds__(256) void ags_k_adam_rows(AgsAdamArgs a, const AgsAdamClock* __restrict__ clk,
                                                        AgsAdamClock host_clk, AgsRowSet touched, float beta1,
                                                        float beta2, float eps, int zero_grad) {
-    if (!clk) clk = &host_clk;
-    const float inv_bc2_sqrt = clk->inv_bc2_sqrt;
     const int k = threadIdx.x & 15;
     const int seg = (k >= 3) + (k >= 6) + (k >= 10) + (k >= 11);
     const int width = seg == 2 ? 4 : (seg == 3 ? 1 : 3);
     const int off = k - (seg == 0 ? 0 : seg == 1 ? 3 : seg == 2 ? 6 : seg == 3 ? 10 : 11);
+    float* pg = const_cast<float*>(seg == 0 ? a.g[0] : seg == 1 ? a.g[1] : seg == 2 ? a.g[2] : seg == 3 ? a.g[3] : a.g[4]);
+    float* pm = seg == 0 ? a.m[0] : seg == 1 ? a.m[1] : seg == 2 ? a.m[2] : seg == 3 ? a.m[3] : a.m[4];
+    float* pv = seg == 0 ? a.v[0] : seg == 1 ? a.v[1] : seg == 2 ? a.v[2] : seg == 3 ? a.v[3] : a.v[4];
+    float* pp = seg == 0 ? a.p[0] : seg == 1 ? a.p[1] : seg == 2 ? a.p[2] : seg == 3 ? a.p[3] : a.p[4];
+    float ss[5], inv_bc2_sqrt;
+    if (clk) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) ss[q] = clk->step_size[q];
+        inv_bc2_sqrt = clk->inv_bc2_sqrt;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) ss[q] = host_clk.step_size[q];
+        inv_bc2_sqrt = host_clk.inv_bc2_sqrt;
+    }
+    const float step_size = seg == 0 ? ss[0] : seg == 1 ? ss[1] : seg == 2 ? ss[2] : seg == 3 ? ss[3] : ss[4];
     const int count = *touched.count;
     const int stride = gridDim.x * 16;
     for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < count; r += stride) {
         if (k >= 14) continue;
         const long long j = (long long)touched.rows[r] * width + off;
-        const float g = a.g[seg][j];
-        float m = a.m[seg][j], v = a.v[seg][j];
+        const float g = pg[j];
+        float m = pm[j], v = pv[j];
         m = m + (1.f - beta1) * (g - m);
         v = v * beta2 + (1.f - beta2) * g * g;
         const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
-        a.m[seg][j] = m;
-        a.v[seg][j] = v;
-        a.p[seg][j] -= clk->step_size[seg] * (m / denom);
-        if (zero_grad) const_cast<float*>(a.g[seg])[j] = 0.f; // consumed: the slab is clean for the next step
+        pm[j] = m;
+        pv[j] = v;
+        pp[j] -= step_size * (m / denom);
+        if (zero_grad) pg[j] = 0.f; // consumed: the slab is clean for the next step
     }
 }
 
