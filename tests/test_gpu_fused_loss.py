@@ -155,3 +155,37 @@ def test_batched_iteration_equals_per_view_and_replays_from_a_graph(agslib):
             assert (a - b).abs().mean() < 2e-3 * travel + 1e-9
         assert torch.allclose(res[0][1], other[1], rtol=1e-3, atol=1e-5)
         assert np.allclose(res[0][2], other[2], rtol=1e-4)
+
+
+def test_stage_frames_and_loss_finish_match_torch(agslib):
+    """ags_stage_frames == four index_select calls (+ zeroed visibility count); ags_loss_finish ==
+    FusedLoss.per_frame_errors / total_loss computed with torch, and it leaves the accumulators clean."""
+    from active_gs_amd.fused_loss import FusedLoss
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(21)
+    K, B, h, w = 7, 4, 36, 52
+    all_view = torch.randn(K, 4, 4, generator=gen).to(dev)
+    all_proj = torch.randn(K, 4, 4, generator=gen).to(dev)
+    all_rgb = torch.rand(K, 3, h, w, generator=gen).to(dev)
+    all_depth = torch.rand(K, 1, h, w, generator=gen).to(dev)
+    loss = FusedLoss(h, w, 1.0, 0.9, B, 8, dev)
+    loss.msum.fill_(5)
+    idx = torch.tensor([6, 0, 3, 3], device=dev)
+    dv, dp = torch.zeros(8, 4, 4, device=dev), torch.zeros(8, 4, 4, device=dev)
+    dr, dd = torch.zeros(8, 3, h, w, device=dev), torch.zeros(8, 1, h, w, device=dev)
+    loss.stage_frames(B, idx, all_view, all_proj, all_rgb, all_depth, dv, dp, dr, dd)
+    assert torch.equal(dv[:B], all_view[idx]) and torch.equal(dp[:B], all_proj[idx])
+    assert torch.equal(dr[:B], all_rgb[idx]) and torch.equal(dd[:B], all_depth[idx])
+    assert float(dv[B:].abs().sum()) == 0 and float(dr[B:].abs().sum()) == 0
+    assert int(loss.msum.abs().sum()) == 0
+    # accumulators as the loss stages would leave them
+    loss.accum.copy_(torch.rand(loss.accum.shape, generator=gen).to(dev) * 100)
+    want_err = loss.per_frame_errors(B).clone()
+    want_total = loss.total_loss().clone()
+    perf = torch.full((K,), 10.0, device=dev)
+    total = torch.zeros(1, device=dev)
+    idx2 = torch.tensor([6, 0, 3, 5], device=dev)
+    loss.finish(B, idx2, perf, total)
+    assert torch.allclose(perf[idx2], want_err, rtol=1e-5) and float(perf[1]) == 10.0
+    assert torch.allclose(total[0], want_total, rtol=1e-5)
+    assert float(loss.accum.abs().sum()) == 0.0
