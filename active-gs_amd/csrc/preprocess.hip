@@ -184,8 +184,8 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         src[0] = z4; src[1] = z4; src[2] = z4; src[3] = z4;
         AgsGeomGrad dg;
-        dg.dmx = a.x; dg.dmy = a.y; dg.dca = a.z; dg.dcb = a.w;
-        dg.dcc = b.x; dg.dop = b.y; dg.ddc = b.z; dg.dgx = b.w;
+        dg.m1x = a.x; dg.m1y = a.y; dg.m2xx = a.z; dg.m2xy = a.w;
+        dg.m2yy = b.x; dg.m0 = b.y; dg.ddc = b.z; dg.dgx = b.w;
         dg.dgy = c.x; dg.dr = c.y; dg.dg = c.z; dg.db = c.w;
         dg.dnx = d.x; dg.dny = d.y; dg.dnz = d.z; dg.pad = 0.f;
         ags_preprocess_bwd(F, V, P, p, sc, q, opacity, dg, dm, ds, dq, &dop, dcol, dm2);
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             src[0] = z4; src[1] = z4; src[2] = z4; src[3] = z4;
             AgsGeomGrad dg;
-            dg.dmx = a.x; dg.dmy = a.y; dg.dca = a.z; dg.dcb = a.w;
-            dg.dcc = b.x; dg.dop = b.y; dg.ddc = b.z; dg.dgx = b.w;
+            dg.m1x = a.x; dg.m1y = a.y; dg.m2xx = a.z; dg.m2xy = a.w;
+            dg.m2yy = b.x; dg.m0 = b.y; dg.ddc = b.z; dg.dgx = b.w;
             dg.dgy = c.x; dg.dr = c.y; dg.dg = c.z; dg.db = c.w;
             dg.dnx = d.x; dg.dny = d.y; dg.dnz = d.z; dg.pad = 0.f;
             ags_preprocess_bwd(F, V, P, p, sc, q, opacity, dg, dm, ds, dq, &dop, dcol, dm2);

@@ -35,10 +35,15 @@ struct AgsGeom {
     float nx, ny, nz, conf; // view-space normal (camera facing), confidence
 };
 
-// Gradient record accumulated by the blend backward, 64 B, same field order idea.
+// Record accumulated by the blend backward, 64 B.  With gp = alpha * dL/dalpha (0 where the 0.99
+// clamp is active) and d = pixel - mean, the first six fields are the RAW MOMENTS of gp over the
+// surfel's pixels: everything the conic, the 2-D mean and the opacity need is linear in them, so the
+// per-(pixel, surfel) work is 8 multiply-adds and the conversion (ags_preprocess_bwd) runs once per surfel:
+//   dL/dconic = (-m2xx/2, -m2xy, -m2yy/2),  dL/do = m0 / o,
+//   dL/dmean2D = -(gx*ddc - ca*m1x - cb*m1y,  gy*ddc - cc*m1y - cb*m1x)      (ddc = sum w * dL/ddepth)
 struct AgsGeomGrad {
-    float dmx, dmy, dca, dcb;
-    float dcc, dop, ddc, dgx; // dop = sum(alpha * dL/dalpha); divided by the opacity in ags_preprocess_bwd
+    float m1x, m1y, m2xx, m2xy;
+    float m2yy, m0, ddc, dgx;
     float dgy, dr, dg, db;
     float dnx, dny, dnz, pad;
 };
@@ -189,14 +194,25 @@ AGS_HD void ags_preprocess_bwd(const AgsFrame& F, const float* V, const float* P
     // caller guarantees the Gaussian was visible in the forward pass
     ags_project(F, V, P, p, sc, q, w);
     // the blend backward accumulates sum(alpha * dL/dalpha) = o * sum(G * dL/dalpha)
-    *dopacity = opacity > 0.f ? dg.dop / opacity : 0.f;
+    *dopacity = opacity > 0.f ? dg.m0 / opacity : 0.f;
     dcolor[0] = dg.dr; dcolor[1] = dg.dg; dcolor[2] = dg.db;
-    dmean2d[0] = dg.dmx; dmean2d[1] = dg.dmy;
 
-    // ---- conic -> cov2D (a,b,c)
+    // ---- raw moments -> gradients of the conic and of the 2-D mean (see AgsGeomGrad)
     const float idet = 1.0f / w.det, idet2 = idet * idet;
     const float a = w.a, b = w.b, c = w.c;
-    const float dka = dg.dca, dkb = dg.dcb, dkc = dg.dcc; // grads of conic (c/det, -b/det, a/det)
+    const float ca = c * idet, cb = -b * idet, cc = a * idet;
+    float gx = 0.f, gy = 0.f;
+    if (F.perpix_depth) { // the depth slopes of the forward record (ags_preprocess_fwd)
+        const float qq0 = -(w.tz * w.tz) / w.ncc;
+        gx = qq0 * (w.sgn * w.nv[0]) / F.fx;
+        gy = qq0 * (w.sgn * w.nv[1]) / F.fy;
+    }
+    const float dmx = -(gx * dg.ddc - ca * dg.m1x - cb * dg.m1y); // d = pixel - mean
+    const float dmy = -(gy * dg.ddc - cc * dg.m1y - cb * dg.m1x);
+    dmean2d[0] = dmx; dmean2d[1] = dmy;
+
+    // ---- conic -> cov2D (a,b,c)
+    const float dka = -0.5f * dg.m2xx, dkb = -dg.m2xy, dkc = -0.5f * dg.m2yy; // grads of conic (c/det, -b/det, a/det)
     const float da = dka * (-c * c * idet2) + dkb * (b * c * idet2) + dkc * (idet - a * c * idet2);
     const float db = dka * (2.f * b * c * idet2) + dkb * (-idet - 2.f * b * b * idet2) + dkc * (2.f * a * b * idet2);
     const float dc = dka * (idet - a * c * idet2) + dkb * (a * b * idet2) + dkc * (-a * a * idet2);
@@ -268,9 +284,9 @@ AGS_HD void ags_preprocess_bwd(const AgsFrame& F, const float* V, const float* P
     for (int k = 0; k < 3; ++k)
         dR[k * 3 + 2] += w.sgn * (V[k * 4 + 0] * dn[0] + V[k * 4 + 1] * dn[1] + V[k * 4 + 2] * dn[2]);
     // ---- mean2D -> clip space
-    const float dphx = dg.dmx * (0.5f * F.W) * w.pw;
-    const float dphy = dg.dmy * (0.5f * F.H) * w.pw;
-    const float dpw = dg.dmx * (0.5f * F.W) * w.phx + dg.dmy * (0.5f * F.H) * w.phy;
+    const float dphx = dmx * (0.5f * F.W) * w.pw;
+    const float dphy = dmy * (0.5f * F.H) * w.pw;
+    const float dpw = dmx * (0.5f * F.W) * w.phx + dmy * (0.5f * F.H) * w.phy;
     const float dphw = -w.pw * w.pw * dpw;
     for (int i = 0; i < 3; ++i) {
         dmean[i] = P[i * 4 + 0] * dphx + P[i * 4 + 1] * dphy + P[i * 4 + 3] * dphw
@@ -409,15 +425,12 @@ AGS_HD void ags_blend_bwd_apply(AgsPixGrad& s, const AgsGeom& g, float dx, float
     const float wd = w * s.dDn;
     acc.ddc += wd; acc.dgx += wd * dx; acc.dgy += wd * dy;
     // the 0.99 clamp passes no gradient; gp = dL/dpower = o*G*dalpha = alpha*dalpha when unclamped.
-    // acc.dop collects alpha*dalpha = o * (G*dalpha); the per-Gaussian backward divides by o once.
+    // m0 collects alpha*dalpha = o * (G*dalpha); the per-Gaussian backward divides by o once.
     const float gp = (alpha < AGS_ALPHA_MAX) ? alpha * dalpha : 0.f;
-    acc.dop += gp;
-    acc.dca += -0.5f * dx * dx * gp;
-    acc.dcb += -dx * dy * gp;
-    acc.dcc += -0.5f * dy * dy * gp;
-    const float ddx = wd * g.gx + gp * (-g.ca * dx - g.cb * dy); // through the per-pixel depth + the conic
-    const float ddy = wd * g.gy + gp * (-g.cc * dy - g.cb * dx);
-    acc.dmx -= ddx; acc.dmy -= ddy; // dx = px - mx
+    const float t = gp * dx, u = gp * dy;
+    acc.m0 += gp;
+    acc.m1x += t; acc.m1y += u;
+    acc.m2xx += t * dx; acc.m2xy += t * dy; acc.m2yy += u * dy;
 }
 
 // `pos1` is the Gaussian's 1-based position in the tile list. Returns true if it contributed.
