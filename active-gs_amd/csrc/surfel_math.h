@@ -30,7 +30,7 @@
 // One projected surfel, 64 B, gathered by the blend kernels.
 struct AgsGeom {
     float mx, my, ca, cb;   // pixel-space mean, conic a,b
-    float cc, o, dc, gx;    // conic c, opacity, centre depth, depth slope x
+    float cc, o, dc, gx;    // conic c, log2(opacity), centre depth, depth slope x
     float gy, r, g, b;      // depth slope y, colour
     float nx, ny, nz, conf; // view-space normal (camera facing), confidence
 };
@@ -64,6 +64,21 @@ AGS_HD float ags_rcp(float x) {
     return r;
 #else
     return 1.0f / x;
+#endif
+}
+
+AGS_HD float ags_log2(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __log2f(x);
+#else
+    return log2f(x);
+#endif
+}
+AGS_HD float ags_exp2(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(x); // v_exp_f32
+#else
+    return exp2f(x);
 #endif
 }
 
@@ -170,7 +185,7 @@ AGS_HD bool ags_preprocess_fwd(const AgsFrame& F, const float* V, const float* P
     radius = (int)rad;
     g.mx = mx; g.my = my;
     g.ca = w.c * idet; g.cb = -w.b * idet; g.cc = w.a * idet;
-    g.o = opacity; g.dc = w.tz;
+    g.o = ags_log2(opacity); g.dc = w.tz; // log2: alpha = exp2(power*log2(e) + g.o), one multiply less per pixel
     if (F.perpix_depth) {
         const float qq = -(w.tz * w.tz) / w.ncc;
         g.gx = qq * (w.sgn * w.nv[0]) / F.fx;
@@ -307,9 +322,10 @@ AGS_HD void ags_preprocess_bwd(const AgsFrame& F, const float* V, const float* P
 // the convex q over the box is 0 when the centre is inside, else it lies on a face nearest
 // to the centre.  A small margin absorbs rounding differences with the per-pixel test.
 AGS_HD bool ags_reaches_box(const AgsGeom& g, float x0, float x1, float y0, float y1) {
-    const float oo = 255.f * g.o;
-    if (!(oo >= 1.f)) return false;
-    const float tau = 2.f * logf(oo) * 1.0001f + 1e-3f;
+    // g.o = log2(opacity): 2 ln(255 o) = 2 ln2 (log2 255 + g.o)
+    const float l255o = 7.99435344f + g.o;
+    if (!(l255o >= 0.f)) return false;
+    const float tau = (2.f * 0.69314718f * 1.0001f) * l255o + 1e-3f;
     const float ax0 = x0 - g.mx, ax1 = x1 - g.mx, ay0 = y0 - g.my, ay1 = y1 - g.my;
     const bool inx = (ax0 <= 0.f) && (ax1 >= 0.f), iny = (ay0 <= 0.f) && (ay1 >= 0.f);
     if (inx && iny) return true;
@@ -346,12 +362,7 @@ AGS_HD void ags_pix_init(AgsPix& s, bool inside) {
 AGS_HD bool ags_alpha(const AgsGeom& g, float px, float py, float& dx, float& dy, float& alpha) {
     dx = px - g.mx; dy = py - g.my;
     const float power = -0.5f * (g.ca * dx * dx + g.cc * dy * dy) - g.cb * dx * dy;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float e = __expf(power);
-#else
-    const float e = expf(power);
-#endif
-    alpha = fminf(AGS_ALPHA_MAX, g.o * e);
+    alpha = fminf(AGS_ALPHA_MAX, ags_exp2(fmaf(power, 1.44269504f, g.o))); // o * exp(power), g.o = log2(o)
     return (power <= 0.f) && (alpha >= AGS_ALPHA_MIN);
 }
 
