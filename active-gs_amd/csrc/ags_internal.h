@@ -10,7 +10,9 @@
 #define AGS_SORT_ITEMS 16
 #define AGS_SORT_TILE (AGS_SORT_THREADS * AGS_SORT_ITEMS) // keys per block per pass
 #define AGS_SORT_MAX_PASSES 8
+#ifndef AGS_PRE_THREADS
 #define AGS_PRE_THREADS 256
+#endif
 
 // Byte offsets of the workspace regions (all 256-B aligned). The first three regions are
 // contiguous so one hipMemsetAsync clears them at the start of a forward pass.
@@ -458,11 +460,13 @@ __device__ __forceinline__ void ags_sort_tile_keys(uint64_t* g, uint32_t K, uint
 }
 
 // Transposed wave reduction of 16 per-lane values (gfx950 v_permlane32_swap / v_permlane16_swap):
-// each swap+add halves the lanes a value is spread over while packing two values into one
-// register, so 16 values cost 8+4 swap/add pairs + 4x4 in-row DPP adds (~43 VALU) instead of
-// 16 x 6 DPP adds + 16 read-backs.  On return every lane of row r (16 lanes) of q[k] holds the
-// wave total of value 4k + {0,2,1,3}[r]; `ags_reduce16_field(lane)` is that value's index
-// for the lanes with (lane & 15) < 4, which then own one total each.
+// every step halves the lanes a value is spread over while PACKING two values into one register, all
+// the way down: 64 -> 32 lanes (8 swap32+add), 32 -> 16 (4 swap16+add), then inside the 16-lane rows
+// 16 -> 8 and 8 -> 4 lanes by adding a row-rotated copy and keeping the two registers' results in
+// different banks (4-lane groups) of ONE register, and finally two quad-permute adds.  On return every
+// lane holds the wave total of exactly one value - value ags_reduce16_field(lane), the same in all
+// four lanes of a quad - so there is no read-back, no select and no second register to look at:
+// ~36 VALU for 16 values instead of 16 x 6 DPP adds + 16 read-backs.
 typedef unsigned int ags_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float ags_swap32_add(float a, float b) {
     const ags_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -472,26 +476,36 @@ __device__ __forceinline__ float ags_swap16_add(float a, float b) {
     const ags_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r.x) + __uint_as_float(r.y); // rows: a0+a1, b0+b1, a2+a3, b2+b3
 }
-__device__ __forceinline__ float ags_row_sum(float v) {
-    v += ags_dpp_f<0xB1>(v);  // quad_perm [1,0,3,2]
-    v += ags_dpp_f<0x4E>(v);  // quad_perm [2,3,0,1]
-    v += ags_dpp_f<0x141>(v); // row_half_mirror
-    v += ags_dpp_f<0x140>(v); // row_mirror
-    return v;
+// x + (x rotated right by ROT lanes within its row of 16: lane i reads lane (i - ROT) mod 16)
+template <int ROT>
+__device__ __forceinline__ float ags_row_ror_add(float x) { return x + ags_dpp_f<0x120 + ROT>(x); }
+// lanes of the banks (4-lane groups of every row) selected by BANKS take `b`, the others keep `a`
+template <int BANKS>
+__device__ __forceinline__ float ags_bank_merge(float a, float b) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b),
+                                                                 0xE4 /* quad_perm [0,1,2,3] */, 0xF, BANKS, false));
 }
 __device__ __forceinline__ int ags_reduce16_field(int lane) {
-    const int row = lane >> 4, k = lane & 15;
-    return 4 * k + ((row == 1) ? 2 : (row == 2) ? 1 : row);
+    // row r of the swap16 stage holds value 4k + {0,2,1,3}[r]; quad c of a row ends up with k = {0,2,1,3}[c]
+    const int row = lane >> 4, quad = (lane >> 2) & 3;
+    const int pr = (row == 1) ? 2 : (row == 2) ? 1 : row, pq = (quad == 1) ? 2 : (quad == 2) ? 1 : quad;
+    return 4 * pq + pr;
 }
-// returns, for a lane with (lane&15) < 4, the wave total of value ags_reduce16_field(lane)
+// returns the wave total of value ags_reduce16_field(lane)
 __device__ __forceinline__ float ags_wave_reduce16(const float v[16], int lane) {
-    float r[8], q[4];
+    float r[8], s[4];
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = ags_swap32_add(v[2 * i], v[2 * i + 1]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) q[k] = ags_row_sum(ags_swap16_add(r[2 * k], r[2 * k + 1]));
-    const int k = lane & 15;
-    return k == 0 ? q[0] : k == 1 ? q[1] : k == 2 ? q[2] : q[3];
+    for (int k = 0; k < 4; ++k) s[k] = ags_swap16_add(r[2 * k], r[2 * k + 1]);
+    // 16 -> 8 lanes: lanes 0-7 of a row keep s[0] / s[2], lanes 8-15 take s[1] / s[3]
+    const float t0 = ags_bank_merge<0xC>(ags_row_ror_add<8>(s[0]), ags_row_ror_add<8>(s[1]));
+    const float t1 = ags_bank_merge<0xC>(ags_row_ror_add<8>(s[2]), ags_row_ror_add<8>(s[3]));
+    // 8 -> 4 lanes: banks 0 and 2 keep t0 (lane i + lane i+4), banks 1 and 3 take t1 (lane i + lane i-4)
+    float u = ags_bank_merge<0xA>(ags_row_ror_add<12>(t0), ags_row_ror_add<4>(t1));
+    u += ags_dpp_f<0xB1>(u); // quad_perm [1,0,3,2]
+    u += ags_dpp_f<0x4E>(u); // quad_perm [2,3,0,1]
+    return u;
 }
 
 // block -> tile map: block b runs on XCD b%8 (observed dispatch order); give every XCD one

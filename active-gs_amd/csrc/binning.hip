@@ -405,7 +405,9 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
                 status[0] = total;
                 status[1] = total < cap ? total : cap;
                 status[2] = total > cap ? 1u : 0u;
-                status[3] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+                uint32_t nv = 0;
+                for (int k = 0; k < AGS_PRE_THREADS / 64; ++k) nv += wtot[k];
+                status[3] = nv;
             }
         }
     }

@@ -14,7 +14,7 @@ __device__ __forceinline__ void ags_load_rows3(const float* __restrict__ base, i
     const int t = threadIdx.x;
     const float* src = base + (size_t)first_row * 3;
     if (rows == AGS_PRE_THREADS && ((uintptr_t)src & 15) == 0) { // block-uniform
-        if (t < 192) reinterpret_cast<float4*>(lds)[t] = reinterpret_cast<const float4*>(src)[t];
+        if (t < AGS_PRE_THREADS * 3 / 4) reinterpret_cast<float4*>(lds)[t] = reinterpret_cast<const float4*>(src)[t];
     } else {
         for (int k = t; k < rows * 3; k += AGS_PRE_THREADS) lds[k] = src[k];
     }
@@ -31,7 +31,7 @@ __device__ __forceinline__ void ags_store_rows3(float* __restrict__ base, int fi
     lds[3 * t] = v[0]; lds[3 * t + 1] = v[1]; lds[3 * t + 2] = v[2];
     __syncthreads();
     if (rows == AGS_PRE_THREADS && ((uintptr_t)dst & 15) == 0) {
-        if (t < 192) {
+        if (t < AGS_PRE_THREADS * 3 / 4) {
             float4 x = reinterpret_cast<const float4*>(lds)[t];
             if (ACCUMULATE) {
                 const float4 o = reinterpret_cast<const float4*>(dst)[t];

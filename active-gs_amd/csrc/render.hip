@@ -226,8 +226,8 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
     }
     const uint32_t maxlast = ags_wave_max_u32(mymax);
     if (maxlast == 0) return; // wave-uniform; no workgroup barrier anywhere in this kernel
-    // lanes (lane&15) < 4 each own one field of the reduced gradient record (15 is padding)
-    const int my_field = ((lane & 15) < 4 && ags_reduce16_field(lane) < 15) ? ags_reduce16_field(lane) : -1;
+    // after the reduction every quad holds one field of the gradient record; its first lane adds it (15 is padding)
+    const int my_field = ((lane & 3) == 0 && ags_reduce16_field(lane) < 15) ? ags_reduce16_field(lane) : -1;
     for (int r = (int)((maxlast - 1) >> 6); r >= 0; --r) {
         const uint32_t k0 = (uint32_t)r << 6;
         ags_wave_lds_sync();
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
             for (int s = 0; s < SLOTS; ++s)
                 if (__any(ok[s])) // wave-uniform branch; inactive lanes contribute with alpha = 0
                     ags_blend_bwd_apply(pg[s], g, dx[s], dy[s], ok[s] ? al[s] : 0.f, acc);
-            const float mine = ags_wave_reduce16(a, lane); // 16 lanes end up owning one total each
+            const float mine = ags_wave_reduce16(a, lane); // every quad ends up with one field's total
             if (my_field >= 0) unsafeAtomicAdd(dgeom + (size_t)st.sid[k] * 16 + my_field, mine);
         }
     }
