@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
         if (STATS) { importance += (size_t)blockIdx.y * (size_t)vs.n; count += (size_t)blockIdx.y * (size_t)vs.n; }
     }
     __shared__ AgsWaveStage stage[4 / SLOTS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63; // wave index in an SGPR: strip masks become scalar tests
     AgsWaveStage& st = stage[wave];
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
         if (dout.d_confidence) dout.d_confidence += po;
     }
     __shared__ AgsWaveStage stage[4 / SLOTS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63; // wave index in an SGPR: strip masks become scalar tests
     AgsWaveStage& st = stage[wave];
     // side job of a step's last backward: advance the Adam device clock.  Nothing in this launch
     // reads it; the per-Gaussian kernel that follows (fused step) or ags_adam_step_device does.
