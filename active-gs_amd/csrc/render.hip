@@ -108,14 +108,18 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
             act &= act - 1;
             const uint32_t mk_bits = ((uint32_t)__builtin_amdgcn_readlane((int)m, k)) >> strip0; // wave-uniform
             const AgsGeom g = st.sg[k];
+            // al[s] = the pixel's alpha if it takes the surfel, else 0 (alpha >= 1/255 > 0 when it does)
             float dx[SLOTS], dy[SLOTS], al[SLOTS];
-            bool ok[SLOTS];
             bool any = false;
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
-                ok[s] = false; dx[s] = dy[s] = al[s] = 0.f;
-                if (mk_bits & (1u << s)) ok[s] = ags_alpha(g, fpx, (float)(py0 + 4 * s), dx[s], dy[s], al[s]) && !pix[s].done;
-                any |= ok[s];
+                dx[s] = dy[s] = al[s] = 0.f;
+                if (mk_bits & (1u << s)) {
+                    float a;
+                    const bool ok = ags_alpha(g, fpx, (float)(py0 + 4 * s), dx[s], dy[s], a) && !pix[s].done;
+                    al[s] = ok ? a : 0.f;
+                }
+                any |= al[s] > 0.f;
             }
             if (!__any(any)) continue;
             const uint32_t pos1 = base - rg.x + k + 1;
@@ -123,8 +127,8 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
             uint32_t wcnt = 0;
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
-                if (__any(ok[s])) { // wave-uniform; lanes that do not take the surfel blend alpha = 0
-                    const float w = ags_blend_apply(pix[s], g, dx[s], dy[s], ok[s] ? al[s] : 0.f, pos1);
+                if (__any(al[s] > 0.f)) { // wave-uniform; lanes that do not take the surfel blend alpha = 0
+                    const float w = ags_blend_apply(pix[s], g, dx[s], dy[s], al[s], pos1);
                     if (STATS) { const float wm = w * mk[s]; wsum += wm; wcnt += (wm > weight_thres) ? 1u : 0u; }
                 }
             }
@@ -241,15 +245,17 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
             const uint32_t mk_bits = ((uint32_t)__builtin_amdgcn_readlane((int)m, k)) >> strip0;
             const AgsGeom g = st.sg[k];
             const uint32_t pos1 = k0 + k + 1;
-            float dx[SLOTS], dy[SLOTS], al[SLOTS];
-            bool ok[SLOTS];
+            float dx[SLOTS], dy[SLOTS], al[SLOTS]; // al[s] = 0 for a pixel that does not take the surfel
             bool any = false;
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
-                ok[s] = false; dx[s] = dy[s] = al[s] = 0.f;
-                if (mk_bits & (1u << s))
-                    ok[s] = ags_alpha(g, fpx, (float)(py0 + 4 * s), dx[s], dy[s], al[s]) && (pos1 <= pg[s].last);
-                any |= ok[s];
+                dx[s] = dy[s] = al[s] = 0.f;
+                if (mk_bits & (1u << s)) {
+                    float a;
+                    const bool ok = ags_alpha(g, fpx, (float)(py0 + 4 * s), dx[s], dy[s], a) && (pos1 <= pg[s].last);
+                    al[s] = ok ? a : 0.f;
+                }
+                any |= al[s] > 0.f;
             }
             if (!__any(any)) continue;
             AgsGeomGrad acc;
@@ -258,8 +264,8 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
             for (int j = 0; j < 16; ++j) a[j] = 0.f;
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s)
-                if (__any(ok[s])) // wave-uniform branch; inactive lanes contribute with alpha = 0
-                    ags_blend_bwd_apply(pg[s], g, dx[s], dy[s], ok[s] ? al[s] : 0.f, acc);
+                if (__any(al[s] > 0.f)) // wave-uniform branch; inactive lanes contribute with alpha = 0
+                    ags_blend_bwd_apply(pg[s], g, dx[s], dy[s], al[s], acc);
             const float mine = ags_wave_reduce16(a, lane); // every quad ends up with one field's total
             if (my_field >= 0) unsafeAtomicAdd(dgeom + (size_t)st.sid[k] * 16 + my_field, mine);
         }
