@@ -21,8 +21,12 @@ HEADERS = ["ags_internal.h", "surfel_math.h", os.path.join("..", "..", "include"
 # (-2.5 % step time); NaN / inf semantics are left alone.
 # densify.hip: same reason as loss.hip - depth2normal relies on (p_neighbour - p_centre) being exactly
 # 0 at replicated borders, which an fma-contracted difference of products is not.
+# preprocess.hip / adam.hip: fp32 divides and square roots as v_rcp / v_sqrt sequences (<= 2.5 ulp) instead of
+# the correctly rounded ~10-instruction expansions: 34 divisions in the per-Gaussian backward alone.
 EXTRA_FLAGS = {"loss.hip": ["-ffp-contract=off"], "densify.hip": ["-ffp-contract=off"],
-               "render.hip": ["-fno-signed-zeros"]}
+               "render.hip": ["-fno-signed-zeros"],
+               "preprocess.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt"],
+               "adam.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]}
 # -fno-slp-vectorize everywhere: hipcc's SLP pass packs pairs of scalar fp32 ops into v_pk_* at the
 # price of register-pair shuffles (25 % v_mov in render_bwd) and VGPRs; scalar code measured
 # faster in every kernel of this library (step -7.5 %).
