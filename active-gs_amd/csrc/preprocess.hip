@@ -260,8 +260,6 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
     float V[16], P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
-    __shared__ float adam_g[FUSED_ADAM ? AGS_ROWS_THREADS * 17 : 1]; // [row][14 gradients], stride 17: no bank conflicts
-    __shared__ int adam_row[FUSED_ADAM ? AGS_ROWS_THREADS : 1];
     const int lane = threadIdx.x;
     // This kernel is a short chain of dependent loads on few rows (latency, not bandwidth), so every
     // load that can be issued early is: the first batch of row ids is fetched while the member count
@@ -285,6 +283,21 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
         float opacity = in.opacities[i];
         float4* src = reinterpret_cast<float4*>(dgeom + i);
         const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+        float am[14], av[14], ap[14]; // FUSED_ADAM: the row's exp_avg / exp_avg_sq / parameters, requested now
+        if (FUSED_ADAM) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                am[k] = adam.m[0][3 * i + k]; av[k] = adam.v[0][3 * i + k]; ap[k] = adam.p[0][3 * i + k];
+                am[3 + k] = adam.m[1][3 * i + k]; av[3 + k] = adam.v[1][3 * i + k]; ap[3 + k] = adam.p[1][3 * i + k];
+                am[11 + k] = adam.m[4][3 * i + k]; av[11 + k] = adam.v[4][3 * i + k]; ap[11 + k] = adam.p[4][3 * i + k];
+            }
+            const float4 m4 = reinterpret_cast<const float4*>(adam.m[2])[i], v4 = reinterpret_cast<const float4*>(adam.v[2])[i],
+                         p4 = reinterpret_cast<const float4*>(adam.p[2])[i];
+            am[6] = m4.x; am[7] = m4.y; am[8] = m4.z; am[9] = m4.w;
+            av[6] = v4.x; av[7] = v4.y; av[8] = v4.z; av[9] = v4.w;
+            ap[6] = p4.x; ap[7] = p4.y; ap[8] = p4.z; ap[9] = p4.w;
+            am[10] = adam.m[3][i]; av[10] = adam.v[3][i]; ap[10] = adam.p[3][i];
+        }
         const bool vis = valid && rad > 0;
         float dm[3] = {0, 0, 0}, ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0}, dm2[2] = {0, 0};
         if (vis) {
@@ -350,54 +363,33 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
             out.d_opacities[i] = dop;
             if (out.d_means2D) { out.d_means2D[3 * i] = dm2[0]; out.d_means2D[3 * i + 1] = dm2[1]; out.d_means2D[3 * i + 2] = 0.f; }
         }
-        if (FUSED_ADAM) {
-            // regroup through LDS: 16 lanes per row, lane k < 14 owns one of the row's 14 floats
-            // (means 0-2, scales 3-5, rotation 6-9, opacity 10, harmonics 11-13), so each row's
-            // 3-4 consecutive floats of a tensor are one small coalesced access
-            float* gl = adam_g + lane * 17;
-            gl[0] = dm[0]; gl[1] = dm[1]; gl[2] = dm[2]; gl[3] = ds[0]; gl[4] = ds[1]; gl[5] = ds[2];
-            gl[6] = dq[0]; gl[7] = dq[1]; gl[8] = dq[2]; gl[9] = dq[3]; gl[10] = dop;
-            gl[11] = dcol[0]; gl[12] = dcol[1]; gl[13] = dcol[2];
-            adam_row[lane] = valid ? i : -1;
-            __syncthreads();
+        if (FUSED_ADAM && valid) {
+            // the row's Adam state was requested together with its inputs (am / av / ap above), so it is
+            // here by now: update in the owning lane and store each tensor's 3-4 floats as one access
             const AgsAdamClock* clk = (const AgsAdamClock*)out.adam_clock;
             const float ib = clk->inv_bc2_sqrt, b1 = out.adam_beta1, b2 = out.adam_beta2, eps = out.adam_eps;
-            const int k = lane & 15;
-            const int seg = (k >= 3) + (k >= 6) + (k >= 10) + (k >= 11);
-            const int width = seg == 2 ? 4 : (seg == 3 ? 1 : 3);
-            const int off = k - (seg == 0 ? 0 : seg == 1 ? 3 : seg == 2 ? 6 : seg == 3 ? 10 : 11);
-            float* pp = seg == 0 ? adam.p[0] : seg == 1 ? adam.p[1] : seg == 2 ? adam.p[2] : seg == 3 ? adam.p[3] : adam.p[4];
-            float* pm = seg == 0 ? adam.m[0] : seg == 1 ? adam.m[1] : seg == 2 ? adam.m[2] : seg == 3 ? adam.m[3] : adam.m[4];
-            float* pv = seg == 0 ? adam.v[0] : seg == 1 ? adam.v[1] : seg == 2 ? adam.v[2] : seg == 3 ? adam.v[3] : adam.v[4];
-            const float step_size = clk->step_size[seg];
-            // two phases so that all 48 loads of the wave are in flight together (the stores of one
-            // row must not order the loads of the next)
-            constexpr int R = AGS_ROWS_THREADS / 4;
-            float mm[R], vv[R], pq[R], gg[R];
-            size_t jj[R];
-            bool on[R];
+            const float gr[14] = {dm[0], dm[1], dm[2], ds[0], ds[1], ds[2], dq[0], dq[1], dq[2], dq[3], dop,
+                                  dcol[0], dcol[1], dcol[2]};
 #pragma unroll
-            for (int t = 0; t < R; ++t) {
-                const int row = t * 4 + (lane >> 4);
-                const int i2 = adam_row[row];
-                on[t] = k < 14 && i2 >= 0;
-                jj[t] = on[t] ? (size_t)i2 * width + off : 0;
-                gg[t] = adam_g[row * 17 + k];
-            }
-#pragma unroll
-            for (int t = 0; t < R; ++t) { mm[t] = pm[jj[t]]; vv[t] = pv[jj[t]]; pq[t] = pp[jj[t]]; }
-#pragma unroll
-            for (int t = 0; t < R; ++t) {
-                const float m = mm[t] + (1.f - b1) * (gg[t] - mm[t]);
-                const float v = vv[t] * b2 + (1.f - b2) * gg[t] * gg[t];
+            for (int e = 0; e < 14; ++e) {
+                const int seg = (e >= 3) + (e >= 6) + (e >= 10) + (e >= 11);
+                const float g = gr[e];
+                const float m = am[e] + (1.f - b1) * (g - am[e]);
+                const float v = av[e] * b2 + (1.f - b2) * g * g;
                 const float denom = sqrtf(v) * ib + eps;
-                if (on[t]) {
-                    pm[jj[t]] = m;
-                    pv[jj[t]] = v;
-                    pp[jj[t]] = pq[t] - step_size * (m / denom);
-                }
+                am[e] = m; av[e] = v;
+                ap[e] -= clk->step_size[seg] * (m / denom);
             }
-            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                adam.m[0][3 * i + k] = am[k]; adam.v[0][3 * i + k] = av[k]; adam.p[0][3 * i + k] = ap[k];
+                adam.m[1][3 * i + k] = am[3 + k]; adam.v[1][3 * i + k] = av[3 + k]; adam.p[1][3 * i + k] = ap[3 + k];
+                adam.m[4][3 * i + k] = am[11 + k]; adam.v[4][3 * i + k] = av[11 + k]; adam.p[4][3 * i + k] = ap[11 + k];
+            }
+            reinterpret_cast<float4*>(adam.m[2])[i] = make_float4(am[6], am[7], am[8], am[9]);
+            reinterpret_cast<float4*>(adam.v[2])[i] = make_float4(av[6], av[7], av[8], av[9]);
+            reinterpret_cast<float4*>(adam.p[2])[i] = make_float4(ap[6], ap[7], ap[8], ap[9]);
+            adam.m[3][i] = am[10]; adam.v[3][i] = av[10]; adam.p[3][i] = ap[10];
         }
     }
 }
