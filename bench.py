@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--binning", choices=["tile_sort", "radix"], default="tile_sort")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
-    ap.add_argument("--graph-steps", type=int, default=int(os.environ.get("AGS_BENCH_GRAPH_STEPS", "10")),
+    ap.add_argument("--graph-steps", type=int, default=int(os.environ.get("AGS_BENCH_GRAPH_STEPS", "25")),
                     help="optimisation steps recorded per hipGraph (single GPU); K steps = K/this replays")
     args = ap.parse_args()
     if os.environ.get("AGS_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack and exit after N s
