@@ -1,7 +1,9 @@
 // Per-tile alpha compositing, forward (F6) and backward (B1).
 //
 // Wave64-native shape, not a 16x16-thread CUDA block: a wavefront owns SLOTS of the four
-// 16x4-pixel strips of a 16x16 tile and every lane owns SLOTS pixels (one per strip), so
+// 8x8-pixel quadrants of a 16x16 tile and every lane owns SLOTS pixels (one per quadrant; the
+// code and the comments below still call a wave's slots its "strips" - they were 16x4 strips until
+// the more compact 8x8 shape measured 5 % fewer (surfel, slot) evaluations), so
 //   * a round stages 64 projected surfels (64 B each, one per lane) into the wave's own
 //     4 KiB of LDS; a wave never waits for another wave (no workgroup barrier);
 //   * each staged record is read from LDS once per wave (broadcast ds_read_b128) and serves
@@ -44,7 +46,8 @@ __device__ __forceinline__ uint32_t ags_stage_one(AgsWaveStage& st, int lane, co
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
         const int s = strip0 + k;
-        m |= ags_reaches_box(me, bx0, bx0 + 15.f, by0 + 4.f * s, by0 + 4.f * s + 3.f) ? (1u << s) : 0u;
+        const float qx0 = bx0 + 8.f * (float)(s & 1), qy0 = by0 + 8.f * (float)(s >> 1); // 8x8 quadrant s
+        m |= ags_reaches_box(me, qx0, qx0 + 7.f, qy0, qy0 + 7.f) ? (1u << s) : 0u;
     }
     return m;
 }
@@ -75,10 +78,11 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     AgsWaveStage& st = stage[wave];
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
-    const int px = tx * AGS_TILE + (lane & 15);
-    const int strip0 = wave * SLOTS;                       // first of this wave's strips
-    const int py0 = ty * AGS_TILE + strip0 * 4 + (lane >> 4);
-    const float fpx = (float)px;
+    const int strip0 = wave * SLOTS;                       // first of this wave's slots (8x8 quadrants of the tile)
+    // quadrant q = strip0 + s sits at (q & 1, q >> 1); lane l is pixel (l & 7, l >> 3) of its quadrant
+    const int pxl = tx * AGS_TILE + (lane & 7), pyl = ty * AGS_TILE + (lane >> 3);
+#define AGS_PX(s) (pxl + 8 * ((strip0 + (s)) & 1))
+#define AGS_PY(s) (pyl + 8 * ((strip0 + (s)) >> 1))
     const uint2 rg = ranges[tile];
     const float bx0 = (float)(tx * AGS_TILE), by0 = (float)(ty * AGS_TILE);
     const uint32_t my_strips = ((1u << SLOTS) - 1u) << strip0;
@@ -89,10 +93,10 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     int alldone = 1;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const bool inside = (px < F.W) && (py0 + 4 * s < F.H);
+        const bool inside = (AGS_PX(s) < F.W) && (AGS_PY(s) < F.H);
         ags_pix_init(pix[s], inside);
         mk[s] = inside ? 1.f : 0.f;
-        if (STATS && mask != nullptr && inside) mk[s] = mask[(size_t)(py0 + 4 * s) * F.W + px] > 0.f ? 1.f : 0.f;
+        if (STATS && mask != nullptr && inside) mk[s] = mask[(size_t)AGS_PY(s) * F.W + AGS_PX(s)] > 0.f ? 1.f : 0.f;
         alldone &= pix[s].done;
     }
     for (uint32_t base = rg.x; base < rg.y; base += 64) {
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
                 dx[s] = dy[s] = al[s] = 0.f;
                 if (mk_bits & (1u << s)) {
                     float a;
-                    const bool ok = ags_alpha(g, fpx, (float)(py0 + 4 * s), dx[s], dy[s], a) && !pix[s].done;
+                    const bool ok = ags_alpha(g, (float)AGS_PX(s), (float)AGS_PY(s), dx[s], dy[s], a) && !pix[s].done;
                     al[s] = ok ? a : 0.f;
                 }
                 any |= al[s] > 0.f;
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     const size_t HW = (size_t)F.H * F.W;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const int py = py0 + 4 * s;
+        const int px = AGS_PX(s), py = AGS_PY(s);
         if (px < F.W && py < F.H) {
             const size_t o = (size_t)py * F.W + px;
             const float T = pix[s].T, A = 1.f - T;
@@ -198,10 +202,8 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
     const uint2 rg = ranges[tile];
     if (rg.y <= rg.x) return;
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
-    const int px = tx * AGS_TILE + (lane & 15);
     const int strip0 = wave * SLOTS;
-    const int py0 = ty * AGS_TILE + strip0 * 4 + (lane >> 4);
-    const float fpx = (float)px;
+    const int pxl = tx * AGS_TILE + (lane & 7), pyl = ty * AGS_TILE + (lane >> 3);
     const float bx0 = (float)(tx * AGS_TILE), by0 = (float)(ty * AGS_TILE);
     const uint32_t my_strips = ((1u << SLOTS) - 1u) << strip0;
     const float bg[3] = {bgp[0], bgp[1], bgp[2]};
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
     uint32_t mymax = 0;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const int py = py0 + 4 * s;
+        const int px = AGS_PX(s), py = AGS_PY(s);
         float dC[3] = {0, 0, 0}, dN[3] = {0, 0, 0}, dD = 0, dO = 0, dCf = 0, dep = 0, opa = 0, Tf = 1.f;
         uint32_t last = 0;
         if (px < F.W && py < F.H) {
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
                 dx[s] = dy[s] = al[s] = 0.f;
                 if (mk_bits & (1u << s)) {
                     float a;
-                    const bool ok = ags_alpha(g, fpx, (float)(py0 + 4 * s), dx[s], dy[s], a) && (pos1 <= pg[s].last);
+                    const bool ok = ags_alpha(g, (float)AGS_PX(s), (float)AGS_PY(s), dx[s], dy[s], a) && (pos1 <= pg[s].last);
                     al[s] = ok ? a : 0.f;
                 }
                 any |= al[s] > 0.f;
