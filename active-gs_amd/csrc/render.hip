@@ -17,7 +17,7 @@
 //     permlane-swap/DPP reduction (ags_wave_reduce16) and issues ONE 15-lane atomic per
 //     (surfel, wave) instead of 64 x SLOTS x 15 atomics.
 // SLOTS = 4 is one wave per tile; SLOTS = 2 / 1 split a tile over 2 / 4 waves (fewer VGPRs,
-// more waves in flight).  Measured best: 2 from 2048 tiles up, 1 below (AGS_RENDER_SLOTS overrides).
+// more waves in flight).  Measured best: 1 below ~12 k tiles in flight, 2 above (AGS_RENDER_SLOTS overrides).
 // Blocks are mapped to tiles XCD-aware (ags_xcd_remap) so one XCD's L2 serves a contiguous
 // band of tiles.  Counterpart of renderCUDA fwd/bwd in SURVEY.md §2.3; arithmetic in
 // surfel_math.h.
@@ -279,10 +279,11 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
 static int ags_pick_slots(int num_tiles) {
     const char* e = getenv("AGS_RENDER_SLOTS");
     if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) return e[0] - '0';
-    // measured: two strips per wave wins from 1200x680 (3225 tiles) up to 2048x2048
-    // (16384 tiles, where one wave per tile is 13 % slower); small images want four waves per tile
-    if (num_tiles >= 2048) return 2;
-    return 1;                        // e.g. 512x512 (1024 tiles), 128x128 planner views
+    // measured (re-measured after the r01-k..o slimming of the per-wave overhead): one slot per
+    // wave (four waves per tile) wins up to ~11 k tiles in flight (1200x680 = 3225, a training batch of 11 views
+    // at 512x512 = 11 264); two slots per wave from 2048x2048 (16 384 tiles, ~500 surfels per tile) up
+    if (num_tiles >= 12288) return 2;
+    return 1;
 }
 
 template <int SLOTS>
