@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 dx[s] = dy[s] = al[s] = 0.f;
-                if (mk_bits & (1u << s)) {
+                if (SLOTS == 1 || (mk_bits & (1u << s))) { // one slot: the ballot above already says it is reached
                     float a;
                     const bool ok = ags_alpha(g, (float)AGS_PX(s), (float)AGS_PY(s), dx[s], dy[s], a) && !pix[s].done;
                     al[s] = ok ? a : 0.f;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
             uint32_t wcnt = 0;
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
-                if (__any(al[s] > 0.f)) { // wave-uniform; lanes that do not take the surfel blend alpha = 0
+                if (SLOTS == 1 || __any(al[s] > 0.f)) { // wave-uniform; lanes that do not take the surfel blend alpha = 0
                     const float w = ags_blend_apply(pix[s], g, dx[s], dy[s], al[s], pos1);
                     if (STATS) { const float wm = w * mk[s]; wsum += wm; wcnt += (wm > weight_thres) ? 1u : 0u; }
                 }
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 dx[s] = dy[s] = al[s] = 0.f;
-                if (mk_bits & (1u << s)) {
+                if (SLOTS == 1 || (mk_bits & (1u << s))) { // one slot: the ballot above already says it is reached
                     float a;
                     const bool ok = ags_alpha(g, (float)AGS_PX(s), (float)AGS_PY(s), dx[s], dy[s], a) && (pos1 <= pg[s].last);
                     al[s] = ok ? a : 0.f;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
             for (int j = 0; j < 16; ++j) a[j] = 0.f;
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s)
-                if (__any(al[s] > 0.f)) // wave-uniform branch; inactive lanes contribute with alpha = 0
+                if (SLOTS == 1 || __any(al[s] > 0.f)) // wave-uniform branch; inactive lanes contribute with alpha = 0
                     ags_blend_bwd_apply(pg[s], g, dx[s], dy[s], al[s], acc);
             const float mine = ags_wave_reduce16(a, lane); // every quad ends up with one field's total
             if (my_field >= 0) unsafeAtomicAdd(dgeom + (size_t)st.sid[k] * 16 + my_field, mine);
