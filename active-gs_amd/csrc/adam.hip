@@ -127,6 +127,82 @@ void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float ep
 }
 
 // ---------------------------------------------------------------------------------------
+// Row exchange of the view-parallel step (the reference sums the views' losses before
+// backward(), gaussian_map.py:113-125): instead of all-reducing the dense 14*N-float slab, a rank
+// ships only the rows its views have shown.  A SEGMENT is 16 floats of header {count, needed, ...}
+// followed by `capacity` 64-byte records {g[0..13], row id, 0}; 16 lanes move one record.
+__device__ __forceinline__ float* ags_row_field(float* const g[5], int k, int row) {
+    const int seg = (k >= 3) + (k >= 6) + (k >= 10) + (k >= 11);
+    const int width = seg == 2 ? 4 : (seg == 3 ? 1 : 3);
+    const int off = k - (seg == 0 ? 0 : seg == 1 ? 3 : seg == 2 ? 6 : seg == 3 ? 10 : 11);
+    float* base = seg == 0 ? g[0] : seg == 1 ? g[1] : seg == 2 ? g[2] : seg == 3 ? g[3] : g[4];
+    return base + (long long)row * width + off;
+}
+
+struct AgsGradPtrs { float* g[5]; };
+
+// slab rows of `rows` -> segment; the rows are zeroed behind the copy, so the slab is all-zero when
+// the unpack launches start adding (every rank then forms the same sums in the same order)
+__global__ __launch_bounds__(256) void ags_k_rows_pack(AgsGradPtrs gp, AgsRowSet rows, float* __restrict__ seg,
+                                                       int capacity) {
+    const int k = threadIdx.x & 15;
+    const int needed = *rows.count;
+    const int count = min(needed, capacity);
+    if (blockIdx.x == 0 && threadIdx.x < 16)
+        seg[threadIdx.x] = __int_as_float(threadIdx.x == 0 ? count : threadIdx.x == 1 ? needed : 0);
+    const int stride = gridDim.x * 16;
+    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < count; r += stride) {
+        const int row = rows.rows[r];
+        float v = 0.f;
+        if (k < 14) {
+            float* p = ags_row_field(gp.g, k, row);
+            v = *p;
+            *p = 0.f;
+        } else if (k == 14) {
+            v = __int_as_float(row);
+        }
+        seg[16 + (long long)r * 16 + k] = v;
+    }
+}
+
+// one rank's segment += into the slab; rows new to `uni` (the union the optimiser steps over) are
+// appended.  Launched once per rank IN RANK ORDER on one stream: a row occurs at most once per
+// segment, so there is no race inside a launch and the summation order is the same on every rank.
+__global__ __launch_bounds__(256) void ags_k_rows_unpack(const float* __restrict__ seg, int capacity, AgsGradPtrs gp,
+                                                         AgsRowSet uni) {
+    const int k = threadIdx.x & 15;
+    const int count = min(__float_as_int(seg[0]), capacity);
+    const int stride = gridDim.x * 16;
+    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < count; r += stride) {
+        const float* rec = seg + 16 + (long long)r * 16;
+        const int row = __float_as_int(rec[14]);
+        if (k < 14) {
+            float* p = ags_row_field(gp.g, k, row);
+            *p += rec[k];
+        } else if (k == 14 && uni.member[row] == 0) {
+            uni.member[row] = 1;
+            uni.rows[atomicAdd(uni.count, 1)] = row;
+        }
+    }
+}
+
+void ags_launch_rows_pack(float* const grads[5], const AgsRowSet& rows, float* segment, int capacity, hipStream_t s) {
+    AgsGradPtrs gp;
+    for (int k = 0; k < 5; ++k) gp.g[k] = grads[k];
+    int blocks = (capacity + 15) / 16;
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(ags_k_rows_pack, dim3(blocks), dim3(256), 0, s, gp, rows, segment, capacity);
+}
+void ags_launch_rows_unpack(const float* segment, int capacity, float* const grads[5], const AgsRowSet& uni,
+                            hipStream_t s) {
+    AgsGradPtrs gp;
+    for (int k = 0; k < 5; ++k) gp.g[k] = grads[k];
+    int blocks = (capacity + 15) / 16;
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(ags_k_rows_unpack, dim3(blocks), dim3(256), 0, s, segment, capacity, gp, uni);
+}
+
+// ---------------------------------------------------------------------------------------
 // Activations (gaussian_map.py:529-549) and their chain rule, one lane per Gaussian.
 __global__ __launch_bounds__(256) void ags_k_activate(AgsActivation a, float* __restrict__ scales,
                                                       float* __restrict__ rotations, float* __restrict__ opacities) {

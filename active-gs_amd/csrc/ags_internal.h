@@ -155,6 +155,8 @@ __device__ __forceinline__ void ags_adam_tick(AgsAdamClock* c, const float lr[5]
     c->inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
 }
 #endif
+void ags_launch_rows_pack(float* const grads[5], const AgsRowSet& rows, float* segment, int capacity, hipStream_t s);
+void ags_launch_rows_unpack(const float* segment, int capacity, float* const grads[5], const AgsRowSet& uni, hipStream_t s);
 void ags_launch_activate(const AgsActivation& a, float* scales, float* rotations, float* opacities, hipStream_t s);
 void ags_launch_activate_bwd(const AgsActivation& a, float* d_scales, float* d_rotations, float* d_opacities,
                              hipStream_t s);

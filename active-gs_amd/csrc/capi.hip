@@ -187,6 +187,27 @@ int ags_adam_step_device(const AgsAdamTensors* t, float beta1, float beta2, floa
     return ags_check_launch();
 }
 
+size_t ags_rows_segment_floats(int32_t capacity) { return capacity < 0 ? 0 : 16 * ((size_t)capacity + 1); }
+
+static bool ags_rows_ok(const AgsRowSet* r) { return r && r->member && r->rows && r->count; }
+
+int ags_rows_pack(const AgsRowSet* rows, float* const grads[5], int32_t capacity, float* segment, ags_stream_t stream) {
+    if (!ags_rows_ok(rows) || !grads || !segment || capacity < 0) return AGS_E_INVALID;
+    for (int k = 0; k < 5; ++k)
+        if (!grads[k]) return AGS_E_INVALID;
+    ags_launch_rows_pack(grads, *rows, segment, capacity, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_rows_unpack(const float* segment, int32_t capacity, float* const grads[5], const AgsRowSet* union_rows,
+                    ags_stream_t stream) {
+    if (!ags_rows_ok(union_rows) || !grads || !segment || capacity < 0) return AGS_E_INVALID;
+    for (int k = 0; k < 5; ++k)
+        if (!grads[k]) return AGS_E_INVALID;
+    ags_launch_rows_unpack(segment, capacity, grads, *union_rows, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
 int ags_activate(const AgsActivation* a, float* scales, float* rotations, float* opacities, ags_stream_t stream) {
     if (!a || a->n < 0) return AGS_E_INVALID;
     if (a->n > 0 && (!a->raw_scales || !a->raw_rotations || !a->raw_opacities || !scales || !rotations || !opacities))

@@ -8,8 +8,10 @@
     optimizer.step() (:126, Adam :259-292) -> ags_adam_step on the raw parameters
 
 Views are independent until the loss mean (:113-124), so with ``torch.distributed``
-initialised each rank renders its own views and ONE all-reduce(sum) of the contiguous
-14*N-float gradient slab precedes the replicated Adam step.
+initialised each rank renders its own views and ONE collective precedes the replicated Adam step
+(SURVEY.md §8e): an all-gather of the rows each rank's views have shown (``RowExchange``; 64 B per
+row, ~1 MB per rank at 200 k surfels @1200x680) or, where that would not be smaller, an
+all-reduce(sum) of the contiguous 14*N-float gradient slab (11 MB).
 """
 from __future__ import annotations
 
@@ -47,6 +49,75 @@ class GradSlab:
         return [g.means3D, g.scales, g.rotations, g.opacities, g.colors]
 
 
+class RowExchange:
+    """Sparse gradient exchange of the view-parallel step over ``ags_rows_pack`` / ``ags_rows_unpack``
+    (include/ags_raster.h): every rank packs the slab rows of its own sticky row set into a fixed
+    size segment, ONE all-gather moves the segments, and every rank adds them into its (now zero)
+    slab in rank order - bit-identical sums on every rank - while collecting the union of the rows,
+    which is what the replicated Adam then steps over.  ``capacity`` (rows per segment) is agreed
+    once with ``agree()``; ``overflowed()`` says whether a rank has outgrown it since."""
+
+    GROWTH, SLACK = 2.0, 4096      # capacity = GROWTH x the largest rank's row count + SLACK
+
+    def __init__(self, n: int, grads: Sequence[torch.Tensor], device, pg):
+        self.n, self.pg, self.device = n, pg, device
+        self.world = torch.distributed.get_world_size(pg)
+        self.rank = torch.distributed.get_rank(pg)
+        self.union = api.RowSet(n, device)
+        self.capacity = None                      # None: not agreed yet; 0: the dense all-reduce is smaller
+        self._grads = (C.c_void_p * 5)(*[ptr(g) for g in grads])
+        self._keep = list(grads)
+        self.send = self.recv = None
+
+    def agree(self, local_rows: int, slab_floats: int) -> int:
+        """Collective (host-synchronous, once per optimiser): capacity = GROWTH x the largest rank's
+        row count + SLACK; 0 if the gathered segments would not be smaller than the dense slab."""
+        t = torch.tensor([int(local_rows)], device=self.device, dtype=torch.int64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+        cap = min(self.n, int(self.GROWTH * int(t.item())) + self.SLACK)
+        seg = int(_lib.load().ags_rows_segment_floats(cap))
+        if seg * self.world >= slab_floats:
+            self.capacity = 0
+            return 0
+        self.capacity = cap
+        self.send = torch.zeros(seg, device=self.device, dtype=torch.float32)
+        self.recv = torch.zeros(self.world, seg, device=self.device, dtype=torch.float32)
+        return cap
+
+    def pack(self, rows: "api.RowSet") -> None:
+        r = rows.c_struct()
+        _lib.check(_lib.load().ags_rows_pack(C.byref(r), C.byref(self._grads), self.capacity, ptr(self.send),
+                                             torch.cuda.current_stream().cuda_stream), "ags_rows_pack")
+
+    def gather(self) -> None:
+        if torch.distributed.get_backend(self.pg) == "nccl":     # RCCL: one all-gather over xGMI
+            torch.distributed.all_gather_into_tensor(self.recv.view(-1), self.send, group=self.pg)
+        else:
+            # transports without a device all-gather (gloo, used by the tests): the same data movement
+            # as an integer all-reduce of a buffer that is zero outside the rank's own segment
+            bits = self.recv.view(torch.int32)
+            bits.zero_()
+            bits[self.rank].copy_(self.send.view(torch.int32))
+            torch.distributed.all_reduce(bits, group=self.pg)
+
+    def unpack(self) -> None:
+        lib, u = _lib.load(), self.union.c_struct()
+        stream = torch.cuda.current_stream().cuda_stream
+        for r in range(self.world):                               # rank order: same sums everywhere
+            _lib.check(lib.ags_rows_unpack(ptr(self.recv[r]), self.capacity, C.byref(self._grads), C.byref(u), stream),
+                       "ags_rows_unpack")
+
+    def overflowed(self) -> bool:
+        """Host-synchronous: has any rank needed more rows than the agreed capacity in the last exchange?"""
+        if not self.capacity:
+            return False
+        needed = self.recv[:, 1].view(torch.int32)
+        return bool((needed > self.capacity).any().item())
+
+    def reset(self) -> None:
+        self.union.reset()
+
+
 class SurfelTrainer:
     """Raw map parameters + fused train step. ``raw`` holds means (N,3), scales (N,3),
     rotations (N,4), opacities (N), harmonics (N,1,3), confidences (N) on the GPU."""
@@ -78,12 +149,17 @@ class SurfelTrainer:
         self.fused_activations = fused_activations
         # Sticky set of the surfels this optimiser's views have shown (api.RowSet): the per-Gaussian
         # backward and Adam launch work for those rows only.  Lossless (untouched rows have zero
-        # gradient and zero moments -> a zero Adam update); single-rank only, because with data
-        # parallelism the all-reduced slab carries rows other ranks have seen.
-        self.rows = api.RowSet(self.n, dev) if (sparse_rows and not self._distributed()) else None
+        # gradient and zero moments -> a zero Adam update).  With data parallelism the ranks exchange
+        # exactly those rows (RowExchange) and Adam steps over the union of all ranks' sets.
+        self.rows = api.RowSet(self.n, dev) if sparse_rows else None
+        self.exchange = None
         if self.rows is not None:
             self.slab.flat.zero_()
-            self.optim.touched = self.rows
+            if self._distributed():
+                self.exchange = RowExchange(self.n, self.slab.as_list(), dev, self.pg)
+                self.optim.touched, self.optim.zero_grad = self.exchange.union, True
+            else:
+                self.optim.touched = self.rows
         self._state = {}
 
     def reset_optimizer(self) -> None:
@@ -97,6 +173,8 @@ class SurfelTrainer:
         self.slab.flat.zero_()
         if self.rows is not None:
             self.rows.reset()
+        if self.exchange is not None:
+            self.exchange.reset()
 
     # -- pieces --------------------------------------------------------------------------
     def _act_struct(self) -> _lib.AgsActivation:
@@ -169,9 +247,65 @@ class SurfelTrainer:
         dist_on = self._distributed()
         ticked = self._local_pass(cams, image_grads, max_instances, tick=device_clock, fuse_adam=not dist_on)
         if dist_on:
-            torch.distributed.all_reduce(self.slab.flat, group=self.pg)
+            self._exchange_gradients()
         if not self.adam_fused:
             self.optim.step(self.slab.as_list(), device_clock=device_clock, pre_ticked=ticked)
+
+    def _row_exchange_on(self) -> bool:
+        """Agree on the segment size the first time (host-synchronous); False = dense all-reduce."""
+        x = self.exchange
+        if x is None:
+            return False
+        if x.capacity is None:
+            if x.agree(int(self.rows.count.item()), self.slab.flat.numel()) == 0:
+                # not worth it: from the next pass on everything is dense again (this pass's slab is
+                # zero outside the listed rows, so its dense all-reduce is still right)
+                self.exchange, self.rows = None, None
+                self.optim.touched, self.optim.zero_grad = None, False
+                return False
+        return True
+
+    def _exchange_gradients(self) -> None:
+        if self._row_exchange_on():
+            self.exchange.pack(self.rows)
+            self.exchange.gather()
+            self.exchange.unpack()
+        else:
+            torch.distributed.all_reduce(self.slab.flat, group=self.pg)
+
+    def _collectives_capturable(self) -> bool:
+        """Can this process group's collectives be recorded into a hipGraph?  Only RCCL's can (they
+        are kernels on the stream; gloo's run on the host).  Probed once with a 1-element all-reduce
+        captured and replayed twice; any error or wrong sum means "no" and the step is captured as
+        graph | collective | graph instead."""
+        if getattr(self, "_capturable", None) is not None:
+            return self._capturable
+        ok = False
+        if torch.distributed.get_backend(self.pg) == "nccl":
+            try:
+                world = torch.distributed.get_world_size(self.pg)
+                t = torch.ones(1, device=self.device)
+                torch.distributed.all_reduce(t, group=self.pg)       # communicator exists before capture
+                t.fill_(1.0)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                        torch.distributed.all_reduce(t, group=self.pg)
+                torch.cuda.current_stream().wait_stream(side)
+                g.replay()
+                g.replay()
+                torch.cuda.synchronize()
+                ok = abs(float(t.item()) - float(world) ** 2) < 0.5
+            except Exception:
+                ok = False
+                torch.cuda.synchronize()
+        # every rank must take the same branch
+        flag = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=self.pg)
+        self._capturable = bool(flag.item())
+        return self._capturable
 
     def capture(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int, repeat: int = 1) -> Callable:
         """Capture one optimisation step into hipGraphs and return a ``replay()`` callable.
@@ -180,23 +314,43 @@ class SurfelTrainer:
         between iterations sits behind a device pointer (camera matrices, image gradients,
         parameters), so a step is a fixed launch sequence: new views are rendered by copying
         their matrices into the captured ``Camera`` tensors before ``replay()``.  With more
-        than one rank the all-reduce stays outside the graphs (graph | collective | graph).
-        Call after at least one eager ``step`` so every buffer exists.  ``repeat`` > 1 (single rank)
+        than one rank the gradient exchange is recorded into the same graph when the transport's
+        collectives are stream operations (RCCL); otherwise it stays outside (graph | collective |
+        graph).  Call after at least one eager ``step`` so every buffer exists.  ``repeat`` > 1
         records that many consecutive optimisation steps in ONE graph, so a replay pays the
         graph-launch latency once per ``repeat`` steps; ``replay.steps`` says how many steps a call
         performs."""
         dist_on = self._distributed()
-        repeat = 1 if dist_on else max(1, int(repeat))
+        rows_x = dist_on and self._row_exchange_on()
+        in_graph = dist_on and self._collectives_capturable()
+        repeat = max(1, int(repeat)) if (not dist_on or in_graph) else 1
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         g_local, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
-            if dist_on:
+            if in_graph:
+                # RCCL collectives are stream operations: the whole step, exchange included, is one graph
+                try:
+                    with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
+                        for _ in range(repeat):
+                            ticked = self._local_pass(cams, image_grads, max_instances, tick=True)
+                            self._exchange_gradients()
+                            self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
+                except Exception:          # deterministic across ranks (same software): all fall back together
+                    torch.cuda.synchronize()
+                    self._capturable = in_graph = False
+                    repeat = 1
+                    g_local = torch.cuda.CUDAGraph()
+            if dist_on and not in_graph:
                 with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
                     ticked = self._local_pass(cams, image_grads, max_instances, tick=True)
+                    if rows_x:
+                        self.exchange.pack(self.rows)
                 with torch.cuda.graph(g_opt, stream=side, capture_error_mode="thread_local"):
+                    if rows_x:
+                        self.exchange.unpack()
                     self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
-            else:
+            elif not dist_on:
                 with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
                     for _ in range(repeat):
                         ticked = self._local_pass(cams, image_grads, max_instances, tick=True, fuse_adam=True)
@@ -206,10 +360,14 @@ class SurfelTrainer:
 
         def replay():
             g_local.replay()
-            if dist_on:
-                torch.distributed.all_reduce(self.slab.flat, group=self.pg)
+            if dist_on and not in_graph:
+                if rows_x:
+                    self.exchange.gather()
+                else:
+                    torch.distributed.all_reduce(self.slab.flat, group=self.pg)
                 g_opt.replay()
 
+        replay.collective_in_graph = in_graph
         self._graphs = (g_local, g_opt)
         replay.steps = repeat
         return replay

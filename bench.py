@@ -156,10 +156,14 @@ def main():
     if not args.eager:
         try:
             one_step = trainer.capture([cam], grads_fn, cap)
-            if args.graph_steps > 1 and world == 1:
+            in_graph = getattr(one_step, "collective_in_graph", False)
+            if world > 1:
+                launch_mode = ("hipGraph replay, gradient exchange recorded in the graph" if in_graph
+                               else "hipGraph replay: graph | collective | graph")
+            if args.graph_steps > 1 and (world == 1 or in_graph):
                 many_steps = trainer.capture([cam], grads_fn, cap, repeat=args.graph_steps)
                 per_replay = many_steps.steps
-                launch_mode = f"hipGraph replay, {per_replay} steps per graph"
+                launch_mode += f", {per_replay} steps per graph"
         except Exception as e:  # never lose the measurement to a capture problem
             launch_mode = f"eager (graph capture failed: {type(e).__name__})"
             many_steps, per_replay = None, 1
@@ -224,6 +228,15 @@ def main():
     if rank == 0:
         T = ((H + 15) // 16) * ((W + 15) // 16)
         rows = int(trainer.rows.count.item()) if getattr(trainer, "rows", None) is not None else None
+        x = getattr(trainer, "exchange", None)
+        if world == 1:
+            exchange = None
+        elif x is not None and x.capacity:
+            exchange = {"kind": "all-gather of member rows (64 B per row)", "rows_per_segment": x.capacity,
+                        "bytes_per_rank": 4 * x.send.numel(), "union_rows": int(x.union.count.item()),
+                        "overflow": x.overflowed()}
+        else:
+            exchange = {"kind": "all-reduce of the dense gradient slab", "bytes_per_rank": 4 * trainer.slab.flat.numel()}
         sb = stage_bytes(N_GAUSS, V, I, P, T, rows)
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         ach = sb[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
@@ -249,8 +262,10 @@ def main():
                        "overflow": bool(info["overflow"]), "binning": args.binning,
                        "launch": launch_mode,
                        "optimizer": ("row-set Adam fused into the per-Gaussian backward (exact: untouched rows "
-                                     f"have zero gradient and moments), {rows} member rows") if rows is not None
-                                    else "dense fused Adam kernel after the gradient all-reduce",
+                                     f"have zero gradient and moments), {rows} member rows") if (rows is not None and world == 1)
+                                    else ("row-set Adam over the union of the ranks' member rows" if rows is not None
+                                          else "dense fused Adam kernel after the gradient all-reduce"),
+                       "exchange": exchange,
                        "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                        "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

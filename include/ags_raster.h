@@ -242,6 +242,26 @@ int ags_adam_step_device(const AgsAdamTensors* t, float beta1, float beta2, floa
                          int32_t pre_ticked /* 1: ags_backward already advanced `state` for this step */,
                          ags_stream_t stream);
 
+/* Row exchange for the view-parallel optimisation step (one rank per GPU, each rendering its own
+ * views of /root/reference/mapping/gaussian_map.py:113-125's batch; the reference itself is single
+ * process and sums the views' losses before backward()).  Instead of all-reducing the dense
+ * gradient slab a rank ships the rows of its AgsRowSet:
+ *   segment = 16 floats of header {int32 count, int32 needed, 0...} + capacity records of 16 floats
+ *             {14 gradient floats in the order means, scales, rotation, opacity, colour; int32 row; 0}
+ * ags_rows_pack   copies the set's rows of the five gradient arrays into `segment` and writes 0
+ *                 behind them (needed > capacity: the excess rows are NOT shipped - the caller sized
+ *                 the segment too small and must treat the step as invalid);
+ * ags_rows_unpack adds a received segment into the gradient arrays and appends rows that are new to
+ *                 `union_rows` (the set the optimiser then steps over with zero_grad = 1).  Call it
+ *                 once per rank's segment, in rank order, on one stream: every rank then forms
+ *                 bit-identical sums, so the replicas cannot drift.
+ * The collective in between (an all-gather of equally sized segments) is the host's business. */
+size_t ags_rows_segment_floats(int32_t capacity);
+int ags_rows_pack(const AgsRowSet* rows, float* const grads[5], int32_t capacity, float* segment,
+                  ags_stream_t stream);
+int ags_rows_unpack(const float* segment, int32_t capacity, float* const grads[5],
+                    const AgsRowSet* union_rows, ags_stream_t stream);
+
 /* Activations of /root/reference/mapping/gaussian_map.py:529-549 (get_scales / get_rotations /
  * get_opacities): scales = clamp(scale_factor*exp(raw), 0, max_scale), rotations =
  * raw/max(|raw|,1e-12), opacities = sigmoid(raw).  One lane per Gaussian. */

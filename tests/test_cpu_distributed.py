@@ -49,3 +49,46 @@ def test_two_rank_view_parallel_training_matches_reference_capture():
         assert torch.equal(r0["view_supports"], d["view_supports"])
         assert torch.allclose(r0["view_scores"], d["view_scores"], atol=1e-4)
         assert r0["losses"] == r1["losses"]
+
+
+def _gather_worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from active_gs_amd.trainer import RowExchange
+        n = 1000
+        grads = [torch.zeros(n, w) for w in (3, 3, 4, 1, 3)]
+        x = RowExchange(n, grads, torch.device("cpu"), None)
+        cap = x.agree(local_rows=40 + 10 * rank, slab_floats=14 * n)          # largest rank: 50 rows
+        assert cap == x.capacity == min(n, 2 * 50 + 4096) or cap == 0
+        small = RowExchange(100000, grads, torch.device("cpu"), None)
+        assert small.agree(local_rows=100 + rank, slab_floats=14 * 100000) == 2 * 101 + 4096
+        gen = torch.Generator().manual_seed(rank)
+        small.send.copy_(torch.randn(small.send.shape, generator=gen))
+        ids = torch.randint(0, 100000, (small.capacity,), generator=gen, dtype=torch.int32)   # denormal bit patterns
+        small.send.view(-1, 16)[1:, 14] = ids.view(torch.float32)
+        small.send[:2] = torch.tensor([small.capacity, small.capacity + rank], dtype=torch.int32).view(torch.float32)
+        small.gather()
+        ret[rank] = dict(cap=cap, send=small.send.view(torch.int32).clone(), recv=small.recv.view(torch.int32).clone(),
+                         overflow=small.overflowed())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_exchange_host_logic_two_ranks():
+    """RowExchange (trainer.py) over gloo: the ranks agree on one segment size, and the gather moves
+    every rank's segment to every rank bit for bit (row ids travel as raw int32 bits)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_gather_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert ret[0]["cap"] == ret[1]["cap"] == 0            # 2 x 4196-row segments >= a 1000-row slab: stay dense
+        for r in (0, 1):
+            assert torch.equal(ret[r]["recv"][0], ret[0]["send"]) and torch.equal(ret[r]["recv"][1], ret[1]["send"])
+            assert ret[r]["overflow"]                         # rank 1 announced capacity + 1 rows

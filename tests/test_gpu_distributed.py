@@ -34,16 +34,18 @@ def _setup(views):
     return raw, cams, grads
 
 
-def _worker(rank, world, port, use_graph, ret):
+def _worker(rank, world, port, use_graph, ret, sparse_rows=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from active_gs_amd.trainer import SurfelTrainer
+        from active_gs_amd.trainer import RowExchange, SurfelTrainer
+        RowExchange.GROWTH, RowExchange.SLACK = 1.25, 64   # small map: the production slack alone would exceed it
         raw, cams, grads = _setup([rank])          # rank r renders view r
-        tr = SurfelTrainer(raw)
+        tr = SurfelTrainer(raw, sparse_rows=sparse_rows)
         fn = lambda v, st: (grads[v][0], grads[v][1], grads[v][2], None, None)
         tr.step(cams, fn, CAP, device_clock=True)
+        assert (tr.exchange is not None and tr.exchange.capacity > 0) == sparse_rows, (tr.rows, tr.exchange)
         if use_graph:
             replay = tr.capture(cams, fn, CAP)
             for _ in range(STEPS - 1):
@@ -52,13 +54,20 @@ def _worker(rank, world, port, use_graph, ret):
             for _ in range(STEPS - 1):
                 tr.step(cams, fn, CAP, device_clock=True)
         torch.cuda.synchronize()
+        if sparse_rows:
+            assert not tr.exchange.overflowed()
+            own, uni = int(tr.rows.count.item()), int(tr.exchange.union.count.item())
+            assert 0 < own <= uni <= N and uni < 2 * tr.exchange.capacity
+            assert float(tr.slab.flat.abs().max()) == 0.0          # consumed rows are re-zeroed every step
         ret[rank] = [p.cpu() for p in tr.params]
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_two_ranks_equal_single_process_two_views(agslib, use_graph):
+@pytest.mark.parametrize("use_graph,sparse_rows", [(False, True), (True, True), (False, False), (True, False)])
+def test_two_ranks_equal_single_process_two_views(agslib, use_graph, sparse_rows):
+    """sparse_rows: the ranks all-gather their member rows (RowExchange) and Adam steps over the
+    union; otherwise the dense slab is all-reduced.  Both must land on the one-process result."""
     from active_gs_amd.trainer import SurfelTrainer
     raw, cams, grads = _setup([0, 1])
     tr = SurfelTrainer(raw)
@@ -70,7 +79,7 @@ def test_two_ranks_equal_single_process_two_views(agslib, use_graph):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(2, port, use_graph, ret), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, use_graph, ret, sparse_rows), nprocs=2, join=True)
         for a, b in zip(ret[0], ret[1]):
             assert torch.equal(a, b)                               # replicas stay identical
         for a, r, init in zip(ret[0], ref, [raw[k].cpu() for k in ("means", "scales", "rotations", "opacities", "harmonics")]):
@@ -130,3 +139,59 @@ def test_fused_map_trainer_two_ranks_match_reference_capture(agslib):
         assert torch.allclose(r0["perf"], d["training_performance"], rtol=1e-3, atol=1e-5)
         assert (r0["supports"] != d["view_supports"]).float().mean() < 2e-3
         assert r0["losses"] == r1["losses"]
+
+
+def test_row_segments_pack_unpack(agslib):
+    """ags_rows_pack / ags_rows_unpack on one GPU, playing three ranks: the slab ends up as the sum of
+    the segments, the union row set as the union, packed rows are zeroed, overflow is reported."""
+    import ctypes as C
+    from active_gs_amd import _lib, raster_api as api
+    from active_gs_amd.trainer import GradSlab
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    n, cap = 5000, 1500
+    seg_floats = int(lib.ags_rows_segment_floats(cap))
+    assert seg_floats == 16 * (cap + 1)
+    gen = torch.Generator().manual_seed(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    slab = GradSlab(n, dev)
+    gp = (C.c_void_p * 5)(*[t.data_ptr() for t in slab.as_list()])
+    segs, dense, members = [], torch.zeros_like(slab.flat), []
+    for rank, count in enumerate((1200, 1, 1500)):
+        rows = api.RowSet(n, dev)
+        idx = torch.randperm(n, generator=gen)[:count].int().to(dev)
+        rows.rows[:count] = idx
+        rows.member[idx.long()] = 1
+        rows.count.fill_(count)
+        slab.flat.zero_()
+        for t, w in zip(slab.as_list(), (3, 3, 4, 1, 3)):
+            t.view(n, w)[idx.long()] = torch.randn(count, w, generator=gen).to(dev)
+        dense += slab.flat
+        seg = torch.full((seg_floats,), 7.0, device=dev)
+        r = rows.c_struct()
+        _lib.check(lib.ags_rows_pack(C.byref(r), C.byref(gp), cap, seg.data_ptr(), stream), "pack")
+        assert float(slab.flat.abs().max()) == 0.0                 # zeroed behind the copy
+        hdr = seg[:16].view(torch.int32).tolist()
+        assert hdr[0] == count and hdr[1] == count and not any(hdr[2:])
+        assert torch.equal(seg[16:16 + 16 * count].view(count, 16)[:, 14].view(torch.int32), idx)
+        segs.append(seg)
+        members.append(idx)
+    uni = api.RowSet(n, dev)
+    u = uni.c_struct()
+    for seg in segs:
+        _lib.check(lib.ags_rows_unpack(seg.data_ptr(), cap, C.byref(gp), C.byref(u), stream), "unpack")
+    want = torch.unique(torch.cat(members))
+    k = int(uni.count.item())
+    assert k == want.numel() and torch.equal(torch.sort(uni.rows[:k]).values, want)
+    assert torch.equal(uni.member.nonzero().flatten().int(), want)
+    # sums formed in segment order, exactly like adding the dense slabs one after another
+    assert torch.equal(slab.flat, dense)
+    # a set larger than the segment: only `capacity` rows travel and the header says so
+    rows = api.RowSet(n, dev)
+    rows.rows[:2000] = torch.arange(2000, dtype=torch.int32, device=dev)
+    rows.count.fill_(2000)
+    seg = torch.zeros(seg_floats, device=dev)
+    r = rows.c_struct()
+    _lib.check(lib.ags_rows_pack(C.byref(r), C.byref(gp), cap, seg.data_ptr(), stream), "pack")
+    assert seg[:2].view(torch.int32).tolist() == [cap, 2000]
+    assert lib.ags_rows_pack(None, C.byref(gp), cap, seg.data_ptr(), stream) != 0
