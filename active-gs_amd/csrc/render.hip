@@ -274,6 +274,187 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Blend backward with the per-surfel reduction on the matrix cores (one 8x8 quadrant per wave).
+//
+// Every one of a surfel's 15 gradient sums is a contraction over the wave's 64 pixels of a per-pixel
+// FACTOR the blend recurrence produces (gp = alpha * dL/dalpha, or the blend weight w) with a
+// per-pixel FEATURE that does not depend on the surfel once the pixel offsets are taken about the
+// quadrant centre (qx, qy) instead of the surfel's mean:
+//     fields 0-5  (m1x m1y m2xx m2xy m2yy m0):  sum_p gp[s][p] * {qx, qy, qx^2, qx qy, qy^2, 1}[p]
+//     fields 6-14 (ddc dgx dgy dr dg db dn*):   sum_p  w[s][p] * {dDn, dDn qx, dDn qy, dC0..2, dN0..2}[p]
+// The wave parks gp and w of the surfels it blends in LDS (rows 0-7: gp of slot i, rows 8-15: w of
+// slot i-8; [row][pixel], conflict-free both ways) and every 8 surfels runs ONE chain of 16
+// v_mfma_f32_16x16x4_f32 (exact f32, an fmaf chain per output) over them: D[row][field] =
+// sum_p LDS[row][p] * FEAT[p][field], lane l supplying A = LDS[l & 15][t + 16 (l >> 4)] and B =
+// FEAT[t + 16 (l >> 4)][l & 15] (16 registers, fixed for the tile).  The gp rows are meaningful in
+// columns 0-5, the w rows in columns 6-14, and the accumulator leaves lane l with column (l & 15)
+// of rows 4 (l >> 4) .. +3: 16 consecutive lanes hold 16 consecutive fields of one surfel's
+// gradient record, so after shifting the moments from the quadrant centre to the surfel's mean
+// ((qx - ox)^2 = qx^2 - 2 ox qx + ox^2: three in-row lane permutes) one atomic instruction adds
+// whole records.  This replaces, per surfel and wave, 15 multiply-adds per pixel and the
+// 38-instruction transposed wave reduction of ags_k_render_bwd<1>; it pays where tile lists are long.
+typedef float ags_f32x4 __attribute__((ext_vector_type(4)));
+
+struct AgsWaveBatch {       // one per wave, in LDS
+    AgsWaveStage st;
+    float gw[16][65];       // rows 0-7: gp of slot i, rows 8-15: w of slot i-8; 65: conflict-free column reads
+    float4 meta[8];         // per slot: {surfel id bits, mean - quadrant centre (x, y), -}
+};
+
+__global__ __launch_bounds__(256) void ags_k_render_bwd_mfma(
+    AgsFrame F, int normalize_depth, const float* __restrict__ bgp, const uint2* __restrict__ ranges,
+    const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
+    const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, AgsImageGrads dout, float* __restrict__ dgeom, int num_tiles,
+    AgsTick tick, AgsViewStride vs) {
+    {
+        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws, po = (size_t)blockIdx.y * (size_t)vs.px;
+        AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(vals, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(final_T, wo);
+        AGS_WS_SHIFT(n_contrib, wo); AGS_WS_SHIFT(dgeom, wo);
+        depth_out += po; opac_out += po;
+        if (dout.d_rgb) dout.d_rgb += 3 * po;
+        if (dout.d_normal) dout.d_normal += 3 * po;
+        if (dout.d_depth) dout.d_depth += po;
+        if (dout.d_opacity) dout.d_opacity += po;
+        if (dout.d_confidence) dout.d_confidence += po;
+    }
+    constexpr int SLOTS = 1;
+    __shared__ AgsWaveBatch batch[4];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    AgsWaveBatch& wb = batch[wave];
+    AgsWaveStage& st = wb.st;
+    if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2, 0);
+    const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
+    const uint2 rg = ranges[tile];
+    if (rg.y <= rg.x) return;
+    const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
+    const int strip0 = wave;
+    const int pxl = tx * AGS_TILE + (lane & 7), pyl = ty * AGS_TILE + (lane >> 3);
+    const float bx0 = (float)(tx * AGS_TILE), by0 = (float)(ty * AGS_TILE);
+    const uint32_t my_strips = 1u << strip0;
+    const float bg[3] = {bgp[0], bgp[1], bgp[2]};
+    const size_t HW = (size_t)F.H * F.W;
+    AgsPixGrad pg;
+    {
+        const int px = AGS_PX(0), py = AGS_PY(0);
+        float dC[3] = {0, 0, 0}, dN[3] = {0, 0, 0}, dD = 0, dO = 0, dCf = 0, dep = 0, opa = 0, Tf = 1.f;
+        uint32_t last = 0;
+        if (px < F.W && py < F.H) {
+            const size_t o = (size_t)py * F.W + px;
+            last = n_contrib[o];
+            if (last) {
+                if (dout.d_rgb) { dC[0] = dout.d_rgb[o]; dC[1] = dout.d_rgb[HW + o]; dC[2] = dout.d_rgb[2 * HW + o]; }
+                if (dout.d_normal) { dN[0] = dout.d_normal[o]; dN[1] = dout.d_normal[HW + o]; dN[2] = dout.d_normal[2 * HW + o]; }
+                if (dout.d_depth) dD = dout.d_depth[o];
+                if (dout.d_opacity) dO = dout.d_opacity[o];
+                if (dout.d_confidence) dCf = dout.d_confidence[o];
+                dep = depth_out[o]; opa = opac_out[o]; Tf = final_T[o];
+            }
+        }
+        ags_pixgrad_init(pg, dC, dN, dD, dO, dCf, dep, opa, Tf, last, bg, normalize_depth);
+    }
+    const uint32_t maxlast = ags_wave_max_u32(pg.last);
+    if (maxlast == 0) return; // wave-uniform; no workgroup barrier anywhere in this kernel
+
+    // ---- B operands: field (lane & 15) of the 16 pixels t + 16 (lane >> 4) --------------------------
+    const int fld = lane & 15, kgrp = lane >> 4;
+    const float cx = bx0 + 8.f * (float)(strip0 & 1) + 3.5f, cy = by0 + 8.f * (float)(strip0 >> 1) + 3.5f; // quadrant centre
+    float FE[16];
+    {
+        // every pixel lane publishes its 16 feature values ([field][pixel], rows of 68 floats: the
+        // 16-byte row reads below are conflict-free); the batch buffer is still unused
+        float* ex = &wb.gw[0][0];
+        const float qx = (float)(lane & 7) - 3.5f, qy = (float)(lane >> 3) - 3.5f;
+        const float feat[16] = {qx, qy, qx * qx, qx * qy, qy * qy, 1.f, pg.dDn, pg.dDn * qx, pg.dDn * qy,
+                                pg.dC0, pg.dC1, pg.dC2, pg.dN0, pg.dN1, pg.dN2, 0.f};
+        static_assert(sizeof(wb.gw) >= (14 * 68 + 64) * 4, "feature exchange fits the batch buffer");
+#pragma unroll
+        for (int f = 0; f < 15; ++f) ex[f * 68 + lane] = feat[f];
+        ags_wave_lds_sync();
+        const float4* row = reinterpret_cast<const float4*>(ex + fld * 68 + 16 * kgrp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fld < 15) v = row[q];
+            FE[4 * q] = v.x; FE[4 * q + 1] = v.y; FE[4 * q + 2] = v.z; FE[4 * q + 3] = v.w;
+        }
+        ags_wave_lds_sync();
+    }
+    // per-lane constants of the shift to the surfel's mean (out = D - cX*X - cY*Y - cZ*Z, see flush)
+    const bool lo = kgrp < 2;                    // rows 0-7 (gp: fields 0-5) / rows 8-15 (w: fields 6-14)
+    const bool lane_valid = lo ? (fld < 6) : (fld >= 6 && fld < 15);
+    const float kx1 = ((lo && fld == 0) || (!lo && fld == 7)) ? 1.f : 0.f, ky1 = ((lo && fld == 1) || (!lo && fld == 8)) ? 1.f : 0.f;
+    const float kxx = (lo && fld == 2) ? 1.f : 0.f, kxy = (lo && fld == 3) ? 1.f : 0.f, kyy = (lo && fld == 4) ? 1.f : 0.f;
+    const float mYx = (lo && fld == 2) ? 2.f : 0.f, mYy = (lo && fld == 3) ? 1.f : 0.f;
+    const float mZx = (lo && fld == 3) ? 1.f : 0.f, mZy = (lo && fld == 4) ? 2.f : 0.f;
+    const int row_base = lane & 48;
+    const int srcX = (row_base + (lo ? 5 : 6)) << 2, srcY = row_base << 2, srcZ = (row_base + 1) << 2; // bpermute byte addresses
+    int nb = 0; // filled slots (wave-uniform)
+
+    auto flush = [&]() {
+        ags_wave_lds_sync();
+        ags_f32x4 d = {0.f, 0.f, 0.f, 0.f}, d_odd = {0.f, 0.f, 0.f, 0.f}; // two chains: a dependent MFMA waits 40 cycles, an independent one 32
+        const float* col = &wb.gw[fld][16 * kgrp];
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(col[t], FE[t], d, 0, 0, 0);
+            d_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(col[t + 1], FE[t + 1], d_odd, 0, 0, 0);
+        }
+        d += d_odd;
+        // lane: field fld of rows 4 kgrp + r, i.e. of slots 4 (kgrp & 1) + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int slot = 4 * (kgrp & 1) + r;
+            const float4 mt = wb.meta[slot];
+            const float ox = mt.y, oy = mt.z;
+            const float X = __int_as_float(__builtin_amdgcn_ds_bpermute(srcX, __float_as_int(d[r])));
+            const float Y = __int_as_float(__builtin_amdgcn_ds_bpermute(srcY, __float_as_int(d[r])));
+            const float Z = __int_as_float(__builtin_amdgcn_ds_bpermute(srcZ, __float_as_int(d[r])));
+            const float cX = kx1 * ox + ky1 * oy - (kxx * ox * ox + kxy * ox * oy + kyy * oy * oy);
+            const float cY = mYx * ox + mYy * oy, cZ = mZx * ox + mZy * oy;
+            const float out = d[r] - cX * X - cY * Y - cZ * Z;
+            if (lane_valid && slot < nb) unsafeAtomicAdd(dgeom + (size_t)__float_as_uint(mt.x) * 16 + fld, out);
+        }
+        ags_wave_lds_sync();
+        nb = 0;
+    };
+
+    for (int r = (int)((maxlast - 1) >> 6); r >= 0; --r) {
+        const uint32_t k0 = (uint32_t)r << 6;
+        ags_wave_lds_sync();
+        uint32_t m = 0;
+        if (k0 + lane < maxlast) m = ags_stage_one<SLOTS>(st, lane, geom, vals[(size_t)(rg.x + k0 + lane) * id_stride], bx0, by0, strip0);
+        ags_wave_lds_sync();
+        unsigned long long act = __ballot((m & my_strips) != 0u);
+        while (act) { // back to front: highest staged position first
+            const int k = 63 - __clzll((long long)act);
+            act &= ~(1ull << k);
+            const AgsGeom g = st.sg[k];
+            const uint32_t pos1 = k0 + k + 1;
+            float dx, dy, a;
+            const bool ok = ags_alpha(g, (float)AGS_PX(0), (float)AGS_PY(0), dx, dy, a) && (pos1 <= pg.last);
+            const float alpha = ok ? a : 0.f;
+            if (!__any(alpha > 0.f)) continue;
+            // the blend recurrence (ags_blend_bwd_apply without its accumulation)
+            const float iom = ags_rcp(1.f - alpha);
+            pg.T = pg.T * iom;
+            const float w = alpha * pg.T;
+            const float dpix = g.dc + g.gx * dx + g.gy * dy;
+            const float gsum = pg.dC0 * g.r + pg.dC1 * g.g + pg.dC2 * g.b + pg.dN0 * g.nx + pg.dN1 * g.ny + pg.dN2 * g.nz
+                             + pg.dDn * dpix + pg.dCf * g.conf + pg.dA;
+            const float dalpha = pg.T * gsum - pg.S * iom;
+            pg.S += w * gsum;
+            const float gp = (alpha < AGS_ALPHA_MAX) ? alpha * dalpha : 0.f;
+            wb.gw[nb][lane] = gp;
+            wb.gw[nb + 8][lane] = w;
+            if (lane == 0) wb.meta[nb] = make_float4(__uint_as_float(st.sid[k]), g.mx - cx, g.my - cy, 0.f);
+            if (++nb == 8) flush();
+        }
+    }
+    if (nb) flush();
+}
+
 // How many strips per wave: one wave per tile when the image has enough tiles to fill the
 // 1024 SIMDs several times over, otherwise split tiles over more waves.
 static int ags_pick_slots(int num_tiles) {
@@ -284,6 +465,13 @@ static int ags_pick_slots(int num_tiles) {
     // at 512x512 = 11 264); two slots per wave from 2048x2048 (16 384 tiles, ~500 surfels per tile) up
     if (num_tiles >= 12288) return 2;
     return 1;
+}
+
+// matrix-core reduction in the blend backward: AGS_BWD_MFMA = 0 never, 1 where one quadrant per wave is
+// picked anyway, 2 always
+static int ags_bwd_mfma() {
+    static const int mode = [] { const char* e = getenv("AGS_BWD_MFMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0; }();
+    return mode;
 }
 
 template <int SLOTS>
@@ -330,7 +518,15 @@ void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
 void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick,
                            const AgsViewStride& vs, hipStream_t s) {
-    switch (ags_pick_slots(L.num_tiles * vs.views)) {
+    const int slots = ags_pick_slots(L.num_tiles * vs.views), mfma = ags_bwd_mfma();
+    if (mfma == 2 || (mfma == 1 && slots == 1)) {
+        hipLaunchKernelGGL(ags_k_render_bwd_mfma, dim3(L.num_tiles, vs.views), dim3(256), 0, s, F, cam.normalize_depth,
+                           cam.bg, (const uint2*)(ws + L.ranges), ids.ids, ids.stride, (const AgsGeom*)(ws + L.geom),
+                           fwd.depth, fwd.opacity, (const float*)(ws + L.final_T),
+                           (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick, vs);
+        return;
+    }
+    switch (slots) {
         case 1: launch_bwd<1>(F, cam, ws, L, ids, fwd, dout, tick, vs, s); break;
         case 2: launch_bwd<2>(F, cam, ws, L, ids, fwd, dout, tick, vs, s); break;
         default: launch_bwd<4>(F, cam, ws, L, ids, fwd, dout, tick, vs, s); break;

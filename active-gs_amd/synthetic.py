@@ -99,14 +99,18 @@ def activate(raw: dict):
 
 
 def make_camera(view: int, height: int, width: int, focal_px: float | None = None, seed_base: int = 1,
-                room: str = "office0"):
+                room: str = "office0", mirror: int = 0):
     """OpenCV c2w (4,4) and normalised intrinsics (3,3) for training view ``view``:
-    position = room centre + U(-1,1) m in x,y (±0.3 m in z), yaw uniform, pitch 0."""
+    position = room centre + U(-1,1) m in x,y (±0.3 m in z), yaw uniform, pitch 0.
+    ``mirror`` (bits 0/1/2 = x/y/z): the same pose reflected through the room's symmetry planes - the
+    box rooms of ``make_room_scene`` are statistically mirror-symmetric, so the eight mirrors of a
+    view carry the same workload while looking at different surfels (bench.py's weak scaling)."""
     g = torch.Generator().manual_seed(seed_base + view)
     r = torch.rand(4, generator=g)
-    pos = torch.tensor([(r[0] * 2 - 1).item(), (r[1] * 2 - 1).item(), (r[2] * 0.6 - 0.3).item()])
+    sx, sy, sz = (-1.0 if mirror & 1 else 1.0), (-1.0 if mirror & 2 else 1.0), (-1.0 if mirror & 4 else 1.0)
+    pos = torch.tensor([sx * (r[0] * 2 - 1).item(), sy * (r[1] * 2 - 1).item(), sz * (r[2] * 0.6 - 0.3).item()])
     yaw = (r[3] * 2 * math.pi).item()
-    fwd = torch.tensor([math.cos(yaw), math.sin(yaw), 0.0])
+    fwd = torch.tensor([sx * math.cos(yaw), sy * math.sin(yaw), 0.0])
     down = torch.tensor([0.0, 0.0, -1.0])
     right = torch.linalg.cross(down, fwd)
     c2w = torch.eye(4)

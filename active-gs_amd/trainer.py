@@ -57,7 +57,7 @@ class RowExchange:
     which is what the replicated Adam then steps over.  ``capacity`` (rows per segment) is agreed
     once with ``agree()``; ``overflowed()`` says whether a rank has outgrown it since."""
 
-    GROWTH, SLACK = 2.0, 4096      # capacity = GROWTH x the largest rank's row count + SLACK
+    GROWTH, SLACK = 1.5, 1024      # capacity = GROWTH x the largest rank's row count + SLACK
 
     def __init__(self, n: int, grads: Sequence[torch.Tensor], device, pg):
         self.n, self.pg, self.device = n, pg, device
@@ -71,12 +71,15 @@ class RowExchange:
 
     def agree(self, local_rows: int, slab_floats: int) -> int:
         """Collective (host-synchronous, once per optimiser): capacity = GROWTH x the largest rank's
-        row count + SLACK; 0 if the gathered segments would not be smaller than the dense slab."""
+        row count + SLACK; 0 if gathering the segments would not move clearly fewer bytes than
+        all-reducing the dense slab."""
         t = torch.tensor([int(local_rows)], device=self.device, dtype=torch.int64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.pg)
         cap = min(self.n, int(self.GROWTH * int(t.item())) + self.SLACK)
         seg = int(_lib.load().ags_rows_segment_floats(cap))
-        if seg * self.world >= slab_floats:
+        # bytes a rank receives: (world-1) segments against 2 (world-1)/world slabs of a ring all-reduce;
+        # the row path also pays world unpack launches, so it has to win by a margin
+        if seg * self.world >= 1.5 * slab_floats:
             self.capacity = 0
             return 0
         self.capacity = cap
