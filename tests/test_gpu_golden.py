@@ -206,3 +206,20 @@ def test_c5_size_scene_16384_tiles(agslib):
     g2 = api.backward(cam, g, st, *[2 * t for t in d])
     assert (2 * res[0][1].means3D - g2.means3D).abs().sum() <= 1e-3 * g2.means3D.abs().sum()
     assert torch.isfinite(g2.scales).all() and float(st.opacity.max()) <= 1.0 and float(st.opacity.min()) >= 0.0
+
+
+def test_matrix_core_backward_passes_the_same_fixtures(agslib):
+    """The opt-in blend backward that reduces on the matrix cores (AGS_BWD_MFMA=2, render.hip:
+    ags_k_render_bwd_mfma) against the same reference fixtures and oracle comparisons as the default
+    kernel.  The switch is read once per process, hence the subprocess."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, AGS_BWD_MFMA="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_golden.py"),
+                        os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "not matrix_core and (oracle or train or properties or c4_size or c5_size or row_set or batched_backward "
+                        "or overfull or alpha_clamp)"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
