@@ -25,15 +25,17 @@
 
 #include "ags_internal.h"
 
-struct AgsWaveStage {   // one per wave, in LDS
-    AgsGeom sg[64];
-    uint32_t sid[64];
+template <int N>
+struct AgsWaveStageT {  // one per wave, in LDS
+    AgsGeom sg[N];
+    uint32_t sid[N];
 };
+typedef AgsWaveStageT<64> AgsWaveStage;
 
 // stage surfel `gid` from lane `lane` and return its strip-reach mask for tile (bx0,by0): bit s is
 // set when the surfel can reach strip s; only this wave's SLOTS strips (from strip0) are tested
-template <int SLOTS>
-__device__ __forceinline__ uint32_t ags_stage_one(AgsWaveStage& st, int lane, const AgsGeom* __restrict__ geom,
+template <int SLOTS, typename STAGE = AgsWaveStage>
+__device__ __forceinline__ uint32_t ags_stage_one(STAGE& st, int lane, const AgsGeom* __restrict__ geom,
                                                   uint32_t gid, float bx0, float by0, int strip0) {
     const float4* src = reinterpret_cast<const float4*>(geom + gid);
     const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
@@ -283,26 +285,29 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
 // quadrant centre (qx, qy) instead of the surfel's mean:
 //     fields 0-5  (m1x m1y m2xx m2xy m2yy m0):  sum_p gp[s][p] * {qx, qy, qx^2, qx qy, qy^2, 1}[p]
 //     fields 6-14 (ddc dgx dgy dr dg db dn*):   sum_p  w[s][p] * {dDn, dDn qx, dDn qy, dC0..2, dN0..2}[p]
-// The wave parks gp and w of the surfels it blends in LDS (rows 0-7: gp of slot i, rows 8-15: w of
-// slot i-8; [row][pixel], conflict-free both ways) and every 8 surfels runs ONE chain of 16
+// The wave parks gp and w of the surfels it blends in LDS (row 2 i: gp of slot i, row 2 i + 1: its w;
+// [row][pixel], conflict-free both ways) and every 8 surfels runs 16
 // v_mfma_f32_16x16x4_f32 (exact f32, an fmaf chain per output) over them: D[row][field] =
 // sum_p LDS[row][p] * FEAT[p][field], lane l supplying A = LDS[l & 15][t + 16 (l >> 4)] and B =
 // FEAT[t + 16 (l >> 4)][l & 15] (16 registers, fixed for the tile).  The gp rows are meaningful in
 // columns 0-5, the w rows in columns 6-14, and the accumulator leaves lane l with column (l & 15)
-// of rows 4 (l >> 4) .. +3: 16 consecutive lanes hold 16 consecutive fields of one surfel's
-// gradient record, so after shifting the moments from the quadrant centre to the surfel's mean
-// ((qx - ox)^2 = qx^2 - 2 ox qx + ox^2: three in-row lane permutes) one atomic instruction adds
-// whole records.  This replaces, per surfel and wave, 15 multiply-adds per pixel and the
+// of rows 4 (l >> 4) .. +3 = (gp, w) of two slots: 16 consecutive lanes hold the 16 consecutive
+// fields of one surfel's gradient record, so after shifting the moments from the quadrant centre
+// to the surfel's mean ((qx - ox)^2 = qx^2 - 2 ox qx + ox^2: four in-row lane permutes per slot) ONE
+// atomic instruction adds the whole records of four surfels.  This replaces, per surfel and wave, 15 multiply-adds per pixel and the
 // 38-instruction transposed wave reduction of ags_k_render_bwd<1>; it pays where tile lists are long.
 typedef float ags_f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef AGS_MFMA_STAGE
+#define AGS_MFMA_STAGE 32   // records staged per round: 32 keeps a wave at 6.4 KB of LDS = 6 waves per SIMD
+#endif
 struct AgsWaveBatch {       // one per wave, in LDS
-    AgsWaveStage st;
-    float gw[16][65];       // rows 0-7: gp of slot i, rows 8-15: w of slot i-8; 65: conflict-free column reads
+    AgsWaveStageT<AGS_MFMA_STAGE> st;
+    float gw[16][68];       // row 2 i: gp of slot i, row 2 i + 1: its w; 68 floats: 16-byte row reads of 16 lanes hit 64 banks
     float4 meta[8];         // per slot: {surfel id bits, mean - quadrant centre (x, y), -}
 };
 
-__global__ __launch_bounds__(256) void ags_k_render_bwd_mfma(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void ags_k_render_bwd_mfma(
     AgsFrame F, int normalize_depth, const float* __restrict__ bgp, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
     const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(256) void ags_k_render_bwd_mfma(
     __shared__ AgsWaveBatch batch[4];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     AgsWaveBatch& wb = batch[wave];
-    AgsWaveStage& st = wb.st;
+    AgsWaveStageT<AGS_MFMA_STAGE>& st = wb.st;
     if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2, 0);
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
@@ -381,50 +386,60 @@ __global__ __launch_bounds__(256) void ags_k_render_bwd_mfma(
         }
         ags_wave_lds_sync();
     }
-    // per-lane constants of the shift to the surfel's mean (out = D - cX*X - cY*Y - cZ*Z, see flush)
-    const bool lo = kgrp < 2;                    // rows 0-7 (gp: fields 0-5) / rows 8-15 (w: fields 6-14)
-    const bool lane_valid = lo ? (fld < 6) : (fld >= 6 && fld < 15);
-    const float kx1 = ((lo && fld == 0) || (!lo && fld == 7)) ? 1.f : 0.f, ky1 = ((lo && fld == 1) || (!lo && fld == 8)) ? 1.f : 0.f;
-    const float kxx = (lo && fld == 2) ? 1.f : 0.f, kxy = (lo && fld == 3) ? 1.f : 0.f, kyy = (lo && fld == 4) ? 1.f : 0.f;
-    const float mYx = (lo && fld == 2) ? 2.f : 0.f, mYy = (lo && fld == 3) ? 1.f : 0.f;
-    const float mZx = (lo && fld == 3) ? 1.f : 0.f, mZy = (lo && fld == 4) ? 2.f : 0.f;
+    // per-lane constants of the shift to the surfel's mean (see flush): which of ox, oy and their products
+    // this lane's field takes
+    const float gx1 = fld == 0 ? 1.f : 0.f, gy1 = fld == 1 ? 1.f : 0.f;                     // gp rows: m1x, m1y
+    const float kxx = fld == 2 ? 1.f : 0.f, kxy = fld == 3 ? 1.f : 0.f, kyy = fld == 4 ? 1.f : 0.f;
+    const float mYx = fld == 2 ? 2.f : 0.f, mYy = fld == 3 ? 1.f : 0.f, mZx = fld == 3 ? 1.f : 0.f, mZy = fld == 4 ? 2.f : 0.f;
+    const float wx1 = fld == 7 ? 1.f : 0.f, wy1 = fld == 8 ? 1.f : 0.f;                     // w rows: dgx, dgy
     const int row_base = lane & 48;
-    const int srcX = (row_base + (lo ? 5 : 6)) << 2, srcY = row_base << 2, srcZ = (row_base + 1) << 2; // bpermute byte addresses
+    const int src0 = row_base << 2, src1 = (row_base + 1) << 2, src5 = (row_base + 5) << 2, src6 = (row_base + 6) << 2; // bpermute byte addresses
     int nb = 0; // filled slots (wave-uniform)
 
     auto flush = [&]() {
         ags_wave_lds_sync();
         ags_f32x4 d = {0.f, 0.f, 0.f, 0.f}, d_odd = {0.f, 0.f, 0.f, 0.f}; // two chains: a dependent MFMA waits 40 cycles, an independent one 32
-        const float* col = &wb.gw[fld][16 * kgrp];
+        const float4* col = reinterpret_cast<const float4*>(&wb.gw[fld][16 * kgrp]);
 #pragma unroll
-        for (int t = 0; t < 16; t += 2) {
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(col[t], FE[t], d, 0, 0, 0);
-            d_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(col[t + 1], FE[t + 1], d_odd, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            const float4 a4 = col[q];
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, FE[4 * q], d, 0, 0, 0);
+            d_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, FE[4 * q + 1], d_odd, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, FE[4 * q + 2], d, 0, 0, 0);
+            d_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, FE[4 * q + 3], d_odd, 0, 0, 0);
         }
         d += d_odd;
-        // lane: field fld of rows 4 kgrp + r, i.e. of slots 4 (kgrp & 1) + r
+        // lane: field fld of rows 4 kgrp + r = (gp, w) of slots 2 kgrp and 2 kgrp + 1
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int slot = 4 * (kgrp & 1) + r;
+        for (int h = 0; h < 2; ++h) {
+            const int slot = 2 * kgrp + h;
             const float4 mt = wb.meta[slot];
             const float ox = mt.y, oy = mt.z;
-            const float X = __int_as_float(__builtin_amdgcn_ds_bpermute(srcX, __float_as_int(d[r])));
-            const float Y = __int_as_float(__builtin_amdgcn_ds_bpermute(srcY, __float_as_int(d[r])));
-            const float Z = __int_as_float(__builtin_amdgcn_ds_bpermute(srcZ, __float_as_int(d[r])));
-            const float cX = kx1 * ox + ky1 * oy - (kxx * ox * ox + kxy * ox * oy + kyy * oy * oy);
-            const float cY = mYx * ox + mYy * oy, cZ = mZx * ox + mZy * oy;
-            const float out = d[r] - cX * X - cY * Y - cZ * Z;
-            if (lane_valid && slot < nb) unsafeAtomicAdd(dgeom + (size_t)__float_as_uint(mt.x) * 16 + fld, out);
+            float* rec = dgeom + (size_t)__float_as_uint(mt.x) * 16 + fld;
+            // gp row: raw moments about the quadrant centre -> about the surfel's mean
+            const float gpv = d[2 * h];
+            const float R0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src5, __float_as_int(gpv)));
+            const float R1x = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(gpv)));
+            const float R1y = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(gpv)));
+            const float c0 = gx1 * ox + gy1 * oy - (kxx * ox * ox + kxy * ox * oy + kyy * oy * oy);
+            const float outg = gpv - c0 * R0 - (mYx * ox + mYy * oy) * R1x - (mZx * ox + mZy * oy) * R1y;
+            // w row: the depth-slope sums move the same way
+            const float wv = d[2 * h + 1];
+            const float Q0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src6, __float_as_int(wv)));
+            const float outw = wv - (wx1 * ox + wy1 * oy) * Q0;
+            if (slot < nb && fld < 15) unsafeAtomicAdd(rec, fld < 6 ? outg : outw);
         }
         ags_wave_lds_sync();
         nb = 0;
     };
 
-    for (int r = (int)((maxlast - 1) >> 6); r >= 0; --r) {
-        const uint32_t k0 = (uint32_t)r << 6;
+    constexpr int RSH = AGS_MFMA_STAGE == 64 ? 6 : 5;
+    for (int r = (int)((maxlast - 1) >> RSH); r >= 0; --r) {
+        const uint32_t k0 = (uint32_t)r << RSH;
         ags_wave_lds_sync();
         uint32_t m = 0;
-        if (k0 + lane < maxlast) m = ags_stage_one<SLOTS>(st, lane, geom, vals[(size_t)(rg.x + k0 + lane) * id_stride], bx0, by0, strip0);
+        if (lane < AGS_MFMA_STAGE && k0 + lane < maxlast)
+            m = ags_stage_one<SLOTS>(st, lane, geom, vals[(size_t)(rg.x + k0 + lane) * id_stride], bx0, by0, strip0);
         ags_wave_lds_sync();
         unsigned long long act = __ballot((m & my_strips) != 0u);
         while (act) { // back to front: highest staged position first
@@ -446,8 +461,8 @@ __global__ __launch_bounds__(256) void ags_k_render_bwd_mfma(
             const float dalpha = pg.T * gsum - pg.S * iom;
             pg.S += w * gsum;
             const float gp = (alpha < AGS_ALPHA_MAX) ? alpha * dalpha : 0.f;
-            wb.gw[nb][lane] = gp;
-            wb.gw[nb + 8][lane] = w;
+            wb.gw[2 * nb][lane] = gp;
+            wb.gw[2 * nb + 1][lane] = w;
             if (lane == 0) wb.meta[nb] = make_float4(__uint_as_float(st.sid[k]), g.mx - cx, g.my - cy, 0.f);
             if (++nb == 8) flush();
         }
@@ -467,10 +482,10 @@ static int ags_pick_slots(int num_tiles) {
     return 1;
 }
 
-// matrix-core reduction in the blend backward: AGS_BWD_MFMA = 0 never, 1 where one quadrant per wave is
-// picked anyway, 2 always
+// matrix-core reduction in the blend backward: AGS_BWD_MFMA = 0 never (the VALU kernels below), 1 where one
+// quadrant per wave would be picked anyway, 2 always (default: measured faster on every configuration)
 static int ags_bwd_mfma() {
-    static const int mode = [] { const char* e = getenv("AGS_BWD_MFMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0; }();
+    static const int mode = [] { const char* e = getenv("AGS_BWD_MFMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
     return mode;
 }
 

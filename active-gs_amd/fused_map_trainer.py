@@ -20,6 +20,15 @@ from .optimizer import FusedAdam
 from .trainer import GradSlab
 
 
+def weighted_choice_without_replacement(weights: torch.Tensor, k: int) -> torch.Tensor:
+    """``k`` distinct indices drawn like ``np.random.choice(len(w), k, replace=False, p=w/sum(w))``
+    (mapping/utils.py:190-228 draws its older frames that way) without leaving the device of
+    ``weights``: successive sampling without replacement is the same as taking the k largest
+    ``log(u_i) / w_i`` with u_i ~ U(0,1) (Efraimidis & Spirakis 2006).  No host synchronisation."""
+    keys = torch.log(torch.rand_like(weights, dtype=torch.float32)) / weights.float().clamp(min=1e-30)
+    return torch.topk(keys, k).indices
+
+
 class FusedMapTrainer(GaussianMapTrainer):
     def __init__(self, raw: dict, frames: List[dict], cfg: Optional[dict] = None, process_group=None,
                  binning_mode: int = api.BIN_TILE_SORT, use_graph: bool = True, num_streams: int = 4,
@@ -360,13 +369,27 @@ class FusedMapTrainer(GaussianMapTrainer):
 
         graph = None
         self._loss.accum.zero_()           # from here on ags_loss_finish leaves it zeroed
+        device_sampler = self.cfg.get("sampler", "host") == "device"
+        n_active, n_random = len(sampler.active_ids), sampler.num_random
         for it in range(total):
-            _, _, _, _, ids = sampler.next_frames(self.training_performance)   # host read of the errors
-            B = len(ids)
+            if device_sampler:
+                # the same draw as np.random.choice(older, n_random, replace=False, p = error / sum) - successive
+                # sampling without replacement == the n_random largest log(u_i) / w_i (Efraimidis-Spirakis) -
+                # from torch's device generator, so the host never reads the errors back
+                B = n_active + n_random
+                if state["idx"] is None or B != state["B"]:
+                    state["idx"], state["B"], graph = torch.empty(B, device=dev, dtype=torch.long), B, None
+                    state["idx"][:n_active] = torch.as_tensor(sampler.active_ids, dtype=torch.long)
+                if n_random > 0:
+                    n_old = len(sampler.older_ids)
+                    state["idx"][n_active:] = weighted_choice_without_replacement(self.training_performance[:n_old], n_random)
+            else:
+                _, _, _, _, ids = sampler.next_frames(self.training_performance)   # host read of the errors
+                B = len(ids)
+                if state["idx"] is None or B != state["B"]:
+                    state["idx"], state["B"], graph = torch.empty(B, device=dev, dtype=torch.long), B, None
+                state["idx"].copy_(torch.as_tensor(ids, dtype=torch.long))
             self._loss.set_batch_total(B)
-            if state["idx"] is None or B != state["B"]:
-                state["idx"], state["B"], graph = torch.empty(B, device=dev, dtype=torch.long), B, None
-            state["idx"].copy_(torch.as_tensor(ids, dtype=torch.long))
             if graph is not None:
                 graph.replay()
             else:

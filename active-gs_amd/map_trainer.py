@@ -19,6 +19,9 @@ from .facade import SurfelRenderer, training_losses
 
 DEFAULT_CFG = dict(bound=(0.001, 10.0), scale_factor=0.01, optimization_steps=10, prune_interval=5, error_thres=0.25,
                    background=(0.0, 0.0, 0.0, 0.0), batch_size=8, active_size=3, use_view_distribution=True,
+                   # "host": the reference's np.random.choice on the host (reads the per-frame errors back every
+                   # iteration); "device" (FusedMapTrainer.train_batched): the same distribution drawn on the GPU
+                   sampler="host",
                    lrs=dict(mean=5e-4, scale=1e-2, rotation=5e-4, opacity=1e-2, harmonic=1e-4))
 
 

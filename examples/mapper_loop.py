@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true", help="launch every iteration eagerly instead of replaying it")
     ap.add_argument("--per-view", action="store_true", help="per-view launches on HIP streams instead of one batch")
+    ap.add_argument("--host-sampler", action="store_true",
+                    help="draw the error-weighted frames with the reference's np.random.choice on the host (one read-back "
+                         "of the per-frame errors per iteration) instead of the same distribution on the GPU")
     args = ap.parse_args()
 
     from active_gs_amd import raster_api as api
@@ -61,7 +64,8 @@ def main():
     z = lambda *s: torch.zeros(*s, device=dev)
     raw = dict(means=z(0, 3), scales=z(0, 3), rotations=z(0, 4), opacities=z(0), harmonics=z(0, 1, 3))
     np.random.seed(0)
-    tr = FusedMapTrainer(raw, [], dict(optimization_steps=args.steps), use_graph=not args.no_graph,
+    tr = FusedMapTrainer(raw, [], dict(optimization_steps=args.steps, sampler="host" if args.host_sampler else "device"),
+                         use_graph=not args.no_graph,
                          num_streams=args.streams, batched=not args.per_view)
 
     def timed(fn):
@@ -88,6 +92,7 @@ def main():
     print(json.dumps(dict(
         workload=f"mapper loop: {args.keyframes} keyframes x {args.steps} iterations @{h}x{w}, batch 8 + 3 active, "
                  f"prune every 5th keyframe, from an empty map",
+        frame_sampler="host (np.random.choice, as the reference)" if args.host_sampler else "device (same distribution)",
         iterations=iters, seconds=round(t_all, 3), ms_per_iteration_incl_growth=round(1e3 * t_all / iters, 3),
         grow_ms_per_keyframe=round(1e3 * t_grow / args.keyframes, 3),
         train_ms_per_keyframe=round(1e3 * t_train / args.keyframes, 3),

@@ -180,3 +180,29 @@ def test_public_header_is_plain_c(tmp_path):
         assert int(out[name]) == C.sizeof(cls), name
         for fname, _ in cls._fields_:
             assert int(out[f"{name}.{fname}"]) == getattr(cls, fname).offset, f"{name}.{fname}"
+
+
+def test_device_frame_sampler_draws_the_reference_distribution():
+    """cfg sampler="device" (fused_map_trainer.weighted_choice_without_replacement) against
+    np.random.choice(replace=False, p=...), which is what the reference's WeightedSampler calls:
+    the same inclusion frequencies and the same distribution of the first pick."""
+    import numpy as np
+    from active_gs_amd.fused_map_trainer import weighted_choice_without_replacement
+    w = torch.tensor([0.5, 1.0, 2.0, 4.0, 0.25, 3.0])
+    k, trials = 3, 20000
+    torch.manual_seed(0)
+    np.random.seed(0)
+    inc_t, inc_n = torch.zeros(6), np.zeros(6)
+    pair_t, pair_n = torch.zeros(6, 6), np.zeros((6, 6))
+    p = (w / w.sum()).numpy().astype(np.float64)
+    p /= p.sum()
+    for _ in range(trials):
+        a = weighted_choice_without_replacement(w, k)
+        assert a.numel() == k and len(set(a.tolist())) == k
+        inc_t[a] += 1
+        pair_t[a[0], a[1]] += 1                      # order matters: topk returns the largest key first
+        b = np.random.choice(6, size=k, replace=False, p=p)
+        inc_n[b] += 1
+        pair_n[b[0], b[1]] += 1
+    assert np.abs(inc_t.numpy() - inc_n).max() / trials < 0.015
+    assert np.abs(pair_t.numpy() - pair_n).max() / trials < 0.01

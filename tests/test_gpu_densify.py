@@ -130,16 +130,19 @@ def test_add_gaussians_and_prune_match_reference_fixture(agslib):
         assert torch.equal(pruned[k].cpu(), g["after_prune"][k]), k
 
 
-def test_mapper_loop_grows_trains_and_prunes(agslib):
+@pytest.mark.parametrize("sampler", ["host", "device"])
+def test_mapper_loop_grows_trains_and_prunes(agslib, sampler):
     """GaussianMap.update() for a few keyframes starting from an EMPTY map: add_gaussians -> train ->
     post_processing (prune every 2nd keyframe here).  Checks the loop's invariants and that the map
-    it builds explains the keyframes better than the freshly spawned surfels did."""
+    it builds explains the keyframes better than the freshly spawned surfels did.  ``sampler``: the
+    reference's host-side np.random.choice or the same distribution drawn on the GPU."""
     from active_gs_amd.fused_map_trainer import FusedMapTrainer
     g = _gold()
     z = lambda *s: torch.zeros(*s, device=DEV)
     raw = dict(means=z(0, 3), scales=z(0, 3), rotations=z(0, 4), opacities=z(0), harmonics=z(0, 1, 3))
     np.random.seed(3)
-    tr = FusedMapTrainer(raw, [], dict(optimization_steps=6, prune_interval=2, batch_size=4, active_size=2),
+    torch.manual_seed(3)
+    tr = FusedMapTrainer(raw, [], dict(optimization_steps=6, prune_interval=2, batch_size=4, active_size=2, sampler=sampler),
                          use_graph=False, num_streams=1)
     assert not tr.is_init
     sizes = []
