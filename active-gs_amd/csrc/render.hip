@@ -437,9 +437,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     for (int r = (int)((maxlast - 1) >> RSH); r >= 0; --r) {
         const uint32_t k0 = (uint32_t)r << RSH;
         ags_wave_lds_sync();
-        uint32_t m = 0;
-        if (lane < AGS_MFMA_STAGE && k0 + lane < maxlast)
-            m = ags_stage_one<SLOTS>(st, lane, geom, vals[(size_t)(rg.x + k0 + lane) * id_stride], bx0, by0, strip0);
+        uint32_t m = 0, my_gid = 0; // the staging lane keeps the surfel id: slot metadata reads it with v_readlane, not from LDS
+        if (lane < AGS_MFMA_STAGE && k0 + lane < maxlast) {
+            my_gid = vals[(size_t)(rg.x + k0 + lane) * id_stride];
+            m = ags_stage_one<SLOTS>(st, lane, geom, my_gid, bx0, by0, strip0);
+        }
         ags_wave_lds_sync();
         unsigned long long act = __ballot((m & my_strips) != 0u);
         while (act) { // back to front: highest staged position first
@@ -463,7 +465,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const float gp = (alpha < AGS_ALPHA_MAX) ? alpha * dalpha : 0.f;
             wb.gw[2 * nb][lane] = gp;
             wb.gw[2 * nb + 1][lane] = w;
-            if (lane == 0) wb.meta[nb] = make_float4(__uint_as_float(st.sid[k]), g.mx - cx, g.my - cy, 0.f);
+            const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)my_gid, k);
+            if (lane == 0) wb.meta[nb] = make_float4(__uint_as_float(sid), g.mx - cx, g.my - cy, 0.f);
             if (++nb == 8) flush();
         }
     }
