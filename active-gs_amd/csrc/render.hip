@@ -13,9 +13,11 @@
 //     of the 64-bit ballot of "reaches one of my strips" (s_ff1), and evaluates only the
 //     reachable strips under scalar branches; `__any` skips the accumulate when no lane takes
 //     the surfel and `__all(done)` ends the wave early;
-//   * the backward reduces each surfel's 15 partial gradients over the wave with a transposed
-//     permlane-swap/DPP reduction (ags_wave_reduce16) and issues ONE 15-lane atomic per
-//     (surfel, wave) instead of 64 x SLOTS x 15 atomics.
+//   * the backward (default: ags_k_render_bwd_mfma, one quadrant per wave) leaves the reduction of
+//     each surfel's 15 partial gradients over the wave's pixels to the f32 matrix cores and adds
+//     four whole gradient records per atomic instruction; the VALU form (ags_k_render_bwd<SLOTS>,
+//     AGS_BWD_MFMA=0) reduces with a transposed permlane-swap/DPP reduction (ags_wave_reduce16) and
+//     issues ONE 15-lane atomic per (surfel, wave) instead of 64 x SLOTS x 15 atomics.
 // SLOTS = 4 is one wave per tile; SLOTS = 2 / 1 split a tile over 2 / 4 waves (fewer VGPRs,
 // more waves in flight).  Measured best: 1 below ~12 k tiles in flight, 2 above (AGS_RENDER_SLOTS overrides).
 // Blocks are mapped to tiles XCD-aware (ags_xcd_remap) so one XCD's L2 serves a contiguous
