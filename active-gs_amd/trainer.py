@@ -284,7 +284,8 @@ class SurfelTrainer:
         if getattr(self, "_capturable", None) is not None:
             return self._capturable
         ok = False
-        if torch.distributed.get_backend(self.pg) == "nccl":
+        import os
+        if os.environ.get("AGS_DP_GRAPH_COLLECTIVES", "1") != "0" and torch.distributed.get_backend(self.pg) == "nccl":
             try:
                 world = torch.distributed.get_world_size(self.pg)
                 t = torch.ones(1, device=self.device)
