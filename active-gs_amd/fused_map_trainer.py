@@ -57,6 +57,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         self._loss = None
         self._loss_bufs = []
         self._cap = 0
+        self._last_need, self._last_need_n = None, 0   # most tile instances a view of the last train() call needed, and the map size then
         self.is_init = len(frames) > 0 and self.means.shape[0] > 0   # gaussian_map.py:35,130
 
     # ---- cached per-frame camera (the intrinsics -> fov step needs host scalars once per frame)
@@ -393,7 +394,10 @@ class FusedMapTrainer(GaussianMapTrainer):
             if graph is not None:
                 graph.replay()
             else:
-                while state["batch"] is None or (it == 0 and not fits()):
+                # the workspace probe (a forward + a status read-back) is skipped when the previous train() call's
+                # views needed well under what the workspace holds - an overflow is still caught after the loop
+                known_fit = self._last_need is not None and 1.5 * self._last_need * (n / max(self._last_need_n, 1)) <= self._cap
+                while state["batch"] is None or (it == 0 and not known_fit and not fits()):
                     keep["batch"] = None               # release the old buffers before the larger ones are made
                     ncap = int(n * 1.3) + 4096
                     self._cap = max(self._cap, 2 * ncap)
@@ -415,10 +419,14 @@ class FusedMapTrainer(GaussianMapTrainer):
                 continue
             losses[it].copy_(loss_now)
         batch = state["batch"]
-        if batch is not None and batch.overflowed(state["B"]):
-            self._cap = int(self._cap * 2)
-            raise RuntimeError("a view outgrew the rasterizer workspace during train(); call train() again "
-                               "(the capacity has been raised)")
+        if batch is not None:
+            status = batch.statuses(state["B"])
+            self._last_need, self._last_need_n = int(status[:, 0].max()), n
+            if bool(status[:, 2].any()):
+                self._cap = int(self._cap * 2)
+                self._last_need = None
+                raise RuntimeError("a view outgrew the rasterizer workspace during train(); call train() again "
+                                   "(the capacity has been raised)")
         self.last_losses = [float(x) for x in losses[:total].cpu()]
         self.post_processing()
 
