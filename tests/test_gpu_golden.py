@@ -208,17 +208,19 @@ def test_c5_size_scene_16384_tiles(agslib):
     assert torch.isfinite(g2.scales).all() and float(st.opacity.max()) <= 1.0 and float(st.opacity.min()) >= 0.0
 
 
-def test_matrix_core_backward_passes_the_same_fixtures(agslib):
-    """The opt-in blend backward that reduces on the matrix cores (AGS_BWD_MFMA=2, render.hip:
-    ags_k_render_bwd_mfma) against the same reference fixtures and oracle comparisons as the default
-    kernel.  The switch is read once per process, hence the subprocess."""
+def test_valu_backward_passes_the_same_fixtures(agslib):
+    """The blend backward has two forms: the default reduces each surfel's gradients on the matrix
+    cores (render.hip: ags_k_render_bwd_mfma), AGS_BWD_MFMA=0 selects the VALU kernels
+    (ags_k_render_bwd<SLOTS>).  Every other test runs the default; this one re-runs the reference
+    fixtures and the oracle comparisons with the VALU form.  The switch is read once per process,
+    hence the subprocess."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, AGS_BWD_MFMA="2")
+    env = dict(os.environ, AGS_BWD_MFMA="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_golden.py"),
                         os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
-                        "not matrix_core and (oracle or train or properties or c4_size or c5_size or row_set or batched_backward "
+                        "not valu_backward and (oracle or train or properties or c4_size or c5_size or row_set or batched_backward "
                         "or overfull or alpha_clamp)"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
