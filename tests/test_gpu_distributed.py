@@ -34,14 +34,14 @@ def _setup(views):
     return raw, cams, grads
 
 
-def _worker(rank, world, port, use_graph, ret, sparse_rows=True):
+def _worker(rank, world, port, use_graph, ret, sparse_rows=True, per_rank=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from active_gs_amd.trainer import RowExchange, SurfelTrainer
         RowExchange.GROWTH, RowExchange.SLACK = 1.25, 64   # small map: the production slack alone would exceed it
-        raw, cams, grads = _setup([rank])          # rank r renders view r
+        raw, cams, grads = _setup([rank + world * k for k in range(per_rank)])   # rank r renders views r, r + world, ...
         tr = SurfelTrainer(raw, sparse_rows=sparse_rows)
         fn = lambda v, st: (grads[v][0], grads[v][1], grads[v][2], None, None)
         tr.step(cams, fn, CAP, device_clock=True)
@@ -64,12 +64,15 @@ def _worker(rank, world, port, use_graph, ret, sparse_rows=True):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph,sparse_rows", [(False, True), (True, True), (False, False), (True, False)])
-def test_two_ranks_equal_single_process_two_views(agslib, use_graph, sparse_rows):
+@pytest.mark.parametrize("use_graph,sparse_rows,per_rank", [(False, True, 1), (True, True, 1), (False, False, 1),
+                                                            (True, False, 1), (True, True, 2)])
+def test_two_ranks_equal_single_process_two_views(agslib, use_graph, sparse_rows, per_rank):
     """sparse_rows: the ranks all-gather their member rows (RowExchange) and Adam steps over the
-    union; otherwise the dense slab is all-reduced.  Both must land on the one-process result."""
+    union; otherwise the dense slab is all-reduced.  Both must land on the one-process result
+    (per_rank = 2: two views per rank, accumulated in place before the exchange)."""
     from active_gs_amd.trainer import SurfelTrainer
-    raw, cams, grads = _setup([0, 1])
+    raw, cams, grads = _setup(list(range(2 * per_rank)))
+    init = [raw[k].clone().cpu() for k in ("means", "scales", "rotations", "opacities", "harmonics")]   # the trainer updates `raw` in place
     tr = SurfelTrainer(raw)
     fn = lambda v, st: (grads[v][0], grads[v][1], grads[v][2], None, None)
     for _ in range(STEPS):
@@ -79,12 +82,15 @@ def test_two_ranks_equal_single_process_two_views(agslib, use_graph, sparse_rows
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(2, port, use_graph, ret, sparse_rows), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, use_graph, ret, sparse_rows, per_rank), nprocs=2, join=True)
         for a, b in zip(ret[0], ret[1]):
             assert torch.equal(a, b)                               # replicas stay identical
-        for a, r, init in zip(ret[0], ref, [raw[k].cpu() for k in ("means", "scales", "rotations", "opacities", "harmonics")]):
-            travel = (r - init).abs().mean()
+        moved = 0
+        for a, r, i0 in zip(ret[0], ref, init):
+            travel = (r - i0).abs().mean()
+            moved += int(travel > 1e-6)
             assert (a - r).abs().mean() < 5e-3 * travel + 1e-9     # Adam eps=1e-15: sign flips on ~0 gradients
+        assert moved >= 4                                          # the optimiser did move the map (scales may sit on their clamp)
 
 
 def _fused_cfg(d):
