@@ -188,10 +188,17 @@ def main():
     # bring the GPU to its sustained clock before the W warm-up steps (a step is ~0.2 ms:
     # W of them alone finish before DVFS has settled)
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.5:
+    while True:
         for _ in range(20):
             one_step()
         torch.cuda.synchronize()
+        go = time.perf_counter() - t_pre < 0.5
+        if world > 1:   # every rank must run the same number of steps (each one is a collective): rank clocks differ
+            flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            go = bool(flag.item())
+        if not go:
+            break
     run_steps(args.warmup)
     torch.cuda.synchronize()
     barrier()
