@@ -287,7 +287,7 @@ def main():
                          "all_stages_GBps": {k: (sb[k] / (stage_ms[k] * 1e-3) / 1e9 if stage_ms[k] > 0 else 0.0)
                                              for k in sb}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only (contract)
             out["cpu_baseline"] = cpu_baseline(raw_cpu, dict(tanx=tanx, tany=tany, bg=bg, view=cm["viewmatrix"][0],
                                                              proj=cm["projmatrix"][0]))
         print(json.dumps(out))
