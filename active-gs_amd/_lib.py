@@ -94,7 +94,7 @@ class AgsCandidates(C.Structure):
 
 EXPORTS = ["ags_workspace_bytes", "ags_workspace_init", "ags_forward", "ags_forward_batch",
            "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_read_status", "ags_adam_step",
-           "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_smooth_depth", "ags_densify_candidates",
+           "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_rows_index", "ags_adam_step_gathered", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_smooth_depth", "ags_densify_candidates",
            "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_compact_plan_bytes", "ags_compact_plan",
            "ags_compact_rows", "ags_profile_enable", "ags_profile_read",
            "ags_error_string", "ags_version"]
@@ -151,6 +151,11 @@ def load() -> C.CDLL:
     lib.ags_rows_pack.argtypes = [C.POINTER(AgsRowSet), C.POINTER(C.c_void_p * 5), C.c_int32, C.c_void_p, C.c_void_p]
     lib.ags_rows_unpack.restype = C.c_int
     lib.ags_rows_unpack.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p * 5), C.POINTER(AgsRowSet), C.c_void_p]
+    lib.ags_rows_index.restype = C.c_int
+    lib.ags_rows_index.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(AgsRowSet), C.c_void_p]
+    lib.ags_adam_step_gathered.restype = C.c_int
+    lib.ags_adam_step_gathered.argtypes = [C.POINTER(AgsAdamTensors), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
+                                           C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]
     lib.ags_activate.restype = C.c_int
     lib.ags_activate.argtypes = [C.POINTER(AgsActivation), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ags_activate_backward.restype = C.c_int

@@ -202,6 +202,86 @@ void ags_launch_rows_unpack(const float* segment, int capacity, float* const gra
     hipLaunchKernelGGL(ags_k_rows_unpack, dim3(blocks), dim3(256), 0, s, segment, capacity, gp, uni);
 }
 
+// Two-launch tail of the row exchange for any number of ranks (instead of one unpack launch per rank
+// plus the row-set Adam): ags_k_rows_index notes, for every record of every segment, where its row
+// sits (slot_table[row * world + rank] = record + 1) and builds the union; ags_k_adam_rows_gathered
+// then runs one 16-lane group per union row, sums the row's gradient from the segments IN RANK ORDER
+// (so every rank forms bit-identical sums), applies the Adam update and leaves the table zeroed.
+__global__ __launch_bounds__(256) void ags_k_rows_index(const float* __restrict__ segs, size_t seg_floats, int capacity,
+                                                        int world, int* __restrict__ slot_table, AgsRowSet uni) {
+    const int rank = blockIdx.y;
+    const float* seg = segs + (size_t)rank * seg_floats;
+    const int count = min(__float_as_int(seg[0]), capacity);
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < count; r += gridDim.x * 256) {
+        const int row = __float_as_int(seg[16 + (size_t)r * 16 + 14]);
+        slot_table[(size_t)row * world + rank] = r + 1;
+        if (atomicCAS(&uni.member[row], 0, 1) == 0) uni.rows[atomicAdd(uni.count, 1)] = row; // several ranks may bring the row
+    }
+}
+
+__global__ __launch_bounds__(256) void ags_k_adam_rows_gathered(AgsAdamArgs a, const AgsAdamClock* __restrict__ clk,
+                                                                AgsRowSet uni, const float* __restrict__ segs,
+                                                                size_t seg_floats, int world, int* __restrict__ slot_table,
+                                                                float beta1, float beta2, float eps) {
+    const int k = threadIdx.x & 15;
+    const int seg = (k >= 3) + (k >= 6) + (k >= 10) + (k >= 11);
+    const int width = seg == 2 ? 4 : (seg == 3 ? 1 : 3);
+    const int off = k - (seg == 0 ? 0 : seg == 1 ? 3 : seg == 2 ? 6 : seg == 3 ? 10 : 11);
+    float* pm = seg == 0 ? a.m[0] : seg == 1 ? a.m[1] : seg == 2 ? a.m[2] : seg == 3 ? a.m[3] : a.m[4];
+    float* pv = seg == 0 ? a.v[0] : seg == 1 ? a.v[1] : seg == 2 ? a.v[2] : seg == 3 ? a.v[3] : a.v[4];
+    float* pp = seg == 0 ? a.p[0] : seg == 1 ? a.p[1] : seg == 2 ? a.p[2] : seg == 3 ? a.p[3] : a.p[4];
+    float ss[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) ss[q] = clk->step_size[q];
+    const float inv_bc2_sqrt = clk->inv_bc2_sqrt;
+    const float step_size = seg == 0 ? ss[0] : seg == 1 ? ss[1] : seg == 2 ? ss[2] : seg == 3 ? ss[3] : ss[4];
+    const int count = *uni.count;
+    const int stride = gridDim.x * 16;
+    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < count; r += stride) {
+        const int row = uni.rows[r];
+        int* tab = slot_table + (size_t)row * world;
+        float g = 0.f;
+        for (int s = 0; s < world; ++s) { // rank order: the same sum on every rank
+            const int t = tab[s];
+            if (t) g += segs[(size_t)s * seg_floats + 16 + (size_t)(t - 1) * 16 + (k < 14 ? k : 0)];
+        }
+        if (k < 14) {
+            const long long j = (long long)row * width + off;
+            float m = pm[j], v = pv[j];
+            m = m + (1.f - beta1) * (g - m);
+            v = v * beta2 + (1.f - beta2) * g * g;
+            const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+            pm[j] = m;
+            pv[j] = v;
+            pp[j] -= step_size * (m / denom);
+        }
+        // the update above needed g, i.e. every lane's table reads have returned (vmcnt is per wave); keep the
+        // compiler from moving the clearing stores ahead of them
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int s = k; s < world; s += 16) tab[s] = 0;
+    }
+}
+
+void ags_launch_rows_index(const float* segs, size_t seg_floats, int capacity, int world, int* slot_table,
+                           const AgsRowSet& uni, hipStream_t s) {
+    int blocks = (capacity + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(ags_k_rows_index, dim3(blocks, world), dim3(256), 0, s, segs, seg_floats, capacity, world, slot_table, uni);
+}
+void ags_launch_adam_gathered(const AgsAdamTensors& t, const float* segs, size_t seg_floats, int world, int* slot_table,
+                              float beta1, float beta2, float eps, void* dev_state, bool pre_ticked, hipStream_t s) {
+    const AgsAdamArgs a = ags_adam_args(t);
+    AgsAdamClock* clk = (AgsAdamClock*)dev_state;
+    if (!pre_ticked)
+        hipLaunchKernelGGL(ags_k_adam_tick, dim3(1), dim3(1), 0, s, clk, t.lr[0], t.lr[1], t.lr[2], t.lr[3], t.lr[4], beta1, beta2, 0);
+    long long rb = (t.numel[3] + 15) / 16; // 16 rows per block
+    if (rb > 16384) rb = 16384;
+    if (rb < 1) return;
+    hipLaunchKernelGGL(ags_k_adam_rows_gathered, dim3((unsigned)rb), dim3(256), 0, s, a, (const AgsAdamClock*)clk, t.touched,
+                       segs, seg_floats, world, slot_table, beta1, beta2, eps);
+}
+
 // ---------------------------------------------------------------------------------------
 // Activations (gaussian_map.py:529-549) and their chain rule, one lane per Gaussian.
 __global__ __launch_bounds__(256) void ags_k_activate(AgsActivation a, float* __restrict__ scales,

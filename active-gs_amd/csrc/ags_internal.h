@@ -157,6 +157,8 @@ __device__ __forceinline__ void ags_adam_tick(AgsAdamClock* c, const float lr[5]
 #endif
 void ags_launch_rows_pack(float* const grads[5], const AgsRowSet& rows, float* segment, int capacity, hipStream_t s);
 void ags_launch_rows_unpack(const float* segment, int capacity, float* const grads[5], const AgsRowSet& uni, hipStream_t s);
+void ags_launch_rows_index(const float* segs, size_t seg_floats, int capacity, int world, int* slot_table, const AgsRowSet& uni, hipStream_t s);
+void ags_launch_adam_gathered(const AgsAdamTensors& t, const float* segs, size_t seg_floats, int world, int* slot_table, float beta1, float beta2, float eps, void* dev_state, bool pre_ticked, hipStream_t s);
 void ags_launch_activate(const AgsActivation& a, float* scales, float* rotations, float* opacities, hipStream_t s);
 void ags_launch_activate_bwd(const AgsActivation& a, float* d_scales, float* d_rotations, float* d_opacities,
                              hipStream_t s);

@@ -208,6 +208,23 @@ int ags_rows_unpack(const float* segment, int32_t capacity, float* const grads[5
     return ags_check_launch();
 }
 
+int ags_rows_index(const float* segments, int32_t world, int32_t capacity, int32_t* slot_table, const AgsRowSet* union_rows,
+                   ags_stream_t stream) {
+    if (!ags_rows_ok(union_rows) || !segments || !slot_table || capacity < 0 || world < 1) return AGS_E_INVALID;
+    ags_launch_rows_index(segments, ags_rows_segment_floats(capacity), capacity, world, slot_table, *union_rows, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_adam_step_gathered(const AgsAdamTensors* t, const float* segments, int32_t world, int32_t capacity, int32_t* slot_table,
+                           float beta1, float beta2, float eps, void* state, int32_t pre_ticked, ags_stream_t stream) {
+    if (!t || !state || !segments || !slot_table || capacity < 0 || world < 1 || !ags_rows_ok(&t->touched)) return AGS_E_INVALID;
+    for (int k = 0; k < 5; ++k)
+        if (t->numel[k] < 0 || (t->numel[k] > 0 && (!t->param[k] || !t->exp_avg[k] || !t->exp_avg_sq[k]))) return AGS_E_INVALID;
+    ags_launch_adam_gathered(*t, segments, ags_rows_segment_floats(capacity), world, slot_table, beta1, beta2, eps, state,
+                             pre_ticked != 0, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
 int ags_activate(const AgsActivation* a, float* scales, float* rotations, float* opacities, ags_stream_t stream) {
     if (!a || a->n < 0) return AGS_E_INVALID;
     if (a->n > 0 && (!a->raw_scales || !a->raw_rotations || !a->raw_opacities || !scales || !rotations || !opacities))

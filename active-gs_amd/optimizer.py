@@ -77,3 +77,14 @@ class FusedAdam:
         else:
             _lib.check(lib.ags_adam_step(C.byref(t), self.betas[0], self.betas[1], self.eps, self.step_count,
                                          stream), "ags_adam_step")
+
+    def step_gathered(self, grads: Sequence[torch.Tensor], segments: torch.Tensor, world: int, capacity: int,
+                      slot_table: torch.Tensor, pre_ticked: bool = False) -> None:
+        """Adam over the ``touched`` rows with every row's gradient summed, in rank order, straight from
+        the all-gathered row segments (``ags_rows_index`` filled ``slot_table``); device clock only."""
+        t = self.tensors_struct(grads)
+        _lib.check(_lib.load().ags_adam_step_gathered(C.byref(t), ptr(segments), int(world), int(capacity), ptr(slot_table),
+                                                      self.betas[0], self.betas[1], self.eps, ptr(self.device_clock),
+                                                      int(pre_ticked), torch.cuda.current_stream().cuda_stream),
+                   "ags_adam_step_gathered")
+

@@ -58,6 +58,9 @@ class RowExchange:
     once with ``agree()``; ``overflowed()`` says whether a rank has outgrown it since."""
 
     GROWTH, SLACK = 1.5, 1024      # capacity = GROWTH x the largest rank's row count + SLACK
+    # after the all-gather: "indexed" = ags_rows_index + ags_adam_step_gathered (two launches for any number of
+    # ranks, no slab round trip); "unpack" = one ags_rows_unpack per rank, then the row-set Adam over the slab
+    TAIL = "indexed"
 
     def __init__(self, n: int, grads: Sequence[torch.Tensor], device, pg):
         self.n, self.pg, self.device = n, pg, device
@@ -85,6 +88,7 @@ class RowExchange:
         self.capacity = cap
         self.send = torch.zeros(seg, device=self.device, dtype=torch.float32)
         self.recv = torch.zeros(self.world, seg, device=self.device, dtype=torch.float32)
+        self.slot_table = torch.zeros(self.n * self.world, device=self.device, dtype=torch.int32)   # kept zeroed by the gathered Adam
         return cap
 
     def pack(self, rows: "api.RowSet") -> None:
@@ -109,6 +113,11 @@ class RowExchange:
         for r in range(self.world):                               # rank order: same sums everywhere
             _lib.check(lib.ags_rows_unpack(ptr(self.recv[r]), self.capacity, C.byref(self._grads), C.byref(u), stream),
                        "ags_rows_unpack")
+
+    def index(self) -> None:
+        u = self.union.c_struct()
+        _lib.check(_lib.load().ags_rows_index(ptr(self.recv), self.world, self.capacity, ptr(self.slot_table), C.byref(u),
+                                              torch.cuda.current_stream().cuda_stream), "ags_rows_index")
 
     def overflowed(self) -> bool:
         """Host-synchronous: has any rank needed more rows than the agreed capacity in the last exchange?"""
@@ -207,8 +216,12 @@ class SurfelTrainer:
 
     # -- one optimisation step -----------------------------------------------------------
     def _distributed(self) -> bool:
-        return torch.distributed.is_available() and torch.distributed.is_initialized() and \
-            torch.distributed.get_world_size(self.pg) > 1
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return False
+        # AGS_DP_FORCE=1 (tests): take the data-parallel path in a one-rank group too, which is how the RCCL
+        # collectives and their capture into the step graph are exercised on a single-GPU box
+        import os
+        return torch.distributed.get_world_size(self.pg) > 1 or os.environ.get("AGS_DP_FORCE") == "1"
 
     def gaussians(self) -> api.Gaussians:
         if self.fused_activations:
@@ -250,8 +263,16 @@ class SurfelTrainer:
         dist_on = self._distributed()
         ticked = self._local_pass(cams, image_grads, max_instances, tick=device_clock, fuse_adam=not dist_on)
         if dist_on:
-            self._exchange_gradients()
-        if not self.adam_fused:
+            self._exchange_gradients(device_clock)
+        self._optimizer_step(device_clock, ticked)
+
+    def _optimizer_step(self, device_clock: bool, ticked: bool) -> None:
+        if self.adam_fused:
+            return
+        x = self.exchange
+        if x is not None and x.capacity and x.TAIL == "indexed" and device_clock:
+            self.optim.step_gathered(self.slab.as_list(), x.recv, x.world, x.capacity, x.slot_table, pre_ticked=ticked)
+        else:
             self.optim.step(self.slab.as_list(), device_clock=device_clock, pre_ticked=ticked)
 
     def _row_exchange_on(self) -> bool:
@@ -268,13 +289,20 @@ class SurfelTrainer:
                 return False
         return True
 
-    def _exchange_gradients(self) -> None:
+    def _exchange_gradients(self, device_clock: bool = True) -> None:
         if self._row_exchange_on():
             self.exchange.pack(self.rows)
             self.exchange.gather()
-            self.exchange.unpack()
+            self._exchange_tail(device_clock)
         else:
             torch.distributed.all_reduce(self.slab.flat, group=self.pg)
+
+    def _exchange_tail(self, device_clock: bool = True) -> None:
+        """What follows the all-gather, up to (not including) the optimiser step."""
+        if self.exchange.TAIL == "indexed" and device_clock:
+            self.exchange.index()
+        else:
+            self.exchange.unpack()
 
     def _collectives_capturable(self) -> bool:
         """Can this process group's collectives be recorded into a hipGraph?  Only RCCL's can (they
@@ -339,7 +367,7 @@ class SurfelTrainer:
                         for _ in range(repeat):
                             ticked = self._local_pass(cams, image_grads, max_instances, tick=True)
                             self._exchange_gradients()
-                            self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
+                            self._optimizer_step(True, ticked)
                 except Exception:          # deterministic across ranks (same software): all fall back together
                     torch.cuda.synchronize()
                     self._capturable = in_graph = False
@@ -352,8 +380,8 @@ class SurfelTrainer:
                         self.exchange.pack(self.rows)
                 with torch.cuda.graph(g_opt, stream=side, capture_error_mode="thread_local"):
                     if rows_x:
-                        self.exchange.unpack()
-                    self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
+                        self._exchange_tail()
+                    self._optimizer_step(True, ticked)
             elif not dist_on:
                 with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
                     for _ in range(repeat):

@@ -106,7 +106,14 @@ def main():
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # test-only hook: AGS_DP_FORCE=1 runs the data-parallel step (exchange, union Adam, collectives in the graph)
+    # in a one-rank RCCL group - the overhead of that path without any wire time, measurable on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("AGS_DP_FORCE") == "1"
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # nccl IS RCCL on ROCm
@@ -160,10 +167,10 @@ def main():
         try:
             one_step = trainer.capture([cam], grads_fn, cap)
             in_graph = getattr(one_step, "collective_in_graph", False)
-            if world > 1:
+            if dist_on:
                 launch_mode = ("hipGraph replay, gradient exchange recorded in the graph" if in_graph
                                else "hipGraph replay: graph | collective | graph")
-            if args.graph_steps > 1 and (world == 1 or in_graph):
+            if args.graph_steps > 1 and (not dist_on or in_graph):
                 many_steps = trainer.capture([cam], grads_fn, cap, repeat=args.graph_steps)
                 per_replay = many_steps.steps
                 launch_mode += f", {per_replay} steps per graph"
@@ -182,7 +189,7 @@ def main():
             one_step()
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
 
     # bring the GPU to its sustained clock before the W warm-up steps (a step is ~0.2 ms:
@@ -193,7 +200,7 @@ def main():
             one_step()
         torch.cuda.synchronize()
         go = time.perf_counter() - t_pre < 0.5
-        if world > 1:   # every rank must run the same number of steps (each one is a collective): rank clocks differ
+        if dist_on:   # every rank must run the same number of steps (each one is a collective): rank clocks differ
             flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
             go = bool(flag.item())
@@ -209,7 +216,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
@@ -239,7 +246,7 @@ def main():
         T = ((H + 15) // 16) * ((W + 15) // 16)
         rows = int(trainer.rows.count.item()) if getattr(trainer, "rows", None) is not None else None
         x = getattr(trainer, "exchange", None)
-        if world == 1:
+        if not dist_on:
             exchange = None
         elif x is not None and x.capacity:
             exchange = {"kind": "all-gather of member rows (64 B per row)", "rows_per_segment": x.capacity,
@@ -273,7 +280,7 @@ def main():
                        "overflow": bool(info["overflow"]), "binning": args.binning,
                        "launch": launch_mode,
                        "optimizer": ("row-set Adam fused into the per-Gaussian backward (exact: untouched rows "
-                                     f"have zero gradient and moments), {rows} member rows") if (rows is not None and world == 1)
+                                     f"have zero gradient and moments), {rows} member rows") if (rows is not None and not dist_on)
                                     else ("row-set Adam over the union of the ranks' member rows" if rows is not None
                                           else "dense fused Adam kernel after the gradient all-reduce"),
                        "exchange": exchange,
@@ -291,7 +298,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(raw_cpu, dict(tanx=tanx, tany=tany, bg=bg, view=cm["viewmatrix"][0],
                                                              proj=cm["projmatrix"][0]))
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()  # rank 0 may still be in the CPU-baseline leg; leave together
         torch.distributed.destroy_process_group()
 

@@ -262,6 +262,19 @@ int ags_rows_pack(const AgsRowSet* rows, float* const grads[5], int32_t capacity
 int ags_rows_unpack(const float* segment, int32_t capacity, float* const grads[5],
                     const AgsRowSet* union_rows, ags_stream_t stream);
 
+/* The same tail in TWO launches for any number of ranks.  `segments` = the all-gather's output (world
+ * segments of ags_rows_segment_floats(capacity) floats, rank order); `slot_table` = n x world int32,
+ * zero-filled once by the caller and left zeroed by every ags_adam_step_gathered.
+ * ags_rows_index          one launch over all segments: slot_table[row][rank] = record + 1, union set built;
+ * ags_adam_step_gathered  Adam over the union rows (t->touched; t->grad is not read) with each row's
+ *                         gradient summed from the segments in rank order - bit-identical on every
+ *                         rank - on the device clock `state` (see ags_adam_step_device). */
+int ags_rows_index(const float* segments, int32_t world, int32_t capacity, int32_t* slot_table,
+                   const AgsRowSet* union_rows, ags_stream_t stream);
+int ags_adam_step_gathered(const struct AgsAdamTensors* t, const float* segments, int32_t world, int32_t capacity,
+                           int32_t* slot_table, float beta1, float beta2, float eps, void* state,
+                           int32_t pre_ticked, ags_stream_t stream);
+
 /* Activations of /root/reference/mapping/gaussian_map.py:529-549 (get_scales / get_rotations /
  * get_opacities): scales = clamp(scale_factor*exp(raw), 0, max_scale), rotations =
  * raw/max(|raw|,1e-12), opacities = sigmoid(raw).  One lane per Gaussian. */

@@ -201,3 +201,75 @@ def test_row_segments_pack_unpack(agslib):
     _lib.check(lib.ags_rows_pack(C.byref(r), C.byref(gp), cap, seg.data_ptr(), stream), "pack")
     assert seg[:2].view(torch.int32).tolist() == [cap, 2000]
     assert lib.ags_rows_pack(None, C.byref(gp), cap, seg.data_ptr(), stream) != 0
+
+
+def test_rccl_collectives_are_captured_into_the_step_graph(agslib):
+    """One-rank RCCL group, data-parallel path forced on (tests/tools/rccl_one_rank.py): torch's RCCL
+    all-gather / all-reduce are recorded inside the step's hipGraph (three steps per graph) and the
+    replays land on the plain trainer's parameters - for the row exchange and for the dense slab."""
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "rccl_one_rank.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout.splitlines(), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_indexed_exchange_tail_equals_unpack_then_adam(agslib):
+    """ags_rows_index + ags_adam_step_gathered (two launches for any number of ranks) against one
+    ags_rows_unpack per rank followed by the row-set Adam: bit-identical parameters and moments, the
+    slot table left zeroed, the same union."""
+    import ctypes as C
+    from active_gs_amd import _lib, raster_api as api
+    from active_gs_amd.optimizer import FusedAdam
+    from active_gs_amd.trainer import GradSlab
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    n, cap, world = 6000, 1500, 5
+    seg_floats = int(lib.ags_rows_segment_floats(cap))
+    gen = torch.Generator().manual_seed(1)
+    stream = torch.cuda.current_stream().cuda_stream
+    slab = GradSlab(n, dev)
+    gp = (C.c_void_p * 5)(*[t.data_ptr() for t in slab.as_list()])
+    recv = torch.zeros(world, seg_floats, device=dev)
+    for rank, count in enumerate((1200, 0, 1500, 3, 700)):            # an empty segment and overlapping rows
+        rows = api.RowSet(n, dev)
+        idx = torch.randperm(n, generator=gen)[:count].int().to(dev)
+        rows.rows[:count] = idx
+        rows.count.fill_(count)
+        for t, w in zip(slab.as_list(), (3, 3, 4, 1, 3)):
+            t.view(n, w)[idx.long()] = torch.randn(count, w, generator=gen).to(dev)
+        r = rows.c_struct()
+        _lib.check(lib.ags_rows_pack(C.byref(r), C.byref(gp), cap, recv[rank].data_ptr(), stream), "pack")
+    assert float(slab.flat.abs().max()) == 0.0
+
+    def fresh():
+        g2 = torch.Generator().manual_seed(2)
+        params = [torch.randn(n, w, generator=g2).to(dev) if w > 1 else torch.randn(n, generator=g2).to(dev) for w in (3, 3, 4, 1, 3)]
+        params[4] = params[4].view(n, 1, 3)
+        opt = FusedAdam(params, [5e-4, 1e-2, 5e-4, 1e-2, 1e-4], eps=1e-15)
+        for t in opt.exp_avg + opt.exp_avg_sq:                         # non-trivial moments
+            t.copy_(torch.rand(t.shape, generator=g2).to(dev) * 1e-3)
+        uni = api.RowSet(n, dev)
+        opt.touched, opt.zero_grad = uni, True
+        return params, opt, uni
+
+    pa, oa, ua = fresh()                                                # A: unpack per rank, then Adam over the slab rows
+    u = ua.c_struct()
+    for rank in range(world):
+        _lib.check(lib.ags_rows_unpack(recv[rank].data_ptr(), cap, C.byref(gp), C.byref(u), stream), "unpack")
+    oa.step(slab.as_list(), device_clock=True)
+    pb, ob, ub = fresh()                                                # B: index, then Adam gathering from the segments
+    table = torch.zeros(n * world, device=dev, dtype=torch.int32)
+    u = ub.c_struct()
+    _lib.check(lib.ags_rows_index(recv.data_ptr(), world, cap, table.data_ptr(), C.byref(u), stream), "index")
+    assert int((table != 0).sum()) == 1200 + 1500 + 3 + 700
+    ob.step_gathered(slab.as_list(), recv, world, cap, table)
+    torch.cuda.synchronize()
+    assert int(table.abs().max()) == 0                                  # left clean for the next step
+    ka, kb = int(ua.count.item()), int(ub.count.item())
+    assert ka == kb and torch.equal(torch.sort(ua.rows[:ka]).values, torch.sort(ub.rows[:kb]).values)
+    for a, b in zip(pa + oa.exp_avg + oa.exp_avg_sq, pb + ob.exp_avg + ob.exp_avg_sq):
+        assert torch.equal(a, b)                                        # the same sums in the same (rank) order
+    assert float(slab.flat.abs().max()) == 0.0
