@@ -50,7 +50,8 @@ class AgsGaussianGrads(C.Structure):
     _fields_ = [("d_means3D", c_f32p), ("d_scales", c_f32p), ("d_rotations", c_f32p), ("d_opacities", c_f32p),
                 ("d_colors", c_f32p), ("d_means2D", c_f32p), ("accumulate", C.c_int32), ("adam_clock", C.c_void_p),
                 ("adam_lr", C.c_float * 5), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float),
-                ("touched", AgsRowSet), ("fused_adam", C.c_void_p), ("adam_eps", C.c_float)]
+                ("touched", AgsRowSet), ("fused_adam", C.c_void_p), ("adam_eps", C.c_float),
+                ("pack_segment", c_f32p), ("pack_capacity", C.c_int32)]
 
 
 class AgsWorkspace(C.Structure):

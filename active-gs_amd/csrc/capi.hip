@@ -135,6 +135,8 @@ int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* 
         const int64_t n64 = in->n;
         if (ne[0] != 3 * n64 || ne[1] != 3 * n64 || ne[2] != 4 * n64 || ne[3] != n64 || ne[4] != 3 * n64) return AGS_E_INVALID;
     }
+    if (din->pack_segment && (!din->touched.rows || !din->touched.count || din->fused_adam || din->accumulate == 2 ||
+                              din->pack_capacity < 0)) return AGS_E_INVALID;
     { StageScope t(AGS_STAGE_RENDER_BWD, s); ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, tick, kOneView, s); }
     { StageScope t(AGS_STAGE_PREPROCESS_BWD, s); ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, kOneView, s); }
     return ags_check_launch();
@@ -146,7 +148,7 @@ int ags_backward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* 
     if (!cam || !in || !fwd || !pg || !dout || !din || !ws || !ws->ptr || views < 1 || views > 65535) return AGS_E_INVALID;
     if (in->n <= 0 || !pg->radii || !fwd->depth || !fwd->opacity) return AGS_E_INVALID;
     if (!din->d_means3D || !din->d_scales || !din->d_rotations || !din->d_opacities || !din->d_colors) return AGS_E_INVALID;
-    if (din->accumulate != 2 || din->fused_adam) return AGS_E_INVALID; // views sum with atomics into a pre-zeroed slab
+    if (din->accumulate != 2 || din->fused_adam || din->pack_segment) return AGS_E_INVALID; // views sum with atomics into a pre-zeroed slab
     if (ws->binning_mode != AGS_BIN_TILE_SORT) return AGS_E_INVALID;
     const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
     if (ws->bytes < (size_t)views * L.total) return AGS_E_WORKSPACE;

@@ -247,7 +247,10 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
 // second kernel and no gradient round trip.  The clock was advanced by the blend backward that
 // ran just before on this stream (AgsTick), so every lane reads finished scalars.
 #define AGS_ROWS_THREADS 64 // one wave per workgroup: the few member rows spread over all CUs
-template <bool FUSED_ADAM>
+// MODE 2 (AgsGaussianGrads.pack_segment): the data-parallel step's last view per rank - the row's
+// totals go straight into the rank's exchange segment (record = the row's position in the list: one
+// 64-byte store per lane, see ags_rows_pack in adam.hip for the layout) and the slab is left zeroed.
+template <int MODE>
 __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsAdamArgs adam,
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
         radii += (size_t)blockIdx.y * (size_t)vs.n;
         AGS_WS_SHIFT(dgeom, (size_t)blockIdx.y * (size_t)vs.ws);
     }
+    constexpr bool FUSED_ADAM = MODE == 1, PACK = MODE == 2;
     float V[16], P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
@@ -268,6 +272,8 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
     const int slot0 = min(blockIdx.x * AGS_ROWS_THREADS + lane, in.n - 1);
     int i_next = out.touched.rows[slot0];
     const int count = *out.touched.count;
+    if (PACK && blockIdx.x == 0 && lane < 16) // segment header: rows shipped, rows the set holds
+        out.pack_segment[lane] = __int_as_float(lane == 0 ? min(count, out.pack_capacity) : lane == 1 ? count : 0);
     for (int base = blockIdx.x * AGS_ROWS_THREADS; base < count; base += gridDim.x * AGS_ROWS_THREADS) { // wave-uniform
         const bool valid = base + lane < count;
         const int i = valid ? i_next : 0;
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
                 if (out.d_means2D) { unsafeAtomicAdd(&out.d_means2D[3 * i], dm2[0]); unsafeAtomicAdd(&out.d_means2D[3 * i + 1], dm2[1]); }
             }
         } else if (out.accumulate) {
-            if (vis || (FUSED_ADAM && valid)) { // the fused step needs the totals of rows this view does not show too
+            if (vis || ((FUSED_ADAM || PACK) && valid)) { // the fused step / the exchange need the totals of rows this view does not show too
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     dm[k] += out.d_means3D[3 * i + k]; ds[k] += out.d_scales[3 * i + k]; dcol[k] += out.d_colors[3 * i + k];
@@ -345,7 +351,14 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
                 dq[0] += o.x; dq[1] += o.y; dq[2] += o.z; dq[3] += o.w;
                 dop += out.d_opacities[i];
             }
-            if (vis) {
+            if (PACK) { // the totals leave in the segment: the earlier views' partial sums are cleared
+                if (valid) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { out.d_means3D[3 * i + k] = 0.f; out.d_scales[3 * i + k] = 0.f; out.d_colors[3 * i + k] = 0.f; }
+                    reinterpret_cast<float4*>(out.d_rotations)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    out.d_opacities[i] = 0.f;
+                }
+            } else if (vis) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     out.d_means3D[3 * i + k] = dm[k]; out.d_scales[3 * i + k] = ds[k]; out.d_colors[3 * i + k] = dcol[k];
@@ -354,7 +367,7 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
                 out.d_opacities[i] = dop;
                 if (out.d_means2D) { out.d_means2D[3 * i] += dm2[0]; out.d_means2D[3 * i + 1] += dm2[1]; }
             }
-        } else if (valid) { // overwrite: member rows this view does not show get their zeros
+        } else if (valid && !PACK) { // overwrite: member rows this view does not show get their zeros
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 out.d_means3D[3 * i + k] = dm[k]; out.d_scales[3 * i + k] = ds[k]; out.d_colors[3 * i + k] = dcol[k];
@@ -362,6 +375,13 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
             reinterpret_cast<float4*>(out.d_rotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
             out.d_opacities[i] = dop;
             if (out.d_means2D) { out.d_means2D[3 * i] = dm2[0]; out.d_means2D[3 * i + 1] = dm2[1]; out.d_means2D[3 * i + 2] = 0.f; }
+        }
+        if (PACK && valid && base + lane < out.pack_capacity) {
+            float4* rec = reinterpret_cast<float4*>(out.pack_segment + 16 + (size_t)(base + lane) * 16);
+            rec[0] = make_float4(dm[0], dm[1], dm[2], ds[0]);
+            rec[1] = make_float4(ds[1], ds[2], dq[0], dq[1]);
+            rec[2] = make_float4(dq[2], dq[3], dop, dcol[0]);
+            rec[3] = make_float4(dcol[1], dcol[2], __int_as_float(i), 0.f);
         }
         if (FUSED_ADAM && valid) {
             // the row's Adam state was requested together with its inputs (am / av / ap above), so it is
@@ -416,11 +436,15 @@ void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const Ag
         int blocks = (in.n + AGS_ROWS_THREADS - 1) / AGS_ROWS_THREADS;
         if (blocks > 16384) blocks = 16384; // fixed grid (the member count lives on the device): idle blocks exit at once
         if (din.fused_adam)
-            hipLaunchKernelGGL(ags_k_preprocess_bwd_rows<true>, dim3(blocks), dim3(AGS_ROWS_THREADS), 0, s, F,
+            hipLaunchKernelGGL(ags_k_preprocess_bwd_rows<1>, dim3(blocks), dim3(AGS_ROWS_THREADS), 0, s, F,
                                cam.viewmatrix, cam.projmatrix, in, radii, (AgsGeomGrad*)(ws + L.dgeom), din,
                                ags_adam_args(*din.fused_adam), vs);
+        else if (din.pack_segment)
+            hipLaunchKernelGGL(ags_k_preprocess_bwd_rows<2>, dim3(blocks), dim3(AGS_ROWS_THREADS), 0, s, F,
+                               cam.viewmatrix, cam.projmatrix, in, radii, (AgsGeomGrad*)(ws + L.dgeom), din,
+                               AgsAdamArgs(), vs);
         else
-            hipLaunchKernelGGL(ags_k_preprocess_bwd_rows<false>, dim3(blocks, vs.views), dim3(AGS_ROWS_THREADS), 0, s, F,
+            hipLaunchKernelGGL(ags_k_preprocess_bwd_rows<0>, dim3(blocks, vs.views), dim3(AGS_ROWS_THREADS), 0, s, F,
                                cam.viewmatrix, cam.projmatrix, in, radii, (AgsGeomGrad*)(ws + L.dgeom), din,
                                AgsAdamArgs(), vs);
         return;

@@ -198,12 +198,14 @@ def alloc_grads(n: int, device, with_means2d: bool = False, zero: bool = False) 
 def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_normal=None, d_depth=None,
              d_opacity=None, d_confidence=None, grads: Optional[GaussianGrads] = None,
              accumulate: bool = False, adam_tick=None, stream: Optional[int] = None,
-             touched: Optional[RowSet] = None, fused_adam=None) -> GaussianGrads:
+             touched: Optional[RowSet] = None, fused_adam=None, pack=None) -> GaussianGrads:
     """Enqueue the backward pass of the view held in ``state``. Asynchronous.
     ``adam_tick`` = (device_clock_tensor, lrs, beta1, beta2): also advance that Adam clock.
     ``touched``: the ``RowSet`` given to this view's ``forward``: only its rows are written.
     ``fused_adam`` = (AgsAdamTensors struct, eps): the launch also performs the optimiser step for
-    the member rows (last view of a single-GPU step; needs ``touched`` and ``adam_tick``)."""
+    the member rows (last view of a single-GPU step; needs ``touched`` and ``adam_tick``).
+    ``pack`` = (segment tensor, capacity): the member rows' totals leave as the rank's exchange segment
+    (last view of a rank's data-parallel step; needs ``touched``), the gradient rows are left zeroed."""
     lib = _lib.load()
     if grads is None:
         grads = alloc_grads(g.n, g.means3D.device)
@@ -228,6 +230,10 @@ def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_norma
         tensors, eps = fused_adam
         din.fused_adam = C.cast(C.pointer(tensors), C.c_void_p)
         din.adam_eps = float(eps)
+    if pack is not None:
+        segment, capacity = pack
+        din.pack_segment = ptr(segment)
+        din.pack_capacity = int(capacity)
     _lib.check(lib.ags_backward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(dout), C.byref(din),
                                 C.byref(ws), _stream() if stream is None else stream), "ags_backward")
     return grads

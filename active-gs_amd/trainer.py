@@ -238,14 +238,20 @@ class SurfelTrainer:
         ticked = False
         self.adam_fused = False
         fuse_adam = fuse_adam and tick and self.rows is not None and self.fused_activations
+        # data-parallel step with an agreed segment size: the rank's last backward writes the exchange segment itself
+        x = self.exchange
+        pack = (x.send, x.capacity) if (x is not None and x.capacity and self.fused_activations and len(cams) > 0) else None
+        self._packed = pack is not None
         for v, cam in enumerate(cams):
             st = self.state_for(cam.image_height, cam.image_width, max_instances)
             api.forward(cam, g, st, touched=self.rows)
             d = image_grads(v, st)
-            last = tick and v == len(cams) - 1
+            final = v == len(cams) - 1
+            last = tick and final
             fused = (self.optim.tensors_struct(self.slab.as_list()), self.optim.eps) if (last and fuse_adam) else None
             api.backward(cam, g, st, *d, grads=self.slab.grads, accumulate=(v > 0),
-                         adam_tick=self.optim.tick_args() if last else None, touched=self.rows, fused_adam=fused)
+                         adam_tick=self.optim.tick_args() if last else None, touched=self.rows, fused_adam=fused,
+                         pack=pack if final else None)
             ticked |= last
             self.adam_fused |= fused is not None
         if len(cams) == 0:
@@ -291,7 +297,8 @@ class SurfelTrainer:
 
     def _exchange_gradients(self, device_clock: bool = True) -> None:
         if self._row_exchange_on():
-            self.exchange.pack(self.rows)
+            if not getattr(self, "_packed", False):      # first step (segment size not agreed yet) or no views on this rank
+                self.exchange.pack(self.rows)
             self.exchange.gather()
             self._exchange_tail(device_clock)
         else:
@@ -376,7 +383,7 @@ class SurfelTrainer:
             if dist_on and not in_graph:
                 with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
                     ticked = self._local_pass(cams, image_grads, max_instances, tick=True)
-                    if rows_x:
+                    if rows_x and not self._packed:
                         self.exchange.pack(self.rows)
                 with torch.cuda.graph(g_opt, stream=side, capture_error_mode="thread_local"):
                     if rows_x:

@@ -152,6 +152,13 @@ typedef struct AgsGaussianGrads {
      * above is still written).  Do not call ags_adam_step* for that step.  Not with accumulate 2. */
     const struct AgsAdamTensors* fused_adam;
     float adam_eps;
+    /* Optional (NULL = off): the data-parallel form of the same idea.  Give it with the LAST view a
+     * rank renders in a step, together with `touched` (accumulate 0 or 1, no fused_adam): instead of
+     * leaving the rows' totals in the gradient arrays the per-Gaussian kernel writes them as the rank's
+     * exchange segment (what ags_rows_pack would produce from them, header included) and leaves the
+     * gradient rows zeroed - no separate pack launch. */
+    float* pack_segment;   /* ags_rows_segment_floats(pack_capacity) floats */
+    int32_t pack_capacity;
 } AgsGaussianGrads;
 
 #define AGS_BIN_TILE_SORT 0 /* tile counting + bucket scatter + per-tile LDS bitonic sort (default) */

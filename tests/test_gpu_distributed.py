@@ -273,3 +273,47 @@ def test_indexed_exchange_tail_equals_unpack_then_adam(agslib):
     for a, b in zip(pa + oa.exp_avg + oa.exp_avg_sq, pb + ob.exp_avg + ob.exp_avg_sq):
         assert torch.equal(a, b)                                        # the same sums in the same (rank) order
     assert float(slab.flat.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("two_views", [False, True])
+def test_backward_writes_the_exchange_segment_itself(agslib, two_views):
+    """AgsGaussianGrads.pack_segment: the last backward of a rank's step leaves the member rows' totals
+    as the exchange segment - the same segment ags_rows_pack makes from the gradient slab (up to the
+    blend backward's atomic summation order), same header and row ids, slab left zeroed."""
+    import ctypes as C
+    from active_gs_amd import _lib, raster_api as api
+    from active_gs_amd.synthetic import activate
+    from active_gs_amd.trainer import GradSlab
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    raw, cams, grads = _setup([0, 1] if two_views else [0])
+    a = activate({k: v for k, v in raw.items()})
+    g = api.Gaussians(a["means"], a["scales"], a["rotations"], a["opacities"], raw["harmonics"].view(-1, 3).contiguous(), a["confidences"])
+    cap = 6000
+    seg_floats = int(lib.ags_rows_segment_floats(cap))
+    stream = torch.cuda.current_stream().cuda_stream
+    segs = []
+    for fused in (False, True):
+        slab, rows = GradSlab(N, dev), api.RowSet(N, dev)
+        seg = torch.full((seg_floats,), 3.0, device=dev)
+        for v, cam in enumerate(cams):
+            st = api.alloc_state(N, H, W, CAP, dev)
+            api.forward(cam, g, st, touched=rows)
+            final = v == len(cams) - 1
+            api.backward(cam, g, st, grads[v][0], grads[v][1], grads[v][2], grads=slab.grads, accumulate=(v > 0),
+                         touched=rows, pack=(seg, cap) if (fused and final) else None)
+        if not fused:
+            gp = (C.c_void_p * 5)(*[t.data_ptr() for t in slab.as_list()])
+            r = rows.c_struct()
+            _lib.check(lib.ags_rows_pack(C.byref(r), C.byref(gp), cap, seg.data_ptr(), stream), "pack")
+        torch.cuda.synchronize()
+        assert float(slab.flat.abs().max()) == 0.0
+        k = int(rows.count.item())
+        assert 0 < k <= cap and seg[:2].view(torch.int32).tolist() == [k, k]
+        recs = seg[16:16 + 16 * k].view(k, 16)
+        order = torch.argsort(recs[:, 14].view(torch.int32))          # list order depends on atomic arrival: compare by row id
+        segs.append((recs[order, 14].view(torch.int32).clone(), recs[order, :14].clone()))
+    assert torch.equal(segs[0][0], segs[1][0])
+    a0, a1 = segs[0][1], segs[1][1]
+    assert float(a0.abs().max()) > 0
+    assert float((a0 - a1).abs().sum() / a0.abs().sum()) < 1e-5
