@@ -309,7 +309,10 @@ struct AgsWaveBatch {       // one per wave, in LDS
     float4 meta[8];         // per slot: {surfel id bits, mean - quadrant centre (x, y), -}
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void ags_k_render_bwd_mfma(
+#ifndef AGS_MFMA_WAVES
+#define AGS_MFMA_WAVES 6      // register budget: 512 / 6 -> 80 VGPRs
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAVES, AGS_MFMA_WAVES))) void ags_k_render_bwd_mfma(
     AgsFrame F, int normalize_depth, const float* __restrict__ bgp, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
     const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
@@ -435,7 +438,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         nb = 0;
     };
 
-    constexpr int RSH = AGS_MFMA_STAGE == 64 ? 6 : 5;
+    constexpr int RSH = AGS_MFMA_STAGE == 64 ? 6 : (AGS_MFMA_STAGE == 32 ? 5 : 4);
+    static_assert((1 << RSH) == AGS_MFMA_STAGE, "records staged per round: 16, 32 or 64");
     for (int r = (int)((maxlast - 1) >> RSH); r >= 0; --r) {
         const uint32_t k0 = (uint32_t)r << RSH;
         ags_wave_lds_sync();
