@@ -50,11 +50,12 @@ class GradSlab:
 
 
 class RowExchange:
-    """Sparse gradient exchange of the view-parallel step over ``ags_rows_pack`` / ``ags_rows_unpack``
-    (include/ags_raster.h): every rank packs the slab rows of its own sticky row set into a fixed
-    size segment, ONE all-gather moves the segments, and every rank adds them into its (now zero)
-    slab in rank order - bit-identical sums on every rank - while collecting the union of the rows,
-    which is what the replicated Adam then steps over.  ``capacity`` (rows per segment) is agreed
+    """Sparse gradient exchange of the view-parallel step (include/ags_raster.h: ``ags_rows_pack`` or
+    ``AgsGaussianGrads.pack_segment``, ``ags_rows_index`` + ``ags_adam_step_gathered``, or
+    ``ags_rows_unpack``): every rank ships the gradient rows of its own sticky row set as a fixed
+    size segment, ONE all-gather moves the segments, and every rank sums them in rank order -
+    bit-identical sums on every rank - over the union of the rows, which is what the replicated
+    Adam steps over.  ``capacity`` (rows per segment) is agreed
     once with ``agree()``; ``overflowed()`` says whether a rank has outgrown it since."""
 
     GROWTH, SLACK = 1.5, 1024      # capacity = GROWTH x the largest rank's row count + SLACK
