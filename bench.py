@@ -118,6 +118,7 @@ def main():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # nccl IS RCCL on ROCm
         else:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # test transport, ranks on one host: never pick a NIC by hostname
             dist.init_process_group(backend)
 
     from active_gs_amd import _lib, raster_api as api

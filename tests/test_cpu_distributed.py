@@ -19,6 +19,7 @@ def _worker(rank, world, port, ret):
     torch.set_num_threads(2)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # both ranks are on this host: never pick a NIC by hostname
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from test_cpu_host_logic import _train_from_fixture
@@ -56,6 +57,7 @@ def _gather_worker(rank, world, port, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # both ranks are on this host: never pick a NIC by hostname
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from active_gs_amd.trainer import RowExchange

@@ -19,7 +19,8 @@ def test_bench_two_ranks_on_one_gpu(agslib):
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
            "--warmup", "3", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=480)
-    assert r.returncode == 0, r.stderr[-2000:]
+    trace = "\n".join(l for l in r.stderr.splitlines() if l.lstrip().startswith(("File ", "Thread ", "Current thread")))
+    assert r.returncode == 0, trace[-3000:] + "\n...\n" + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                  # exactly one JSON line, from rank 0
     d = json.loads(lines[0])

@@ -37,6 +37,7 @@ def _setup(views):
 def _worker(rank, world, port, use_graph, ret, sparse_rows=True, per_rank=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # both ranks are on this host: never pick a NIC by hostname
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from active_gs_amd.trainer import RowExchange, SurfelTrainer
@@ -112,6 +113,7 @@ def _fused_worker(rank, world, port, ret):
     import numpy as np
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # both ranks are on this host: never pick a NIC by hostname
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from active_gs_amd.fused_map_trainer import FusedMapTrainer
