@@ -14,6 +14,7 @@ import torch
 from . import densify
 from . import raster_api as api
 from .camera import camera_matrices
+from .dist_util import all_reduce_
 from .fused_loss import FusedLoss
 from .map_trainer import GaussianMapTrainer, WeightedFrameSampler
 from .optimizer import FusedAdam
@@ -179,13 +180,13 @@ class FusedMapTrainer(GaussianMapTrainer):
             if not mine:
                 self._loss.msum.zero_()
             if self.world > 1:
-                dist.all_reduce(self._loss.msum, group=self.pg)
+                all_reduce_(self._loss.msum, group=self.pg)
             if S > 1 or not mine:
                 slab.flat.zero_()
             fan_out(bwd_view)
             if self.world > 1:
-                dist.all_reduce(slab.flat, group=self.pg)
-                dist.all_reduce(self._loss.accum, group=self.pg)  # 64 x (4+2B) floats
+                all_reduce_(slab.flat, group=self.pg)
+                all_reduce_(self._loss.accum, group=self.pg)  # 64 x (4+2B) floats
             self.training_performance[torch.as_tensor(ids, device=self.device)] = self._loss.per_frame_errors(B)
             optim.step(slab.as_list())
             self.last_losses.append(self._loss.total_loss())

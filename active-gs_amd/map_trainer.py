@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .dist_util import all_reduce_
 from .facade import SurfelRenderer, training_losses
 
 DEFAULT_CFG = dict(bound=(0.001, 10.0), scale_factor=0.01, optimization_steps=10, prune_interval=5, error_thres=0.25,
@@ -121,7 +122,7 @@ class GaussianMapTrainer:
             else:
                 msum = torch.zeros(1, h, w, dtype=torch.long, device=self.device)
             if self.world > 1:
-                dist.all_reduce(msum, group=self.pg)
+                all_reduce_(msum, group=self.pg)
             per_frame_all = torch.zeros(B, device=self.device)
             if mine:
                 total, per_frame = training_losses(rgb, depth, normal, opacity, d2n, rgb_gt[mine], depth_gt[mine],
@@ -135,7 +136,7 @@ class GaussianMapTrainer:
                 loss_val = torch.zeros(1, device=self.device)
             if self.world > 1:
                 flat = torch.cat([g.reshape(-1) for g in grads] + [per_frame_all, loss_val])
-                dist.all_reduce(flat, group=self.pg)            # one collective: 14N grads + B errors + loss
+                all_reduce_(flat, group=self.pg)            # one collective: 14N grads + B errors + loss
                 o = 0
                 for i, g in enumerate(grads):
                     grads[i] = flat[o:o + g.numel()].view_as(g)
@@ -167,7 +168,7 @@ class GaussianMapTrainer:
             seen_i = (counts[-1] >= 1.0).to(torch.int32) if newest_here else torch.zeros(n, dtype=torch.int32, device=self.device)
             if self.world > 1:
                 both = torch.stack([counts_sum, seen_i])
-                torch.distributed.all_reduce(both, group=self.pg)  # counts over all views + newest view's row
+                all_reduce_(both, group=self.pg)  # counts over all views + newest view's row
                 counts_sum, seen_i = both[0], both[1]
             seen = seen_i > 0
             self.view_supports += seen.float()

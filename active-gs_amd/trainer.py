@@ -21,6 +21,7 @@ from typing import Callable, Optional, Sequence
 import torch
 
 from . import _lib, raster_api as api
+from .dist_util import all_reduce_
 from ._lib import ptr
 
 DEFAULT_LRS = dict(mean=5e-4, scale=1e-2, rotation=5e-4, opacity=1e-2, harmonic=1e-4)  # incremental.yaml:27-32
@@ -78,7 +79,7 @@ class RowExchange:
         row count + SLACK; 0 if gathering the segments would not move clearly fewer bytes than
         all-reducing the dense slab."""
         t = torch.tensor([int(local_rows)], device=self.device, dtype=torch.int64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+        all_reduce_(t, torch.distributed.ReduceOp.MAX, self.pg)
         cap = min(self.n, int(self.GROWTH * int(t.item())) + self.SLACK)
         seg = int(_lib.load().ags_rows_segment_floats(cap))
         # bytes a rank receives: (world-1) segments against 2 (world-1)/world slabs of a ring all-reduce;
@@ -101,12 +102,11 @@ class RowExchange:
         if torch.distributed.get_backend(self.pg) == "nccl":     # RCCL: one all-gather over xGMI
             torch.distributed.all_gather_into_tensor(self.recv.view(-1), self.send, group=self.pg)
         else:
-            # transports without a device all-gather (gloo, used by the tests): the same data movement
-            # as an integer all-reduce of a buffer that is zero outside the rank's own segment
-            bits = self.recv.view(torch.int32)
-            bits.zero_()
-            bits[self.rank].copy_(self.send.view(torch.int32))
-            torch.distributed.all_reduce(bits, group=self.pg)
+            # transports without a device all-gather (gloo, used by the tests): gathered on the host
+            mine = self.send.cpu()
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            torch.distributed.all_gather(parts, mine, group=self.pg)
+            self.recv.copy_(torch.stack(parts))
 
     def unpack(self) -> None:
         lib, u = _lib.load(), self.union.c_struct()
@@ -303,7 +303,7 @@ class SurfelTrainer:
             self.exchange.gather()
             self._exchange_tail(device_clock)
         else:
-            torch.distributed.all_reduce(self.slab.flat, group=self.pg)
+            all_reduce_(self.slab.flat, group=self.pg)
 
     def _exchange_tail(self, device_clock: bool = True) -> None:
         """What follows the all-gather, up to (not including) the optimiser step."""
@@ -343,7 +343,7 @@ class SurfelTrainer:
                 torch.cuda.synchronize()
         # every rank must take the same branch
         flag = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
-        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=self.pg)
+        all_reduce_(flag, torch.distributed.ReduceOp.MIN, self.pg)
         self._capturable = bool(flag.item())
         return self._capturable
 
@@ -404,7 +404,7 @@ class SurfelTrainer:
                 if rows_x:
                     self.exchange.gather()
                 else:
-                    torch.distributed.all_reduce(self.slab.flat, group=self.pg)
+                    all_reduce_(self.slab.flat, group=self.pg)
                 g_opt.replay()
 
         replay.collective_in_graph = in_graph

@@ -124,6 +124,7 @@ def main():
     from active_gs_amd import _lib, raster_api as api
     from active_gs_amd.camera import camera_matrices
     from active_gs_amd.synthetic import make_camera, make_room_scene
+    from active_gs_amd.dist_util import all_reduce_
     from active_gs_amd.trainer import SurfelTrainer
 
     lib = _lib.load()
@@ -203,7 +204,7 @@ def main():
         go = time.perf_counter() - t_pre < 0.5
         if dist_on:   # every rank must run the same number of steps (each one is a collective): rank clocks differ
             flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            all_reduce_(flag, torch.distributed.ReduceOp.MAX)
             go = bool(flag.item())
         if not go:
             break
@@ -219,7 +220,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        all_reduce_(t, torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
     st = trainer.state_for(H, W, cap)
     info = api.read_status(st)
