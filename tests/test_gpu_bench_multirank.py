@@ -35,8 +35,11 @@ def test_bench_two_ranks_on_one_gpu(agslib):
                 with open(os.path.join(out, "bench_multirank_stall.log"), "w") as f:
                     f.write(r.stderr + "\n==== stdout ====\n" + first.stdout + r.stdout)
             trace = [l for l in r.stderr.splitlines() if " in " in l and "line " in l and ", line" not in l]   # faulthandler frames
-            pytest.skip("two bench ranks sharing the GPU over gloo stalled twice on this node; watchdog stacks:\n" +
-                        "\n".join(trace[-60:]))
+            msg = ("two bench ranks sharing the GPU over gloo stalled twice on this node; watchdog stacks:\n" +
+                   "\n".join(trace[-60:]))
+            if os.environ.get("AGS_TEST_STALL_XFAIL") == "1":
+                pytest.xfail(msg)
+            pytest.fail(msg)     # a deadlock regression looks exactly like this: it must not turn into a green run
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                  # exactly one JSON line, from rank 0
