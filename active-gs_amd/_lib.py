@@ -61,7 +61,8 @@ class AgsWorkspace(C.Structure):
 
 class AgsStatus(C.Structure):
     _fields_ = [("num_instances", C.c_uint32), ("num_sorted", C.c_uint32), ("overflow", C.c_uint32),
-                ("num_visible", C.c_uint32), ("reserved", C.c_uint32 * 12)]
+                ("num_visible", C.c_uint32), ("peak_instances", C.c_uint32), ("overflow_passes", C.c_uint32),
+                ("reserved", C.c_uint32 * 10)]
 
 
 class AgsAdamTensors(C.Structure):

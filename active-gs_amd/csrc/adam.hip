@@ -219,10 +219,19 @@ __global__ __launch_bounds__(256) void ags_k_rows_index(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void ags_k_adam_rows_gathered(AgsAdamArgs a, const AgsAdamClock* __restrict__ clk,
+__global__ __launch_bounds__(256) void ags_k_adam_rows_gathered(AgsAdamArgs a, AgsAdamClock* __restrict__ clk,
                                                                 AgsRowSet uni, const float* __restrict__ segs,
-                                                                size_t seg_floats, int world, int* __restrict__ slot_table,
+                                                                size_t seg_floats, int world, int capacity,
+                                                                int* __restrict__ slot_table,
                                                                 float beta1, float beta2, float eps) {
+    // A rank whose row set has outgrown the agreed segment shipped only part of its gradient (header word 1 =
+    // rows it holds > capacity).  Every rank sees every header, so all of them take the same decision with no
+    // further exchange: the step is NOT applied (parameters, moments and the step counter stay as they were,
+    // the slot table is still cleaned) and counted in clk->skipped; the host reads that counter every few steps,
+    // agrees on a larger segment and repeats the refused steps (trainer.SurfelTrainer).
+    bool over = false;
+    for (int s = 0; s < world; ++s) over |= __float_as_int(segs[(size_t)s * seg_floats + 1]) > capacity;   // wave-uniform
+    if (over && blockIdx.x == 0 && threadIdx.x == 0) { clk->step -= 1; clk->skipped += 1; }   // nobody reads the clock in a refused step
     const int k = threadIdx.x & 15;
     const int seg = (k >= 3) + (k >= 6) + (k >= 10) + (k >= 11);
     const int width = seg == 2 ? 4 : (seg == 3 ? 1 : 3);
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(256) void ags_k_adam_rows_gathered(AgsAdamArgs a, c
             const int t = tab[s];
             if (t) g += segs[(size_t)s * seg_floats + 16 + (size_t)(t - 1) * 16 + (k < 14 ? k : 0)];
         }
-        if (k < 14) {
+        if (k < 14 && !over) {
             const long long j = (long long)row * width + off;
             float m = pm[j], v = pv[j];
             m = m + (1.f - beta1) * (g - m);
@@ -269,8 +278,9 @@ void ags_launch_rows_index(const float* segs, size_t seg_floats, int capacity, i
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     hipLaunchKernelGGL(ags_k_rows_index, dim3(blocks, world), dim3(256), 0, s, segs, seg_floats, capacity, world, slot_table, uni);
 }
-void ags_launch_adam_gathered(const AgsAdamTensors& t, const float* segs, size_t seg_floats, int world, int* slot_table,
-                              float beta1, float beta2, float eps, void* dev_state, bool pre_ticked, hipStream_t s) {
+void ags_launch_adam_gathered(const AgsAdamTensors& t, const float* segs, size_t seg_floats, int world, int capacity,
+                              int* slot_table, float beta1, float beta2, float eps, void* dev_state, bool pre_ticked,
+                              hipStream_t s) {
     const AgsAdamArgs a = ags_adam_args(t);
     AgsAdamClock* clk = (AgsAdamClock*)dev_state;
     if (!pre_ticked)
@@ -278,8 +288,8 @@ void ags_launch_adam_gathered(const AgsAdamTensors& t, const float* segs, size_t
     long long rb = (t.numel[3] + 15) / 16; // 16 rows per block
     if (rb > 16384) rb = 16384;
     if (rb < 1) return;
-    hipLaunchKernelGGL(ags_k_adam_rows_gathered, dim3((unsigned)rb), dim3(256), 0, s, a, (const AgsAdamClock*)clk, t.touched,
-                       segs, seg_floats, world, slot_table, beta1, beta2, eps);
+    hipLaunchKernelGGL(ags_k_adam_rows_gathered, dim3((unsigned)rb), dim3(256), 0, s, a, clk, t.touched,
+                       segs, seg_floats, world, capacity, slot_table, beta1, beta2, eps);
 }
 
 // ---------------------------------------------------------------------------------------

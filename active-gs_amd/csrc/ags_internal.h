@@ -87,7 +87,9 @@ static inline AgsFrame ags_make_frame(const AgsCamera* c) {
 }
 
 // Device-resident optimiser clock shared by adam.hip, render.hip (tick) and preprocess.hip (fused step)
-struct AgsAdamClock { int step; float step_size[5]; float inv_bc2_sqrt; float pad[9]; };
+// `skipped`: optimisation steps ags_adam_step_gathered refused (a rank's row set had outgrown the agreed exchange
+// segment): sticky, cleared when the caller zeroes the clock together with the optimiser state
+struct AgsAdamClock { int step; float step_size[5]; float inv_bc2_sqrt; int skipped; float pad[8]; };
 struct AgsAdamArgs {
     float* p[5];
     const float* g[5];
@@ -158,7 +160,7 @@ __device__ __forceinline__ void ags_adam_tick(AgsAdamClock* c, const float lr[5]
 void ags_launch_rows_pack(float* const grads[5], const AgsRowSet& rows, float* segment, int capacity, hipStream_t s);
 void ags_launch_rows_unpack(const float* segment, int capacity, float* const grads[5], const AgsRowSet& uni, hipStream_t s);
 void ags_launch_rows_index(const float* segs, size_t seg_floats, int capacity, int world, int* slot_table, const AgsRowSet& uni, hipStream_t s);
-void ags_launch_adam_gathered(const AgsAdamTensors& t, const float* segs, size_t seg_floats, int world, int* slot_table, float beta1, float beta2, float eps, void* dev_state, bool pre_ticked, hipStream_t s);
+void ags_launch_adam_gathered(const AgsAdamTensors& t, const float* segs, size_t seg_floats, int world, int capacity, int* slot_table, float beta1, float beta2, float eps, void* dev_state, bool pre_ticked, hipStream_t s);
 void ags_launch_activate(const AgsActivation& a, float* scales, float* rotations, float* opacities, hipStream_t s);
 void ags_launch_activate_bwd(const AgsActivation& a, float* d_scales, float* d_rotations, float* d_opacities,
                              hipStream_t s);

@@ -10,6 +10,13 @@
 // wave-wide digit matching with __ballot (64-bit) — no LDS sort, no atomics in the ranks.
 #include "ags_internal.h"
 
+// AgsStatus.peak_instances / overflow_passes: written by the ONE thread that publishes a pass's status block;
+// passes on one workspace are stream-ordered, so plain read-modify-write is enough (no atomics)
+__device__ __forceinline__ void ags_status_sticky(uint32_t* status, uint32_t total, uint32_t cap) {
+    if (total > status[4]) status[4] = total;
+    if (total > cap) status[5] += 1u;
+}
+
 // ------------------------------------------------------------------ F2: scan of block sums
 // number of visible surfels = sum of the per-block counts the preprocess kernel left
 __device__ __forceinline__ uint32_t ags_sum_block_vis(const uint32_t* __restrict__ block_vis, int nblk, uint32_t* sh16) {
@@ -54,6 +61,7 @@ __global__ __launch_bounds__(1024) void ags_k_scan_blocks(uint32_t* __restrict__
         status[1] = total < cap ? total : cap;
         status[2] = total > cap ? 1u : 0u;
         status[3] = nvis;
+        ags_status_sticky(status, total, cap);
     }
 }
 
@@ -334,6 +342,7 @@ __global__ __launch_bounds__(1024) void ags_k_scan_tiles(const uint32_t* __restr
         status[1] = total < cap ? total : cap;
         status[2] = total > cap ? 1u : 0u;
         status[3] = nvis;
+        ags_status_sticky(status, total, cap);
     }
 }
 
@@ -405,6 +414,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
                 status[0] = total;
                 status[1] = total < cap ? total : cap;
                 status[2] = total > cap ? 1u : 0u;
+                ags_status_sticky(status, total, cap);
                 uint32_t nv = 0;
                 for (int k = 0; k < AGS_PRE_THREADS / 64; ++k) nv += wtot[k];
                 status[3] = nv;

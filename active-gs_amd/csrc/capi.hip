@@ -58,7 +58,11 @@ int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* o
     const bool radix = ws->binning_mode == AGS_BIN_RADIX;
     // tile-sort mode is self-cleaning (see ags_workspace_init); the radix path re-zeroes its digit
     // totals and tile ranges every pass
-    if ((radix || in->n == 0) && hipMemsetAsync(base + L.status, 0, L.clear_bytes, s) != hipSuccess) return AGS_E_LAUNCH;
+    // (status words 0-3 and everything behind the status block; the sticky words 4-5 of AgsStatus survive)
+    if (radix || in->n == 0) {
+        if (hipMemsetAsync(base + L.status, 0, 16, s) != hipSuccess) return AGS_E_LAUNCH;
+        if (hipMemsetAsync(base + L.totals, 0, L.clear_bytes - L.totals, s) != hipSuccess) return AGS_E_LAUNCH;
+    }
     if (in->n > 0) {
         { StageScope t(AGS_STAGE_PREPROCESS, s); ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, !radix, pg->touched, kOneView, s); }
         { StageScope t(AGS_STAGE_BINNING, s);
@@ -222,7 +226,7 @@ int ags_adam_step_gathered(const AgsAdamTensors* t, const float* segments, int32
     if (!t || !state || !segments || !slot_table || capacity < 0 || world < 1 || !ags_rows_ok(&t->touched)) return AGS_E_INVALID;
     for (int k = 0; k < 5; ++k)
         if (t->numel[k] < 0 || (t->numel[k] > 0 && (!t->param[k] || !t->exp_avg[k] || !t->exp_avg_sq[k]))) return AGS_E_INVALID;
-    ags_launch_adam_gathered(*t, segments, ags_rows_segment_floats(capacity), world, slot_table, beta1, beta2, eps, state,
+    ags_launch_adam_gathered(*t, segments, ags_rows_segment_floats(capacity), world, capacity, slot_table, beta1, beta2, eps, state,
                              pre_ticked != 0, (hipStream_t)stream);
     return ags_check_launch();
 }

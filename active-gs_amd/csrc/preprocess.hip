@@ -352,7 +352,7 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
                 dop += out.d_opacities[i];
             }
             if (PACK) { // the totals leave in the segment: the earlier views' partial sums are cleared
-                if (valid) {
+                if (valid && base + lane < out.pack_capacity) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) { out.d_means3D[3 * i + k] = 0.f; out.d_scales[3 * i + k] = 0.f; out.d_colors[3 * i + k] = 0.f; }
                     reinterpret_cast<float4*>(out.d_rotations)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -376,12 +376,25 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
             out.d_opacities[i] = dop;
             if (out.d_means2D) { out.d_means2D[3 * i] = dm2[0]; out.d_means2D[3 * i + 1] = dm2[1]; out.d_means2D[3 * i + 2] = 0.f; }
         }
-        if (PACK && valid && base + lane < out.pack_capacity) {
-            float4* rec = reinterpret_cast<float4*>(out.pack_segment + 16 + (size_t)(base + lane) * 16);
-            rec[0] = make_float4(dm[0], dm[1], dm[2], ds[0]);
-            rec[1] = make_float4(ds[1], ds[2], dq[0], dq[1]);
-            rec[2] = make_float4(dq[2], dq[3], dop, dcol[0]);
-            rec[3] = make_float4(dcol[1], dcol[2], __int_as_float(i), 0.f);
+        if (PACK && valid) {
+            if (base + lane < out.pack_capacity) {
+                float4* rec = reinterpret_cast<float4*>(out.pack_segment + 16 + (size_t)(base + lane) * 16);
+                rec[0] = make_float4(dm[0], dm[1], dm[2], ds[0]);
+                rec[1] = make_float4(ds[1], ds[2], dq[0], dq[1]);
+                rec[2] = make_float4(dq[2], dq[3], dop, dcol[0]);
+                rec[3] = make_float4(dcol[1], dcol[2], __int_as_float(i), 0.f);
+            } else {
+                // the segment is full (the caller sized it too small: header word 1 > capacity says so): like
+                // ags_rows_pack, rows that do not travel keep their totals in the gradient arrays, so nothing
+                // is lost - the caller restores the shipped rows (ags_rows_unpack of its own segment), agrees
+                // on a larger segment and exchanges again, or repeats the step
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    out.d_means3D[3 * i + k] = dm[k]; out.d_scales[3 * i + k] = ds[k]; out.d_colors[3 * i + k] = dcol[k];
+                }
+                reinterpret_cast<float4*>(out.d_rotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+                out.d_opacities[i] = dop;
+            }
         }
         if (FUSED_ADAM && valid) {
             // the row's Adam state was requested together with its inputs (am / av / ap above), so it is

@@ -100,9 +100,57 @@ class FusedMapTrainer(GaussianMapTrainer):
             return False
         return True
 
+    def _check_capacity_sticky(self, slots) -> bool:
+        """After a loop: did ANY pass on these workspaces since they were initialised need more tile instances
+        than they hold (``AgsStatus.peak_instances / overflow_passes``)?  Raises ``_cap`` if so.  With several
+        ranks the answer is agreed (MAX) so that all of them repeat the call together."""
+        peak, bad = 0, 0
+        for s in slots:
+            info = api.read_status(self._states[s])
+            peak, bad = max(peak, info["peak_instances"]), bad + info["overflow_passes"]
+        if self.world > 1:
+            t = torch.tensor([peak, bad], device=self.device, dtype=torch.int64)
+            all_reduce_(t, torch.distributed.ReduceOp.MAX, self.pg)
+            peak, bad = int(t[0]), int(t[1])
+        if bad:
+            self._cap = max(int(peak * 1.5) + 4096, self._cap + 1)
+            return False
+        return True
+
+    # ---- a train() call is all-or-nothing: a view that outgrows its workspace in ANY iteration truncates its
+    # tile lists (wrong gradients, no crash), so the loops below only note it (sticky status words, read once
+    # after the loop) and the call is then repeated from a snapshot with larger workspaces
+    def _snapshot(self) -> dict:
+        import numpy as np
+        snap = {k: getattr(self, k).clone() for k in ("means", "scales", "rotations", "opacities", "harmonics",
+                                                     "training_performance")}
+        snap["np_rng"] = np.random.get_state()           # the reference's sampler draws from numpy's global stream
+        snap["cuda_rng"] = torch.cuda.get_rng_state(self.device)   # cfg["sampler"] = "device"
+        return snap
+
+    def _restore(self, snap: dict) -> None:
+        import numpy as np
+        for k in ("means", "scales", "rotations", "opacities", "harmonics", "training_performance"):
+            getattr(self, k).copy_(snap[k])
+        np.random.set_state(snap["np_rng"])
+        torch.cuda.set_rng_state(snap["cuda_rng"], self.device)
+
+    def _all_or_nothing(self, run, steps) -> None:
+        snap = self._snapshot()
+        for _ in range(6):
+            if run(steps):
+                self.post_processing()
+                return
+            self.overflow_retries = getattr(self, "overflow_retries", 0) + 1
+            self._restore(snap)
+        raise RuntimeError("train(): the rasterizer workspace kept overflowing after six enlargements")
+
     def train(self, steps: Optional[int] = None):
         if self.batched and self._uniform_frames():
             return self.train_batched(steps)
+        self._all_or_nothing(self._train_views, steps)
+
+    def _train_views(self, steps: Optional[int] = None) -> bool:
         dist = torch.distributed
         lrs = self.cfg["lrs"]
         for name in ("means", "scales", "rotations", "opacities", "harmonics"):
@@ -175,8 +223,13 @@ class FusedMapTrainer(GaussianMapTrainer):
                     for slot in range(len(mine)):   # allocate outside the side streams
                         self._state(slot, n, h, w)
                 fan_out(fwd_view)
-                if it > 0 or self._check_capacity(range(len(mine))):
+                # first iteration: cheap early sizing (nothing has been stepped yet).  Later iterations are
+                # covered by the sticky status words read once after the loop.  (world > 1: no per-rank
+                # re-run here, the ranks' collectives must stay aligned.)
+                if it > 0 or self.world > 1 or self._check_capacity(range(len(mine))):
                     break
+                for slot in range(len(mine)):       # re-allocated (fresh sticky words) by _state() above on the re-run
+                    self._states.pop(slot, None)
             if not mine:
                 self._loss.msum.zero_()
             if self.world > 1:
@@ -190,11 +243,13 @@ class FusedMapTrainer(GaussianMapTrainer):
             self.training_performance[torch.as_tensor(ids, device=self.device)] = self._loss.per_frame_errors(B)
             optim.step(slab.as_list())
             self.last_losses.append(self._loss.total_loss())
-        if not self._check_capacity(self._states.keys()):
-            raise RuntimeError("a view outgrew the rasterizer workspace during train(); call train() again "
-                               "(the capacity has been raised)")
+        used = [s for s in self._states if isinstance(s, int)]
+        if not self._check_capacity_sticky(used):
+            for s in used:
+                self._states.pop(s)
+            return False
         self.last_losses = [float(x) for x in self.last_losses]
-        self.post_processing()
+        return True
 
     def _render_counts(self, frame_ids, extr, intr, depth_gt, params, hw):
         """Count render of post_processing straight through the C ABI (forward only, importance /
@@ -287,6 +342,9 @@ class FusedMapTrainer(GaussianMapTrainer):
         return len(shapes) == 1 and len(tans) == 1   # one AgsFrame for the whole batch
 
     def train_batched(self, steps: Optional[int] = None):
+        self._all_or_nothing(self._train_batched, steps)
+
+    def _train_batched(self, steps: Optional[int] = None) -> bool:
         """``train`` with the B views of an iteration in ONE set of launches: 4 forward kernels, 2 loss
         kernels, 2 backward kernels and the row-set Adam per ITERATION instead of per view (a 512x512
         view is 1024 tiles - a quarter of what the GPU holds).  The sampled frames' poses and
@@ -421,15 +479,15 @@ class FusedMapTrainer(GaussianMapTrainer):
             losses[it].copy_(loss_now)
         batch = state["batch"]
         if batch is not None:
-            status = batch.statuses(state["B"])
-            self._last_need, self._last_need_n = int(status[:, 0].max()), n
-            if bool(status[:, 2].any()):
-                self._cap = int(self._cap * 2)
+            status = batch.statuses()                     # every slot, sticky words: any pass of any iteration
+            self._last_need, self._last_need_n = int(status[:, 4].max()), n
+            if bool(status[:, 5].any()):
+                self._cap = max(int(self._last_need * 1.5) + 4096, self._cap + 1)
                 self._last_need = None
-                raise RuntimeError("a view outgrew the rasterizer workspace during train(); call train() again "
-                                   "(the capacity has been raised)")
+                keep["batch"] = None                      # too small: the repeat allocates a larger one
+                return False
         self.last_losses = [float(x) for x in losses[:total].cpu()]
-        self.post_processing()
+        return True
 
     # ------------------------------------------------------------------ hipGraph iteration
     def _graph_ok(self) -> bool:
@@ -442,6 +500,9 @@ class FusedMapTrainer(GaussianMapTrainer):
         and one field of view).  Falls back to ``train`` when those conditions do not hold."""
         if not self._graph_ok():
             return self.train(steps)
+        self._all_or_nothing(self._train_graph, steps)
+
+    def _train_graph(self, steps: Optional[int] = None) -> bool:
         lrs = self.cfg["lrs"]
         for name in ("means", "scales", "rotations", "opacities", "harmonics"):
             setattr(self, name, getattr(self, name).contiguous())
@@ -495,12 +556,7 @@ class FusedMapTrainer(GaussianMapTrainer):
             _, _, _, _, ids = sampler.next_frames(self.training_performance)
             stage(ids)
             if it == 0:
-                while True:       # eager first iteration: sizes the workspaces, creates every buffer
-                    optim.device_clock.zero_()
-                    iteration(tick=True)
-                    if self._check_capacity(range(B)):
-                        break
-                    raise RuntimeError("workspace grown during the first iteration; call train_graph() again")
+                iteration(tick=True)   # eager first iteration: creates every buffer (an overflow shows in the sticky status)
             else:
                 if graph is None:
                     side = torch.cuda.Stream()
@@ -513,8 +569,10 @@ class FusedMapTrainer(GaussianMapTrainer):
                 graph.replay()
             self.training_performance[torch.as_tensor(ids, device=dev)] = self._loss.per_frame_errors(B)
             self.last_losses.append(self._loss.total_loss())
-        if not self._check_capacity(range(B)):
-            raise RuntimeError("a view outgrew the rasterizer workspace during train_graph(); call it again")
+        if not self._check_capacity_sticky(range(B)):
+            for b in range(B):
+                self._states.pop(b)
+            return False
         self.last_losses = [float(x) for x in self.last_losses]
         self._graph = graph
-        self.post_processing()
+        return True

@@ -29,13 +29,28 @@ class FusedAdam:
         self.exp_avg = [torch.zeros_like(p) for p in params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in params]
         self.step_count = 0
-        # device-resident clock {int step; float step_size[5]; float inv_sqrt_bc2; ...} for graph replay
+        # device-resident clock {int step; float step_size[5]; float inv_sqrt_bc2; int skipped; ...} for graph replay
         self.device_clock = torch.zeros(16, device=params[0].device, dtype=torch.int32)
+        self._clock_on_device = None   # where the ONE logical step counter currently lives (see use_clock)
         # optional raster_api.RowSet: update only the surfels this optimiser's views have shown
         # (exact: the others have zero gradient and zero moments, so the dense update is 0)
         self.touched = None
         # with ``touched``: gradient rows are zeroed as they are consumed (slabs the views add into atomically)
         self.zero_grad = False
+
+    def use_clock(self, device: bool) -> None:
+        """There is one logical step counter; it lives either in ``step_count`` (host, ``ags_adam_step``) or in
+        ``device_clock`` (``ags_adam_step_device``, what a captured graph replays on).  Switching between the two
+        carries the count over, so bias correction never restarts with warm moments (eager host-clock steps
+        followed by ``capture()``, or the other way round).  Device -> host costs one 4-byte read-back."""
+        if self._clock_on_device is device:
+            return
+        if device:
+            if self.step_count:
+                self.device_clock[0] = self.step_count
+        elif self._clock_on_device is not None:
+            self.step_count = int(self.device_clock[0].item())
+        self._clock_on_device = device
 
     def tick_args(self):
         """What ``raster_api.backward(adam_tick=...)`` needs to advance this optimizer's device clock."""
@@ -67,6 +82,7 @@ class FusedAdam:
         (``ags_adam_step_device``), so the call can be captured in a hipGraph and replayed;
         ``pre_ticked`` says the step's last backward launch already advanced that clock."""
         lib = _lib.load()
+        self.use_clock(device_clock)
         if not device_clock:
             self.step_count += 1
         t = self.tensors_struct(grads)

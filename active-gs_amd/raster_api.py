@@ -175,7 +175,7 @@ def read_status(state: ForwardState) -> dict:
     ws = state.ws_struct()
     _lib.check(lib.ags_read_status(C.byref(ws), C.byref(st), _stream()), "ags_read_status")
     return dict(num_instances=st.num_instances, num_sorted=st.num_sorted, overflow=bool(st.overflow),
-                num_visible=st.num_visible)
+                num_visible=st.num_visible, peak_instances=st.peak_instances, overflow_passes=st.overflow_passes)
 
 
 @dataclass
@@ -423,13 +423,15 @@ class ViewBatch:
         return self.states
 
     def statuses(self, views: Optional[int] = None) -> torch.Tensor:
-        """Blocking: the first four words of every view's status block in ONE transfer ->
-        (views, 4) int64 on the host: instances needed, instances sorted, overflow flag, visible."""
+        """Blocking: the first six words of every view's status block (``AgsStatus``) in ONE transfer ->
+        (views, 6) int64 on the host: instances needed, instances sorted, overflow flag, visible, and the two
+        sticky words - peak instances and number of overflowed passes since the workspaces were (re)bound."""
         V = self.num_views if views is None else int(views)
         per = self._per
-        words = self.workspace[:self.num_views * per].view(self.num_views, per)[:V, :16].contiguous().view(torch.int32).view(V, 4)
+        words = self.workspace[:self.num_views * per].view(self.num_views, per)[:V, :24].contiguous().view(torch.int32).view(V, 6)
         return (words.cpu().to(torch.int64)) & 0xFFFFFFFF
 
     def overflowed(self, views: Optional[int] = None) -> bool:
-        """Blocking: did any view need more tile instances than ``max_instances``?"""
+        """Blocking: did any view need more tile instances than ``max_instances`` in its LAST pass?
+        (``statuses()[:, 5]``: in any pass since ``bind``.)"""
         return bool(self.statuses(views)[:, 2].any())

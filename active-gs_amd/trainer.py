@@ -70,17 +70,20 @@ class RowExchange:
         self.rank = torch.distributed.get_rank(pg)
         self.union = api.RowSet(n, device)
         self.capacity = None                      # None: not agreed yet; 0: the dense all-reduce is smaller
+        self.agreements = 0                       # how often agree() ran (1 + the number of regrowths)
         self._grads = (C.c_void_p * 5)(*[ptr(g) for g in grads])
         self._keep = list(grads)
         self.send = self.recv = None
 
     def agree(self, local_rows: int, slab_floats: int) -> int:
-        """Collective (host-synchronous, once per optimiser): capacity = GROWTH x the largest rank's
-        row count + SLACK; 0 if gathering the segments would not move clearly fewer bytes than
-        all-reducing the dense slab."""
+        """Collective (host-synchronous; on the first step of an optimiser and again whenever a rank has
+        outgrown the segment): capacity = GROWTH x the largest rank's row count + SLACK, never smaller
+        than before; 0 if gathering the segments would not move clearly fewer bytes than all-reducing the
+        dense slab."""
         t = torch.tensor([int(local_rows)], device=self.device, dtype=torch.int64)
         all_reduce_(t, torch.distributed.ReduceOp.MAX, self.pg)
-        cap = min(self.n, int(self.GROWTH * int(t.item())) + self.SLACK)
+        cap = min(self.n, max(int(self.GROWTH * int(t.item())) + self.SLACK, (self.capacity or 0) + 1))
+        self.agreements += 1
         seg = int(_lib.load().ags_rows_segment_floats(cap))
         # bytes a rank receives: (world-1) segments against 2 (world-1)/world slabs of a ring all-reduce;
         # the row path also pays world unpack launches, so it has to win by a margin
@@ -121,11 +124,23 @@ class RowExchange:
                                               torch.cuda.current_stream().cuda_stream), "ags_rows_index")
 
     def overflowed(self) -> bool:
-        """Host-synchronous: has any rank needed more rows than the agreed capacity in the last exchange?"""
+        """Host-synchronous: has any rank needed more rows than the agreed capacity in the last exchange?
+        Every rank reads the same gathered headers, so every rank gets the same answer."""
         if not self.capacity:
             return False
         needed = self.recv[:, 1].view(torch.int32)
         return bool((needed > self.capacity).any().item())
+
+    def needed_rows(self) -> int:
+        """Host-synchronous: the largest row count any rank reported in the last exchange."""
+        return int(self.recv[:, 1].view(torch.int32).max().item()) if self.capacity else 0
+
+    def restore_own(self) -> None:
+        """Undo this rank's pack: add its own segment back into the gradient arrays (the rows that did not fit
+        never left them), so the arrays hold the rank's complete gradient again."""
+        lib, u = _lib.load(), self.union.c_struct()
+        _lib.check(lib.ags_rows_unpack(ptr(self.send), self.capacity, C.byref(self._grads), C.byref(u),
+                                       torch.cuda.current_stream().cuda_stream), "ags_rows_unpack")
 
     def reset(self) -> None:
         self.union.reset()
@@ -174,11 +189,18 @@ class SurfelTrainer:
             else:
                 self.optim.touched = self.rows
         self._state = {}
+        # steps since the last look at the device-side overflow notes (refused exchange steps, workspace
+        # overflow), with what is needed to repeat them: see check_overflow()
+        self._pending = []
+        self.exchange_regrowths = 0
+
+    CHECK_EVERY = 16     # optimisation steps between two reads of the overflow notes (one 64-byte D2H each)
 
     def reset_optimizer(self) -> None:
         """What the reference does at the start of every ``train()`` call (``init_training``,
         gaussian_map.py:259-292): a fresh Adam.  Moments, step counter, gradient slab and the sticky
         row set are cleared together (the row set's losslessness rests on exactly that)."""
+        self.check_overflow()              # settle the previous optimiser's steps first
         for t in self.optim.exp_avg + self.optim.exp_avg_sq:
             t.zero_()
         self.optim.step_count = 0
@@ -262,16 +284,84 @@ class SurfelTrainer:
         return ticked
 
     def step(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int,
-             world_views: Optional[int] = None, device_clock: bool = False) -> None:
+             device_clock: bool = True) -> None:
         """``cams``: this rank's views. ``image_grads(view_index, state)`` returns the five
         image gradients (d_rgb, d_normal, d_depth, d_opacity, d_confidence; None = zero)
         for that view, already divided by the GLOBAL number of views where the loss is a
-        batch mean.  Asynchronous except for the collective."""
+        batch mean.  Asynchronous except for the collective and, every ``CHECK_EVERY`` steps, one small
+        read-back (``check_overflow``).  ``device_clock`` (default): the Adam step counter lives on the GPU,
+        the same clock ``capture()`` replays on; False = the host-side counter of ``ags_adam_step``."""
+        self.optim.use_clock(device_clock)
+        self._step_once(cams, image_grads, max_instances, device_clock)
+        self._pending.append((cams, image_grads, max_instances, device_clock))
+        if len(self._pending) >= self.CHECK_EVERY:
+            self.check_overflow()
+
+    def _step_once(self, cams, image_grads, max_instances, device_clock) -> None:
         dist_on = self._distributed()
         ticked = self._local_pass(cams, image_grads, max_instances, tick=device_clock, fuse_adam=not dist_on)
         if dist_on:
             self._exchange_gradients(device_clock)
         self._optimizer_step(device_clock, ticked)
+
+    # -- overflow: noted on the device, looked at every few steps, repaired without losing a gradient row ----
+    def refused_steps(self) -> int:
+        """Host-synchronous: optimisation steps the gathered Adam refused since the counter was last cleared
+        (a rank's row set had outgrown the agreed exchange segment; ``ags_adam_step_gathered``)."""
+        return int(self.optim.device_clock[7].item())
+
+    def workspace_overflows(self) -> dict:
+        """Host-synchronous: per view size, (overflowed passes, peak tile instances) since the workspace was made."""
+        out = {}
+        for key, st in self._state.items():
+            info = api.read_status(st)
+            if info["overflow_passes"]:
+                out[key] = (info["overflow_passes"], info["peak_instances"])
+        return out
+
+    def regrow_exchange(self) -> int:
+        """Collective.  If the gathered Adam has refused steps, agree on a larger segment (or fall back to the
+        dense all-reduce) and clear the counter.  Returns the number of refused steps: the caller repeats
+        them (``check_overflow`` does; a captured replay has to be re-captured first, its segment size is
+        part of the graph)."""
+        k = self.refused_steps() if self.exchange is not None and self.exchange.capacity else 0
+        if k:
+            self.exchange_regrowths += 1
+            self.optim.device_clock[7] = 0
+            self.slab.flat.zero_()       # rows that did not fit the segment kept their totals here (ags_rows_pack contract)
+            if self.exchange.agree(int(self.rows.count.item()), self.slab.flat.numel()) == 0:
+                self._go_dense()
+        return k
+
+    def _go_dense(self) -> None:
+        # from the next pass on everything is dense: dense per-Gaussian backward (overwrites the whole slab),
+        # all-reduce of the slab, dense Adam (rows outside the old union have zero moments: a zero update)
+        self.exchange, self.rows = None, None
+        self.optim.touched, self.optim.zero_grad = None, False
+
+    def check_overflow(self) -> int:
+        """Settle the steps taken since the last call (host-synchronous, collective when ranks are present):
+        * a view that needed more tile instances than ``max_instances`` in any of them raises (its tile lists
+          were truncated: the gradients of those steps were wrong);
+        * steps the row exchange refused because a rank had outgrown the agreed segment are repeated after
+          agreeing on a larger one - no gradient row is dropped, the replicas never diverge.
+        Returns the number of repeated steps."""
+        pending, self._pending = self._pending, []
+        bad = self.workspace_overflows()
+        if bad:
+            raise RuntimeError(f"a view outgrew its rasterizer workspace {bad} (view size -> overflowed passes, "
+                               "instances needed): raise max_instances; the last steps used truncated tile lists")
+        redone = 0
+        while True:
+            k = self.regrow_exchange()
+            if k == 0:
+                return redone
+            if k > len(pending):
+                raise RuntimeError(f"{k} refused steps but only {len(pending)} remembered: call check_overflow() "
+                                   "at least every CHECK_EVERY steps")
+            for args in pending[-k:]:
+                self._step_once(*args)
+            redone += k
 
     def _optimizer_step(self, device_clock: bool, ticked: bool) -> None:
         if self.adam_fused:
@@ -291,8 +381,7 @@ class SurfelTrainer:
             if x.agree(int(self.rows.count.item()), self.slab.flat.numel()) == 0:
                 # not worth it: from the next pass on everything is dense again (this pass's slab is
                 # zero outside the listed rows, so its dense all-reduce is still right)
-                self.exchange, self.rows = None, None
-                self.optim.touched, self.optim.zero_grad = None, False
+                self._go_dense()
                 return False
         return True
 
@@ -301,6 +390,22 @@ class SurfelTrainer:
             if not getattr(self, "_packed", False):      # first step (segment size not agreed yet) or no views on this rank
                 self.exchange.pack(self.rows)
             self.exchange.gather()
+            x = self.exchange
+            if not (x.TAIL == "indexed" and device_clock) and not torch.cuda.is_current_stream_capturing():
+                # host-driven tail (ags_rows_unpack + row-set Adam): it cannot refuse a step on the device, so
+                # the headers are read right here (every rank sees the same ones) and an outgrown segment is
+                # repaired inside the step: own rows back into the slab, larger segment, pack and gather again
+                while x.overflowed():
+                    self.exchange_regrowths += 1
+                    x.restore_own()
+                    if x.agree(int(self.rows.count.item()), self.slab.flat.numel()) == 0:
+                        # dense from here on; this step: the slab holds the rank's whole gradient again
+                        x.union.reset()
+                        self._go_dense()
+                        all_reduce_(self.slab.flat, group=self.pg)
+                        return
+                    x.pack(self.rows)
+                    x.gather()
             self._exchange_tail(device_clock)
         else:
             all_reduce_(self.slab.flat, group=self.pg)
@@ -360,6 +465,8 @@ class SurfelTrainer:
         records that many consecutive optimisation steps in ONE graph, so a replay pays the
         graph-launch latency once per ``repeat`` steps; ``replay.steps`` says how many steps a call
         performs."""
+        self.check_overflow()              # settle the eager steps first: a capture bakes the segment size in
+        self.optim.use_clock(True)
         dist_on = self._distributed()
         rows_x = dist_on and self._row_exchange_on()
         in_graph = dist_on and self._collectives_capturable()
@@ -410,4 +517,7 @@ class SurfelTrainer:
         replay.collective_in_graph = in_graph
         self._graphs = (g_local, g_opt)
         replay.steps = repeat
+        # After some replays: ``trainer.regrow_exchange()`` (collective, host-synchronous) returns the number of
+        # steps the exchange refused since the last look; if it is not 0, capture again (the new segment size is
+        # part of the graph) and replay that many steps more.  ``trainer.workspace_overflows()`` likewise.
         return replay

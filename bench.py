@@ -3,9 +3,13 @@
 
 One step = one optimisation step of the hot path on resident data: activations ->
 forward rasterization -> backward rasterization (with fixed synthetic image gradients) ->
-activation backward -> [all-reduce of the gradient slab when N>1] -> fused Adam.
+activation backward -> [exchange of the gradient rows when N>1] -> fused Adam.
 Workload at every N: BASELINE.json configs[1] per GPU (office0 stand-in, 200k surfels,
 1200x680, one view per rank, weak scaling).  Prints ONE JSON line on rank 0.
+
+``python bench.py --gpus N`` with N > 1 and no RANK in the environment launches the N ranks itself
+(``python -m torch.distributed.run``, one process per GPU, RCCL) BEFORE this process touches the GPU and
+relays rank 0's line; under ``torch.distributed.run`` (RANK set) it is one of the ranks.
 """
 import argparse
 import json
@@ -21,6 +25,8 @@ import torch  # noqa: E402
 N_GAUSS = 200_000
 H, W = 680, 1200
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_HBM_FILE = "pmc_hbm_bytes.json"   # per-stage HBM bytes per launch of this command (rocprofv3 --pmc, committed)
+PMC_SQ_FILE = "sq_counters.json"      # per-stage SQ instruction counters per launch of this command
 
 
 def stage_bytes(N, V, I, P, T, rows=None):
@@ -45,10 +51,14 @@ def stage_bytes(N, V, I, P, T, rows=None):
 STAGE_IDS = {"preprocess": 0, "binning": 1, "render_fwd": 2, "render_bwd": 3, "preprocess_bwd": 4}
 
 
-def cpu_baseline(raw_cpu, cam_cpu, budget_s=15.0, max_threads=16):
+def cpu_baseline(raw_cpu, cam_cpu, d_img_cpu, gpu_check, budget_s=15.0, max_threads=16):
     """The oracle (oracle/surfel_oracle.py, PyTorch CPU, fp32) timed on this host: the full
     per-Gaussian stage + binning of the same view, then fwd+bwd of strided batches of tiles
-    until ~budget_s of CPU time is spent, extrapolated to all non-empty tiles."""
+    until ~budget_s of CPU time is spent, extrapolated to all non-empty tiles.
+
+    The images and gradients the oracle computes on the way are not thrown away: ``gpu_check(tile_mask)``
+    runs the HIP path on the same (initial) parameters with the same image gradients restricted to the tiles
+    the oracle covered, and the two are compared -> the ``parity`` object of the JSON line."""
     from active_gs_amd.synthetic import activate
     from oracle.surfel_oracle import OracleSettings, bin_instances, preprocess, render_tiles
     cores = min(os.cpu_count() or 1, max_threads)  # many small ops: more threads only add overhead
@@ -65,18 +75,74 @@ def cpu_baseline(raw_cpu, cam_cpu, budget_s=15.0, max_threads=16):
     nonempty = torch.nonzero(ranges[:, 1] > ranges[:, 0]).flatten().tolist()
     order = nonempty[::37] + [t for k in range(1, 37) for t in nonempty[k::37]]  # strided, spatially spread
     done, t_tiles, batch = 0, 0.0, 16
+    tiles_x = (W + 15) // 16
+    covered = torch.zeros(H, W)
+    images = {k: torch.zeros(c, H, W) for k, c in (("rgb", 3), ("normal", 3), ("depth", 1), ("opacity", 1))}
     while done < len(order) and t_tiles < budget_s:
         sample = order[done:done + batch]
+        m = torch.zeros(H, W)
+        for t in sample:
+            ty, tx = divmod(t, tiles_x)
+            m[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = 1.0
         t0 = time.perf_counter()
         R = render_tiles(G, so, ranges, S, tiles=sample)
-        (R["rgb"].sum() + R["depth"].sum() + R["normal"].sum()).backward(retain_graph=True)
+        # the bench step's own image gradients, on the tiles of this batch
+        ((R["rgb"] * (d_img_cpu[0] * m)).sum() + (R["normal"] * (d_img_cpu[1] * m)).sum()
+         + (R["depth"] * (d_img_cpu[2] * m)).sum()).backward(retain_graph=True)
         t_tiles += time.perf_counter() - t0
         done += len(sample)
+        covered += m
+        for k in images:
+            images[k] += R[k].detach() * m
     est = t_pre + t_tiles * len(nonempty) / max(done, 1)
-    return {"value": N_GAUSS / est, "unit": "Gaussians/s", "cores": cores, "kind": "port",
+    base = {"value": N_GAUSS / est, "unit": "Gaussians/s", "cores": cores, "kind": "port",
             "sample": f"oracle (PyTorch CPU fp32, {cores} threads): full preprocess+binning of the 200k-surfel "
                       f"1200x680 view ({t_pre:.1f}s) + fwd+bwd of {done} of {len(nonempty)} non-empty tiles "
                       f"({t_tiles:.1f}s), extrapolated to all tiles"}
+    # ---- parity of the HIP path against what the oracle just computed (checker role only)
+    gpu_images, gpu_grads = gpu_check(covered)
+    npx = float(covered.sum())
+    l1 = {k: float(((gpu_images[k] - images[k]) * covered).abs().sum() / (npx * images[k].shape[0])) for k in images}
+    ref_grads = {"means3D": ins[0].grad, "opacities": ins[2].grad.reshape(-1), "colors": ins[4].grad, "scales": ins[5].grad,
+                 "rotations": ins[6].grad}
+    rel = {k: float((gpu_grads[k] - r).abs().sum() / r.abs().sum().clamp_min(1e-30)) for k, r in ref_grads.items()}
+    parity = {"parity_rgb_L1": l1["rgb"], "parity_grad_rel": max(rel.values()),
+              "image_L1": l1, "grad_rel_L1": rel, "tiles_compared": done, "tiles_nonempty": len(nonempty),
+              "tolerance": {"rgb_L1": 1e-4, "grad_rel": 1e-3},
+              "ok": bool(l1["rgb"] < 1e-4 and max(rel.values()) < 1e-3),
+              "what": "HIP forward+backward of the bench view (initial parameters, the bench step's image gradients "
+                      "restricted to the compared tiles) against the oracle's fp32 images / autograd gradients"}
+    return base, parity
+
+
+def launch_ranks(args) -> int:
+    """``--gpus N`` without a launcher: start N ranks (one per GPU) as a child job and relay rank 0's JSON line.
+    Runs before anything in this process has touched the GPU (no GPU state to share, no re-exec)."""
+    import socket
+    import subprocess
+    share = os.environ.get("AGS_BENCH_SHARE_GPU") == "1"
+    if not share:
+        have = torch.cuda.device_count()            # counting devices does not initialise the GPU
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s)", file=sys.stderr)
+            return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    other = [l for l in r.stdout.splitlines() if not l.startswith("{")]
+    if other:
+        print("\n".join(other), file=sys.stderr)
+    if r.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: the {args.gpus}-rank job exited with code {r.returncode} and {len(lines)} result line(s)",
+              file=sys.stderr)
+        return r.returncode or 1
+    print(lines[0])
+    return 0
 
 
 def main():
@@ -90,6 +156,10 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=int(os.environ.get("AGS_BENCH_GRAPH_STEPS", "25")),
                     help="optimisation steps recorded per hipGraph (single GPU); K steps = K/this replays")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     if os.environ.get("AGS_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack and exit after N s
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["AGS_BENCH_WATCHDOG"]), exit=True)
@@ -97,6 +167,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU fallback")
     # test-only hooks (tests/test_gpu_bench_multirank.py): several ranks on ONE GPU over gloo, to
@@ -157,7 +230,7 @@ def main():
     grads_fn = lambda v, st: (d_img[0], d_img[1], d_img[2], None, None)
 
     def eager_step():
-        trainer.step([cam], grads_fn, cap, world_views=world, device_clock=True)
+        trainer.step([cam], grads_fn, cap)
 
     for _ in range(3):
         eager_step()  # creates every buffer before capture
@@ -172,10 +245,13 @@ def main():
             if dist_on:
                 launch_mode = ("hipGraph replay, gradient exchange recorded in the graph" if in_graph
                                else "hipGraph replay: graph | collective | graph")
-            if args.graph_steps > 1 and (not dist_on or in_graph):
-                many_steps = trainer.capture([cam], grads_fn, cap, repeat=args.graph_steps)
+            # steps per graph: the largest divisor of K that is <= --graph-steps, so that the timed region is
+            # whole replays of ONE graph and this string describes exactly what was timed
+            rep = max(d for d in range(1, max(1, args.graph_steps) + 1) if args.steps % d == 0)
+            if rep > 1 and (not dist_on or in_graph):
+                many_steps = trainer.capture([cam], grads_fn, cap, repeat=rep)
                 per_replay = many_steps.steps
-                launch_mode += f", {per_replay} steps per graph"
+            launch_mode += f", {per_replay} step(s) per graph, {args.steps // per_replay} replay(s) timed"
         except Exception as e:  # never lose the measurement to a capture problem
             launch_mode = f"eager (graph capture failed: {type(e).__name__})"
             many_steps, per_replay = None, 1
@@ -224,6 +300,7 @@ def main():
         elapsed = t.item()
     st = trainer.state_for(H, W, cap)
     info = api.read_status(st)
+    refused = trainer.refused_steps() if dist_on else 0      # steps the row exchange refused (segment outgrown)
 
     # per-stage kernel time: the same K steps launched eagerly with library-owned HIP events
     # around every stage (events cannot be timed inside a replayed graph)
@@ -253,52 +330,107 @@ def main():
         elif x is not None and x.capacity:
             exchange = {"kind": "all-gather of member rows (64 B per row)", "rows_per_segment": x.capacity,
                         "bytes_per_rank": 4 * x.send.numel(), "union_rows": int(x.union.count.item()),
-                        "overflow": x.overflowed()}
+                        "overflow": x.overflowed(), "refused_steps": refused, "regrowths": trainer.exchange_regrowths}
         else:
             exchange = {"kind": "all-reduce of the dense gradient slab", "bytes_per_rank": 4 * trainer.slab.flat.numel()}
         sb = stage_bytes(N_GAUSS, V, I, P, T, rows)
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         ach = sb[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_hbm_bytes.json")
-        if os.path.exists(pmc_path):
-            try:
-                traffic = json.load(open(pmc_path)).get(dom, {}).get("traffic")
-            except Exception:
-                traffic = None
+        # Counter figures cannot be collected from inside this process: they come from the committed rocprofv3
+        # --pmc runs of THIS command on this build (profiles/, made by profiles/experiments/pmc_run.sh) and are
+        # labelled as such; per-launch instruction counts and HBM bytes of a fixed workload do not depend on the run.
+        traffic, traffic_src, valu = None, None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", PMC_HBM_FILE)))
+            traffic = pm.get(dom, {}).get("traffic")
+            traffic_src = f"profiles/{PMC_HBM_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                          f"session {pm.get('_session', '?')}; not collected in this run)"
+        except Exception:
+            pass
+        try:
+            sq = json.load(open(os.path.join(ROOT, "profiles", PMC_SQ_FILE)))
+            blend = {}
+            for k in ("render_fwd", "render_bwd"):
+                act = sq.get(k, {}).get("SQ_ACTIVE_INST_VALU")
+                if act and stage_ms[k] > 0:
+                    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; 256 CUs x 4 SIMDs at 2.4 GHz
+                    blend[k] = {"valu_busy_frac": act * 4.0 / (stage_ms[k] * 1e-3 * 2.4e9 * 1024),
+                                "valu_insts_per_launch": sq[k].get("SQ_INSTS_VALU")}
+            if blend:
+                valu = {"bound": "valu", "kernel": dom if dom in blend else "render_bwd",
+                        "achieved": blend.get(dom, blend.get("render_bwd", {})).get("valu_busy_frac"), "peak": 1.0,
+                        "unit": "fraction of VALU issue cycles busy (1024 SIMDs x 2.4 GHz)", "kernels": blend,
+                        "source": f"instruction counters from profiles/{PMC_SQ_FILE} (session {sq.get('_session', '?')}, "
+                                  "not collected in this run) / this run's HIP-event stage times"}
+        except Exception:
+            pass
         ms_per_step = elapsed / args.steps * 1e3
+        step_s = elapsed / args.steps
         out = {
             "metric": "splatted-Gaussians/s (fwd+bwd) @1200x680; achieved HBM GB/s vs peak",
-            "value": N_GAUSS * world / (elapsed / args.steps),
+            "value": N_GAUSS * world / step_s,
             "unit": "Gaussians/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "office0 stand-in (seeded box room), 200k surfels, 1200x680, 1 view per GPU (rank r: "
                                    "view 0 mirrored through the room's symmetry planes = equal work per rank), "
-                                   "step = activations + fwd + bwd + grad all-reduce (N>1) + Adam",
+                                   "step = activations + fwd + bwd (fed fixed random image gradients d_rgb, d_normal, "
+                                   "d_depth: no loss head in the step) + gradient-row exchange (N>1) + Adam",
                        "gaussians": N_GAUSS, "image": [H, W], "views_per_gpu": 1, "visible": V,
                        "tile_instances": I, "parallelism": f"view-parallel dp{world}",
-                       "overflow": bool(info["overflow"]), "binning": args.binning,
+                       "overflow": bool(info["overflow"]) or bool(info["overflow_passes"]) or refused > 0,
+                       "binning": args.binning,
                        "launch": launch_mode,
                        "optimizer": ("row-set Adam fused into the per-Gaussian backward (exact: untouched rows "
                                      f"have zero gradient and moments), {rows} member rows") if (rows is not None and not dist_on)
                                     else ("row-set Adam over the union of the ranks' member rows" if rows is not None
                                           else "dense fused Adam kernel after the gradient all-reduce"),
                        "exchange": exchange,
+                       # `value` counts SUBMITTED Gaussians (the metric's definition): most of them are culled
+                       # by this view.  The rates below count what reaches the blend kernels.
+                       "derived_rates": {"visible_gaussians_per_s": V * world / step_s,
+                                         "tile_instances_per_s": I * world / step_s,
+                                         "visible_fraction": V / N_GAUSS},
                        "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                        "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-                       "stage_mean_ms": {k: round(v, 4) for k, v in stage_mean_ms.items()}},
+                       "stage_mean_ms": {k: round(v, 4) for k, v in stage_mean_ms.items()},
+                       "stage_timing": f"HIP events on the launch stream around every stage of {args.steps} eager steps "
+                                       "run right after the timed region (medians); an event pair reads ~3 us more than "
+                                       "rocprofv3's kernel duration"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": sb[dom],
                          "all_stages_GBps": {k: (sb[k] / (stage_ms[k] * 1e-3) / 1e9 if stage_ms[k] > 0 else 0.0)
-                                             for k in sb}},
+                                             for k in sb},
+                         "whole_step_GBps": sum(sb.values()) / step_s / 1e9},
         }
+        if valu is not None:
+            out["roofline_valu"] = valu
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only (contract)
-            out["cpu_baseline"] = cpu_baseline(raw_cpu, dict(tanx=tanx, tany=tany, bg=bg, view=cm["viewmatrix"][0],
-                                                             proj=cm["projmatrix"][0]))
+            d_cpu = [t.cpu() for t in d_img]
+
+            def gpu_check(tile_mask):
+                """HIP forward + backward on the INITIAL parameters (the trainer has moved its copy) with the step's
+                image gradients restricted to the tiles the oracle covered."""
+                from active_gs_amd.synthetic import activate
+                a0 = activate(raw_cpu)
+                g0 = api.Gaussians(*(a0[k].to(dev).contiguous() for k in ("means", "scales", "rotations", "opacities",
+                                                                          "colors", "confidences")))
+                s0 = api.alloc_state(N_GAUSS, H, W, cap, dev)
+                api.forward(cam, g0, s0)
+                m = tile_mask.to(dev)
+                gr = api.backward(cam, g0, s0, (d_img[0] * m).contiguous(), (d_img[1] * m).contiguous(),
+                                  (d_img[2] * m).contiguous())
+                torch.cuda.synchronize()
+                assert not api.read_status(s0)["overflow"]
+                imgs = {"rgb": s0.rgb.cpu(), "normal": s0.normal.cpu(), "depth": s0.depth.cpu(), "opacity": s0.opacity.cpu()}
+                grads = {k: getattr(gr, k).cpu() for k in ("means3D", "opacities", "colors", "scales", "rotations")}
+                return imgs, grads
+
+            out["cpu_baseline"], out["parity"] = cpu_baseline(
+                raw_cpu, dict(tanx=tanx, tany=tany, bg=bg, view=cm["viewmatrix"][0], proj=cm["projmatrix"][0]), d_cpu, gpu_check)
         print(json.dumps(out))
     if dist_on:
         torch.distributed.barrier()  # rank 0 may still be in the CPU-baseline leg; leave together

@@ -156,7 +156,8 @@ typedef struct AgsGaussianGrads {
      * rank renders in a step, together with `touched` (accumulate 0 or 1, no fused_adam): instead of
      * leaving the rows' totals in the gradient arrays the per-Gaussian kernel writes them as the rank's
      * exchange segment (what ags_rows_pack would produce from them, header included) and leaves the
-     * gradient rows zeroed - no separate pack launch. */
+     * gradient rows zeroed - no separate pack launch.  Like ags_rows_pack, rows beyond pack_capacity do not
+     * travel and KEEP their totals in the gradient arrays (header word 1 > pack_capacity tells). */
     float* pack_segment;   /* ags_rows_segment_floats(pack_capacity) floats */
     int32_t pack_capacity;
 } AgsGaussianGrads;
@@ -176,7 +177,12 @@ typedef struct AgsStatus {
     uint32_t num_sorted;    /* min(num_instances, max_instances) */
     uint32_t overflow;      /* 1 when num_instances > max_instances */
     uint32_t num_visible;   /* Gaussians that passed the cull */
-    uint32_t reserved[12];
+    /* STICKY since the last ags_workspace_init (every forward on this workspace updates, none clears):
+     * a loop that renders many views without reading the block back after each one reads these once at
+     * the end; an overflow in ANY of its passes shows, with the size that would have been enough. */
+    uint32_t peak_instances;  /* max of num_instances over the passes */
+    uint32_t overflow_passes; /* number of passes whose num_instances exceeded max_instances */
+    uint32_t reserved[10];
 } AgsStatus;
 
 /* Bytes of workspace for n Gaussians, an h x w image and room for max_instances instances.
@@ -242,7 +248,7 @@ int ags_adam_step(const AgsAdamTensors* t, float beta1, float beta2, float eps, 
 
 /* Graph-replayable form: the 1-based step counter lives on the device.  `state` is a
  * caller-owned, zero-initialised 64-byte device buffer { int32 step; float step_size[5];
- * float inv_sqrt_bc2; ... }; each call first bumps the counter and refreshes the bias
+ * float inv_sqrt_bc2; int32 skipped_steps (see ags_adam_step_gathered); ... }; each call first bumps the counter and refreshes the bias
  * corrections on the device (in double), then runs the same update.  Capturing this call in
  * a hipGraph and replaying it k times performs Adam steps 1..k. */
 int ags_adam_step_device(const AgsAdamTensors* t, float beta1, float beta2, float eps, void* state,
@@ -256,8 +262,9 @@ int ags_adam_step_device(const AgsAdamTensors* t, float beta1, float beta2, floa
  *   segment = 16 floats of header {int32 count, int32 needed, 0...} + capacity records of 16 floats
  *             {14 gradient floats in the order means, scales, rotation, opacity, colour; int32 row; 0}
  * ags_rows_pack   copies the set's rows of the five gradient arrays into `segment` and writes 0
- *                 behind them (needed > capacity: the excess rows are NOT shipped - the caller sized
- *                 the segment too small and must treat the step as invalid);
+ *                 behind them (needed > capacity: the excess rows are NOT shipped and stay in the gradient
+ *                 arrays - the caller sized the segment too small: it adds its own segment back with
+ *                 ags_rows_unpack, packs again with a larger capacity and repeats the exchange);
  * ags_rows_unpack adds a received segment into the gradient arrays and appends rows that are new to
  *                 `union_rows` (the set the optimiser then steps over with zero_grad = 1).  Call it
  *                 once per rank's segment, in rank order, on one stream: every rank then forms
@@ -275,7 +282,13 @@ int ags_rows_unpack(const float* segment, int32_t capacity, float* const grads[5
  * ags_rows_index          one launch over all segments: slot_table[row][rank] = record + 1, union set built;
  * ags_adam_step_gathered  Adam over the union rows (t->touched; t->grad is not read) with each row's
  *                         gradient summed from the segments in rank order - bit-identical on every
- *                         rank - on the device clock `state` (see ags_adam_step_device). */
+ *                         rank - on the device clock `state` (see ags_adam_step_device).
+ *                         If ANY segment's header says its rank holds more rows than `capacity` (that rank
+ *                         shipped only part of its gradient) the step is REFUSED on the device: parameters,
+ *                         moments and the step counter are left exactly as they were, the slot table is still
+ *                         cleaned, and state->skipped_steps (int32 at byte 28) is incremented.  Row sets only
+ *                         grow, so every later step is refused too until the caller - who reads that counter
+ *                         every few steps - exchanges with a larger capacity and repeats the refused steps. */
 int ags_rows_index(const float* segments, int32_t world, int32_t capacity, int32_t* slot_table,
                    const AgsRowSet* union_rows, ags_stream_t stream);
 int ags_adam_step_gathered(const struct AgsAdamTensors* t, const float* segments, int32_t world, int32_t capacity,

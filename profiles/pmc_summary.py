@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, csv) per kernel.
 
-Usage: pmc_summary.py fetch_counter_collection.csv write_counter_collection.csv [out.json]
+Usage: pmc_summary.py fetch_counter_collection.csv write_counter_collection.csv [out.json [session-tag]]
 FETCH_SIZE / WRITE_SIZE are in KiB (TCC_EA0 request counters); per
 /opt/skills/guides/MI355X_MICROARCH.md §HBM, FETCH_SIZE counts 128-B requests of wide
 (16 B/lane) coalesced streams at 64 B on gfx950, so the read side of such kernels is up to 2x
@@ -46,5 +46,10 @@ for k in sorted(fetch, key=lambda k: -fetch[k]):
             stage_bytes[st][1] += w
             break
 if len(sys.argv) > 3:
-    json.dump({k: {"fetch_raw": round(v[0]), "write": round(v[1]), "traffic": round(2 * v[0] + v[1])}
-               for k, v in stage_bytes.items()}, open(sys.argv[3], "w"), indent=1)
+    out = {k: {"fetch_raw": round(v[0]), "write": round(v[1]), "traffic": round(2 * v[0] + v[1])}
+           for k, v in stage_bytes.items()}
+    out["_session"] = sys.argv[4] if len(sys.argv) > 4 else "?"
+    out["_note"] = ("bytes per launch, summed over the kernels of a bench stage (bench.py --eager under rocprofv3 --pmc, "
+                    "FETCH_SIZE and WRITE_SIZE in separate passes); traffic = 2*fetch_raw + write (gfx950 FETCH_SIZE "
+                    "counts 128-B requests of wide streaming reads at 64 B: MI355X_MICROARCH.md, HBM section)")
+    json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -38,3 +38,44 @@ def product_settings(S, dev):
         projmatrix=S.projmatrix.to(dev), sh_degree=0, campos=(S.campos if S.campos is not None else torch.zeros(3)).to(dev),
         prefiltered=False, render_mask=mask.to(dev), weight_thres=S.weight_thres, debug=False,
         config=S.config.to(dev))
+
+
+def oracle_on_tiles(ins, S, image_grads, tiles=None, max_tiles=None, batch=32, fullest=0):
+    """Oracle forward + autograd backward over a SET of tiles (full-size scenes: the per-Gaussian stage and the
+    binning run in full, the per-tile blend only where asked), with the given image gradients (rgb, normal,
+    depth, opacity, confidence; None = zero) restricted to those tiles.
+
+    tiles=None: every non-empty tile, or - with ``max_tiles`` - a strided, spatially spread subset of them plus the
+    ``fullest`` longest tile lists.  Returns (images dict masked to the covered tiles, pixel mask (H,W), aux dict);
+    the gradients are left in ``ins[i].grad``."""
+    from oracle.surfel_oracle import bin_instances, preprocess, render_tiles
+    G = preprocess(*ins, S)
+    so, ranges = bin_instances(G)
+    H, W = S.image_height, S.image_width
+    tiles_x = (W + 15) // 16
+    lens = ranges[:, 1] - ranges[:, 0]
+    nonempty = torch.nonzero(lens > 0).flatten().tolist()
+    if tiles is None:
+        tiles = nonempty
+        if max_tiles is not None and len(nonempty) > max_tiles:
+            keep = set(torch.topk(lens, min(fullest, len(nonempty))).indices.tolist()) if fullest else set()
+            stride = max(1, len(nonempty) // max(1, max_tiles - len(keep)))
+            keep.update(nonempty[::stride])
+            tiles = sorted(keep)
+    covered = torch.zeros(H, W)
+    names = ("rgb", "normal", "depth", "opacity", "confidence")
+    images = {k: torch.zeros(3 if k in ("rgb", "normal") else 1, H, W) for k in names}
+    for b0 in range(0, len(tiles), batch):
+        sample = tiles[b0:b0 + batch]
+        m = torch.zeros(H, W)
+        for t in sample:
+            ty, tx = divmod(t, tiles_x)
+            m[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = 1.0
+        R = render_tiles(G, so, ranges, S, tiles=sample)
+        loss = sum((R[k] * (g * m)).sum() for k, g in zip(names, image_grads) if g is not None)
+        loss.backward(retain_graph=True)
+        covered += m
+        for k in names:
+            images[k] += R[k].detach() * m
+    aux = dict(G=G, ranges=ranges, tiles=tiles, nonempty=len(nonempty), max_list=int(lens.max()), instances=int(lens.sum()))
+    return images, covered, aux

@@ -206,3 +206,25 @@ def test_device_frame_sampler_draws_the_reference_distribution():
         pair_n[b[0], b[1]] += 1
     assert np.abs(inc_t.numpy() - inc_n).max() / trials < 0.015
     assert np.abs(pair_t.numpy() - pair_n).max() / trials < 0.01
+
+
+def test_bench_gpus_flag_launches_ranks_or_refuses():
+    """``bench.py --gpus N`` is not decorative: without a launcher it starts N ranks itself (here, with no GPU, both
+    ranks stop at the no-CPU-fallback check and the parent reports the failed job with a non-zero exit code and no
+    result line); under a launcher whose WORLD_SIZE disagrees it refuses to print a line for the wrong job size."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["AGS_BENCH_SHARE_GPU"] = "1"                       # skip the device-count check of the launcher
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "2-rank job" in r.stderr
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env2, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "0"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0

@@ -1,5 +1,6 @@
-"""bench.py's N>1 path end to end (process group, graph | all-reduce | graph step, barriers, max over
-ranks, one JSON line from rank 0) with two ranks sharing the single GPU over gloo."""
+"""bench.py's N>1 path end to end (``python bench.py --gpus 2`` launching its own two ranks, process group,
+graph | collective | graph step, barriers, max over ranks, one JSON line relayed from rank 0) with the two ranks
+sharing the single GPU over gloo."""
 import json
 import os
 import socket
@@ -14,11 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_two_ranks_on_one_gpu(agslib):
     def launch():
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-        env = dict(os.environ, AGS_BENCH_SHARE_GPU="1", AGS_BENCH_BACKEND="gloo", AGS_BENCH_WATCHDOG="150")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
-               "--warmup", "3", "--no-cpu-baseline"]
+        # the driver's command shape: bench.py finds no RANK in the environment and launches the two ranks itself
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        env.update(AGS_BENCH_SHARE_GPU="1", AGS_BENCH_BACKEND="gloo", AGS_BENCH_WATCHDOG="150")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+               "--no-cpu-baseline"]
         return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=480)
 
     r = launch()
@@ -46,8 +47,30 @@ def test_bench_two_ranks_on_one_gpu(agslib):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"] == "view-parallel dp2" and not d["config"]["overflow"]
-    assert d["config"]["launch"].startswith("hipGraph")
-    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert d["config"]["launch"].startswith("hipGraph") and "replay(s) timed" in d["config"]["launch"]
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"}
+    assert d["config"]["exchange"]["refused_steps"] == 0 and d["config"]["derived_rates"]["tile_instances_per_s"] > 0
+
+
+def test_bench_single_rank_contract_fields(agslib):
+    """The N=1 line the driver records: every field describes the timed region (whole replays of one graph), the
+    derived rates, both roofline objects, and the parity of the HIP path against the oracle on the bench view."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["vs_baseline"] is None
+    assert "20 step(s) per graph, 1 replay(s) timed" in d["config"]["launch"]
+    assert abs(d["value"] - 200_000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    dr = d["config"]["derived_rates"]
+    assert 0 < dr["visible_gaussians_per_s"] < dr["tile_instances_per_s"] < d["value"]
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and not d["config"]["overflow"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    p = d["parity"]
+    assert p["ok"] and p["parity_rgb_L1"] < 1e-4 and p["parity_grad_rel"] < 1e-3 and p["tiles_compared"] > 100
 
 
 def test_torch_free_cabi_demo(agslib):

@@ -125,6 +125,67 @@ def test_two_ranks_equal_single_process_two_views(agslib, use_graph, sparse_rows
         assert moved >= 4                                          # the optimiser did move the map (scales may sit on their clamp)
 
 
+MOVE_STEPS = 7
+
+
+def _moving_worker(rank, world, port, tail, ret):
+    """every step each rank renders a NEW view: the sticky row sets keep growing past the (tightly) agreed segment"""
+    _watchdog()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from active_gs_amd.trainer import RowExchange, SurfelTrainer
+        RowExchange.GROWTH, RowExchange.SLACK, RowExchange.TAIL = 1.0, 4, tail   # no head-room at all
+        SurfelTrainer.CHECK_EVERY = 3
+        raw, cams, grads = _setup([world * s + rank for s in range(MOVE_STEPS)])
+        tr = SurfelTrainer(raw)
+        caps = []
+        for s in range(MOVE_STEPS):
+            fn = lambda v, st, s=s: (grads[s][0], grads[s][1], grads[s][2], None, None)
+            tr.step([cams[s]], fn, CAP)
+            caps.append(tr.exchange.capacity if tr.exchange is not None else -1)
+        redone = tr.check_overflow()
+        torch.cuda.synchronize()
+        assert tr.refused_steps() == 0
+        if tr.exchange is not None:
+            assert not tr.exchange.overflowed() and tr.exchange.capacity >= int(tr.rows.count.item())
+        ret[rank] = dict(params=[p.cpu() for p in tr.params], regrowths=tr.exchange_regrowths, caps=caps,
+                         step=int(tr.optim.device_clock[0].item()), m=[t.cpu() for t in tr.optim.exp_avg])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tail", ["indexed", "unpack"])
+def test_moving_cameras_outgrow_the_segment_without_losing_a_gradient_row(agslib, tail):
+    """Two ranks, a new view per rank and step, a segment agreed with no head-room: the exchange overflows again
+    and again.  "indexed" tail: the gathered Adam refuses those steps on the device, the trainer notices at its
+    next look (every 3 steps here), agrees on a larger segment and repeats them; "unpack" tail: the host sees
+    the headers after the all-gather and repairs the exchange inside the step.  Either way the result is the
+    single-process run over all views - no gradient row dropped, same step count, replicas bit-identical."""
+    from active_gs_amd.trainer import SurfelTrainer
+    raw, cams, grads = _setup(list(range(2 * MOVE_STEPS)))
+    init = [raw[k].clone().cpu() for k in ("means", "scales", "rotations", "opacities", "harmonics")]
+    tr = SurfelTrainer(raw)
+    for s in range(MOVE_STEPS):
+        fn = lambda v, st, s=s: (grads[2 * s + v][0], grads[2 * s + v][1], grads[2 * s + v][2], None, None)
+        tr.step([cams[2 * s], cams[2 * s + 1]], fn, CAP)
+    torch.cuda.synchronize()
+    ref = [p.cpu() for p in tr.params]
+    ret = _spawn_two(_moving_worker, (tail,))
+    assert ret[0]["regrowths"] >= 2 and ret[0]["regrowths"] == ret[1]["regrowths"], ret[0]["caps"]
+    assert ret[0]["step"] == ret[1]["step"] == MOVE_STEPS           # refused steps did not advance the clock; repeats did
+    for a, b in zip(ret[0]["params"] + ret[0]["m"], ret[1]["params"] + ret[1]["m"]):
+        assert torch.equal(a, b)
+    moved = 0
+    for a, r, i0 in zip(ret[0]["params"], ref, init):
+        travel = (r - i0).abs().mean()
+        moved += int(travel > 1e-6)
+        assert (a - r).abs().mean() < 5e-3 * travel + 1e-9
+    assert moved >= 4
+
+
 def _fused_cfg(d):
     cfg = d["cfg"]
     return dict(bound=tuple(cfg["bound"]), scale_factor=cfg["scale_factor"], optimization_steps=cfg["optimization_steps"],
