@@ -62,7 +62,7 @@ class AgsWorkspace(C.Structure):
 class AgsStatus(C.Structure):
     _fields_ = [("num_instances", C.c_uint32), ("num_sorted", C.c_uint32), ("overflow", C.c_uint32),
                 ("num_visible", C.c_uint32), ("peak_instances", C.c_uint32), ("overflow_passes", C.c_uint32),
-                ("reserved", C.c_uint32 * 10)]
+                ("max_tile_instances", C.c_uint32), ("needed_instances", C.c_uint32), ("reserved", C.c_uint32 * 8)]
 
 
 class AgsAdamTensors(C.Structure):

@@ -129,16 +129,27 @@ struct AgsViewStride {
 // `ids` + `id_stride`: sorted Gaussian ids per instance; stride 2 when they are the low
 // words of the 64-bit (depth|id) keys of the tile-sort mode.
 struct AgsIdList { const uint32_t* ids; int stride; };
+// emit: 0 = nothing (radix mode counts rect tiles only), 1 = count the reachable tiles (tile-sort mode),
+// 2 = AGS_BIN_DIRECT: take a key slot in the tile's own slot range and write the key
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
-                           const AgsLayout& L, int* radii, bool count_tiles, const AgsRowSet& touched,
+                           const AgsLayout& L, int* radii, int emit, const AgsRowSet& touched,
                            const AgsViewStride& vs, hipStream_t s);
+void ags_launch_direct_sort(char* ws, const AgsLayout& L, const AgsViewStride& vs, hipStream_t s);
+// AGS_BIN_DIRECT bookkeeping, kept in the (otherwise radix-only) digit-total words of the workspace: 64 partial
+// sums of the tiles' list lengths, 64 partial maxima, 64 partial counts of visible surfels - spread so that the
+// tiles' / waves' atomics do not serialise on one word; the forward blend kernel's first wave reduces them into
+// the status block and leaves them zeroed again
+#define AGS_PART_SUM 0
+#define AGS_PART_MAX 64
+#define AGS_PART_VIS 128
+static inline uint32_t ags_direct_tile_cap(const AgsLayout& L) { return (uint32_t)(L.cap / (L.num_tiles > 0 ? L.num_tiles : 1)); }
 void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s);
 void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L,
                              const AgsViewStride& vs, hipStream_t s);
 AgsIdList ags_sorted_ids(char* ws, const AgsLayout& L, int binning_mode);
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs,
-                           hipStream_t s);
+                           bool direct, hipStream_t s);
 void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick,
                            const AgsViewStride& vs, hipStream_t s);
@@ -187,6 +198,30 @@ void ags_launch_compact_plan(int n, const int32_t* keep, int32_t* dst_index, int
 void ags_launch_compact_rows(int n, int width, const int32_t* dst_index, const float* src, float* dst, hipStream_t s);
 void ags_launch_prune_keep(int n, const float* prune_mask, const float* raw_opacities, float min_opacity, int32_t* keep,
                            hipStream_t s);
+
+// ---- experiment builds only (-DAGS_TIMELINE, profiles/experiments/timeline.py): every wave notes the shader clock
+// (s_memtime) at a few phase boundaries into a caller-provided buffer [kernel][wave][8]; compiled out otherwise.
+#define AGS_TL_WAVES 16384
+#if defined(AGS_TIMELINE) && defined(__HIPCC__)
+#define AGS_TL_DEFINE(tu)                                                                                          \
+    static __device__ unsigned long long* ags_tl_buf = nullptr;                                                    \
+    void ags_tl_set_##tu(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(ags_tl_buf), &p, sizeof(p)); }
+#define AGS_TL(kid, wave_id, phase)                                                                                \
+    do {                                                                                                           \
+        if ((threadIdx.x & 63) == 0 && ags_tl_buf && (unsigned)(wave_id) < AGS_TL_WAVES)                           \
+            ags_tl_buf[(((size_t)(kid) * AGS_TL_WAVES) + (wave_id)) * 8 + (phase)] = __builtin_readcyclecounter(); \
+    } while (0)
+#define AGS_TL_VAL(kid, wave_id, phase, v)                                                                         \
+    do {                                                                                                           \
+        if ((threadIdx.x & 63) == 0 && ags_tl_buf && (unsigned)(wave_id) < AGS_TL_WAVES)                           \
+            ags_tl_buf[(((size_t)(kid) * AGS_TL_WAVES) + (wave_id)) * 8 + (phase)] = (unsigned long long)(v);      \
+    } while (0)
+#else
+#define AGS_TL_DEFINE(tu)
+#define AGS_TL(kid, wave_id, phase) do { } while (0)
+#define AGS_TL_VAL(kid, wave_id, phase, v) do { } while (0)
+#endif
+void ags_tl_set_preprocess(void*); void ags_tl_set_binning(void*); void ags_tl_set_render(void*);
 
 #if defined(__HIPCC__)
 // ---- wave64 helpers (gfx950): DPP reductions, no LDS, no ds_bpermute
@@ -271,6 +306,7 @@ __device__ __forceinline__ void ags_for_each_tile(uint32_t cnt, uint32_t x0, uin
 // exclusive prefix kept in LDS; the tile must pass the exact reach test (ags_reaches_box) -
 // tiles of the D3 rect that no pixel of the surfel can reach are never emitted (they would
 // contribute nothing: identical images, fewer instances to sort, gather and blend).
+// f(hit, tile, owner's payload word, owner's lane in this wave).
 struct AgsEmitRec { uint32_t excl, xy, wd, pa; float mx, my, ca, cb, cc, o; }; // per lane, in LDS
 
 // counter[t] += 1 for every `active` lane, returning the lane's old value (its slot).
@@ -333,8 +369,8 @@ __device__ __forceinline__ void ags_emit_tiles_balanced(AgsEmitRec* wave_lds, ui
         const uint32_t j = base + lane;
         bool hit = false;
         uint32_t tile = 0, owner = 0;
+        int lo = 0;
         if (j < total) {
-            int lo = 0;
 #pragma unroll
             for (int step = 32; step > 0; step >>= 1)
                 if (wave_lds[lo + step].excl <= j) lo += step; // largest lane with excl <= j
@@ -347,7 +383,7 @@ __device__ __forceinline__ void ags_emit_tiles_balanced(AgsEmitRec* wave_lds, ui
             hit = ags_reaches_box(og, bx, bx + (AGS_TILE - 1), by, by + (AGS_TILE - 1));
             tile = ty * tiles_x + tx; owner = r.pa;
         }
-        f(hit, tile, owner); // called by the whole wave (wave-uniform control flow): see ags_wave_agg_inc
+        f(hit, tile, owner, lo); // called by the whole wave (wave-uniform control flow): see ags_wave_agg_inc; lo = owner's lane
     }
     __builtin_amdgcn_wave_barrier();
 }

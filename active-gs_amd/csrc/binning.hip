@@ -10,11 +10,15 @@
 // wave-wide digit matching with __ballot (64-bit) — no LDS sort, no atomics in the ranks.
 #include "ags_internal.h"
 
+AGS_TL_DEFINE(binning)
+
 // AgsStatus.peak_instances / overflow_passes: written by the ONE thread that publishes a pass's status block;
 // passes on one workspace are stream-ordered, so plain read-modify-write is enough (no atomics)
 __device__ __forceinline__ void ags_status_sticky(uint32_t* status, uint32_t total, uint32_t cap) {
     if (total > status[4]) status[4] = total;
     if (total > cap) status[5] += 1u;
+    status[6] = 0u;      // max_tile_instances: not tracked in the scan-based modes
+    status[7] = total;   // needed_instances
 }
 
 // ------------------------------------------------------------------ F2: scan of block sums
@@ -258,6 +262,7 @@ int ags_sort_passes(int num_tiles) {
 }
 
 AgsIdList ags_sorted_ids(char* ws, const AgsLayout& L, int binning_mode) {
+    // (AGS_BIN_DIRECT leaves its keys in keys0 like AGS_BIN_TILE_SORT, at tile * tile_cap instead of a scanned offset)
     if (binning_mode == AGS_BIN_RADIX)  // payloads end in buffer (passes & 1)
         return AgsIdList{(const uint32_t*)(ws + ((ags_sort_passes(L.num_tiles) & 1) ? L.vals1 : L.vals0)), 1};
     return AgsIdList{(const uint32_t*)(ws + L.keys0), 2}; // low word of (depth<<32 | id), little endian
@@ -368,6 +373,8 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
     __shared__ uint32_t depth_bits[AGS_PRE_THREADS];
     __shared__ uint32_t pre[SCAN ? AGS_BUCKET_SCAN_TILES + 1 : 1]; // pre[t] = instances of tiles < t
     __shared__ uint32_t wtot[AGS_PRE_THREADS / 64];
+    [[maybe_unused]] const int tl_w = blockIdx.x * (AGS_PRE_THREADS / 64) + (threadIdx.x >> 6);
+    AGS_TL(1, tl_w, 0);
     if (SCAN) {
         constexpr int PER = AGS_BUCKET_SCAN_TILES / AGS_PRE_THREADS; // 16 consecutive tiles per lane
         const int t0 = threadIdx.x * PER;
@@ -421,6 +428,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
             }
         }
     }
+    AGS_TL(1, tl_w, 1);
     const int i = blockIdx.x * AGS_PRE_THREADS + threadIdx.x;
     const uint32_t cnt = (i < n) ? tiles[i] : 0u;
     uint32_t x0 = 0, y0 = 0, wd = 1;
@@ -434,9 +442,10 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
         g.mx = r0.x; g.my = r0.y; g.ca = r0.z; g.cb = r0.w; g.cc = r1.x; g.o = r1.y;
         depth_bits[threadIdx.x] = __float_as_uint(r1.z);
     }
+    AGS_TL(1, tl_w, 2);
     // same predicate and same inputs as the counting pass in ags_k_preprocess<true>
     ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, x0, y0, wd, (uint32_t)threadIdx.x, g, tiles_x,
-                            [&](bool hit, uint32_t t, uint32_t owner_tid) {
+                            [&](bool hit, uint32_t t, uint32_t owner_tid, int) {
 #ifdef AGS_EXP_BUCKET_NOATOMIC
         if (hit && t == 0xFFFFFFFFu) keys[0] = 1;
 #else
@@ -451,6 +460,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
         }
 #endif
     });
+    AGS_TL(1, tl_w, 3);
 }
 
 // The per-tile sort (ags_sort_tile_keys, ags_internal.h) as its own launch: one 256-thread workgroup
@@ -465,9 +475,43 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort(const uint2* __restrict__
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(keys, wo);
     }
     __shared__ uint64_t sk[AGS_TSORT_LDS_KEYS];
+    if (threadIdx.x < 64) AGS_TL(5, blockIdx.x, 0);
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
     ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS, false>(keys + rg.x, rg.y - rg.x, sk, threadIdx.x);
+    if (threadIdx.x < 64) { AGS_TL(5, blockIdx.x, 1); AGS_TL_VAL(5, blockIdx.x, 6, rg.y - rg.x); }
+}
+
+// AGS_BIN_DIRECT: the keys already sit in the tile's own slot range [tile * tile_cap, + count) (written by the
+// per-Gaussian kernel); this sorts them, publishes the tile's range for the blend kernels and adds the tile's
+// list length to the spread partial sums / maxima the forward blend kernel turns into the status block.
+__global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict__ ranges, uint64_t* keys,
+                                                              const uint32_t* __restrict__ tile_count, uint32_t tile_cap,
+                                                              uint32_t* __restrict__ partial, int num_tiles, AgsViewStride vs) {
+    { // (offsets are 0 for a single view)
+        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
+        AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(keys, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(partial, wo);
+    }
+    __shared__ uint64_t sk[AGS_TSORT_LDS_KEYS];
+    if (threadIdx.x < 64) AGS_TL(5, blockIdx.x, 0);
+    const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
+    const uint32_t cnt = tile_count[tile];
+    const uint32_t K = cnt < tile_cap ? cnt : tile_cap, base = (uint32_t)tile * tile_cap;
+    if (threadIdx.x == 0) {
+        ranges[tile] = make_uint2(base, base + K);
+        if (cnt) {
+            atomicAdd(&partial[AGS_PART_SUM + (tile & 63)], cnt);
+            atomicMax(&partial[AGS_PART_MAX + (tile & 63)], cnt);
+        }
+    }
+    ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS, false>(keys + base, K, sk, threadIdx.x);
+    if (threadIdx.x < 64) { AGS_TL(5, blockIdx.x, 1); AGS_TL_VAL(5, blockIdx.x, 6, K); }
+}
+
+void ags_launch_direct_sort(char* ws, const AgsLayout& L, const AgsViewStride& vs, hipStream_t s) {
+    hipLaunchKernelGGL(ags_k_tile_sort_direct, dim3(L.num_tiles, vs.views), dim3(256), 0, s, (uint2*)(ws + L.ranges),
+                       (uint64_t*)(ws + L.keys0), (const uint32_t*)(ws + L.tile_count), ags_direct_tile_cap(L),
+                       (uint32_t*)(ws + L.totals), L.num_tiles, vs);
 }
 
 void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L,

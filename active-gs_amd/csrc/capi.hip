@@ -49,13 +49,15 @@ int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* o
     if (in->n > 0 && (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences))
         return AGS_E_INVALID;
     if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll) return AGS_E_INVALID;
-    if (ws->binning_mode != AGS_BIN_TILE_SORT && ws->binning_mode != AGS_BIN_RADIX) return AGS_E_INVALID;
+    if (ws->binning_mode != AGS_BIN_TILE_SORT && ws->binning_mode != AGS_BIN_RADIX && ws->binning_mode != AGS_BIN_DIRECT)
+        return AGS_E_INVALID;
     const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
     if (ws->bytes < L.total) return AGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char* base = (char*)ws->ptr;
     const AgsFrame F = ags_make_frame(cam);
-    const bool radix = ws->binning_mode == AGS_BIN_RADIX;
+    const bool radix = ws->binning_mode == AGS_BIN_RADIX, direct = ws->binning_mode == AGS_BIN_DIRECT;
+    if (direct && ags_direct_tile_cap(L) < 1) return AGS_E_WORKSPACE;   // not even one key slot per tile
     // tile-sort mode is self-cleaning (see ags_workspace_init); the radix path re-zeroes its digit
     // totals and tile ranges every pass
     // (status words 0-3 and everything behind the status block; the sticky words 4-5 of AgsStatus survive)
@@ -64,12 +66,16 @@ int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* o
         if (hipMemsetAsync(base + L.totals, 0, L.clear_bytes - L.totals, s) != hipSuccess) return AGS_E_LAUNCH;
     }
     if (in->n > 0) {
-        { StageScope t(AGS_STAGE_PREPROCESS, s); ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, !radix, pg->touched, kOneView, s); }
+        { StageScope t(AGS_STAGE_PREPROCESS, s);
+          ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, radix ? 0 : direct ? 2 : 1, pg->touched, kOneView, s); }
         { StageScope t(AGS_STAGE_BINNING, s);
-          if (radix) ags_launch_binning(F, *in, base, L, s); else ags_launch_tile_binning(F, *in, base, L, kOneView, s); }
+          if (radix) ags_launch_binning(F, *in, base, L, s);
+          else if (direct) ags_launch_direct_sort(base, L, kOneView, s);
+          else ags_launch_tile_binning(F, *in, base, L, kOneView, s); }
     }
     { StageScope t(AGS_STAGE_RENDER_FWD, s);
-      ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, kOneView, s); }
+      ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, kOneView,
+                            direct && in->n > 0, s); }
     return ags_check_launch();
 }
 
@@ -87,17 +93,19 @@ int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* i
     if (cam->want_stats && (!pg->importance || !pg->count)) return AGS_E_INVALID;
     if (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences) return AGS_E_INVALID;
     if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll) return AGS_E_INVALID;
-    if (ws->binning_mode != AGS_BIN_TILE_SORT) return AGS_E_INVALID;
+    if (ws->binning_mode != AGS_BIN_TILE_SORT && ws->binning_mode != AGS_BIN_DIRECT) return AGS_E_INVALID;
     const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
     if (ws->bytes < (size_t)views * L.total) return AGS_E_WORKSPACE;
+    const bool direct = ws->binning_mode == AGS_BIN_DIRECT;
+    if (direct && ags_direct_tile_cap(L) < 1) return AGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char* base = (char*)ws->ptr;
     const AgsFrame F = ags_make_frame(cam);
     AgsViewStride vs;
     vs.ws = (long long)L.total; vs.px = (long long)cam->image_height * cam->image_width; vs.n = in->n; vs.views = views;
-    ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, true, pg->touched, vs, s);
-    ags_launch_tile_binning(F, *in, base, L, vs, s);
-    ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, vs, s);
+    ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, direct ? 2 : 1, pg->touched, vs, s);
+    if (direct) ags_launch_direct_sort(base, L, vs, s); else ags_launch_tile_binning(F, *in, base, L, vs, s);
+    ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, vs, direct, s);
     return ags_check_launch();
 }
 
@@ -153,7 +161,7 @@ int ags_backward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* 
     if (in->n <= 0 || !pg->radii || !fwd->depth || !fwd->opacity) return AGS_E_INVALID;
     if (!din->d_means3D || !din->d_scales || !din->d_rotations || !din->d_opacities || !din->d_colors) return AGS_E_INVALID;
     if (din->accumulate != 2 || din->fused_adam || din->pack_segment) return AGS_E_INVALID; // views sum with atomics into a pre-zeroed slab
-    if (ws->binning_mode != AGS_BIN_TILE_SORT) return AGS_E_INVALID;
+    if (ws->binning_mode != AGS_BIN_TILE_SORT && ws->binning_mode != AGS_BIN_DIRECT) return AGS_E_INVALID;
     const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
     if (ws->bytes < (size_t)views * L.total) return AGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -390,6 +398,14 @@ int ags_compact_rows(int32_t n, int32_t width, const int32_t* dst_index, const f
     ags_launch_compact_rows(n, width, dst_index, src, dst, (hipStream_t)stream);
     return ags_check_launch();
 }
+
+#ifdef AGS_TIMELINE
+// experiment builds only: buffer of 8 kernels x AGS_TL_WAVES waves x 8 uint64 (see AGS_TL in ags_internal.h)
+int ags_debug_timeline(void* device_buffer) {
+    ags_tl_set_preprocess(device_buffer); ags_tl_set_binning(device_buffer); ags_tl_set_render(device_buffer);
+    return AGS_OK;
+}
+#endif
 
 const char* ags_error_string(int code) {
     switch (code) {

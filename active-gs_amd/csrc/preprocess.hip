@@ -4,6 +4,8 @@
 // Counterpart of the preprocess / preprocess-backward stages listed in SURVEY.md §2.3.
 #include "ags_internal.h"
 
+AGS_TL_DEFINE(preprocess)
+
 // Coalesced access to the reference's (N,3) row-major arrays: the block's 256 rows are 3072
 // contiguous bytes, moved as 192 x 16-byte lane accesses and transposed through LDS (a stride-3
 // LDS access is conflict-free: 3 is coprime with the 32 banks), instead of three 12-byte-stride
@@ -60,43 +62,76 @@ __device__ __forceinline__ void ags_activate_inplace(const AgsGaussians& in, flo
     opacity = 1.0f / (1.0f + expf(-opacity));
 }
 
-template <bool COUNT_TILES, bool AGG>
+// The block's rows of three (N,3) arrays at once: all three global reads are issued before the first wait and ONE
+// barrier separates the LDS writes from the transposed reads (three ags_load_rows3 calls cost six barriers and
+// three load latencies in a row - this kernel is a latency chain).
+__device__ __forceinline__ void ags_load_rows3x3(const float* __restrict__ b0, const float* __restrict__ b1,
+                                                 const float* __restrict__ b2, int first_row, int rows, float* lds,
+                                                 float o0[3], float o1[3], float o2[3]) {
+    const int t = threadIdx.x;
+    const float *s0 = b0 + (size_t)first_row * 3, *s1 = b1 + (size_t)first_row * 3, *s2 = b2 + (size_t)first_row * 3;
+    float *l0 = lds, *l1 = lds + 3 * AGS_PRE_THREADS, *l2 = lds + 6 * AGS_PRE_THREADS;
+    if (rows == AGS_PRE_THREADS && (((uintptr_t)s0 | (uintptr_t)s1 | (uintptr_t)s2) & 15) == 0) { // block-uniform
+        if (t < AGS_PRE_THREADS * 3 / 4) {
+            const float4 a = reinterpret_cast<const float4*>(s0)[t], b = reinterpret_cast<const float4*>(s1)[t],
+                         c = reinterpret_cast<const float4*>(s2)[t];
+            reinterpret_cast<float4*>(l0)[t] = a; reinterpret_cast<float4*>(l1)[t] = b; reinterpret_cast<float4*>(l2)[t] = c;
+        }
+    } else {
+        for (int k = t; k < rows * 3; k += AGS_PRE_THREADS) { l0[k] = s0[k]; l1[k] = s1[k]; l2[k] = s2[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o0[k] = l0[3 * t + k]; o1[k] = l1[3 * t + k]; o2[k] = l2[3 * t + k]; }
+}
+
+struct AgsDirectEmit { uint64_t* keys; uint32_t tile_cap; uint32_t* partial; };
+
+// EMIT: 0 = nothing, 1 = count the tiles a surfel reaches (tile-sort binning), 2 = AGS_BIN_DIRECT: take a slot in
+// the tile's own key range with ONE returning atomic and write the (depth | id) key at once
+template <int EMIT, bool AGG>
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     AgsGeom* __restrict__ geom, uint32_t* __restrict__ tiles, ushort4* __restrict__ rect,
     int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_vis,
-    uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom, AgsRowSet touched, AgsViewStride vs) {
+    uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom, AgsRowSet touched, AgsDirectEmit direct,
+    AgsViewStride vs) {
     { // batched forward: this workgroup's view // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
         Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
         radii += (size_t)blockIdx.y * (size_t)vs.n;
         AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(tiles, wo); AGS_WS_SHIFT(rect, wo); AGS_WS_SHIFT(block_sums, wo);
         AGS_WS_SHIFT(block_vis, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(dgeom, wo);
+        if (EMIT == 2) { AGS_WS_SHIFT(direct.keys, wo); AGS_WS_SHIFT(direct.partial, wo); }
     }
     __shared__ uint32_t wsum[AGS_PRE_THREADS / 64], wvis[AGS_PRE_THREADS / 64];
-    __shared__ AgsEmitRec emit[COUNT_TILES ? AGS_PRE_THREADS : 1];
-    __shared__ __attribute__((aligned(16))) float rows3[3 * AGS_PRE_THREADS];
+    __shared__ AgsEmitRec emit[EMIT ? AGS_PRE_THREADS : 1];
+    __shared__ __attribute__((aligned(16))) float rows3[9 * AGS_PRE_THREADS];
     float V[16], P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
+    [[maybe_unused]] const int tl_w = blockIdx.x * (AGS_PRE_THREADS / 64) + (threadIdx.x >> 6);
+    AGS_TL(0, tl_w, 0);
     const int first = blockIdx.x * AGS_PRE_THREADS;
     const int i = first + threadIdx.x;
     const int rows = min(AGS_PRE_THREADS, in.n - first);
     uint32_t cnt = 0, vis = 0;
     uint32_t rx0 = 0, ry0 = 0, rwd = 1;
     AgsGeom g;
-    g.mx = g.my = g.ca = g.cb = g.cc = g.o = 0.f;
+    g.mx = g.my = g.ca = g.cb = g.cc = g.o = 0.f; g.dc = 0.f;
     float p[3], sc[3], col[3];
-    ags_load_rows3(in.means3D, first, rows, rows3, p);
-    ags_load_rows3(in.scales, first, rows, rows3, sc);
-    ags_load_rows3(in.colors, first, rows, rows3, col);
+    // the row's other inputs are requested before the barrier inside the transposed load
+    const int ic = i < in.n ? i : in.n - 1;
+    const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[ic];
+    float opacity = in.opacities[ic];
+    const float conf = in.confidences[ic];
+    ags_load_rows3x3(in.means3D, in.scales, in.colors, first, rows, rows3, p, sc, col);
+    AGS_TL(0, tl_w, 1);
     if (i < in.n) {
-        const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
         float q[4] = {q4.x, q4.y, q4.z, q4.w};
-        float opacity = in.opacities[i];
         if (in.raw_params) { float rv[3], qi; ags_activate_inplace(in, sc, q, opacity, rv, qi); }
         int radius = 0, rc[4];
-        if (ags_preprocess_fwd(F, V, P, p, sc, q, opacity, col, in.confidences[i], 0.f, 0.f, g, radius, rc)) {
+        if (ags_preprocess_fwd(F, V, P, p, sc, q, opacity, col, conf, 0.f, 0.f, g, radius, rc)) {
             float4* dst = reinterpret_cast<float4*>(geom + i);
             dst[0] = make_float4(g.mx, g.my, g.ca, g.cb);
             dst[1] = make_float4(g.cc, g.o, g.dc, g.gx);
@@ -106,14 +141,15 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             dgeom[4 * (size_t)i + 0] = z4; dgeom[4 * (size_t)i + 1] = z4;
             dgeom[4 * (size_t)i + 2] = z4; dgeom[4 * (size_t)i + 3] = z4;
-            rect[i] = make_ushort4((unsigned short)rc[0], (unsigned short)rc[1], (unsigned short)rc[2], (unsigned short)rc[3]);
+            if (EMIT != 2) rect[i] = make_ushort4((unsigned short)rc[0], (unsigned short)rc[1], (unsigned short)rc[2], (unsigned short)rc[3]);
             cnt = (uint32_t)((rc[2] - rc[0]) * (rc[3] - rc[1]));
             rx0 = (uint32_t)rc[0]; ry0 = (uint32_t)rc[1]; rwd = (uint32_t)(rc[2] - rc[0]);
             vis = 1;
         }
         radii[i] = radius;
-        tiles[i] = cnt;
+        if (EMIT != 2) tiles[i] = cnt;
     }
+    AGS_TL(0, tl_w, 2);
     if (touched.member) { // sticky row set of the optimisation loop: insert first-time-visible surfels
         // (after the first few steps of a keyframe nothing is new and this is one sparse read)
         const bool fresh = vis && touched.member[i] == 0 && atomicExch(&touched.member[i], 1) == 0;
@@ -126,26 +162,44 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
             if (fresh) touched.rows[base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = i;
         }
     }
-    if (COUNT_TILES)  // tile-sort binning: how many surfels can reach each tile
+    AGS_TL(0, tl_w, 3);
+    if (EMIT == 1)  // tile-sort binning: how many surfels can reach each tile
         ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, rx0, ry0, rwd, 0u, g, F.tiles_x,
-                                [&](bool hit, uint32_t t, uint32_t) {
+                                [&](bool hit, uint32_t t, uint32_t, int) {
 #ifdef AGS_EXP_PRE_NOCOUNT
                                     if (hit && t == 0xFFFFFFFFu) tile_count[0] = 1;
 #else
                                     ags_wave_agg_inc<AGG, false>(tile_count, t, hit);
 #endif
                                 });
-    const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { wsum[wave] = ws; wvis[wave] = wv; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t a = 0, b = 0;
-#pragma unroll
-        for (int k = 0; k < AGS_PRE_THREADS / 64; ++k) { a += wsum[k]; b += wvis[k]; }
-        block_sums[blockIdx.x] = a;
-        block_vis[blockIdx.x] = b;  // summed by the (single-workgroup) scan kernel: no fan-in atomics
+    if (EMIT == 2) { // one-pass binning: the tile's counter hands out the slot, the key is written at once
+        const uint32_t wave_first = (uint32_t)(first + (threadIdx.x & ~63));
+        ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, rx0, ry0, rwd, __float_as_uint(g.dc), g, F.tiles_x,
+                                [&](bool hit, uint32_t t, uint32_t depth_bits, int owner_lane) {
+                                    const uint32_t got = ags_wave_agg_inc<AGG, true>(tile_count, t, hit);
+                                    if (hit && got < direct.tile_cap)
+                                        direct.keys[(size_t)t * direct.tile_cap + got] =
+                                            ((uint64_t)depth_bits << 32) | (wave_first + (uint32_t)owner_lane);
+                                });
     }
+    AGS_TL(0, tl_w, 4);
+    const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
+    if (EMIT == 2) { // no block-level reduction (and no barrier): one spread atomic per wave that shows anything
+        if ((threadIdx.x & 63) == 0 && wv) atomicAdd(&direct.partial[AGS_PART_VIS + (blockIdx.x & 63)], wv);
+    } else {
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { wsum[wave] = ws; wvis[wave] = wv; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t a = 0, b = 0;
+#pragma unroll
+            for (int k = 0; k < AGS_PRE_THREADS / 64; ++k) { a += wsum[k]; b += wvis[k]; }
+            block_sums[blockIdx.x] = a;
+            block_vis[blockIdx.x] = b;  // summed by the (single-workgroup) scan kernel: no fan-in atomics
+        }
+    }
+    AGS_TL(0, tl_w, 5);
+    AGS_TL_VAL(0, tl_w, 6, ws | ((unsigned long long)wv << 32));
 }
 
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
@@ -265,6 +319,7 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
     const int lane = threadIdx.x;
+    AGS_TL(4, blockIdx.x, 0);
     // This kernel is a short chain of dependent loads on few rows (latency, not bandwidth), so every
     // load that can be issued early is: the first batch of row ids is fetched while the member count
     // is still in flight (the list is zero-filled past `count`, so any slot holds a valid row), and
@@ -425,19 +480,23 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
             adam.m[3][i] = am[10]; adam.v[3][i] = av[10]; adam.p[3][i] = ap[10];
         }
     }
+    AGS_TL(4, blockIdx.x, 1);
+    AGS_TL_VAL(4, blockIdx.x, 6, count);
 }
 
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
-                           const AgsLayout& L, int* radii, bool count_tiles, const AgsRowSet& touched,
+                           const AgsLayout& L, int* radii, int emit, const AgsRowSet& touched,
                            const AgsViewStride& vs, hipStream_t s) {
-#define AGS_LAUNCH_PRE(COUNT, AGG)                                                                                       \
-    hipLaunchKernelGGL((ags_k_preprocess<COUNT, AGG>), dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, F,         \
+    const AgsDirectEmit direct = {(uint64_t*)(ws + L.keys0), ags_direct_tile_cap(L), (uint32_t*)(ws + L.totals)};
+#define AGS_LAUNCH_PRE(EMIT, AGG)                                                                                        \
+    hipLaunchKernelGGL((ags_k_preprocess<EMIT, AGG>), dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, F,          \
                        cam.viewmatrix, cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),             \
                        (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.block_vis),      \
-                       (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched, vs)
-    if (!count_tiles) AGS_LAUNCH_PRE(false, false);
-    else if (L.num_tiles <= AGS_AGG_MAX_TILES) AGS_LAUNCH_PRE(true, true);
-    else AGS_LAUNCH_PRE(true, false);
+                       (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched, direct, vs)
+    const bool agg = L.num_tiles <= AGS_AGG_MAX_TILES;
+    if (emit == 0) AGS_LAUNCH_PRE(0, false);
+    else if (emit == 1) { if (agg) AGS_LAUNCH_PRE(1, true); else AGS_LAUNCH_PRE(1, false); }
+    else { if (agg) AGS_LAUNCH_PRE(2, true); else AGS_LAUNCH_PRE(2, false); }
 #undef AGS_LAUNCH_PRE
 }
 

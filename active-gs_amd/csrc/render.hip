@@ -27,6 +27,8 @@
 
 #include "ags_internal.h"
 
+AGS_TL_DEFINE(render)
+
 template <int N>
 struct AgsWaveStageT {  // one per wave, in LDS
     AgsGeom sg[N];
@@ -56,10 +58,57 @@ __device__ __forceinline__ uint32_t ags_stage_one(STAGE& st, int lane, const Ags
     return m;
 }
 
+// the same in two halves, so that independent work can sit between the gather and its use: issue = the four
+// 16-byte loads of the record; commit = park it in the wave's LDS stage and compute the reach mask
+struct AgsRec4 { float4 r0, r1, r2, r3; };
+__device__ __forceinline__ AgsRec4 ags_stage_issue(const AgsGeom* __restrict__ geom, uint32_t gid) {
+    const float4* src = reinterpret_cast<const float4*>(geom + gid);
+    AgsRec4 r;
+    r.r0 = src[0]; r.r1 = src[1]; r.r2 = src[2]; r.r3 = src[3];
+    return r;
+}
+template <int SLOTS, typename STAGE>
+__device__ __forceinline__ uint32_t ags_stage_commit(STAGE& st, int lane, const AgsRec4& r, uint32_t gid, float bx0,
+                                                     float by0, int strip0) {
+    float4* dst = reinterpret_cast<float4*>(&st.sg[lane]);
+    dst[0] = r.r0; dst[1] = r.r1; dst[2] = r.r2; dst[3] = r.r3;
+    st.sid[lane] = gid;
+    AgsGeom me;
+    me.mx = r.r0.x; me.my = r.r0.y; me.ca = r.r0.z; me.cb = r.r0.w; me.cc = r.r1.x; me.o = r.r1.y;
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const int s = strip0 + k;
+        const float qx0 = bx0 + 8.f * (float)(s & 1), qy0 = by0 + 8.f * (float)(s >> 1);
+        m |= ags_reaches_box(me, qx0, qx0 + 7.f, qy0, qy0 + 7.f) ? (1u << s) : 0u;
+    }
+    return m;
+}
+
 __device__ __forceinline__ void ags_wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// AGS_BIN_DIRECT: nobody has added up the view's instance count yet (there is no scan): the first wave of the
+// forward blend kernel turns the spread partial sums / maxima (ags_k_tile_sort_direct, ags_k_preprocess<2>) into the
+// status block and leaves them zeroed for the next pass.  status == nullptr: the other binning modes.
+struct AgsFinalize { uint32_t* status; uint32_t* partial; uint32_t tile_cap; };
+
+__device__ __forceinline__ void ags_finalize_status(const AgsFinalize& fin, int num_tiles, int lane) {
+    uint32_t s = fin.partial[AGS_PART_SUM + lane], m = fin.partial[AGS_PART_MAX + lane], v = fin.partial[AGS_PART_VIS + lane];
+    fin.partial[AGS_PART_SUM + lane] = 0u; fin.partial[AGS_PART_MAX + lane] = 0u; fin.partial[AGS_PART_VIS + lane] = 0u;
+    s = ags_wave_sum_u32(s); m = ags_wave_max_u32(m); v = ags_wave_sum_u32(v);
+    if (lane == 0) {
+        const unsigned long long need64 = (unsigned long long)m * (unsigned long long)num_tiles;
+        const uint32_t need = need64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)need64;
+        const bool over = m > fin.tile_cap;
+        fin.status[0] = s; fin.status[1] = s; fin.status[2] = over ? 1u : 0u; fin.status[3] = v;
+        if (need > fin.status[4]) fin.status[4] = need;
+        if (over) fin.status[5] += 1u;
+        fin.status[6] = m; fin.status[7] = need;
+    }
 }
 
 template <int SLOTS, bool STATS>
@@ -68,11 +117,12 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     const float* __restrict__ mask, const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
     int id_stride, const AgsGeom* __restrict__ geom, AgsImages out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ importance, int* __restrict__ count, int num_tiles,
-    uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_fill, AgsViewStride vs) {
+    uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_fill, AgsFinalize fin, AgsViewStride vs) {
     { // batched forward: this workgroup's view // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws, po = (size_t)blockIdx.y * (size_t)vs.px;
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(vals, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(final_T, wo);
         AGS_WS_SHIFT(n_contrib, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(tile_fill, wo);
+        if (fin.status) { AGS_WS_SHIFT(fin.status, wo); AGS_WS_SHIFT(fin.partial, wo); }
         if (mask) mask += po;
         out.rgb += 3 * po; out.normal += 3 * po; out.depth += po; out.opacity += po; out.confidence += po;
         if (STATS) { importance += (size_t)blockIdx.y * (size_t)vs.n; count += (size_t)blockIdx.y * (size_t)vs.n; }
@@ -80,6 +130,9 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     __shared__ AgsWaveStage stage[4 / SLOTS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63; // wave index in an SGPR: strip masks become scalar tests
     AgsWaveStage& st = stage[wave];
+    [[maybe_unused]] const int tl_w = blockIdx.x * (4 / SLOTS) + wave;
+    AGS_TL(2, tl_w, 0);
+    if (fin.status && blockIdx.x == 0 && wave == 0) ags_finalize_status(fin, num_tiles, lane);   // wave-uniform
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
     const int strip0 = wave * SLOTS;                       // first of this wave's slots (8x8 quadrants of the tile)
@@ -103,6 +156,8 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
         if (STATS && mask != nullptr && inside) mk[s] = mask[(size_t)AGS_PY(s) * F.W + AGS_PX(s)] > 0.f ? 1.f : 0.f;
         alldone &= pix[s].done;
     }
+    AGS_TL(2, tl_w, 1);
+    [[maybe_unused]] uint32_t tl_iters = 0;
     for (uint32_t base = rg.x; base < rg.y; base += 64) {
         if (__all(alldone)) break;
         ags_wave_lds_sync();
@@ -111,6 +166,8 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
         if (idx < rg.y) m = ags_stage_one<SLOTS>(st, lane, geom, vals[(size_t)idx * id_stride], bx0, by0, strip0);
         ags_wave_lds_sync();
         unsigned long long act = __ballot((m & my_strips) != 0u); // staged surfels that reach my strips
+        if (base == rg.x) AGS_TL(2, tl_w, 2);
+        tl_iters += (uint32_t)__builtin_popcountll(act);
         while (act) {
             const int k = __ffsll((long long)act) - 1;
             act &= act - 1;
@@ -154,6 +211,9 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) alldone &= pix[s].done;
     }
+    AGS_TL(2, tl_w, 3);
+    AGS_TL_VAL(2, tl_w, 5, rg.y - rg.x);
+    AGS_TL_VAL(2, tl_w, 6, tl_iters);
     const float bg0 = bgp[0], bg1 = bgp[1], bg2 = bgp[2];
     const size_t HW = (size_t)F.H * F.W;
 #pragma unroll
@@ -171,6 +231,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
             n_contrib[o] = pix[s].last;
         }
     }
+    AGS_TL(2, tl_w, 4);
 }
 
 #ifdef AGS_BWD_WAVES   // experiment knob: force a register budget for N resident waves per SIMD
@@ -335,6 +396,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WA
     AgsWaveBatch& wb = batch[wave];
     AgsWaveStageT<AGS_MFMA_STAGE>& st = wb.st;
     if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2, 0);
+    [[maybe_unused]] const int tl_w = blockIdx.x * 4 + wave;
+    AGS_TL(3, tl_w, 0);
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
     if (rg.y <= rg.x) return;
@@ -345,7 +408,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WA
     const uint32_t my_strips = 1u << strip0;
     const float bg[3] = {bgp[0], bgp[1], bgp[2]};
     const size_t HW = (size_t)F.H * F.W;
+    // Load order = dependency depth.  A wave's prologue is a chain of dependent loads (ids -> records; n_contrib ->
+    // the pixel's gradients) and at short lists the prologue is a third of the wave's life, so everything that can be
+    // requested at once is: when the whole list fits ONE staging round (most tiles of a 1200x680 view) the ids are
+    // requested before the pixel's inputs and the records as soon as the ids are here - the pixel set-up and the
+    // feature exchange below then run while the gather is in flight.  The pixel's inputs are requested together with
+    // n_contrib, not behind it.
+    const uint32_t list_len = rg.y - rg.x;
+#ifdef AGS_EXP_NO_EARLY   // experiment knob: the prologue as it was (ids and records requested behind the pixel set-up)
+    const bool early = false;
+#else
+    const bool early = list_len <= (uint32_t)AGS_MFMA_STAGE;                  // wave-uniform
+#endif
+    uint32_t gid_early = 0;
+    if (early && lane < (int)list_len) gid_early = vals[(size_t)(rg.x + lane) * id_stride];
     AgsPixGrad pg;
+    AgsRec4 rec_early = {};
     {
         const int px = AGS_PX(0), py = AGS_PY(0);
         float dC[3] = {0, 0, 0}, dN[3] = {0, 0, 0}, dD = 0, dO = 0, dCf = 0, dep = 0, opa = 0, Tf = 1.f;
@@ -353,18 +431,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WA
         if (px < F.W && py < F.H) {
             const size_t o = (size_t)py * F.W + px;
             last = n_contrib[o];
-            if (last) {
-                if (dout.d_rgb) { dC[0] = dout.d_rgb[o]; dC[1] = dout.d_rgb[HW + o]; dC[2] = dout.d_rgb[2 * HW + o]; }
-                if (dout.d_normal) { dN[0] = dout.d_normal[o]; dN[1] = dout.d_normal[HW + o]; dN[2] = dout.d_normal[2 * HW + o]; }
-                if (dout.d_depth) dD = dout.d_depth[o];
-                if (dout.d_opacity) dO = dout.d_opacity[o];
-                if (dout.d_confidence) dCf = dout.d_confidence[o];
-                dep = depth_out[o]; opa = opac_out[o]; Tf = final_T[o];
-            }
+            if (dout.d_rgb) { dC[0] = dout.d_rgb[o]; dC[1] = dout.d_rgb[HW + o]; dC[2] = dout.d_rgb[2 * HW + o]; }
+            if (dout.d_normal) { dN[0] = dout.d_normal[o]; dN[1] = dout.d_normal[HW + o]; dN[2] = dout.d_normal[2 * HW + o]; }
+            if (dout.d_depth) dD = dout.d_depth[o];
+            if (dout.d_opacity) dO = dout.d_opacity[o];
+            if (dout.d_confidence) dCf = dout.d_confidence[o];
+            dep = depth_out[o]; opa = opac_out[o]; Tf = final_T[o];
         }
+        if (early && lane < (int)list_len) rec_early = ags_stage_issue(geom, gid_early);   // needs only the ids
+        if (!last) { dC[0] = dC[1] = dC[2] = dN[0] = dN[1] = dN[2] = dD = dO = dCf = dep = opa = 0.f; Tf = 1.f; }
         ags_pixgrad_init(pg, dC, dN, dD, dO, dCf, dep, opa, Tf, last, bg, normalize_depth);
     }
+    // park the early records now (not across the feature exchange: sixteen more live registers there spill)
+    uint32_t m_early = 0;
+    if (early && lane < (int)list_len) m_early = ags_stage_commit<SLOTS>(st, lane, rec_early, gid_early, bx0, by0, strip0);
     const uint32_t maxlast = ags_wave_max_u32(pg.last);
+    AGS_TL(3, tl_w, 1);
     if (maxlast == 0) return; // wave-uniform; no workgroup barrier anywhere in this kernel
 
     // ---- B operands: field (lane & 15) of the 16 pixels t + 16 (lane >> 4) --------------------------
@@ -400,6 +482,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WA
     const int row_base = lane & 48;
     const int src0 = row_base << 2, src1 = (row_base + 1) << 2, src5 = (row_base + 5) << 2, src6 = (row_base + 6) << 2; // bpermute byte addresses
     int nb = 0; // filled slots (wave-uniform)
+    AGS_TL(3, tl_w, 2);
+    [[maybe_unused]] uint32_t tl_iters = 0, tl_flush = 0;
 
     auto flush = [&]() {
         ags_wave_lds_sync();
@@ -444,12 +528,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WA
         const uint32_t k0 = (uint32_t)r << RSH;
         ags_wave_lds_sync();
         uint32_t m = 0, my_gid = 0; // the staging lane keeps the surfel id: slot metadata reads it with v_readlane, not from LDS
-        if (lane < AGS_MFMA_STAGE && k0 + lane < maxlast) {
+        if (early) {                       // the only round (r == 0): the records were parked in the prologue
+            if (lane < (int)maxlast) { my_gid = gid_early; m = m_early; }
+        } else if (lane < AGS_MFMA_STAGE && k0 + lane < maxlast) {
             my_gid = vals[(size_t)(rg.x + k0 + lane) * id_stride];
             m = ags_stage_one<SLOTS>(st, lane, geom, my_gid, bx0, by0, strip0);
         }
         ags_wave_lds_sync();
         unsigned long long act = __ballot((m & my_strips) != 0u);
+        if (r == (int)((maxlast - 1) >> RSH)) AGS_TL(3, tl_w, 3);
+        tl_iters += (uint32_t)__builtin_popcountll(act);
         while (act) { // back to front: highest staged position first
             const int k = 63 - __clzll((long long)act);
             act &= ~(1ull << k);
@@ -473,10 +561,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WA
             wb.gw[2 * nb + 1][lane] = w;
             const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)my_gid, k);
             if (lane == 0) wb.meta[nb] = make_float4(__uint_as_float(sid), g.mx - cx, g.my - cy, 0.f);
-            if (++nb == 8) flush();
+            if (++nb == 8) { flush(); ++tl_flush; }
         }
     }
-    if (nb) flush();
+    AGS_TL(3, tl_w, 4);
+    if (nb) { flush(); ++tl_flush; }
+    AGS_TL(3, tl_w, 5);
+    AGS_TL_VAL(3, tl_w, 6, tl_iters | ((unsigned long long)tl_flush << 32));
+    AGS_TL_VAL(3, tl_w, 7, maxlast);
 }
 
 // How many strips per wave: one wave per tile when the image has enough tiles to fill the
@@ -500,7 +592,9 @@ static int ags_bwd_mfma() {
 
 template <int SLOTS>
 static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L, AgsIdList ids,
-                       const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs, hipStream_t s) {
+                       const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs, bool direct, hipStream_t s) {
+    AgsFinalize fin = {nullptr, nullptr, 0u};
+    if (direct) fin = AgsFinalize{(uint32_t*)(ws + L.status), (uint32_t*)(ws + L.totals), ags_direct_tile_cap(L)};
     const uint2* ranges = (const uint2*)(ws + L.ranges);
     const AgsGeom* geom = (const AgsGeom*)(ws + L.geom);
     float* fT = (float*)(ws + L.final_T);
@@ -510,12 +604,12 @@ static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, true>), dim3(L.num_tiles, vs.views), block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
-                           (uint32_t*)(ws + L.tile_fill), vs);
+                           (uint32_t*)(ws + L.tile_fill), fin, vs);
     else
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, false>), dim3(L.num_tiles, vs.views), block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
-                           (uint32_t*)(ws + L.tile_fill), vs);
+                           (uint32_t*)(ws + L.tile_fill), fin, vs);
 }
 
 template <int SLOTS>
@@ -530,12 +624,12 @@ static void launch_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
 
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs,
-                           hipStream_t s) {
+                           bool direct, hipStream_t s) {
     // strips per wave by the number of tiles in flight: a batch of views fills the GPU like one big image
     switch (ags_pick_slots(L.num_tiles * vs.views)) {
-        case 1: launch_fwd<1>(F, cam, ws, L, ids, out, pg, vs, s); break;
-        case 2: launch_fwd<2>(F, cam, ws, L, ids, out, pg, vs, s); break;
-        default: launch_fwd<4>(F, cam, ws, L, ids, out, pg, vs, s); break;
+        case 1: launch_fwd<1>(F, cam, ws, L, ids, out, pg, vs, direct, s); break;
+        case 2: launch_fwd<2>(F, cam, ws, L, ids, out, pg, vs, direct, s); break;
+        default: launch_fwd<4>(F, cam, ws, L, ids, out, pg, vs, direct, s); break;
     }
 }
 

@@ -32,7 +32,7 @@ def weighted_choice_without_replacement(weights: torch.Tensor, k: int) -> torch.
 
 class FusedMapTrainer(GaussianMapTrainer):
     def __init__(self, raw: dict, frames: List[dict], cfg: Optional[dict] = None, process_group=None,
-                 binning_mode: int = api.BIN_TILE_SORT, use_graph: bool = True, num_streams: int = 4,
+                 binning_mode: int = api.BIN_DIRECT, use_graph: bool = True, num_streams: int = 4,
                  batched: bool = True):
         super().__init__(raw, frames, cfg, process_group=process_group)
         # single rank, frames of one size and field of view: all views of an iteration go through ONE
@@ -94,7 +94,7 @@ class FusedMapTrainer(GaussianMapTrainer):
                              max_scale=0.05)
 
     def _check_capacity(self, slots) -> bool:
-        need = max((api.read_status(self._states[s])["num_instances"] for s in slots), default=0)
+        need = max((api.read_status(self._states[s])["needed"] for s in slots), default=0)
         if need > self._cap:
             self._cap = int(need * 1.5) + 4096
             return False
@@ -269,7 +269,7 @@ class FusedMapTrainer(GaussianMapTrainer):
                                       want_stats=True, front_only=True, render_masks=masks,
                                       binning_mode=self.binning_mode)
                 batch.render(vm, pm)
-                need = int(batch.statuses()[:, 0].max())
+                need = int(batch.statuses()[:, 7].max())
                 if need <= self._cap:
                     return batch.count.clone()
                 self._cap = int(need * 1.5) + 4096
@@ -421,7 +421,7 @@ class FusedMapTrainer(GaussianMapTrainer):
             torch.index_select(all_view, 0, idx, out=batch.viewmats[:B])
             torch.index_select(all_proj, 0, idx, out=batch.projmats[:B])
             batch.forward(B)
-            need = int(batch.statuses(B)[:, 0].max())
+            need = int(batch.statuses(B)[:, 7].max())
             if need <= self._cap:
                 return True
             self._cap = int(need * 1.5) + 4096

@@ -103,7 +103,7 @@ class ForwardState:
     radii: torch.Tensor
     workspace: torch.Tensor
     max_instances: int
-    binning_mode: int = 0  # AGS_BIN_TILE_SORT (default) | 1 = AGS_BIN_RADIX
+    binning_mode: int = 2  # AGS_BIN_DIRECT (default) | 0 = AGS_BIN_TILE_SORT | 1 = AGS_BIN_RADIX
 
     def images_struct(self) -> _lib.AgsImages:
         return _lib.AgsImages(ptr(self.rgb), ptr(self.normal), ptr(self.depth), ptr(self.opacity), ptr(self.confidence))
@@ -131,10 +131,13 @@ def workspace_bytes(n: int, h: int, w: int, max_instances: int) -> int:
     return int(_lib.load().ags_workspace_bytes(n, h, w, max_instances))
 
 
-BIN_TILE_SORT, BIN_RADIX = 0, 1
+BIN_TILE_SORT, BIN_RADIX, BIN_DIRECT = 0, 1, 2
 
 
-def alloc_state(n: int, h: int, w: int, max_instances: int, device, binning_mode: int = BIN_TILE_SORT) -> ForwardState:
+def alloc_state(n: int, h: int, w: int, max_instances: int, device, binning_mode: int = BIN_DIRECT) -> ForwardState:
+    """Buffers + workspace for views of one size.  ``max_instances``: key slots of the workspace; what a view needs is
+    ``read_status(state)["needed"]`` (mode-aware: total tile instances for the scan-based modes, tiles x longest
+    tile list for ``BIN_DIRECT``, whose tiles own ``max_instances // tiles`` slots each)."""
     f = dict(device=device, dtype=torch.float32)
     st = ForwardState(
         rgb=torch.empty(3, h, w, **f), normal=torch.empty(3, h, w, **f), depth=torch.empty(1, h, w, **f),
@@ -175,7 +178,8 @@ def read_status(state: ForwardState) -> dict:
     ws = state.ws_struct()
     _lib.check(lib.ags_read_status(C.byref(ws), C.byref(st), _stream()), "ags_read_status")
     return dict(num_instances=st.num_instances, num_sorted=st.num_sorted, overflow=bool(st.overflow),
-                num_visible=st.num_visible, peak_instances=st.peak_instances, overflow_passes=st.overflow_passes)
+                num_visible=st.num_visible, peak_instances=st.peak_instances, overflow_passes=st.overflow_passes,
+                max_tile_instances=st.max_tile_instances, needed=st.needed_instances)
 
 
 @dataclass
@@ -302,7 +306,7 @@ class ViewBatch:
     def __init__(self, g: Gaussians, num_views: int, height: int, width: int, tanfovx: float, tanfovy: float,
                  bg: torch.Tensor, max_instances: int, num_streams: int = 8, want_stats: bool = False,
                  front_only: bool = False, render_masks: Optional[torch.Tensor] = None,
-                 binning_mode: int = BIN_TILE_SORT, mode: str = "batched", capacity_n: Optional[int] = None):
+                 binning_mode: int = BIN_DIRECT, mode: str = "batched", capacity_n: Optional[int] = None):
         if mode not in ("batched", "streams"):
             raise ValueError("mode is 'batched' or 'streams'")
         dev = g.means3D.device
@@ -423,12 +427,13 @@ class ViewBatch:
         return self.states
 
     def statuses(self, views: Optional[int] = None) -> torch.Tensor:
-        """Blocking: the first six words of every view's status block (``AgsStatus``) in ONE transfer ->
-        (views, 6) int64 on the host: instances needed, instances sorted, overflow flag, visible, and the two
-        sticky words - peak instances and number of overflowed passes since the workspaces were (re)bound."""
+        """Blocking: the first eight words of every view's status block (``AgsStatus``) in ONE transfer ->
+        (views, 8) int64 on the host: [0] tile instances, [1] instances sorted, [2] overflow flag, [3] visible,
+        the two sticky words since the workspaces were (re)bound - [4] peak of the needed capacity, [5] number of
+        overflowed passes - and [6] longest tile list, [7] the capacity (``max_instances``) this view needs."""
         V = self.num_views if views is None else int(views)
         per = self._per
-        words = self.workspace[:self.num_views * per].view(self.num_views, per)[:V, :24].contiguous().view(torch.int32).view(V, 6)
+        words = self.workspace[:self.num_views * per].view(self.num_views, per)[:V, :32].contiguous().view(torch.int32).view(V, 8)
         return (words.cpu().to(torch.int64)) & 0xFFFFFFFF
 
     def overflowed(self, views: Optional[int] = None) -> bool:

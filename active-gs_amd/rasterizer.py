@@ -38,8 +38,8 @@ class GaussianRasterizationSettings(NamedTuple):
     config: torch.Tensor
 
 
-# Binning algorithm used by the drop-in module (raster_api.BIN_TILE_SORT | BIN_RADIX).
-BINNING_MODE = api.BIN_TILE_SORT
+# Binning algorithm used by the drop-in module (raster_api.BIN_DIRECT | BIN_TILE_SORT | BIN_RADIX).
+BINNING_MODE = api.BIN_DIRECT
 
 # Tile-instance capacity remembered per (device, image size): the forward pass sizes its
 # workspace from the last view's need and re-runs only when a view overflows it.
@@ -79,8 +79,8 @@ class _RasterizeSurfels(torch.autograd.Function):
             st = api.read_status(state)  # one 64-byte D2H, like upstream's num_rendered read-back
             if not st["overflow"]:
                 break
-            cap = int(st["num_instances"] * 1.25) + 1024
-        _capacity_hint[key] = max(int(st["num_instances"] * 1.5) + 1024, 1 << 16)
+            cap = int(st["needed"] * 1.25) + 1024
+        _capacity_hint[key] = max(int(st["needed"] * 1.5) + 1024, 1 << 16)
         ctx.cam, ctx.g, ctx.state = cam, g, state
         ctx.need_m2d = means2D.requires_grad
         ctx.opac_shape = opacities.shape

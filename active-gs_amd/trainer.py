@@ -151,7 +151,7 @@ class SurfelTrainer:
     rotations (N,4), opacities (N), harmonics (N,1,3), confidences (N) on the GPU."""
 
     def __init__(self, raw: dict, lrs: Optional[dict] = None, scale_factor: float = 0.01, max_scale: float = 0.05,
-                 eps: float = 1e-15, process_group=None, binning_mode: int = api.BIN_TILE_SORT,
+                 eps: float = 1e-15, process_group=None, binning_mode: int = api.BIN_DIRECT,
                  fused_activations: bool = True, sparse_rows: bool = True):
         from .optimizer import FusedAdam
         lrs = {**DEFAULT_LRS, **(lrs or {})}

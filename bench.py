@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--binning", choices=["tile_sort", "radix"], default="tile_sort")
+    ap.add_argument("--binning", choices=["direct", "tile_sort", "radix"], default="direct")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--graph-steps", type=int, default=int(os.environ.get("AGS_BENCH_GRAPH_STEPS", "25")),
                     help="optimisation steps recorded per hipGraph (single GPU); K steps = K/this replays")
@@ -211,17 +211,18 @@ def main():
     tanx, tany = cm["tanfov"][0, 0].item(), cm["tanfov"][0, 1].item()
     bg = torch.zeros(4)
     cam = api.Camera(H, W, tanx, tany, cm["viewmatrix"][0].to(dev), cm["projmatrix"][0].to(dev), bg.to(dev))
-    trainer = SurfelTrainer(raw, binning_mode=api.BIN_RADIX if args.binning == "radix" else api.BIN_TILE_SORT)
+    bin_mode = {"direct": api.BIN_DIRECT, "tile_sort": api.BIN_TILE_SORT, "radix": api.BIN_RADIX}[args.binning]
+    trainer = SurfelTrainer(raw, binning_mode=bin_mode)
 
     # size the workspace from one probing forward (outside the timed region)
     g = trainer.gaussians()
-    probe = api.alloc_state(N_GAUSS, H, W, 16_000_000, dev)
+    probe = api.alloc_state(N_GAUSS, H, W, 16_000_000, dev, bin_mode)
     api.forward(cam, g, probe)
     info = api.read_status(probe)
     assert not info["overflow"], info
     I, V = info["num_instances"], info["num_visible"]
     del probe
-    cap = int(I * 1.3) + 4096
+    cap = int(info["needed"] * 1.3) + 4096   # direct binning: tiles x longest tile list; else the instance total
 
     gen = torch.Generator().manual_seed(1234 + rank)
     P = H * W
@@ -418,7 +419,7 @@ def main():
                 a0 = activate(raw_cpu)
                 g0 = api.Gaussians(*(a0[k].to(dev).contiguous() for k in ("means", "scales", "rotations", "opacities",
                                                                           "colors", "confidences")))
-                s0 = api.alloc_state(N_GAUSS, H, W, cap, dev)
+                s0 = api.alloc_state(N_GAUSS, H, W, cap, dev, bin_mode)
                 api.forward(cam, g0, s0)
                 m = tile_mask.to(dev)
                 gr = api.backward(cam, g0, s0, (d_img[0] * m).contiguous(), (d_img[1] * m).contiguous(),

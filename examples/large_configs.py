@@ -40,7 +40,7 @@ def run(tag, n, h, w, views, room, steps, warmup):
         for cam in cams:
             st = trainer.state_for(h, w, cap)
             api.forward(cam, trainer.gaussians(), st)
-            need = max(need, api.read_status(st)["num_instances"])
+            need = max(need, api.read_status(st)["needed"])
         if need <= cap:
             break
         cap = int(need * 1.25)

@@ -162,13 +162,18 @@ typedef struct AgsGaussianGrads {
     int32_t pack_capacity;
 } AgsGaussianGrads;
 
-#define AGS_BIN_TILE_SORT 0 /* tile counting + bucket scatter + per-tile LDS bitonic sort (default) */
+#define AGS_BIN_TILE_SORT 0 /* tile counting + bucket scatter + per-tile LDS bitonic sort */
 #define AGS_BIN_RADIX 1     /* duplicate-with-keys + global stable LSD radix sort */
+#define AGS_BIN_DIRECT 2    /* ONE pass over the surfels: every tile owns max_instances / tiles key slots, the per-Gaussian
+                             * kernel takes a slot with one returning atomic and writes the key at once (no counting pass,
+                             * no scan, no second emission pass); per-tile sort as in AGS_BIN_TILE_SORT.  Overflows when ONE
+                             * tile's list exceeds its slots (AgsStatus.needed_instances says what would do).  Same per-tile
+                             * (depth, id) order and bit-identical images as the other two modes. */
 typedef struct AgsWorkspace {
     void* ptr;    /* device, 256-byte aligned */
     size_t bytes; /* >= ags_workspace_bytes(n,h,w,max_instances) */
     int64_t max_instances; /* capacity in (Gaussian,tile) instances */
-    int32_t binning_mode;  /* AGS_BIN_*; both give the same per-tile (depth, id) order */
+    int32_t binning_mode;  /* AGS_BIN_*; all give the same per-tile (depth, id) order */
 } AgsWorkspace;
 
 /* Device-side status block = the first 64 bytes of the workspace. */
@@ -180,9 +185,13 @@ typedef struct AgsStatus {
     /* STICKY since the last ags_workspace_init (every forward on this workspace updates, none clears):
      * a loop that renders many views without reading the block back after each one reads these once at
      * the end; an overflow in ANY of its passes shows, with the size that would have been enough. */
-    uint32_t peak_instances;  /* max of num_instances over the passes */
-    uint32_t overflow_passes; /* number of passes whose num_instances exceeded max_instances */
-    uint32_t reserved[10];
+    uint32_t peak_instances;  /* max of needed_instances over the passes */
+    uint32_t overflow_passes; /* number of passes that overflowed the workspace */
+    /* per pass again: */
+    uint32_t max_tile_instances; /* longest tile list of the view (0 in AGS_BIN_RADIX mode) */
+    uint32_t needed_instances;   /* the max_instances that would have held this view in this binning mode:
+                                  * num_instances, or tiles * max_tile_instances for AGS_BIN_DIRECT */
+    uint32_t reserved[8];
 } AgsStatus;
 
 /* Bytes of workspace for n Gaussians, an h x w image and room for max_instances instances.

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Per-wave phase timelines of one optimisation step (C2 bench workload by default) from a -DAGS_TIMELINE build:
+    python profiles/experiments/build_exp.py "tl=-DAGS_TIMELINE"      (here: cross-compiles)
+    AGS_LIB_PATH=scratch/libags_tl.so python profiles/experiments/timeline.py [--n 200000 --h 680 --w 1200]
+Every wave notes s_memtime (shader clock) at phase boundaries; this prints, per kernel, when waves start and end
+relative to the kernel's first wave and how long each phase takes (median / p90 / max, in cycles and us @2.4 GHz)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=200_000)
+ap.add_argument("--h", type=int, default=680)
+ap.add_argument("--w", type=int, default=1200)
+ap.add_argument("--room", default="office0")
+ap.add_argument("--mult", type=float, default=1.0)
+args = ap.parse_args()
+
+from active_gs_amd import _lib, raster_api as api  # noqa: E402
+from active_gs_amd.camera import camera_matrices  # noqa: E402
+from active_gs_amd.synthetic import make_camera, make_room_scene  # noqa: E402
+from active_gs_amd.trainer import SurfelTrainer  # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+raw = {k: v.to(dev) for k, v in make_room_scene(args.n, args.room, seed=0).items()}
+if args.mult != 1.0:
+    raw["scales"][:, :2] += float(np.log(args.mult))
+c2w, K = make_camera(0, args.h, args.w, room=args.room)
+cm = camera_matrices(c2w[None], K[None], 0.001, 10.0)
+cam = api.Camera(args.h, args.w, cm["tanfov"][0, 0].item(), cm["tanfov"][0, 1].item(), cm["viewmatrix"][0].to(dev),
+                 cm["projmatrix"][0].to(dev), torch.zeros(4, device=dev))
+tr = SurfelTrainer(raw)
+probe = api.alloc_state(args.n, args.h, args.w, 40_000_000, dev)
+api.forward(cam, tr.gaussians(), probe)
+info = api.read_status(probe)
+del probe
+cap = int(info["num_instances"] * 1.3) + 4096
+P = args.h * args.w
+gen = torch.Generator().manual_seed(1234)
+d_img = [(torch.randn(c, args.h, args.w, generator=gen) / P).to(dev) for c in (3, 3, 1)]
+fn = lambda v, st: (d_img[0], d_img[1], d_img[2], None, None)
+for _ in range(30):
+    tr.step([cam], fn, cap)
+torch.cuda.synchronize()
+NW = 16384
+buf = torch.zeros(8 * NW * 8, dtype=torch.int64, device=dev)
+lib.ags_debug_timeline.argtypes = [C.c_void_p]
+lib.ags_debug_timeline(buf.data_ptr())
+tr.step([cam], fn, cap)
+torch.cuda.synchronize()
+lib.ags_debug_timeline(None)
+t = buf.cpu().numpy().reshape(8, NW, 8).astype(np.int64)
+print(f"workload: n={args.n} {args.h}x{args.w} visible={info['num_visible']} instances={info['num_instances']}")
+GHZ = 2.4
+KERNELS = {0: ("preprocess", ["rows loaded", "math+stores", "row set", "emit(count)", "block sums"]),
+           1: ("bucket", ["tile scan", "loads", "emit(keys)"]),
+           5: ("tile_sort", ["sort"]),
+           2: ("render_fwd", ["pixel init", "first staging", "blend loop", "stores"]),
+           3: ("render_bwd_mfma", ["pixel loads", "feature exchange", "first staging", "blend loop", "last flush"]),
+           4: ("preprocess_bwd_rows", ["all"])}
+
+
+def pct(x, q):
+    return float(np.percentile(x, q)) if len(x) else 0.0
+
+
+t0_all = None
+for kid, (name, phases) in KERNELS.items():
+    a = t[kid]
+    ok = a[:, 0] > 0
+    if not ok.any():
+        continue
+    a = a[ok]
+    nph = len(phases)
+    # waves that returned early leave later stamps at 0: keep complete ones for the phase statistics
+    full = a[a[:, nph] > 0]
+    start0 = a[:, 0].min()
+    end = np.where(a[:, 1:nph + 1] > 0, a[:, 1:nph + 1], 0).max(axis=1)
+    print(f"\n== {name}: {len(a)} waves ({len(full)} complete); kernel span first start -> last end "
+          f"{(end.max() - start0) / GHZ / 1e3:.2f} us (clock assumed {GHZ} GHz; per-XCD counters may be offset)")
+    st = a[:, 0] - start0
+    print(f"   wave start  p50 {pct(st, 50) / GHZ / 1e3:.2f}  p90 {pct(st, 90) / GHZ / 1e3:.2f}  max {st.max() / GHZ / 1e3:.2f} us")
+    life = end - a[:, 0]
+    print(f"   wave life   p50 {pct(life, 50) / GHZ / 1e3:.2f}  p90 {pct(life, 90) / GHZ / 1e3:.2f}  max {life.max() / GHZ / 1e3:.2f} us"
+          f"   sum of lives / 1024 SIMDs = {life.sum() / 1024 / GHZ / 1e3:.2f} us")
+    for p, label in enumerate(phases):
+        d = full[:, p + 1] - full[:, p]
+        print(f"   {label:18s} p50 {pct(d, 50):8.0f} cyc  p90 {pct(d, 90):8.0f}  max {d.max() if len(d) else 0:8.0f}   (p50 {pct(d, 50) / GHZ / 1e3:.2f} us)")
+    if kid in (2, 3):
+        it = full[:, 6] & 0xFFFFFFFF
+        loop = full[:, 3 if kid == 2 else 4] - full[:, 2 if kid == 2 else 3]
+        print(f"   blended (surfel, wave) pairs per wave: mean {it.mean():.1f} p90 {pct(it, 90):.0f} max {it.max()}; "
+              f"cycles per pair (loop / pairs): {loop.sum() / max(it.sum(), 1):.0f}")
+        if kid == 3:
+            fl = full[:, 6] >> 32
+            print(f"   flushes per wave: mean {fl.mean():.2f}; list length (maxlast) mean {full[:, 7].mean():.1f}")
+        else:
+            print(f"   list length mean {full[:, 5].mean():.1f} max {full[:, 5].max()}")

@@ -72,8 +72,9 @@ def oracle_on_tiles(ins, S, image_grads, tiles=None, max_tiles=None, batch=32, f
             ty, tx = divmod(t, tiles_x)
             m[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = 1.0
         R = render_tiles(G, so, ranges, S, tiles=sample)
-        loss = sum((R[k] * (g * m)).sum() for k, g in zip(names, image_grads) if g is not None)
-        loss.backward(retain_graph=True)
+        terms = [(R[k] * (g * m)).sum() for k, g in zip(names, image_grads) if g is not None]
+        if terms:
+            sum(terms).backward(retain_graph=True)
         covered += m
         for k in names:
             images[k] += R[k].detach() * m

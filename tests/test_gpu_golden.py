@@ -153,7 +153,7 @@ def test_c4_size_scene_both_binning_modes(agslib):
     gen = torch.Generator().manual_seed(0)
     d = [(torch.randn(c, h, w, generator=gen) / (h * w)).to(dev) for c in (3, 3, 1)]
     res = []
-    for mode in (api.BIN_TILE_SORT, api.BIN_RADIX):
+    for mode in (api.BIN_TILE_SORT, api.BIN_RADIX, api.BIN_DIRECT):
         st = api.alloc_state(n, h, w, 8_000_000, dev, mode)
         api.forward(cam, g, st)
         info = api.read_status(st)
@@ -162,11 +162,13 @@ def test_c4_size_scene_both_binning_modes(agslib):
         torch.cuda.synchronize()
         res.append((st, gr, info))
     assert res[0][2]["num_instances"] <= res[1][2]["num_instances"]
-    for name in ("rgb", "normal", "depth", "opacity", "confidence", "radii"):
-        assert torch.equal(getattr(res[0][0], name), getattr(res[1][0], name)), name
-    for name in ("means3D", "scales", "rotations", "opacities", "colors"):
-        x, y = getattr(res[0][1], name), getattr(res[1][1], name)
-        assert (x - y).abs().sum() <= 1e-3 * y.abs().sum(), name
+    for other in (1, 2):
+        for name in ("rgb", "normal", "depth", "opacity", "confidence", "radii"):
+            assert torch.equal(getattr(res[0][0], name), getattr(res[other][0], name)), (other, name)
+        for name in ("means3D", "scales", "rotations", "opacities", "colors"):
+            x, y = getattr(res[0][1], name), getattr(res[other][1], name)
+            assert (x - y).abs().sum() <= 1e-3 * y.abs().sum(), (other, name)
+    assert res[2][2]["num_instances"] == res[0][2]["num_instances"]
     assert torch.isfinite(res[0][1].means3D).all() and float(res[0][0].opacity.max()) <= 1.0
 
 
@@ -189,7 +191,7 @@ def test_c5_size_scene_16384_tiles(agslib):
     gen = torch.Generator().manual_seed(0)
     d = [(torch.randn(c, h, w, generator=gen) / (h * w)).to(dev) for c in (3, 3, 1)]
     res = []
-    for mode in (api.BIN_TILE_SORT, api.BIN_RADIX):
+    for mode in (api.BIN_TILE_SORT, api.BIN_RADIX, api.BIN_DIRECT):
         st = api.alloc_state(n, h, w, 24_000_000, dev, mode)
         api.forward(cam, g, st)
         info = api.read_status(st)
@@ -197,11 +199,13 @@ def test_c5_size_scene_16384_tiles(agslib):
         gr = api.backward(cam, g, st, *d)
         torch.cuda.synchronize()
         res.append((st, gr, info))
-    for name in ("rgb", "normal", "depth", "opacity", "confidence", "radii"):
-        assert torch.equal(getattr(res[0][0], name), getattr(res[1][0], name)), name
-    for name in ("means3D", "scales", "rotations", "opacities", "colors"):
-        x, y = getattr(res[0][1], name), getattr(res[1][1], name)
-        assert (x - y).abs().sum() <= 1e-3 * y.abs().sum(), name
+    for other in (1, 2):
+        for name in ("rgb", "normal", "depth", "opacity", "confidence", "radii"):
+            assert torch.equal(getattr(res[0][0], name), getattr(res[other][0], name)), (other, name)
+        for name in ("means3D", "scales", "rotations", "opacities", "colors"):
+            x, y = getattr(res[0][1], name), getattr(res[other][1], name)
+            assert (x - y).abs().sum() <= 1e-3 * y.abs().sum(), (other, name)
+    assert res[2][2]["num_instances"] == res[0][2]["num_instances"]
     st = res[0][0]
     g2 = api.backward(cam, g, st, *[2 * t for t in d])
     assert (2 * res[0][1].means3D - g2.means3D).abs().sum() <= 1e-3 * g2.means3D.abs().sum()

@@ -13,13 +13,13 @@ RGB_TOL = 1e-4
 GRAD_TOL = 1e-3
 
 
-@pytest.fixture(params=["tile_sort", "radix"])
+@pytest.fixture(params=["direct", "tile_sort", "radix"])
 def binning(request):
-    """Run the parity cases with both binning algorithms of the C ABI."""
+    """Run the parity cases with all three binning algorithms of the C ABI."""
     import active_gs_amd.rasterizer as R
     from active_gs_amd import raster_api as api
     old = R.BINNING_MODE
-    R.BINNING_MODE = api.BIN_RADIX if request.param == "radix" else api.BIN_TILE_SORT
+    R.BINNING_MODE = {"direct": api.BIN_DIRECT, "tile_sort": api.BIN_TILE_SORT, "radix": api.BIN_RADIX}[request.param]
     yield request.param
     R.BINNING_MODE = old
 
@@ -164,16 +164,27 @@ def test_binning_modes_agree_bitwise_on_order(agslib):
     g = api.Gaussians(*(a[k].to(dev).contiguous() for k in ("means", "scales", "rotations", "opacities", "colors",
                                                               "confidences")))
     outs = []
-    for mode in (api.BIN_TILE_SORT, api.BIN_RADIX):
+    for mode in (api.BIN_TILE_SORT, api.BIN_RADIX, api.BIN_DIRECT):
         st = api.alloc_state(g.n, cam.image_height, cam.image_width, 1 << 21, dev, mode)
         api.forward(cam, g, st)
         info = api.read_status(st)
         assert not info["overflow"]
         outs.append((st, info))
-    # tile-sort mode also drops (surfel, tile) pairs no pixel can reach; radix keeps the D3 rect
+    # tile-sort / direct mode also drop (surfel, tile) pairs no pixel can reach; radix keeps the D3 rect
     assert 0 < outs[0][1]["num_instances"] <= outs[1][1]["num_instances"]
-    for name in ("rgb", "normal", "depth", "opacity", "confidence", "radii"):
-        assert torch.equal(getattr(outs[0][0], name), getattr(outs[1][0], name)), name
+    assert outs[2][1]["num_instances"] == outs[0][1]["num_instances"] and outs[2][1]["num_visible"] == outs[0][1]["num_visible"]
+    tiles = ((cam.image_height + 15) // 16) * ((cam.image_width + 15) // 16)
+    assert outs[2][1]["needed"] == tiles * outs[2][1]["max_tile_instances"] and outs[0][1]["needed"] == outs[0][1]["num_instances"]
+    # the direct mode's per-tile ranges hold the same id lists as the scan-based layout
+    for other in (1, 2):
+        for name in ("rgb", "normal", "depth", "opacity", "confidence", "radii"):
+            assert torch.equal(getattr(outs[0][0], name), getattr(outs[other][0], name)), (other, name)
+    # a second pass on the same workspaces: the direct mode's spread counters were left clean
+    for st, info in outs:
+        api.forward(cam, g, st)
+        again = api.read_status(st)
+        assert again["num_instances"] == info["num_instances"] and again["peak_instances"] == info["needed"]
+        assert again["overflow_passes"] == 0
 
 
 def test_workspace_overflow_is_flagged_not_fatal(agslib):
@@ -189,7 +200,34 @@ def test_workspace_overflow_is_flagged_not_fatal(agslib):
         api.forward(cam, g, st)
         info = api.read_status(st)
         assert info["overflow"] and info["num_instances"] > 64 and info["num_sorted"] == 64
+        assert info["needed"] == info["num_instances"] == info["peak_instances"] and info["overflow_passes"] == 1
         assert torch.isfinite(st.rgb).all()
+    # direct mode: every tile owns max_instances // tiles key slots; ONE over-full tile overflows the pass, the status
+    # says what capacity would do, and a workspace of exactly that size renders the reference image
+    tiles = ((cam.image_height + 15) // 16) * ((cam.image_width + 15) // 16)
+    ref = api.alloc_state(g.n, cam.image_height, cam.image_width, 1 << 20, dev, api.BIN_TILE_SORT)
+    api.forward(cam, g, ref)
+    st = api.alloc_state(g.n, cam.image_height, cam.image_width, tiles * 4, dev, api.BIN_DIRECT)   # 4 slots per tile
+    api.forward(cam, g, st)
+    info = api.read_status(st)
+    assert info["overflow"] and info["max_tile_instances"] > 4 and info["needed"] == tiles * info["max_tile_instances"]
+    assert info["overflow_passes"] == 1 and torch.isfinite(st.rgb).all()
+    assert info["num_instances"] == api.read_status(ref)["num_instances"]
+    st2 = api.alloc_state(g.n, cam.image_height, cam.image_width, info["needed"], dev, api.BIN_DIRECT)
+    api.forward(cam, g, st2)
+    info2 = api.read_status(st2)
+    assert not info2["overflow"] and info2["overflow_passes"] == 0 and torch.equal(st2.rgb, ref.rgb)
+    assert lib_rc_too_small(api, cam, g, dev, tiles)
+
+
+def lib_rc_too_small(api, cam, g, dev, tiles):
+    """fewer key slots than tiles: the direct mode cannot run at all -> AGS_E_WORKSPACE, not a crash"""
+    st = api.alloc_state(g.n, cam.image_height, cam.image_width, max(1, tiles - 1), dev, api.BIN_DIRECT)
+    try:
+        api.forward(cam, g, st)
+    except RuntimeError as e:
+        return "workspace" in str(e)
+    return False
 
 
 def test_graph_replay_matches_eager_steps(agslib):
@@ -378,7 +416,7 @@ def test_overfull_tiles_and_huge_footprints(agslib):
     gen = torch.Generator().manual_seed(5)
     d = [torch.randn(c, S.image_height, S.image_width, generator=gen).to(dev) for c in (3, 3, 1, 1, 1)]
     res = []
-    for mode in (api.BIN_TILE_SORT, api.BIN_RADIX):
+    for mode in (api.BIN_TILE_SORT, api.BIN_RADIX, api.BIN_DIRECT):
         st = api.alloc_state(g.n, S.image_height, S.image_width, 1 << 22, dev, mode)
         api.forward(cam, g, st)
         info = api.read_status(st)
@@ -390,11 +428,12 @@ def test_overfull_tiles_and_huge_footprints(agslib):
         grads = api.backward(cam, g, st, *d)
         torch.cuda.synchronize()
         res.append((st, grads))
-    for name in ("rgb", "normal", "depth", "opacity", "confidence"):
-        assert torch.equal(getattr(res[0][0], name), getattr(res[1][0], name)), name
-    for name in ("means3D", "scales", "rotations", "opacities", "colors"):
-        x, y = getattr(res[0][1], name), getattr(res[1][1], name)
-        assert (x - y).abs().sum() <= 1e-3 * y.abs().sum()
+    for other in (1, 2):
+        for name in ("rgb", "normal", "depth", "opacity", "confidence"):
+            assert torch.equal(getattr(res[0][0], name), getattr(res[other][0], name)), (other, name)
+        for name in ("means3D", "scales", "rotations", "opacities", "colors"):
+            x, y = getattr(res[0][1], name), getattr(res[other][1], name)
+            assert (x - y).abs().sum() <= 1e-3 * y.abs().sum()
     ins = [a["means"].clone().requires_grad_(True), torch.zeros(g.n, 3), a["opacities"][:, None].clone().requires_grad_(True),
            a["confidences"], a["colors"].clone().requires_grad_(True), a["scales"].clone().requires_grad_(True),
            a["rotations"].clone().requires_grad_(True)]
