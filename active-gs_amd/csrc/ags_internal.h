@@ -34,6 +34,7 @@ struct AgsLayout {
     size_t final_T;     // P * f32
     size_t n_contrib;   // P * u32
     size_t dgeom;       // n * AgsGeomGrad (backward)
+    size_t tile_order;  // T * u32: AGS_BIN_DIRECT: the blend kernels' block -> tile map, heaviest tiles of every XCD band first
     size_t total;
     int64_t cap;
     int nb_cap;         // sort blocks at capacity
@@ -71,6 +72,7 @@ static inline AgsLayout ags_make_layout(int n, int h, int w, int64_t cap) {
     L.final_T = o; o += ags_align256(P * 4);
     L.n_contrib = o; o += ags_align256(P * 4);
     L.dgeom = o; o += ags_align256((size_t)n * sizeof(AgsGeomGrad));
+    L.tile_order = o; o += ags_align256((size_t)L.num_tiles * 4);
     L.total = o;
     return L;
 }
@@ -139,9 +141,14 @@ void ags_launch_direct_sort(char* ws, const AgsLayout& L, const AgsViewStride& v
 // sums of the tiles' list lengths, 64 partial maxima, 64 partial counts of visible surfels - spread so that the
 // tiles' / waves' atomics do not serialise on one word; the forward blend kernel's first wave reduces them into
 // the status block and leaves them zeroed again
+// slot k (0..63) owns one 128-byte line: words 32 k + {0: sum, 1: max, 2: visible}
+#ifndef AGS_PART_STRIDE
+#define AGS_PART_STRIDE 32
+#endif
 #define AGS_PART_SUM 0
-#define AGS_PART_MAX 64
-#define AGS_PART_VIS 128
+#define AGS_PART_MAX 1
+#define AGS_PART_VIS 2
+#define AGS_PART(slot, what) (((slot) & 63) * AGS_PART_STRIDE + (what))
 static inline uint32_t ags_direct_tile_cap(const AgsLayout& L) { return (uint32_t)(L.cap / (L.num_tiles > 0 ? L.num_tiles : 1)); }
 void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L, hipStream_t s);
 void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L,
@@ -152,7 +159,7 @@ void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
                            bool direct, hipStream_t s);
 void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick,
-                           const AgsViewStride& vs, hipStream_t s);
+                           const AgsViewStride& vs, bool direct, hipStream_t s);
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
                                const AgsLayout& L, const int* radii, const AgsGaussianGrads& din,
                                const AgsViewStride& vs, hipStream_t s);
@@ -555,5 +562,19 @@ __device__ __forceinline__ float ags_wave_reduce16(const float v[16], int lane) 
 __device__ __forceinline__ int ags_xcd_remap(int b, int n) {
     const int q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+// first tile and number of tiles of XCD x's band under that map
+__device__ __forceinline__ int ags_xcd_band(int x, int n, int& size) {
+    const int q = n >> 3, r = n & 7;
+    size = q + (x < r ? 1 : 0);
+    return x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+}
+// Block -> tile map of the blend kernels.  `order` (AGS_BIN_DIRECT, written by ags_k_tile_sort_direct) lists every
+// band's tiles by DESCENDING list length: blocks are dispatched in index order, so each XCD starts its heaviest
+// tiles first and fills the tail of the launch with the lightest ones (longest-processing-time-first) - without
+// it the launch ends when the last of the late-starting heavy tiles does.  nullptr: plain band order.
+__device__ __forceinline__ int ags_block_tile(const uint32_t* __restrict__ order, int b, int n) {
+    const int t = ags_xcd_remap(b, n);      // = band start + k: also the slot of the band's k-th heaviest tile
+    return order ? (int)order[t] : t;
 }
 #endif

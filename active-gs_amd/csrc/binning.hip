@@ -487,22 +487,41 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort(const uint2* __restrict__
 // list length to the spread partial sums / maxima the forward blend kernel turns into the status block.
 __global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict__ ranges, uint64_t* keys,
                                                               const uint32_t* __restrict__ tile_count, uint32_t tile_cap,
-                                                              uint32_t* __restrict__ partial, int num_tiles, AgsViewStride vs) {
+                                                              uint32_t* __restrict__ partial, uint32_t* __restrict__ order,
+                                                              int num_tiles, AgsViewStride vs) {
     { // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(keys, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(partial, wo);
+        AGS_WS_SHIFT(order, wo);
     }
     __shared__ uint64_t sk[AGS_TSORT_LDS_KEYS];
+    __shared__ uint32_t rank_part[4];
     if (threadIdx.x < 64) AGS_TL(5, blockIdx.x, 0);
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint32_t cnt = tile_count[tile];
     const uint32_t K = cnt < tile_cap ? cnt : tile_cap, base = (uint32_t)tile * tile_cap;
+    { // this tile's place in its band's heaviest-first order (ags_block_tile): the number of band tiles with a longer
+      // list (ties: lower index first) - exact, deterministic, no counters to reset; <= T/8 counts read per workgroup
+        int band_size;
+        const int band0 = ags_xcd_band(blockIdx.x & 7, num_tiles, band_size);
+        uint32_t ahead = 0;
+        for (int j = threadIdx.x; j < band_size; j += 256) {
+            const uint32_t c = tile_count[band0 + j];
+            ahead += (c > cnt || (c == cnt && band0 + j < tile)) ? 1u : 0u;
+        }
+        ahead = ags_wave_sum_u32(ahead);
+        if ((threadIdx.x & 63) == 0) rank_part[threadIdx.x >> 6] = ahead;
+        __syncthreads();
+        if (threadIdx.x == 0) order[band0 + rank_part[0] + rank_part[1] + rank_part[2] + rank_part[3]] = (uint32_t)tile;
+    }
     if (threadIdx.x == 0) {
         ranges[tile] = make_uint2(base, base + K);
+#ifndef AGS_EXP_NO_PARTIALS
         if (cnt) {
-            atomicAdd(&partial[AGS_PART_SUM + (tile & 63)], cnt);
-            atomicMax(&partial[AGS_PART_MAX + (tile & 63)], cnt);
+            atomicAdd(&partial[AGS_PART(blockIdx.x, AGS_PART_SUM)], cnt);
+            atomicMax(&partial[AGS_PART(blockIdx.x, AGS_PART_MAX)], cnt);
         }
+#endif
     }
     ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS, false>(keys + base, K, sk, threadIdx.x);
     if (threadIdx.x < 64) { AGS_TL(5, blockIdx.x, 1); AGS_TL_VAL(5, blockIdx.x, 6, K); }
@@ -511,7 +530,7 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict_
 void ags_launch_direct_sort(char* ws, const AgsLayout& L, const AgsViewStride& vs, hipStream_t s) {
     hipLaunchKernelGGL(ags_k_tile_sort_direct, dim3(L.num_tiles, vs.views), dim3(256), 0, s, (uint2*)(ws + L.ranges),
                        (uint64_t*)(ws + L.keys0), (const uint32_t*)(ws + L.tile_count), ags_direct_tile_cap(L),
-                       (uint32_t*)(ws + L.totals), L.num_tiles, vs);
+                       (uint32_t*)(ws + L.totals), (uint32_t*)(ws + L.tile_order), L.num_tiles, vs);
 }
 
 void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L,

@@ -149,7 +149,8 @@ int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* 
     }
     if (din->pack_segment && (!din->touched.rows || !din->touched.count || din->fused_adam || din->accumulate == 2 ||
                               din->pack_capacity < 0)) return AGS_E_INVALID;
-    { StageScope t(AGS_STAGE_RENDER_BWD, s); ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, tick, kOneView, s); }
+    { StageScope t(AGS_STAGE_RENDER_BWD, s);
+      ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, tick, kOneView, ws->binning_mode == AGS_BIN_DIRECT, s); }
     { StageScope t(AGS_STAGE_PREPROCESS_BWD, s); ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, kOneView, s); }
     return ags_check_launch();
 }
@@ -175,7 +176,8 @@ int ags_backward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* 
         for (int k = 0; k < 5; ++k) tick.lr[k] = din->adam_lr[k];
         tick.beta1 = din->adam_beta1; tick.beta2 = din->adam_beta2;
     }
-    ags_launch_render_bwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *fwd, *dout, tick, vs, s);
+    ags_launch_render_bwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *fwd, *dout, tick, vs,
+                          ws->binning_mode == AGS_BIN_DIRECT, s);
     ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, vs, s);
     return ags_check_launch();
 }

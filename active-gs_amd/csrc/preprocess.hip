@@ -185,7 +185,9 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     AGS_TL(0, tl_w, 4);
     const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
     if (EMIT == 2) { // no block-level reduction (and no barrier): one spread atomic per wave that shows anything
-        if ((threadIdx.x & 63) == 0 && wv) atomicAdd(&direct.partial[AGS_PART_VIS + (blockIdx.x & 63)], wv);
+#ifndef AGS_EXP_NO_PARTIALS
+        if ((threadIdx.x & 63) == 0 && wv) atomicAdd(&direct.partial[AGS_PART(blockIdx.x, AGS_PART_VIS)], wv);
+#endif
     } else {
         const int wave = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) { wsum[wave] = ws; wvis[wave] = wv; }

@@ -97,8 +97,10 @@ __device__ __forceinline__ void ags_wave_lds_sync() {
 struct AgsFinalize { uint32_t* status; uint32_t* partial; uint32_t tile_cap; };
 
 __device__ __forceinline__ void ags_finalize_status(const AgsFinalize& fin, int num_tiles, int lane) {
-    uint32_t s = fin.partial[AGS_PART_SUM + lane], m = fin.partial[AGS_PART_MAX + lane], v = fin.partial[AGS_PART_VIS + lane];
-    fin.partial[AGS_PART_SUM + lane] = 0u; fin.partial[AGS_PART_MAX + lane] = 0u; fin.partial[AGS_PART_VIS + lane] = 0u;
+    uint32_t s = fin.partial[AGS_PART(lane, AGS_PART_SUM)], m = fin.partial[AGS_PART(lane, AGS_PART_MAX)],
+             v = fin.partial[AGS_PART(lane, AGS_PART_VIS)];
+    fin.partial[AGS_PART(lane, AGS_PART_SUM)] = 0u; fin.partial[AGS_PART(lane, AGS_PART_MAX)] = 0u;
+    fin.partial[AGS_PART(lane, AGS_PART_VIS)] = 0u;
     s = ags_wave_sum_u32(s); m = ags_wave_max_u32(m); v = ags_wave_sum_u32(v);
     if (lane == 0) {
         const unsigned long long need64 = (unsigned long long)m * (unsigned long long)num_tiles;
@@ -117,12 +119,14 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     const float* __restrict__ mask, const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
     int id_stride, const AgsGeom* __restrict__ geom, AgsImages out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ importance, int* __restrict__ count, int num_tiles,
-    uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_fill, AgsFinalize fin, AgsViewStride vs) {
+    uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_fill, AgsFinalize fin,
+    const uint32_t* __restrict__ order, AgsViewStride vs) {
     { // batched forward: this workgroup's view // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws, po = (size_t)blockIdx.y * (size_t)vs.px;
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(vals, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(final_T, wo);
         AGS_WS_SHIFT(n_contrib, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(tile_fill, wo);
         if (fin.status) { AGS_WS_SHIFT(fin.status, wo); AGS_WS_SHIFT(fin.partial, wo); }
+        if (order) AGS_WS_SHIFT(order, wo);
         if (mask) mask += po;
         out.rgb += 3 * po; out.normal += 3 * po; out.depth += po; out.opacity += po; out.confidence += po;
         if (STATS) { importance += (size_t)blockIdx.y * (size_t)vs.n; count += (size_t)blockIdx.y * (size_t)vs.n; }
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     [[maybe_unused]] const int tl_w = blockIdx.x * (4 / SLOTS) + wave;
     AGS_TL(2, tl_w, 0);
     if (fin.status && blockIdx.x == 0 && wave == 0) ags_finalize_status(fin, num_tiles, lane);   // wave-uniform
-    const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
+    const int tile = ags_block_tile(order, blockIdx.x, num_tiles);
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
     const int strip0 = wave * SLOTS;                       // first of this wave's slots (8x8 quadrants of the tile)
     // quadrant q = strip0 + s sits at (q & 1, q >> 1); lane l is pixel (l & 7, l >> 3) of its quadrant
@@ -245,11 +249,12 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
     const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
     const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, AgsImageGrads dout, float* __restrict__ dgeom, int num_tiles,
-    AgsTick tick, AgsViewStride vs) {
+    AgsTick tick, const uint32_t* __restrict__ order, AgsViewStride vs) {
     { // batched backward: this workgroup's view // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws, po = (size_t)blockIdx.y * (size_t)vs.px;
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(vals, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(final_T, wo);
         AGS_WS_SHIFT(n_contrib, wo); AGS_WS_SHIFT(dgeom, wo);
+        if (order) AGS_WS_SHIFT(order, wo);
         depth_out += po; opac_out += po;
         if (dout.d_rgb) dout.d_rgb += 3 * po;
         if (dout.d_normal) dout.d_normal += 3 * po;
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
     // side job of a step's last backward: advance the Adam device clock.  Nothing in this launch
     // reads it; the per-Gaussian kernel that follows (fused step) or ags_adam_step_device does.
     if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2, 0);
-    const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
+    const int tile = ags_block_tile(order, blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
     if (rg.y <= rg.x) return;
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
@@ -378,11 +383,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WA
     const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
     const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, AgsImageGrads dout, float* __restrict__ dgeom, int num_tiles,
-    AgsTick tick, AgsViewStride vs) {
+    AgsTick tick, const uint32_t* __restrict__ order, AgsViewStride vs) {
     {
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws, po = (size_t)blockIdx.y * (size_t)vs.px;
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(vals, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(final_T, wo);
         AGS_WS_SHIFT(n_contrib, wo); AGS_WS_SHIFT(dgeom, wo);
+        if (order) AGS_WS_SHIFT(order, wo);
         depth_out += po; opac_out += po;
         if (dout.d_rgb) dout.d_rgb += 3 * po;
         if (dout.d_normal) dout.d_normal += 3 * po;
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WA
     if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2, 0);
     [[maybe_unused]] const int tl_w = blockIdx.x * 4 + wave;
     AGS_TL(3, tl_w, 0);
-    const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
+    const int tile = ags_block_tile(order, blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
     if (rg.y <= rg.x) return;
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
@@ -571,6 +577,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WA
     AGS_TL_VAL(3, tl_w, 7, maxlast);
 }
 
+// experiment knob: AGS_NO_LPT=1 keeps the plain band order of the block -> tile map in AGS_BIN_DIRECT mode
+static bool ags_use_lpt() {
+    static const bool on = getenv("AGS_NO_LPT") == nullptr;
+    return on;
+}
+
 // How many strips per wave: one wave per tile when the image has enough tiles to fill the
 // 1024 SIMDs several times over, otherwise split tiles over more waves.
 static int ags_pick_slots(int num_tiles) {
@@ -595,6 +607,7 @@ static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
                        const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs, bool direct, hipStream_t s) {
     AgsFinalize fin = {nullptr, nullptr, 0u};
     if (direct) fin = AgsFinalize{(uint32_t*)(ws + L.status), (uint32_t*)(ws + L.totals), ags_direct_tile_cap(L)};
+    const uint32_t* order = (direct && ags_use_lpt()) ? (const uint32_t*)(ws + L.tile_order) : nullptr;
     const uint2* ranges = (const uint2*)(ws + L.ranges);
     const AgsGeom* geom = (const AgsGeom*)(ws + L.geom);
     float* fT = (float*)(ws + L.final_T);
@@ -604,22 +617,22 @@ static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, true>), dim3(L.num_tiles, vs.views), block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
-                           (uint32_t*)(ws + L.tile_fill), fin, vs);
+                           (uint32_t*)(ws + L.tile_fill), fin, order, vs);
     else
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, false>), dim3(L.num_tiles, vs.views), block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
-                           (uint32_t*)(ws + L.tile_fill), fin, vs);
+                           (uint32_t*)(ws + L.tile_fill), fin, order, vs);
 }
 
 template <int SLOTS>
 static void launch_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L, AgsIdList ids,
-                       const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick, const AgsViewStride& vs,
-                       hipStream_t s) {
+                       const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick, const uint32_t* order,
+                       const AgsViewStride& vs, hipStream_t s) {
     hipLaunchKernelGGL((ags_k_render_bwd<SLOTS>), dim3(L.num_tiles, vs.views), dim3(64 * (4 / SLOTS)), 0, s, F,
                        cam.normalize_depth, cam.bg, (const uint2*)(ws + L.ranges), ids.ids, ids.stride,
                        (const AgsGeom*)(ws + L.geom), fwd.depth, fwd.opacity, (const float*)(ws + L.final_T),
-                       (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick, vs);
+                       (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick, order, vs);
 }
 
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
@@ -635,18 +648,19 @@ void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
 
 void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick,
-                           const AgsViewStride& vs, hipStream_t s) {
+                           const AgsViewStride& vs, bool direct, hipStream_t s) {
+    const uint32_t* order = (direct && ags_use_lpt()) ? (const uint32_t*)(ws + L.tile_order) : nullptr;
     const int slots = ags_pick_slots(L.num_tiles * vs.views), mfma = ags_bwd_mfma();
     if (mfma == 2 || (mfma == 1 && slots == 1)) {
         hipLaunchKernelGGL(ags_k_render_bwd_mfma, dim3(L.num_tiles, vs.views), dim3(256), 0, s, F, cam.normalize_depth,
                            cam.bg, (const uint2*)(ws + L.ranges), ids.ids, ids.stride, (const AgsGeom*)(ws + L.geom),
                            fwd.depth, fwd.opacity, (const float*)(ws + L.final_T),
-                           (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick, vs);
+                           (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick, order, vs);
         return;
     }
     switch (slots) {
-        case 1: launch_bwd<1>(F, cam, ws, L, ids, fwd, dout, tick, vs, s); break;
-        case 2: launch_bwd<2>(F, cam, ws, L, ids, fwd, dout, tick, vs, s); break;
-        default: launch_bwd<4>(F, cam, ws, L, ids, fwd, dout, tick, vs, s); break;
+        case 1: launch_bwd<1>(F, cam, ws, L, ids, fwd, dout, tick, order, vs, s); break;
+        case 2: launch_bwd<2>(F, cam, ws, L, ids, fwd, dout, tick, order, vs, s); break;
+        default: launch_bwd<4>(F, cam, ws, L, ids, fwd, dout, tick, order, vs, s); break;
     }
 }

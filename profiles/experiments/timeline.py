@@ -20,6 +20,7 @@ ap.add_argument("--h", type=int, default=680)
 ap.add_argument("--w", type=int, default=1200)
 ap.add_argument("--room", default="office0")
 ap.add_argument("--mult", type=float, default=1.0)
+ap.add_argument("--binning", default="direct")
 args = ap.parse_args()
 
 from active_gs_amd import _lib, raster_api as api  # noqa: E402
@@ -36,12 +37,13 @@ c2w, K = make_camera(0, args.h, args.w, room=args.room)
 cm = camera_matrices(c2w[None], K[None], 0.001, 10.0)
 cam = api.Camera(args.h, args.w, cm["tanfov"][0, 0].item(), cm["tanfov"][0, 1].item(), cm["viewmatrix"][0].to(dev),
                  cm["projmatrix"][0].to(dev), torch.zeros(4, device=dev))
-tr = SurfelTrainer(raw)
-probe = api.alloc_state(args.n, args.h, args.w, 40_000_000, dev)
+MODE = {"direct": api.BIN_DIRECT, "tile_sort": api.BIN_TILE_SORT}[args.binning]
+tr = SurfelTrainer(raw, binning_mode=MODE)
+probe = api.alloc_state(args.n, args.h, args.w, 40_000_000, dev, MODE)
 api.forward(cam, tr.gaussians(), probe)
 info = api.read_status(probe)
 del probe
-cap = int(info["num_instances"] * 1.3) + 4096
+cap = int(info["needed"] * 1.3) + 4096
 P = args.h * args.w
 gen = torch.Generator().manual_seed(1234)
 d_img = [(torch.randn(c, args.h, args.w, generator=gen) / P).to(dev) for c in (3, 3, 1)]
