@@ -11,9 +11,9 @@
 // (ags_internal.h); advanced either by this 1-thread kernel or on the side of the step's last
 // ags_backward launch (AgsGaussianGrads.adam_clock).
 __global__ void ags_k_adam_tick(AgsAdamClock* c, float lr0, float lr1, float lr2, float lr3, float lr4,
-                                float beta1, float beta2, int host_step) {
+                                float beta1, float beta2) {
     const float lr[5] = {lr0, lr1, lr2, lr3, lr4};
-    ags_adam_tick(c, lr, beta1, beta2, host_step);
+    ags_adam_tick(c, lr, beta1, beta2);
 }
 
 __global__ __launch_bounds__(256) void ags_k_adam(AgsAdamArgs a, AgsAdamClock host_clk,
@@ -106,7 +106,7 @@ void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float ep
         // the clock was advanced by the step's last ags_backward launch
     } else if (clk) {
         hipLaunchKernelGGL(ags_k_adam_tick, dim3(1), dim3(1), 0, s, clk, t.lr[0], t.lr[1], t.lr[2], t.lr[3], t.lr[4],
-                           beta1, beta2, 0);
+                           beta1, beta2);
     } else { // host-side clock: scalars travel as kernel arguments
         const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
         hc.step = step;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void ags_k_adam_rows_gathered(AgsAdamArgs a, A
     // agrees on a larger segment and repeats the refused steps (trainer.SurfelTrainer).
     bool over = false;
     for (int s = 0; s < world; ++s) over |= __float_as_int(segs[(size_t)s * seg_floats + 1]) > capacity;   // wave-uniform
-    if (over && blockIdx.x == 0 && threadIdx.x == 0) { clk->step -= 1; clk->skipped += 1; }   // nobody reads the clock in a refused step
+    if (over && blockIdx.x == 0 && threadIdx.x == 0) { ags_adam_untick(clk); clk->skipped += 1; }   // nobody reads the clock in a refused step
     const int k = threadIdx.x & 15;
     const int seg = (k >= 3) + (k >= 6) + (k >= 10) + (k >= 11);
     const int width = seg == 2 ? 4 : (seg == 3 ? 1 : 3);
@@ -284,7 +284,7 @@ void ags_launch_adam_gathered(const AgsAdamTensors& t, const float* segs, size_t
     const AgsAdamArgs a = ags_adam_args(t);
     AgsAdamClock* clk = (AgsAdamClock*)dev_state;
     if (!pre_ticked)
-        hipLaunchKernelGGL(ags_k_adam_tick, dim3(1), dim3(1), 0, s, clk, t.lr[0], t.lr[1], t.lr[2], t.lr[3], t.lr[4], beta1, beta2, 0);
+        hipLaunchKernelGGL(ags_k_adam_tick, dim3(1), dim3(1), 0, s, clk, t.lr[0], t.lr[1], t.lr[2], t.lr[3], t.lr[4], beta1, beta2);
     long long rb = (t.numel[3] + 15) / 16; // 16 rows per block
     if (rb > 16384) rb = 16384;
     if (rb < 1) return;

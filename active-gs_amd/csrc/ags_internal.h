@@ -34,7 +34,6 @@ struct AgsLayout {
     size_t final_T;     // P * f32
     size_t n_contrib;   // P * u32
     size_t dgeom;       // n * AgsGeomGrad (backward)
-    size_t tile_order;  // T * u32: AGS_BIN_DIRECT: the blend kernels' block -> tile map, heaviest tiles of every XCD band first
     size_t total;
     int64_t cap;
     int nb_cap;         // sort blocks at capacity
@@ -72,7 +71,6 @@ static inline AgsLayout ags_make_layout(int n, int h, int w, int64_t cap) {
     L.final_T = o; o += ags_align256(P * 4);
     L.n_contrib = o; o += ags_align256(P * 4);
     L.dgeom = o; o += ags_align256((size_t)n * sizeof(AgsGeomGrad));
-    L.tile_order = o; o += ags_align256((size_t)L.num_tiles * 4);
     L.total = o;
     return L;
 }
@@ -91,7 +89,11 @@ static inline AgsFrame ags_make_frame(const AgsCamera* c) {
 // Device-resident optimiser clock shared by adam.hip, render.hip (tick) and preprocess.hip (fused step)
 // `skipped`: optimisation steps ags_adam_step_gathered refused (a rank's row set had outgrown the agreed exchange
 // segment): sticky, cleared when the caller zeroes the clock together with the optimiser state
-struct AgsAdamClock { int step; float step_size[5]; float inv_bc2_sqrt; int skipped; float pad[8]; };
+// `pow1/pow2`: beta1^step, beta2^step as running products in double (two multiplies per tick instead of two generic
+// pow() calls - several hundred fp64 instructions that used to sit in the blend backward's code); `prev*`: their
+// values before the last tick, which a refused step restores.
+struct AgsAdamClock { int step; float step_size[5]; float inv_bc2_sqrt; int skipped; double pow1, pow2, prev1, prev2; };
+static_assert(sizeof(AgsAdamClock) == 64, "the Adam device clock is a 64-byte block");
 struct AgsAdamArgs {
     float* p[5];
     const float* g[5];
@@ -166,13 +168,19 @@ void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const Ag
 void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, void* dev_state,
                      bool pre_ticked, hipStream_t s);
 #if defined(__HIPCC__)
-__device__ __forceinline__ void ags_adam_tick(AgsAdamClock* c, const float lr[5], float beta1, float beta2, int host_step) {
-    const int step = host_step > 0 ? host_step : c->step + 1;
-    c->step = step;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    for (int k = 0; k < 5; ++k) c->step_size[k] = (float)((double)lr[k] / bc1);
-    c->inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+__device__ __forceinline__ void ags_adam_tick(AgsAdamClock* c, const float lr[5], float beta1, float beta2) {
+    const int before = c->step;
+    const double p1 = before > 0 ? c->pow1 : 1.0, p2 = before > 0 ? c->pow2 : 1.0;
+    const double q1 = p1 * (double)beta1, q2 = p2 * (double)beta2;
+    c->prev1 = p1; c->prev2 = p2; c->pow1 = q1; c->pow2 = q2;
+    c->step = before + 1;
+    const double inv_bc1 = 1.0 / (1.0 - q1);
+    for (int k = 0; k < 5; ++k) c->step_size[k] = (float)((double)lr[k] * inv_bc1);
+    c->inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - q2));
+}
+// a refused step (ags_adam_step_gathered): as if the last tick had not happened
+__device__ __forceinline__ void ags_adam_untick(AgsAdamClock* c) {
+    c->step -= 1; c->pow1 = c->prev1; c->pow2 = c->prev2;
 }
 #endif
 void ags_launch_rows_pack(float* const grads[5], const AgsRowSet& rows, float* segment, int capacity, hipStream_t s);
@@ -443,9 +451,13 @@ __device__ __forceinline__ void ags_bitonic_finish_lds(uint64_t* sk, uint32_t n,
 //   larger:         chunks of LDS_KEYS are sorted in LDS, then only the steps whose partners are
 //                   >= LDS_KEYS apart run on the (L2-resident) global slice and every stage is finished
 //                   chunk by chunk in LDS again: 3 global passes for 8192 keys instead of 91
+// `dst`: where the sorted keys go (g itself = in place; elsewhere: g is left in whatever state the sort needed)
 template <int NT, int LDS_KEYS, bool BARRIER_AT_END = true>
-__device__ __forceinline__ void ags_sort_tile_keys(uint64_t* g, uint32_t K, uint64_t* sk, int tid) {
-    if (K < 2) return;
+__device__ __forceinline__ void ags_sort_tile_keys(uint64_t* g, uint32_t K, uint64_t* sk, int tid, uint64_t* dst) {
+    if (K < 2) {
+        if (K == 1 && dst != g && tid == 0) dst[0] = g[0];
+        return;
+    }
     if (K <= 64) {
         if (!BARRIER_AT_END && tid >= 64) return; // stand-alone sort kernel: the other waves are done
         if (tid < 64) {
@@ -457,13 +469,13 @@ __device__ __forceinline__ void ags_sort_tile_keys(uint64_t* g, uint32_t K, uint
                                        (uint32_t)__builtin_amdgcn_readlane((int)lo, j);
                 rank += (other < mine) ? 1u : 0u;
             }
-            if (tid < (int)K) g[rank] = mine; // all loads happened before the first store (same wave)
+            if (tid < (int)K) dst[rank] = mine; // all loads happened before the first store (same wave)
         }
     } else if (K <= (uint32_t)LDS_KEYS) {
         for (uint32_t t = tid; t < K; t += NT) sk[t] = g[t];
         __syncthreads();
         ags_bitonic<NT>(sk, K, tid);
-        for (uint32_t t = tid; t < K; t += NT) g[t] = sk[t];
+        for (uint32_t t = tid; t < K; t += NT) dst[t] = sk[t];
     } else {
         constexpr uint32_t C = LDS_KEYS; // power of two
         // phase 1: every chunk sorted ascending on its own
@@ -504,6 +516,8 @@ __device__ __forceinline__ void ags_sort_tile_keys(uint64_t* g, uint32_t K, uint
                 __syncthreads();
             }
         }
+        if (dst != g)   // (every thread's own stores above are visible to it; other threads' through the barriers)
+            for (uint32_t t = tid; t < K; t += NT) dst[t] = a[t];
     }
     if (BARRIER_AT_END) __syncthreads();
 }
@@ -569,12 +583,21 @@ __device__ __forceinline__ int ags_xcd_band(int x, int n, int& size) {
     size = q + (x < r ? 1 : 0);
     return x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
 }
-// Block -> tile map of the blend kernels.  `order` (AGS_BIN_DIRECT, written by ags_k_tile_sort_direct) lists every
-// band's tiles by DESCENDING list length: blocks are dispatched in index order, so each XCD starts its heaviest
-// tiles first and fills the tail of the launch with the lightest ones (longest-processing-time-first) - without
-// it the launch ends when the last of the late-starting heavy tiles does.  nullptr: plain band order.
-__device__ __forceinline__ int ags_block_tile(const uint32_t* __restrict__ order, int b, int n) {
-    const int t = ags_xcd_remap(b, n);      // = band start + k: also the slot of the band's k-th heaviest tile
-    return order ? (int)order[t] : t;
+// Block -> tile map of the blend kernels.
+//  * scan-based binning modes (tile_cap == 0): block b blends tile ags_xcd_remap(b), whose sorted ids are
+//    ranges[tile] = [begin, end) of the key array.
+//  * AGS_BIN_DIRECT (tile_cap > 0): block b blends SLOT ags_xcd_remap(b).  ags_k_tile_sort_direct gave every tile
+//    a slot inside its XCD band by DESCENDING list length and left ranges[slot] = {tile, count} and the tile's
+//    sorted keys at slot * tile_cap.  Blocks are dispatched in index order, so every XCD starts its heaviest tiles
+//    first and fills the tail of the launch with the lightest (longest-processing-time-first: without it a launch
+//    ends when the last late-starting heavy tile does) - and a block knows where its ids are before it knows which
+//    tile it has: the header and the first 64 ids are requested together (one dependent load level less than
+//    slot -> tile -> range -> ids).
+__device__ __forceinline__ int ags_block_slot(const uint2* __restrict__ ranges, int b, int n, uint32_t tile_cap, uint2& rg) {
+    const int t = ags_xcd_remap(b, n);
+    const uint2 h = ranges[t];
+    if (tile_cap == 0) { rg = h; return t; }
+    rg.x = (uint32_t)t * tile_cap; rg.y = rg.x + h.y;
+    return (int)h.x;
 }
 #endif

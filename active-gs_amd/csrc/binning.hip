@@ -262,7 +262,8 @@ int ags_sort_passes(int num_tiles) {
 }
 
 AgsIdList ags_sorted_ids(char* ws, const AgsLayout& L, int binning_mode) {
-    // (AGS_BIN_DIRECT leaves its keys in keys0 like AGS_BIN_TILE_SORT, at tile * tile_cap instead of a scanned offset)
+    if (binning_mode == AGS_BIN_DIRECT)  // sorted copies in keys1, at slot * tile_cap (ags_k_tile_sort_direct)
+        return AgsIdList{(const uint32_t*)(ws + L.keys1), 2};
     if (binning_mode == AGS_BIN_RADIX)  // payloads end in buffer (passes & 1)
         return AgsIdList{(const uint32_t*)(ws + ((ags_sort_passes(L.num_tiles) & 1) ? L.vals1 : L.vals0)), 1};
     return AgsIdList{(const uint32_t*)(ws + L.keys0), 2}; // low word of (depth<<32 | id), little endian
@@ -478,44 +479,45 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort(const uint2* __restrict__
     if (threadIdx.x < 64) AGS_TL(5, blockIdx.x, 0);
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
-    ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS, false>(keys + rg.x, rg.y - rg.x, sk, threadIdx.x);
+    ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS, false>(keys + rg.x, rg.y - rg.x, sk, threadIdx.x, keys + rg.x);
     if (threadIdx.x < 64) { AGS_TL(5, blockIdx.x, 1); AGS_TL_VAL(5, blockIdx.x, 6, rg.y - rg.x); }
 }
 
-// AGS_BIN_DIRECT: the keys already sit in the tile's own slot range [tile * tile_cap, + count) (written by the
-// per-Gaussian kernel); this sorts them, publishes the tile's range for the blend kernels and adds the tile's
-// list length to the spread partial sums / maxima the forward blend kernel turns into the status block.
-__global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict__ ranges, uint64_t* keys,
-                                                              const uint32_t* __restrict__ tile_count, uint32_t tile_cap,
-                                                              uint32_t* __restrict__ partial, uint32_t* __restrict__ order,
-                                                              int num_tiles, AgsViewStride vs) {
+// AGS_BIN_DIRECT: the unsorted keys sit in the tile's own range [tile * tile_cap, + count) of keys0 (written by the
+// per-Gaussian kernel).  This gives the tile its SLOT - its place in its XCD band's heaviest-first order - sorts the
+// keys into keys1 at slot * tile_cap, leaves the header ranges[slot] = {tile, count} for the blend kernels
+// (ags_block_slot) and adds the list length to the spread partial sums / maxima the forward blend kernel turns into
+// the status block.
+__global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict__ ranges, uint64_t* keys_in,
+                                                              uint64_t* keys_out, const uint32_t* __restrict__ tile_count,
+                                                              uint32_t tile_cap, uint32_t* __restrict__ partial, int num_tiles,
+                                                              AgsViewStride vs) {
     { // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
-        AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(keys, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(partial, wo);
-        AGS_WS_SHIFT(order, wo);
+        AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(keys_in, wo); AGS_WS_SHIFT(keys_out, wo); AGS_WS_SHIFT(tile_count, wo);
+        AGS_WS_SHIFT(partial, wo);
     }
     __shared__ uint64_t sk[AGS_TSORT_LDS_KEYS];
     __shared__ uint32_t rank_part[4];
     if (threadIdx.x < 64) AGS_TL(5, blockIdx.x, 0);
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint32_t cnt = tile_count[tile];
-    const uint32_t K = cnt < tile_cap ? cnt : tile_cap, base = (uint32_t)tile * tile_cap;
-    { // this tile's place in its band's heaviest-first order (ags_block_tile): the number of band tiles with a longer
-      // list (ties: lower index first) - exact, deterministic, no counters to reset; <= T/8 counts read per workgroup
-        int band_size;
-        const int band0 = ags_xcd_band(blockIdx.x & 7, num_tiles, band_size);
-        uint32_t ahead = 0;
-        for (int j = threadIdx.x; j < band_size; j += 256) {
-            const uint32_t c = tile_count[band0 + j];
-            ahead += (c > cnt || (c == cnt && band0 + j < tile)) ? 1u : 0u;
-        }
-        ahead = ags_wave_sum_u32(ahead);
-        if ((threadIdx.x & 63) == 0) rank_part[threadIdx.x >> 6] = ahead;
-        __syncthreads();
-        if (threadIdx.x == 0) order[band0 + rank_part[0] + rank_part[1] + rank_part[2] + rank_part[3]] = (uint32_t)tile;
+    const uint32_t K = cnt < tile_cap ? cnt : tile_cap;
+    // the tile's slot: band start + number of band tiles with a longer list (ties: lower index first) - exact,
+    // deterministic, no counters to reset; <= T/8 counts read per workgroup
+    int band_size;
+    const int band0 = ags_xcd_band(blockIdx.x & 7, num_tiles, band_size);
+    uint32_t ahead = 0;
+    for (int j = threadIdx.x; j < band_size; j += 256) {
+        const uint32_t c = tile_count[band0 + j];
+        ahead += (c > cnt || (c == cnt && band0 + j < tile)) ? 1u : 0u;
     }
+    ahead = ags_wave_sum_u32(ahead);
+    if ((threadIdx.x & 63) == 0) rank_part[threadIdx.x >> 6] = ahead;
+    __syncthreads();
+    const uint32_t slot = (uint32_t)band0 + rank_part[0] + rank_part[1] + rank_part[2] + rank_part[3];
     if (threadIdx.x == 0) {
-        ranges[tile] = make_uint2(base, base + K);
+        ranges[slot] = make_uint2((uint32_t)tile, K);
 #ifndef AGS_EXP_NO_PARTIALS
         if (cnt) {
             atomicAdd(&partial[AGS_PART(blockIdx.x, AGS_PART_SUM)], cnt);
@@ -523,14 +525,15 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict_
         }
 #endif
     }
-    ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS, false>(keys + base, K, sk, threadIdx.x);
+    ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS, false>(keys_in + (size_t)tile * tile_cap, K, sk, threadIdx.x,
+                                                       keys_out + (size_t)slot * tile_cap);
     if (threadIdx.x < 64) { AGS_TL(5, blockIdx.x, 1); AGS_TL_VAL(5, blockIdx.x, 6, K); }
 }
 
 void ags_launch_direct_sort(char* ws, const AgsLayout& L, const AgsViewStride& vs, hipStream_t s) {
     hipLaunchKernelGGL(ags_k_tile_sort_direct, dim3(L.num_tiles, vs.views), dim3(256), 0, s, (uint2*)(ws + L.ranges),
-                       (uint64_t*)(ws + L.keys0), (const uint32_t*)(ws + L.tile_count), ags_direct_tile_cap(L),
-                       (uint32_t*)(ws + L.totals), (uint32_t*)(ws + L.tile_order), L.num_tiles, vs);
+                       (uint64_t*)(ws + L.keys0), (uint64_t*)(ws + L.keys1), (const uint32_t*)(ws + L.tile_count),
+                       ags_direct_tile_cap(L), (uint32_t*)(ws + L.totals), L.num_tiles, vs);
 }
 
 void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L,

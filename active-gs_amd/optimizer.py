@@ -47,6 +47,10 @@ class FusedAdam:
             return
         if device:
             if self.step_count:
+                # the device clock keeps beta^step as running products (doubles at bytes 32..47; float betas as the kernels see them)
+                b1, b2 = (float(torch.tensor(b, dtype=torch.float32).item()) for b in self.betas)
+                pows = torch.tensor([b1 ** self.step_count, b2 ** self.step_count], dtype=torch.float64)
+                self.device_clock[8:12] = pows.view(torch.int32).to(self.device_clock.device)
                 self.device_clock[0] = self.step_count
         elif self._clock_on_device is not None:
             self.step_count = int(self.device_clock[0].item())

@@ -257,7 +257,8 @@ int ags_adam_step(const AgsAdamTensors* t, float beta1, float beta2, float eps, 
 
 /* Graph-replayable form: the 1-based step counter lives on the device.  `state` is a
  * caller-owned, zero-initialised 64-byte device buffer { int32 step; float step_size[5];
- * float inv_sqrt_bc2; int32 skipped_steps (see ags_adam_step_gathered); ... }; each call first bumps the counter and refreshes the bias
+ * float inv_sqrt_bc2; int32 skipped_steps (see ags_adam_step_gathered); double beta1^step, beta2^step and their
+ * values one step earlier }; each call first bumps the counter and refreshes the bias
  * corrections on the device (in double), then runs the same update.  Capturing this call in
  * a hipGraph and replaying it k times performs Adam steps 1..k. */
 int ags_adam_step_device(const AgsAdamTensors* t, float beta1, float beta2, float eps, void* state,

@@ -96,12 +96,33 @@ for kid, (name, phases) in KERNELS.items():
         d = full[:, p + 1] - full[:, p]
         print(f"   {label:18s} p50 {pct(d, 50):8.0f} cyc  p90 {pct(d, 90):8.0f}  max {d.max() if len(d) else 0:8.0f}   (p50 {pct(d, 50) / GHZ / 1e3:.2f} us)")
     if kid in (2, 3):
+        # where each wave ran (HW_REG_HW_ID | XCC_ID << 32, noted by the wave): per SIMD, how many waves were resident
+        # on average between the SIMD's first start and last end, and how long that span was (one clock per XCD)
+        hw = a[:, 7]
+        simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; xcc = (hw >> 32) & 15
+        key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+        spans, occ, first = [], [], []
+        x0 = {}
+        for x in np.unique(xcc):
+            x0[x] = a[xcc == x, 0].min()
+        for k in np.unique(key):
+            sel = key == k
+            s0, e1 = a[sel, 0].min(), end[sel].max()
+            spans.append((e1 - s0) / GHZ / 1e3); occ.append(life[sel].sum() / max(e1 - s0, 1))
+            first.append((s0 - x0[xcc[sel][0]]) / GHZ / 1e3)
+        xs = [(end[xcc == x].max() - x0[x]) / GHZ / 1e3 for x in np.unique(xcc)]
+        print(f"   {len(spans)} SIMDs on {len(x0)} XCDs saw waves; per XCD first start -> last end: {min(xs):.2f} .. {max(xs):.2f} us")
+        print(f"   per SIMD: busy span p50 {pct(spans, 50):.2f} p10 {pct(spans, 10):.2f} p90 {pct(spans, 90):.2f} us; first wave starts "
+              f"p50 {pct(first, 50):.2f} p90 {pct(first, 90):.2f} us after the XCD's first; resident waves (time average) "
+              f"p50 {pct(occ, 50):.2f} p10 {pct(occ, 10):.2f} p90 {pct(occ, 90):.2f}; waves per SIMD p50 "
+              f"{pct([int((key == k).sum()) for k in np.unique(key)], 50):.0f}")
+    if kid in (2, 3):
         it = full[:, 6] & 0xFFFFFFFF
         loop = full[:, 3 if kid == 2 else 4] - full[:, 2 if kid == 2 else 3]
         print(f"   blended (surfel, wave) pairs per wave: mean {it.mean():.1f} p90 {pct(it, 90):.0f} max {it.max()}; "
               f"cycles per pair (loop / pairs): {loop.sum() / max(it.sum(), 1):.0f}")
         if kid == 3:
             fl = full[:, 6] >> 32
-            print(f"   flushes per wave: mean {fl.mean():.2f}; list length (maxlast) mean {full[:, 7].mean():.1f}")
+            print(f"   flushes per wave: mean {fl.mean():.2f}")
         else:
             print(f"   list length mean {full[:, 5].mean():.1f} max {full[:, 5].max()}")
