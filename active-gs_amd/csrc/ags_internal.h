@@ -593,11 +593,23 @@ __device__ __forceinline__ int ags_xcd_band(int x, int n, int& size) {
 //    ends when the last late-starting heavy tile does) - and a block knows where its ids are before it knows which
 //    tile it has: the header and the first 64 ids are requested together (one dependent load level less than
 //    slot -> tile -> range -> ids).
-__device__ __forceinline__ int ags_block_slot(const uint2* __restrict__ ranges, int b, int n, uint32_t tile_cap, uint2& rg) {
-    const int t = ags_xcd_remap(b, n);
+__device__ __forceinline__ int ags_slot_tile(const uint2* __restrict__ ranges, int t, uint32_t tile_cap, uint2& rg) {
     const uint2 h = ranges[t];
     if (tile_cap == 0) { rg = h; return t; }
     rg.x = (uint32_t)t * tile_cap; rg.y = rg.x + h.y;
     return (int)h.x;
+}
+// The blend kernels run ONE WAVE PER WORKGROUP (64 threads): a workgroup's LDS and wave slots are released only when
+// its LAST wave ends, and the quadrants of a tile differ a lot in work - with the four quadrant waves of a tile in one
+// workgroup a third of the wave slots sat empty behind each tile's slowest quadrant (measured: 3.9 of 6 resident waves
+// per SIMD in the blend backward).  Wave-workgroup b of a launch of 8 * ags_wave_blocks_per_xcd(n, W) serves slot
+// band(b % 8) + (b / 8) / W, quadrant group (b / 8) % W: the W waves of a tile stay on one XCD (its L2 holds the tile's
+// records) and are dispatched back to back; the few workgroups beyond a shorter band exit at once.
+static inline int ags_wave_blocks_per_xcd(int num_tiles, int waves_per_tile) { return ((num_tiles + 7) / 8) * waves_per_tile; }
+__device__ __forceinline__ bool ags_wave_block(int b, int n, int W, int& slot, int& wave) {
+    int size;
+    const int band0 = ags_xcd_band(b & 7, n, size), j = b >> 3;
+    slot = band0 + j / W; wave = j % W;
+    return j < size * W;
 }
 #endif

@@ -191,7 +191,7 @@ __device__ __forceinline__ void ags_finalize_status(const AgsFinalize& fin, int 
 }
 
 template <int SLOTS, bool STATS>
-__global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
+__global__ __launch_bounds__(64) void ags_k_render_fwd(
     AgsFrame F, int normalize_depth, float weight_thres, const float* __restrict__ bgp,
     const float* __restrict__ mask, const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
     int id_stride, const AgsGeom* __restrict__ geom, AgsImages out, float* __restrict__ final_T,
@@ -207,20 +207,21 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
         out.rgb += 3 * po; out.normal += 3 * po; out.depth += po; out.opacity += po; out.confidence += po;
         if (STATS) { importance += (size_t)blockIdx.y * (size_t)vs.n; count += (size_t)blockIdx.y * (size_t)vs.n; }
     }
-    __shared__ AgsWaveStageQ<SLOTS, 64, false> stage[4 / SLOTS];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63; // wave index in an SGPR: strip masks become scalar tests
-    AgsWaveStageQ<SLOTS, 64, false>& st = stage[wave];
-    [[maybe_unused]] const int tl_w = blockIdx.x * (4 / SLOTS) + wave;
+    __shared__ AgsWaveStageQ<SLOTS, 64, false> st;
+    const int lane = threadIdx.x;
+    int slot, wave;   // blockIdx-derived: SGPRs, strip masks become scalar tests
+    if (!ags_wave_block(blockIdx.x, num_tiles, 4 / SLOTS, slot, wave)) return;
+    [[maybe_unused]] const int tl_w = slot * (4 / SLOTS) + wave;
     AGS_TL(2, tl_w, 0);
     AGS_PRIO_HIGH();
-    if (fin.status && blockIdx.x == 0 && wave == 0) ags_finalize_status(fin, num_tiles, lane);   // wave-uniform
+    if (fin.status && blockIdx.x == 0) ags_finalize_status(fin, num_tiles, lane);   // wave-uniform
     // direct binning: the first 64 ids of the block's slot are requested before the slot's header says which tile
     // this is and how long its list (ags_block_slot); lanes beyond the list hold a stale key and are masked below
     uint32_t spec_id = 0;
     if (tile_cap && (uint32_t)lane < tile_cap)
-        spec_id = vals[((size_t)ags_xcd_remap(blockIdx.x, num_tiles) * tile_cap + lane) * id_stride];
+        spec_id = vals[((size_t)slot * tile_cap + lane) * id_stride];
     uint2 rg;
-    const int tile = ags_block_slot(ranges, blockIdx.x, num_tiles, tile_cap, rg);
+    const int tile = ags_slot_tile(ranges, slot, tile_cap, rg);
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
     const int strip0 = wave * SLOTS;                       // first of this wave's slots (8x8 quadrants of the tile)
     // quadrant q = strip0 + s sits at (q & 1, q >> 1); lane l is pixel (l & 7, l >> 3) of its quadrant
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
     const float bx0 = (float)(tx * AGS_TILE), by0 = (float)(ty * AGS_TILE);
     const uint32_t my_strips = ((1u << SLOTS) - 1u) << strip0;
     // last consumer of this tile's binning counters: leave them zero for the next forward pass
-    if (threadIdx.x == 0) { tile_count[tile] = 0u; tile_fill[tile] = 0u; }
+    if (wave == 0 && lane == 0) { tile_count[tile] = 0u; tile_fill[tile] = 0u; }
     // the lane's pixel relative to the centre of its quadrant - the same in every quadrant the wave owns
     const float qx = (float)(lane & 7) - 3.5f, qy = (float)(lane >> 3) - 3.5f;
     AgsPix pix[SLOTS];
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) void ags_k_render_fwd(
 #define AGS_BWD_ATTR
 #endif
 template <int SLOTS>
-__global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bwd(
+__global__ __launch_bounds__(64) AGS_BWD_ATTR void ags_k_render_bwd(
     AgsFrame F, int normalize_depth, const float* __restrict__ bgp, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
     const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
@@ -357,14 +358,15 @@ __global__ __launch_bounds__(64 * (4 / SLOTS)) AGS_BWD_ATTR void ags_k_render_bw
         if (dout.d_opacity) dout.d_opacity += po;
         if (dout.d_confidence) dout.d_confidence += po;
     }
-    __shared__ AgsWaveStage stage[4 / SLOTS];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63; // wave index in an SGPR: strip masks become scalar tests
-    AgsWaveStage& st = stage[wave];
+    __shared__ AgsWaveStage st;
+    const int lane = threadIdx.x;
+    int slot, wave;
+    if (!ags_wave_block(blockIdx.x, num_tiles, 4 / SLOTS, slot, wave)) return;
     // side job of a step's last backward: advance the Adam device clock.  Nothing in this launch
     // reads it; the per-Gaussian kernel that follows (fused step) or ags_adam_step_device does.
     if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2);
     uint2 rg;
-    const int tile = ags_block_slot(ranges, blockIdx.x, num_tiles, tile_cap, rg);
+    const int tile = ags_slot_tile(ranges, slot, tile_cap, rg);
     if (rg.y <= rg.x) return;
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
     const int strip0 = wave * SLOTS;
@@ -472,7 +474,7 @@ struct AgsWaveBatch {       // one per wave, in LDS (6784 B: six workgroups of f
 #ifndef AGS_MFMA_WAVES
 #define AGS_MFMA_WAVES 6      // register budget: 512 / 6 -> 80 VGPRs
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAVES, AGS_MFMA_WAVES))) void ags_k_render_bwd_mfma(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAVES, AGS_MFMA_WAVES))) void ags_k_render_bwd_mfma(
     AgsFrame F, int normalize_depth, const float* __restrict__ bgp, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
     const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
@@ -490,20 +492,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WA
         if (dout.d_confidence) dout.d_confidence += po;
     }
     constexpr int SLOTS = 1;
-    __shared__ AgsWaveBatch batch[4];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    AgsWaveBatch& wb = batch[wave];
+    __shared__ AgsWaveBatch wb;
+    const int lane = threadIdx.x;
+    int slot, wave;
+    if (!ags_wave_block(blockIdx.x, num_tiles, 4, slot, wave)) return;
     AgsWaveStageQ<1, AGS_MFMA_STAGE, true>& st = wb.st;
     if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2);
-    [[maybe_unused]] const int tl_w = blockIdx.x * 4 + wave;
+    [[maybe_unused]] const int tl_w = slot * 4 + wave;
     AGS_TL(3, tl_w, 0);
     AGS_PRIO_HIGH();
     // direct binning: the slot's first ids are requested before its header (which tile, how long a list) is here
     uint32_t gid_early = 0;
     if (tile_cap && lane < AGS_MFMA_STAGE && (uint32_t)lane < tile_cap)
-        gid_early = vals[((size_t)ags_xcd_remap(blockIdx.x, num_tiles) * tile_cap + lane) * id_stride];
+        gid_early = vals[((size_t)slot * tile_cap + lane) * id_stride];
     uint2 rg;
-    const int tile = ags_block_slot(ranges, blockIdx.x, num_tiles, tile_cap, rg);
+    const int tile = ags_slot_tile(ranges, slot, tile_cap, rg);
     if (rg.y <= rg.x) return;
     const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
     const int strip0 = wave;
@@ -720,14 +723,14 @@ static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
     const AgsGeom* geom = (const AgsGeom*)(ws + L.geom);
     float* fT = (float*)(ws + L.final_T);
     uint32_t* nc = (uint32_t*)(ws + L.n_contrib);
-    const dim3 block(64 * (4 / SLOTS));
+    const dim3 block(64), grid(8 * ags_wave_blocks_per_xcd(L.num_tiles, 4 / SLOTS), vs.views);
     if (cam.want_stats)
-        hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, true>), dim3(L.num_tiles, vs.views), block, 0, s, F, cam.normalize_depth,
+        hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, true>), grid, block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
                            (uint32_t*)(ws + L.tile_fill), fin, tile_cap, vs);
     else
-        hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, false>), dim3(L.num_tiles, vs.views), block, 0, s, F, cam.normalize_depth,
+        hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, false>), grid, block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
                            (uint32_t*)(ws + L.tile_fill), fin, tile_cap, vs);
@@ -737,7 +740,7 @@ template <int SLOTS>
 static void launch_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L, AgsIdList ids,
                        const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick, uint32_t tile_cap,
                        const AgsViewStride& vs, hipStream_t s) {
-    hipLaunchKernelGGL((ags_k_render_bwd<SLOTS>), dim3(L.num_tiles, vs.views), dim3(64 * (4 / SLOTS)), 0, s, F,
+    hipLaunchKernelGGL((ags_k_render_bwd<SLOTS>), dim3(8 * ags_wave_blocks_per_xcd(L.num_tiles, 4 / SLOTS), vs.views), dim3(64), 0, s, F,
                        cam.normalize_depth, cam.bg, (const uint2*)(ws + L.ranges), ids.ids, ids.stride,
                        (const AgsGeom*)(ws + L.geom), fwd.depth, fwd.opacity, (const float*)(ws + L.final_T),
                        (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick, tile_cap, vs);
@@ -760,7 +763,7 @@ void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
     const uint32_t tile_cap = direct ? ags_direct_tile_cap(L) : 0u;
     const int slots = ags_pick_slots(L.num_tiles * vs.views), mfma = ags_bwd_mfma();
     if (mfma == 2 || (mfma == 1 && slots == 1)) {
-        hipLaunchKernelGGL(ags_k_render_bwd_mfma, dim3(L.num_tiles, vs.views), dim3(256), 0, s, F, cam.normalize_depth,
+        hipLaunchKernelGGL(ags_k_render_bwd_mfma, dim3(8 * ags_wave_blocks_per_xcd(L.num_tiles, 4), vs.views), dim3(64), 0, s, F, cam.normalize_depth,
                            cam.bg, (const uint2*)(ws + L.ranges), ids.ids, ids.stride, (const AgsGeom*)(ws + L.geom),
                            fwd.depth, fwd.opacity, (const float*)(ws + L.final_T),
                            (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick, tile_cap, vs);
