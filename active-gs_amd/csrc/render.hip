@@ -128,16 +128,20 @@ struct AgsStagedRec {
     float4 c;              // nx, ny, nz, conf
     float4 slot[SLOTS];    // E0, E1, E2, D0 of quadrant strip0 + s
 };
-template <int SLOTS, int N, bool OXY>
-struct AgsWaveStageQ {     // one per wave, in LDS
+template <int SLOTS, int N, bool SID>
+struct AgsWaveStageQ {     // one per wave, in LDS (allocated in 1280-byte granules: profiles/experiments/lds_granule.cpp)
     AgsStagedRec<SLOTS> sg[N];
-    uint32_t sid[N];
-    float2 oxy[OXY ? N : 1];   // mean - centre of the wave's FIRST quadrant (the backward's moment shift)
+    uint32_t sid[N];       // surfel ids (forward: the importance / count atomics)
 };
-// park record `r` of surfel `gid` from lane `lane` in quadrant-local form; returns its strip-reach mask
-template <int SLOTS, int N, bool OXY>
-__device__ __forceinline__ uint32_t ags_stage_commit_q(AgsWaveStageQ<SLOTS, N, OXY>& st, int lane, const AgsRec4& r, uint32_t gid,
-                                                       float bx0, float by0, int strip0) {
+template <int SLOTS, int N>
+struct AgsWaveStageQ<SLOTS, N, false> {
+    AgsStagedRec<SLOTS> sg[N];
+};
+// park record `r` of surfel `gid` from lane `lane` in quadrant-local form; returns its strip-reach mask;
+// oxy (optional): mean - centre of the wave's FIRST quadrant (the backward's moment shift)
+template <int SLOTS, int N, bool SID>
+__device__ __forceinline__ uint32_t ags_stage_commit_q(AgsWaveStageQ<SLOTS, N, SID>& st, int lane, const AgsRec4& r, uint32_t gid,
+                                                       float bx0, float by0, int strip0, float2* oxy = nullptr) {
     AgsGeom g;
     g.mx = r.r0.x; g.my = r.r0.y; g.ca = r.r0.z; g.cb = r.r0.w; g.cc = r.r1.x; g.o = r.r1.y; g.dc = r.r1.z; g.gx = r.r1.w;
     g.gy = r.r2.x;
@@ -155,10 +159,10 @@ __device__ __forceinline__ uint32_t ags_stage_commit_q(AgsWaveStageQ<SLOTS, N, O
         AgsQuadCoef q;
         ags_quad_coeffs(g, qx0 + 3.5f, qy0 + 3.5f, q);
         d.slot[k] = make_float4(q.E0, q.E1, q.E2, q.D0);
-        if (OXY && k == 0) st.oxy[lane] = make_float2(g.mx - (qx0 + 3.5f), g.my - (qy0 + 3.5f));
+        if (k == 0 && oxy) *oxy = make_float2(g.mx - (qx0 + 3.5f), g.my - (qy0 + 3.5f));
         m |= ags_reaches_box(g, qx0, qx0 + 7.f, qy0, qy0 + 7.f) ? (1u << s) : 0u;
     }
-    st.sid[lane] = gid;
+    if constexpr (SID) st.sid[lane] = gid;
     return m;
 }
 
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
         out.rgb += 3 * po; out.normal += 3 * po; out.depth += po; out.opacity += po; out.confidence += po;
         if (STATS) { importance += (size_t)blockIdx.y * (size_t)vs.n; count += (size_t)blockIdx.y * (size_t)vs.n; }
     }
-    __shared__ AgsWaveStageQ<SLOTS, 64, false> st;
+    __shared__ AgsWaveStageQ<SLOTS, 64, STATS> st;
     const int lane = threadIdx.x;
     int slot, wave;   // blockIdx-derived: SGPRs, strip masks become scalar tests
     if (!ags_wave_block(blockIdx.x, num_tiles, 4 / SLOTS, slot, wave)) return;
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
         uint32_t m = 0;
         if (idx < rg.y) {
             const uint32_t gid = (tile_cap && base == rg.x) ? spec_id : vals[(size_t)idx * id_stride];
-            m = ags_stage_commit_q<SLOTS, 64, false>(st, lane, ags_stage_issue(geom, gid), gid, bx0, by0, strip0);
+            m = ags_stage_commit_q<SLOTS, 64, STATS>(st, lane, ags_stage_issue(geom, gid), gid, bx0, by0, strip0);
         }
         ags_wave_lds_sync();
         unsigned long long act = __ballot((m & my_strips) != 0u); // staged surfels that reach my strips
@@ -299,10 +303,12 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
             if (STATS) {
                 const float ts = ags_wave_sum(wsum);
                 const uint32_t tc = ags_wave_sum_u32(wcnt);
-                if (lane == 0 && ts > 0.f) {
-                    const uint32_t gid = st.sid[k];
-                    atomicAdd(&importance[gid], ts);
-                    if (tc) atomicAdd(&count[gid], (int)tc);
+                if constexpr (STATS) {
+                    if (lane == 0 && ts > 0.f) {
+                        const uint32_t gid = st.sid[k];
+                        atomicAdd(&importance[gid], ts);
+                        if (tc) atomicAdd(&count[gid], (int)tc);
+                    }
                 }
             }
         }
@@ -466,8 +472,8 @@ typedef float ags_f32x4 __attribute__((ext_vector_type(4)));
 #ifndef AGS_MFMA_STAGE
 #define AGS_MFMA_STAGE 32   // records staged per round: 32 keeps a wave at 6.4 KB of LDS = 6 waves per SIMD
 #endif
-struct AgsWaveBatch {       // one per wave, in LDS (6784 B: six workgroups of four waves per CU)
-    AgsWaveStageQ<1, AGS_MFMA_STAGE, true> st;
+struct AgsWaveBatch {       // one per wave, in LDS: 2048 + 4352 = 6400 B = five 1280-byte granules -> 25 waves per CU
+    AgsStagedRec<1> sg[AGS_MFMA_STAGE];
     float gw[16][68];       // row 2 i: gp of slot i, row 2 i + 1: its w; 68 floats: 16-byte row reads of 16 lanes hit 64 banks
 };
 
@@ -496,7 +502,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
     const int lane = threadIdx.x;
     int slot, wave;
     if (!ags_wave_block(blockIdx.x, num_tiles, 4, slot, wave)) return;
-    AgsWaveStageQ<1, AGS_MFMA_STAGE, true>& st = wb.st;
+    AgsWaveStageQ<1, AGS_MFMA_STAGE, false>& st = *reinterpret_cast<AgsWaveStageQ<1, AGS_MFMA_STAGE, false>*>(&wb.sg[0]);
+    static_assert(sizeof(AgsWaveBatch) <= 6400, "the blend backward's LDS per wave: five 1280-byte granules");
     if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2);
     [[maybe_unused]] const int tl_w = slot * 4 + wave;
     AGS_TL(3, tl_w, 0);
@@ -549,9 +556,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
         ags_pixgrad_init(pg, dC, dN, dD, dO, dCf, dep, opa, Tf, last, bg, normalize_depth);
     }
     // park the early records now (not across the feature exchange: sixteen more live registers there spill)
-    uint32_t m_early = 0;
+    // the staging lane keeps its surfel's id and (mean - quadrant centre): the batch slots take them with v_readlane
+    uint32_t m_early = 0, my_gid = gid_early;
+    float2 my_oxy = make_float2(0.f, 0.f);
     if (early && lane < (int)list_len)
-        m_early = ags_stage_commit_q<1, AGS_MFMA_STAGE, true>(st, lane, rec_early, gid_early, bx0, by0, strip0);
+        m_early = ags_stage_commit_q<1, AGS_MFMA_STAGE, false>(st, lane, rec_early, gid_early, bx0, by0, strip0, &my_oxy);
     const uint32_t maxlast = ags_wave_max_u32(pg.last);
     AGS_TL(3, tl_w, 1);
     if (maxlast == 0) return; // wave-uniform; no workgroup barrier anywhere in this kernel
@@ -647,8 +656,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
         if (early) {                       // the only round (r == 0): the records were parked in the prologue
             if (lane < (int)maxlast) m = m_early;
         } else if (lane < AGS_MFMA_STAGE && k0 + lane < maxlast) {
-            const uint32_t my_gid = vals[(size_t)(rg.x + k0 + lane) * id_stride];
-            m = ags_stage_commit_q<1, AGS_MFMA_STAGE, true>(st, lane, ags_stage_issue(geom, my_gid), my_gid, bx0, by0, strip0);
+            my_gid = vals[(size_t)(rg.x + k0 + lane) * id_stride];
+            m = ags_stage_commit_q<1, AGS_MFMA_STAGE, false>(st, lane, ags_stage_issue(geom, my_gid), my_gid, bx0, by0, strip0, &my_oxy);
         }
         ags_wave_lds_sync();
         unsigned long long act = __ballot((m & my_strips) != 0u);
@@ -681,8 +690,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             wb.gw[2 * nb + 1][lane] = w;
             {
                 const bool mine = lane == 16 * (nb >> 1) + (nb & 1);
-                const float2 oc = st.oxy[k];
-                slot_sid = mine ? st.sid[k] : slot_sid; slot_ox = mine ? oc.x : slot_ox; slot_oy = mine ? oc.y : slot_oy;
+                const uint32_t ksid = (uint32_t)__builtin_amdgcn_readlane((int)my_gid, k);
+                const float kox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_oxy.x), k));
+                const float koy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_oxy.y), k));
+                slot_sid = mine ? ksid : slot_sid; slot_ox = mine ? kox : slot_ox; slot_oy = mine ? koy : slot_oy;
             }
             if (++nb == 8) { flush(); ++tl_flush; }
         }

@@ -59,6 +59,8 @@ tr.step([cam], fn, cap)
 torch.cuda.synchronize()
 lib.ags_debug_timeline(None)
 t = buf.cpu().numpy().reshape(8, NW, 8).astype(np.int64)
+if os.environ.get("AGS_TL_DUMP"):
+    np.savez_compressed(os.environ["AGS_TL_DUMP"], t=t[[2, 3]])
 print(f"workload: n={args.n} {args.h}x{args.w} visible={info['num_visible']} instances={info['num_instances']}")
 GHZ = 2.4
 KERNELS = {0: ("preprocess", ["rows loaded", "math+stores", "row set", "emit(count)", "block sums"]),
