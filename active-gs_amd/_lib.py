@@ -67,7 +67,8 @@ class AgsStatus(C.Structure):
 
 class AgsAdamTensors(C.Structure):
     _fields_ = [("param", c_f32p * 5), ("grad", c_f32p * 5), ("exp_avg", c_f32p * 5), ("exp_avg_sq", c_f32p * 5),
-                ("numel", C.c_int64 * 5), ("lr", C.c_float * 5), ("touched", AgsRowSet), ("zero_grad", C.c_int32)]
+                ("numel", C.c_int64 * 5), ("lr", C.c_float * 5), ("touched", AgsRowSet), ("zero_grad", C.c_int32),
+                ("state_rows", c_f32p)]
 
 
 class AgsLossConfig(C.Structure):

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void ags_k_adam(AgsAdamArgs a, AgsAdamClock ho
 // outside the set have g = m = v = 0, for which the dense update above is exactly 0.
 __global__ __launch_bounds__(256) void ags_k_adam_rows(AgsAdamArgs a, const AgsAdamClock* __restrict__ clk,
                                                        AgsAdamClock host_clk, AgsRowSet touched, float beta1,
-                                                       float beta2, float eps, int zero_grad) {
+                                                       float beta2, float eps, int zero_grad, int n_rows) {
     const int k = threadIdx.x & 15;
     const int seg = (k >= 3) + (k >= 6) + (k >= 10) + (k >= 11);
     const int width = seg == 2 ? 4 : (seg == 3 ? 1 : 3);
@@ -78,18 +78,23 @@ __global__ __launch_bounds__(256) void ags_k_adam_rows(AgsAdamArgs a, const AgsA
         inv_bc2_sqrt = host_clk.inv_bc2_sqrt;
     }
     const float step_size = seg == 0 ? ss[0] : seg == 1 ? ss[1] : seg == 2 ? ss[2] : seg == 3 ? ss[3] : ss[4];
-    const int count = *touched.count;
+    // touched.rows == nullptr: every row (the dense step over interleaved moments: same lane layout, row = r)
+    const int count = touched.rows ? *touched.count : n_rows;
     const int stride = gridDim.x * 16;
     for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < count; r += stride) {
         if (k >= 14) continue;
-        const long long j = (long long)touched.rows[r] * width + off;
+        const int row = touched.rows ? touched.rows[r] : r;
+        const long long j = (long long)row * width + off;
+        // interleaved moments (AgsAdamTensors.state_rows): the row's 28 floats are one 112-byte piece
+        float* qm = a.st ? a.st + (long long)row * 28 + k : pm + j;
+        float* qv = a.st ? a.st + (long long)row * 28 + 14 + k : pv + j;
         const float g = pg[j];
-        float m = pm[j], v = pv[j];
+        float m = *qm, v = *qv;
         m = m + (1.f - beta1) * (g - m);
         v = v * beta2 + (1.f - beta2) * g * g;
         const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
-        pm[j] = m;
-        pv[j] = v;
+        *qm = m;
+        *qv = v;
         pp[j] -= step_size * (m / denom);
         if (zero_grad) pg[j] = 0.f; // consumed: the slab is clean for the next step
     }
@@ -113,11 +118,11 @@ void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float ep
         for (int k = 0; k < 5; ++k) hc.step_size[k] = (float)((double)t.lr[k] / bc1);
         hc.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     }
-    if (t.touched.rows) {
+    if (t.touched.rows || t.state_rows) { // row-set step, or the dense step over interleaved moments (all rows)
         long long rb = (t.numel[3] + 15) / 16; // 16 rows per block
         if (rb > 16384) rb = 16384;
         hipLaunchKernelGGL(ags_k_adam_rows, dim3((unsigned)rb), dim3(256), 0, s, a, (const AgsAdamClock*)clk, hc,
-                           t.touched, beta1, beta2, eps, t.zero_grad);
+                           t.touched, beta1, beta2, eps, t.touched.rows ? t.zero_grad : 0, (int)t.numel[3]);
         return;
     }
     long long blocks = (run + 255) / 256;
@@ -256,12 +261,14 @@ __global__ __launch_bounds__(256) void ags_k_adam_rows_gathered(AgsAdamArgs a, A
         }
         if (k < 14 && !over) {
             const long long j = (long long)row * width + off;
-            float m = pm[j], v = pv[j];
+            float* qm = a.st ? a.st + (long long)row * 28 + k : pm + j;
+            float* qv = a.st ? a.st + (long long)row * 28 + 14 + k : pv + j;
+            float m = *qm, v = *qv;
             m = m + (1.f - beta1) * (g - m);
             v = v * beta2 + (1.f - beta2) * g * g;
             const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
-            pm[j] = m;
-            pv[j] = v;
+            *qm = m;
+            *qv = v;
             pp[j] -= step_size * (m / denom);
         }
         // the update above needed g, i.e. every lane's table reads have returned (vmcnt is per wave); keep the

@@ -101,6 +101,7 @@ struct AgsAdamArgs {
     float* v[5];
     long long end[5]; // cumulative element counts
     float lr[5];
+    float* st;        // AgsAdamTensors.state_rows: (n, 28) interleaved moments, or nullptr (then m / v)
 };
 // "advance this Adam clock on the side" request carried by a backward launch (clock == nullptr: off)
 struct AgsTick { AgsAdamClock* clock; float lr[5]; float beta1, beta2; };
@@ -113,6 +114,7 @@ inline AgsAdamArgs ags_adam_args(const AgsAdamTensors& t) {
         a.end[k] = run;
         a.lr[k] = t.lr[k];
     }
+    a.st = t.state_rows;
     return a;
 }
 

@@ -109,12 +109,18 @@ int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* i
     return ags_check_launch();
 }
 
-static int ags_adam_check(const AgsAdamTensors* t) {
+static bool ags_adam_map_shaped(const AgsAdamTensors* t) {   // the five map tensors: 3n, 3n, 4n, n, 3n
+    const int64_t n = t->numel[3];
+    return t->numel[0] == 3 * n && t->numel[1] == 3 * n && t->numel[2] == 4 * n && t->numel[4] == 3 * n && n <= 0x7FFFFFFF;
+}
+static int ags_adam_check(const AgsAdamTensors* t, bool need_grad = true) {
     if (!t) return AGS_E_INVALID;
     for (int k = 0; k < 5; ++k) {
         if (t->numel[k] < 0) return AGS_E_INVALID;
-        if (t->numel[k] > 0 && (!t->param[k] || !t->grad[k] || !t->exp_avg[k] || !t->exp_avg_sq[k])) return AGS_E_INVALID;
+        if (t->numel[k] > 0 && (!t->param[k] || (need_grad && !t->grad[k]))) return AGS_E_INVALID;
+        if (t->numel[k] > 0 && !t->state_rows && (!t->exp_avg[k] || !t->exp_avg_sq[k])) return AGS_E_INVALID;
     }
+    if (t->state_rows && !ags_adam_map_shaped(t)) return AGS_E_INVALID;
     return AGS_OK;
 }
 
@@ -124,8 +130,11 @@ int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* 
     if (!cam || !in || !fwd || !pg || !dout || !din || !ws || !ws->ptr) return AGS_E_INVALID;
     if (in->n == 0) return AGS_OK;
     if (!pg->radii || !fwd->depth || !fwd->opacity) return AGS_E_INVALID;
-    if (!din->d_means3D || !din->d_scales || !din->d_rotations || !din->d_opacities || !din->d_colors)
-        return AGS_E_INVALID;
+    {   // all five gradient arrays, or - fused optimiser step, overwrite mode - none at all
+        const int have = (din->d_means3D != nullptr) + (din->d_scales != nullptr) + (din->d_rotations != nullptr) +
+                         (din->d_opacities != nullptr) + (din->d_colors != nullptr);
+        if (have != 5 && !(have == 0 && din->fused_adam && din->accumulate == 0 && !din->d_means2D)) return AGS_E_INVALID;
+    }
     const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
     if (ws->bytes < L.total) return AGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -142,7 +151,7 @@ int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* 
     }
     if (din->fused_adam) {
         if (!din->touched.rows || !din->touched.count || !din->adam_clock || din->accumulate == 2) return AGS_E_INVALID;
-        if (int e = ags_adam_check(din->fused_adam)) return e;
+        if (int e = ags_adam_check(din->fused_adam, false)) return e;
         const int64_t* ne = din->fused_adam->numel; // the five map tensors: 3n, 3n, 4n, n, 3n
         const int64_t n64 = in->n;
         if (ne[0] != 3 * n64 || ne[1] != 3 * n64 || ne[2] != 4 * n64 || ne[3] != n64 || ne[4] != 3 * n64) return AGS_E_INVALID;
@@ -235,7 +244,8 @@ int ags_adam_step_gathered(const AgsAdamTensors* t, const float* segments, int32
                            float beta1, float beta2, float eps, void* state, int32_t pre_ticked, ags_stream_t stream) {
     if (!t || !state || !segments || !slot_table || capacity < 0 || world < 1 || !ags_rows_ok(&t->touched)) return AGS_E_INVALID;
     for (int k = 0; k < 5; ++k)
-        if (t->numel[k] < 0 || (t->numel[k] > 0 && (!t->param[k] || !t->exp_avg[k] || !t->exp_avg_sq[k]))) return AGS_E_INVALID;
+        if (t->numel[k] < 0 || (t->numel[k] > 0 && (!t->param[k] || (!t->state_rows && (!t->exp_avg[k] || !t->exp_avg_sq[k]))))) return AGS_E_INVALID;
+    if (t->state_rows && !ags_adam_map_shaped(t)) return AGS_E_INVALID;
     ags_launch_adam_gathered(*t, segments, ags_rows_segment_floats(capacity), world, capacity, slot_table, beta1, beta2, eps, state,
                              pre_ticked != 0, (hipStream_t)stream);
     return ags_check_launch();

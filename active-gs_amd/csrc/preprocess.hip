@@ -350,16 +350,30 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
         if (FUSED_ADAM) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                am[k] = adam.m[0][3 * i + k]; av[k] = adam.v[0][3 * i + k]; ap[k] = adam.p[0][3 * i + k];
-                am[3 + k] = adam.m[1][3 * i + k]; av[3 + k] = adam.v[1][3 * i + k]; ap[3 + k] = adam.p[1][3 * i + k];
-                am[11 + k] = adam.m[4][3 * i + k]; av[11 + k] = adam.v[4][3 * i + k]; ap[11 + k] = adam.p[4][3 * i + k];
+                ap[k] = adam.p[0][3 * i + k]; ap[3 + k] = adam.p[1][3 * i + k]; ap[11 + k] = adam.p[4][3 * i + k];
             }
-            const float4 m4 = reinterpret_cast<const float4*>(adam.m[2])[i], v4 = reinterpret_cast<const float4*>(adam.v[2])[i],
-                         p4 = reinterpret_cast<const float4*>(adam.p[2])[i];
-            am[6] = m4.x; am[7] = m4.y; am[8] = m4.z; am[9] = m4.w;
-            av[6] = v4.x; av[7] = v4.y; av[8] = v4.z; av[9] = v4.w;
+            const float4 p4 = reinterpret_cast<const float4*>(adam.p[2])[i];
             ap[6] = p4.x; ap[7] = p4.y; ap[8] = p4.z; ap[9] = p4.w;
-            am[10] = adam.m[3][i]; av[10] = adam.v[3][i]; ap[10] = adam.p[3][i];
+            ap[10] = adam.p[3][i];
+            if (adam.st) { // interleaved moments: the row's 28 floats as seven 16-byte accesses of one 112-byte piece
+                const float4* sr = reinterpret_cast<const float4*>(adam.st + (size_t)i * 28);
+                float mv[28];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) { const float4 x = sr[q]; mv[4 * q] = x.x; mv[4 * q + 1] = x.y; mv[4 * q + 2] = x.z; mv[4 * q + 3] = x.w; }
+#pragma unroll
+                for (int e = 0; e < 14; ++e) { am[e] = mv[e]; av[e] = mv[14 + e]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    am[k] = adam.m[0][3 * i + k]; av[k] = adam.v[0][3 * i + k];
+                    am[3 + k] = adam.m[1][3 * i + k]; av[3 + k] = adam.v[1][3 * i + k];
+                    am[11 + k] = adam.m[4][3 * i + k]; av[11 + k] = adam.v[4][3 * i + k];
+                }
+                const float4 m4 = reinterpret_cast<const float4*>(adam.m[2])[i], v4 = reinterpret_cast<const float4*>(adam.v[2])[i];
+                am[6] = m4.x; am[7] = m4.y; am[8] = m4.z; am[9] = m4.w;
+                av[6] = v4.x; av[7] = v4.y; av[8] = v4.z; av[9] = v4.w;
+                am[10] = adam.m[3][i]; av[10] = adam.v[3][i];
+            }
         }
         const bool vis = valid && rad > 0;
         float dm[3] = {0, 0, 0}, ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0}, dm2[2] = {0, 0};
@@ -424,7 +438,8 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
                 out.d_opacities[i] = dop;
                 if (out.d_means2D) { out.d_means2D[3 * i] += dm2[0]; out.d_means2D[3 * i + 1] += dm2[1]; }
             }
-        } else if (valid && !PACK) { // overwrite: member rows this view does not show get their zeros
+        } else if (valid && !PACK && out.d_means3D) { // overwrite: member rows this view does not show get their zeros
+            // (d_* all NULL: fused optimiser step whose gradient never leaves the registers)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 out.d_means3D[3 * i + k] = dm[k]; out.d_scales[3 * i + k] = ds[k]; out.d_colors[3 * i + k] = dcol[k];
@@ -472,14 +487,28 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                adam.m[0][3 * i + k] = am[k]; adam.v[0][3 * i + k] = av[k]; adam.p[0][3 * i + k] = ap[k];
-                adam.m[1][3 * i + k] = am[3 + k]; adam.v[1][3 * i + k] = av[3 + k]; adam.p[1][3 * i + k] = ap[3 + k];
-                adam.m[4][3 * i + k] = am[11 + k]; adam.v[4][3 * i + k] = av[11 + k]; adam.p[4][3 * i + k] = ap[11 + k];
+                adam.p[0][3 * i + k] = ap[k]; adam.p[1][3 * i + k] = ap[3 + k]; adam.p[4][3 * i + k] = ap[11 + k];
             }
-            reinterpret_cast<float4*>(adam.m[2])[i] = make_float4(am[6], am[7], am[8], am[9]);
-            reinterpret_cast<float4*>(adam.v[2])[i] = make_float4(av[6], av[7], av[8], av[9]);
             reinterpret_cast<float4*>(adam.p[2])[i] = make_float4(ap[6], ap[7], ap[8], ap[9]);
-            adam.m[3][i] = am[10]; adam.v[3][i] = av[10]; adam.p[3][i] = ap[10];
+            adam.p[3][i] = ap[10];
+            if (adam.st) {
+                float4* sr = reinterpret_cast<float4*>(adam.st + (size_t)i * 28);
+                float mv[28];
+#pragma unroll
+                for (int e = 0; e < 14; ++e) { mv[e] = am[e]; mv[14 + e] = av[e]; }
+#pragma unroll
+                for (int q = 0; q < 7; ++q) sr[q] = make_float4(mv[4 * q], mv[4 * q + 1], mv[4 * q + 2], mv[4 * q + 3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    adam.m[0][3 * i + k] = am[k]; adam.v[0][3 * i + k] = av[k];
+                    adam.m[1][3 * i + k] = am[3 + k]; adam.v[1][3 * i + k] = av[3 + k];
+                    adam.m[4][3 * i + k] = am[11 + k]; adam.v[4][3 * i + k] = av[11 + k];
+                }
+                reinterpret_cast<float4*>(adam.m[2])[i] = make_float4(am[6], am[7], am[8], am[9]);
+                reinterpret_cast<float4*>(adam.v[2])[i] = make_float4(av[6], av[7], av[8], av[9]);
+                adam.m[3][i] = am[10]; adam.v[3][i] = av[10];
+            }
         }
     }
     AGS_TL(4, blockIdx.x, 1);

@@ -26,8 +26,23 @@ class FusedAdam:
         self.lrs = [float(x) for x in lrs]
         self.betas = betas
         self.eps = eps
-        self.exp_avg = [torch.zeros_like(p) for p in params]
-        self.exp_avg_sq = [torch.zeros_like(p) for p in params]
+        # The moments are private state (the reference's torch.optim.Adam keeps them per tensor and never looks at them,
+        # gaussian_map.py:259-292), so they are laid out for the kernels: interleaved per surfel, (n, 28) floats
+        # {exp_avg[14], exp_avg_sq[14]} (AgsAdamTensors.state_rows) - a member row of the row-set steps then costs one
+        # 112-byte piece of state instead of ten 4..16-byte pieces of ten arrays.  exp_avg / exp_avg_sq stay available
+        # as (strided) views of it.  Tensors that are not the five map tensors get the plain per-tensor layout.
+        n = params[3].numel()
+        self.state_rows = None
+        if [p.numel() for p in params] == [3 * n, 3 * n, 4 * n, n, 3 * n] and n > 0:
+            self.state_rows = torch.zeros(n, 28, device=params[0].device, dtype=torch.float32)
+            cols = ((0, 3), (3, 6), (6, 10), (10, 11), (11, 14))
+            self.exp_avg = [self.state_rows[:, a:b].view(*p.shape) if p.dim() != 1 else self.state_rows[:, a]
+                            for (a, b), p in zip(cols, params)]
+            self.exp_avg_sq = [self.state_rows[:, 14 + a:14 + b].view(*p.shape) if p.dim() != 1 else self.state_rows[:, 14 + a]
+                               for (a, b), p in zip(cols, params)]
+        else:
+            self.exp_avg = [torch.zeros_like(p) for p in params]
+            self.exp_avg_sq = [torch.zeros_like(p) for p in params]
         self.step_count = 0
         # device-resident clock {int step; float step_size[5]; float inv_sqrt_bc2; int skipped; ...} for graph replay
         self.device_clock = torch.zeros(16, device=params[0].device, dtype=torch.int32)
@@ -71,13 +86,15 @@ class FusedAdam:
                 g = g.contiguous()
             t.param[k] = ptr(self.params[k])
             t.grad[k] = ptr(g)
-            t.exp_avg[k] = ptr(self.exp_avg[k])
-            t.exp_avg_sq[k] = ptr(self.exp_avg_sq[k])
+            if self.state_rows is None:
+                t.exp_avg[k] = ptr(self.exp_avg[k])
+                t.exp_avg_sq[k] = ptr(self.exp_avg_sq[k])
             t.numel[k] = self.params[k].numel()
             t.lr[k] = self.lrs[k]
         if self.touched is not None:
             t.touched = self.touched.c_struct()
             t.zero_grad = int(self.zero_grad)
+        t.state_rows = ptr(self.state_rows)
         self._keep = grads
         return t
 

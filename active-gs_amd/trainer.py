@@ -189,6 +189,7 @@ class SurfelTrainer:
             else:
                 self.optim.touched = self.rows
         self._state = {}
+        self._no_grads = api.GaussianGrads(None, None, None, None, None)
         # steps since the last look at the device-side overflow notes (refused exchange steps, workspace
         # overflow), with what is needed to repeat them: see check_overflow()
         self._pending = []
@@ -272,7 +273,9 @@ class SurfelTrainer:
             final = v == len(cams) - 1
             last = tick and final
             fused = (self.optim.tensors_struct(self.slab.as_list()), self.optim.eps) if (last and fuse_adam) else None
-            api.backward(cam, g, st, *d, grads=self.slab.grads, accumulate=(v > 0),
+            # a fused step over ONE view: the gradient never leaves the registers (no slab rows written at all)
+            grads = self._no_grads if (fused is not None and v == 0) else self.slab.grads
+            api.backward(cam, g, st, *d, grads=grads, accumulate=(v > 0),
                          adam_tick=self.optim.tick_args() if last else None, touched=self.rows, fused_adam=fused,
                          pack=pack if final else None)
             ticked |= last

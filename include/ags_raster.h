@@ -149,7 +149,9 @@ typedef struct AgsGaussianGrads {
      * of a single-GPU optimisation step, together with `touched` and `adam_clock`: after adding
      * this view's gradients the per-Gaussian kernel applies ags_adam_step_device's update to every
      * member row while its gradient is still in registers (fused_adam->grad is ignored, the slab
-     * above is still written).  Do not call ags_adam_step* for that step.  Not with accumulate 2. */
+     * above is still written - unless all five d_* pointers are NULL, which is allowed in this mode
+     * with accumulate = 0: the gradient then never leaves the registers).  Do not call ags_adam_step*
+     * for that step.  Not with accumulate 2. */
     const struct AgsAdamTensors* fused_adam;
     float adam_eps;
     /* Optional (NULL = off): the data-parallel form of the same idea.  Give it with the LAST view a
@@ -251,6 +253,14 @@ typedef struct AgsAdamTensors {
     AgsRowSet touched; /* optional: update the member rows only (exact, see AgsRowSet) */
     int32_t zero_grad; /* with `touched`: write 0 over every gradient row once it is consumed, so that a slab the
                         * views accumulate into atomically (accumulate = 2) needs no memset per step */
+    /* Optional (NULL = off): the optimiser's moments interleaved per surfel instead of in exp_avg / exp_avg_sq (which
+     * are then ignored and may be NULL): (n, 28) floats, row i = { exp_avg of the row's 14 parameters in the order
+     * means 0-2, scales 3-5, rotation 6-9, opacity 10, harmonics 11-13; exp_avg_sq in the same order }.  The moments
+     * are the optimiser's private state (torch.optim.Adam keeps them per tensor, gaussian_map.py:259-292 never looks at
+     * them), so their layout is free: one 112-byte piece per row instead of ten 4..16-byte pieces in ten arrays is
+     * what the row-set forms of the step want (a member row costs 2 memory sectors of state instead of 10).
+     * Needs numel = { 3n, 3n, 4n, n, 3n }. */
+    float* state_rows;
 } AgsAdamTensors;
 int ags_adam_step(const AgsAdamTensors* t, float beta1, float beta2, float eps, int32_t step,
                   ags_stream_t stream);
