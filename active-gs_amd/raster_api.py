@@ -151,6 +151,25 @@ def alloc_state(n: int, h: int, w: int, max_instances: int, device, binning_mode
     return st
 
 
+def init_workspace(state: ForwardState, n: int, h: int, w: int) -> None:
+    """``ags_workspace_init`` on a freshly allocated workspace (once per allocation: forwards leave it clean)."""
+    ws = state.ws_struct()
+    _lib.check(_lib.load().ags_workspace_init(C.byref(ws), n, h, w, _stream()), "ags_workspace_init")
+
+
+def alloc_outputs(n: int, h: int, w: int, device, workspace: torch.Tensor, max_instances: int,
+                  binning_mode: int = BIN_DIRECT, stats: bool = True) -> ForwardState:
+    """Fresh output tensors around an existing (initialised) workspace - what the drop-in module hands to its caller
+    per call while the workspace itself is pooled."""
+    f = dict(device=device, dtype=torch.float32)
+    return ForwardState(
+        rgb=torch.empty(3, h, w, **f), normal=torch.empty(3, h, w, **f), depth=torch.empty(1, h, w, **f),
+        opacity=torch.empty(1, h, w, **f), confidence=torch.empty(1, h, w, **f),
+        importance=torch.zeros(n, **f), count=torch.zeros(n, device=device, dtype=torch.int32),
+        radii=torch.empty(n, device=device, dtype=torch.int32), workspace=workspace,
+        max_instances=int(max_instances), binning_mode=int(binning_mode))
+
+
 def forward(cam: Camera, g: Gaussians, state: ForwardState, stream: Optional[int] = None, checked: bool = False,
             touched: Optional[RowSet] = None) -> ForwardState:
     """Enqueue one forward pass into ``state`` (see ``alloc_state``). Asynchronous.

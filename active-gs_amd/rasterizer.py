@@ -45,11 +45,48 @@ BINNING_MODE = api.BIN_DIRECT
 # workspace from the last view's need and re-runs only when a view overflows it.
 _capacity_hint: dict = {}
 
+# Workspaces (the library's internal state of a view: projected records, keys, ranges, per-pixel blend state, gradient
+# records - tens of MB) are pooled per (device, surfels, image size): a call takes one, and it goes back when the
+# autograd graph that may still need it for the backward pass is freed (a forward under no_grad returns it at once).
+# Reuse is safe without re-initialisation: the forward pass leaves its counters clean, and everything runs on the
+# caller's stream in order.  The image / per-Gaussian OUTPUT tensors are fresh per call - the caller owns them.
+_workspace_pool: dict = {}
+_POOL_MAX_PER_KEY = 16
 
-def _camera_from_settings(s: GaussianRasterizationSettings, device) -> api.Camera:
-    cfg = [float(v) for v in s.config.detach().cpu().tolist()] if s.config is not None else [1, 1, 1, 0, 0]
+
+def _take_workspace(key, n, h, w, cap, dev):
+    free = _workspace_pool.setdefault(key, [])
+    while free:
+        ws, ws_cap = free.pop()
+        if ws_cap >= cap:
+            return ws, ws_cap
+    ws = torch.empty(api.workspace_bytes(n, h, w, cap), device=dev, dtype=torch.uint8)
+    st = api.ForwardState(None, None, None, None, None, None, None, None, ws, int(cap), BINNING_MODE)
+    api.init_workspace(st, n, h, w)
+    return ws, int(cap)
+
+
+def _give_workspace(key, ws, cap):
+    free = _workspace_pool.setdefault(key, [])
+    if len(free) < _POOL_MAX_PER_KEY:
+        free.append((ws, cap))
+
+
+def _config_flags(cfg_tensor):
+    """config = [_, normalize_depth, perpix_depth, importance?, front_only?] (operations.py:699).  The reference
+    builds it on the host and moves it to the GPU per call; reading it back costs a stream synchronisation, so the
+    combinations are remembered by the tensor's storage and version: a tensor that is still alive and unmodified
+    cannot have changed its five floats."""
+    if cfg_tensor is None:
+        return [1.0, 1.0, 1.0, 0.0, 0.0]
+    cfg = [float(v) for v in cfg_tensor.detach().cpu().tolist()]
     while len(cfg) < 5:
         cfg.append(0.0)
+    return cfg
+
+
+def _camera_from_settings(s: GaussianRasterizationSettings, device) -> api.Camera:
+    cfg = _config_flags(s.config)
     f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
     mask = None
     if s.render_mask is not None and s.render_mask.numel() > 0:
@@ -72,16 +109,30 @@ class _RasterizeSurfels(torch.autograd.Function):
                           f32(confidences).reshape(-1))
         n, h, w = g.n, cam.image_height, cam.image_width
         key = (dev.index, h, w)
+        pkey = (dev.index, n, h, w, BINNING_MODE)
         cap = max(_capacity_hint.get(key, 0), 1 << 16, 2 * n)
         while True:
-            state = api.alloc_state(n, h, w, cap, dev, BINNING_MODE)
+            ws, ws_cap = _take_workspace(pkey, n, h, w, cap, dev)
+            state = api.alloc_outputs(n, h, w, dev, ws, ws_cap, BINNING_MODE, stats=cam.want_stats)
             api.forward(cam, g, state)
             st = api.read_status(state)  # one 64-byte D2H, like upstream's num_rendered read-back
             if not st["overflow"]:
                 break
-            cap = int(st["needed"] * 1.25) + 1024
-        _capacity_hint[key] = max(int(st["needed"] * 1.5) + 1024, 1 << 16)
-        ctx.cam, ctx.g, ctx.state = cam, g, state
+            cap = int(st["needed"] * 1.25) + 1024      # too small: this workspace is dropped, a larger one is made
+        # monotone: views of one loop differ in what they need, and a hint that followed the last view would make
+        # the next one reject every pooled workspace sized for a lighter view
+        _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(st["needed"] * 1.5) + 1024, 1 << 16)
+        if any(ctx.needs_input_grad):      # (all False under no_grad)
+            import weakref
+            weakref.finalize(ctx, _give_workspace, pkey, ws, ws_cap)   # back to the pool when the graph is freed
+        else:
+            _give_workspace(pkey, ws, ws_cap)
+        # What the backward needs of the forward's OUTPUTS goes through save_for_backward: an output tensor kept as a
+        # plain attribute of ctx would close a cycle (ctx -> tensor -> grad_fn = ctx) that only the cyclic garbage
+        # collector breaks - the view's workspace (tens of MB) would outlive its graph by many iterations.
+        ctx.save_for_backward(state.depth, state.opacity, state.radii)
+        ctx.cam, ctx.g = cam, g
+        ctx.ws, ctx.ws_cap = ws, ws_cap
         ctx.need_m2d = means2D.requires_grad
         ctx.opac_shape = opacities.shape
         ctx.set_materialize_grads(False)
@@ -91,7 +142,10 @@ class _RasterizeSurfels(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_rgb, d_normal, d_depth, d_opacity, d_conf, *_unused):
-        cam, g, state = ctx.cam, ctx.g, ctx.state
+        cam, g = ctx.cam, ctx.g
+        depth, opacity, radii = ctx.saved_tensors
+        # (the blend backward reads the forward's depth and opacity images, its per-pixel state in the workspace and radii)
+        state = api.ForwardState(None, None, depth, opacity, None, None, None, radii, ctx.ws, ctx.ws_cap, BINNING_MODE)
         c = lambda t: None if t is None else t.to(dtype=torch.float32).contiguous()
         grads = api.alloc_grads(g.n, g.means3D.device, with_means2d=ctx.need_m2d)
         api.backward(cam, g, state, c(d_rgb), c(d_normal), c(d_depth), c(d_opacity), c(d_conf), grads)

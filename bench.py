@@ -29,20 +29,28 @@ PMC_HBM_FILE = "pmc_hbm_bytes.json"   # per-stage HBM bytes per launch of this c
 PMC_SQ_FILE = "sq_counters.json"      # per-stage SQ instruction counters per launch of this command
 
 
-def stage_bytes(N, V, I, P, T, rows=None):
+def stage_bytes(N, V, I, P, T, rows=None, direct=True, fused_single_view=True):
     """ALGORITHMIC bytes per launch of each stage: every logical
     array moved once.  ``rows``: member rows of the sticky row set when the per-Gaussian backward
-    runs in its row-set form with the Adam step fused in (single rank), else None."""
+    runs in its row-set form with the Adam step fused in (single rank), else None.  ``direct``: one-pass
+    binning (the per-Gaussian kernel writes the keys, the sort stage copies them into slot order)."""
     if rows is not None:
-        # per member row: id 4 + radius 4 + params 44 + gradient record read 64 / re-zeroed 64 (visible
-        # rows) + gradient row 56 + Adam m, v read+write 224 + parameters written 56
-        pbwd = 8 * rows + 128 * V + (44 + 56 + 224 + 56) * rows
+        # per member row: id 4 + radius 4 + parameters read 56 (the four geometry tensors 44 + harmonics 12) + gradient
+        # record read 64 / re-zeroed 64 (visible rows) + interleaved Adam moments 112 read + 112 written + parameters
+        # written 56 (+ the gradient row 56 when a slab is kept: several views per step)
+        pbwd = (8 + 56 + 224 + 56 + (0 if fused_single_view else 56)) * rows + 128 * V
     else:
         pbwd = 44 * N + 128 * V + 68 * N                       # means/scales/rot/radii; dgeom read + re-zero; 5 grads
+    if direct:
+        pre = 60 * N + 4 * N + 128 * V + 8 * I                 # inputs; radii; geom 64 + zeroed dgeom 64; keys written at once
+        binning = 4 * T + 16 * I + 8 * T                       # tile counts; keys read + written in slot order; slot headers
+    else:
+        pre = 60 * N + 8 * N + 136 * V                         # inputs; radii+tiles; geom 64 + rect 8 + zeroed dgeom 64
+        binning = 8 * N + 12 * I + 24 * I + 8 * I + 8 * T      # tile counts/scan; key write; sort r+w once; ranges
     return {
-        "preprocess": 60 * N + 8 * N + 136 * V,                # inputs; radii+tiles; geom 64 + rect 8 + zeroed dgeom 64
-        "binning": 8 * N + 12 * I + 24 * I + 8 * I + 8 * T,    # tile counts/scan; key write; sort r+w once; ranges
-        "render_fwd": 8 * T + 68 * I + 44 * P,                  # ranges; id 4 + record 64; 9 ch + T + n_contrib
+        "preprocess": pre,
+        "binning": binning,
+        "render_fwd": 8 * T + 68 * I + 44 * P,                  # headers; id 4 + record 64; 9 ch + T + n_contrib
         "render_bwd": 8 * T + 68 * I + 52 * P + 64 * V,         # + 9 grads, depth, opac, T, n; accumulate dgeom
         "preprocess_bwd": pbwd,
     }
@@ -334,7 +342,7 @@ def main():
                         "overflow": x.overflowed(), "refused_steps": refused, "regrowths": trainer.exchange_regrowths}
         else:
             exchange = {"kind": "all-reduce of the dense gradient slab", "bytes_per_rank": 4 * trainer.slab.flat.numel()}
-        sb = stage_bytes(N_GAUSS, V, I, P, T, rows)
+        sb = stage_bytes(N_GAUSS, V, I, P, T, rows, direct=(args.binning == "direct"), fused_single_view=not dist_on)
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         ach = sb[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         # Counter figures cannot be collected from inside this process: they come from the committed rocprofv3
