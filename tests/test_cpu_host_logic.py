@@ -228,3 +228,42 @@ def test_bench_gpus_flag_launches_ranks_or_refuses():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "0"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0
+
+
+def test_reference_written_checkpoint_loads_and_ours_has_what_its_load_reads(tmp_path):
+    """tests/golden/map_ref.th was written by the REFERENCE's GaussianMap.save (gaussian_map.py:491-507; generated by
+    tests/golden/make_map_ref.py, which also ran the reference's load() on a file from map_io.save_map - recorded in
+    map_ref.json).  Here: map_io.load_map reads the reference's file, and a file from map_io.save_map offers every
+    access the reference's load() makes (:509-527), with the same types."""
+    import json
+    from active_gs_amd import map_io
+    gold = os.path.join(ROOT, "tests", "golden")
+    meta = json.load(open(os.path.join(gold, "map_ref.json")))
+    assert meta["reference_load_of_map_io_file"] == "ok"
+    raw, cfg = map_io.load_map(os.path.join(gold, "map_ref.th"))
+    n = raw["means"].shape[0]
+    assert n == 300 and raw["scales"].shape == (n, 3) and raw["rotations"].shape == (n, 4) and raw["harmonics"].shape == (n, 1, 3)
+    assert raw["opacities"].shape == (n,) and raw["view_means"].shape == (n, 3) and raw["view_supports"].shape == (n,)
+    assert float(raw["scales"][:, 2].max()) == -1e10                       # raw (pre-activation) tensors: z-scale of a surfel
+    assert cfg["bound"] == (0.001, 10.0) and cfg["scale_factor"] == 0.01 and cfg["background"] == (0.0, 0.0, 0.0, 0.0)
+    assert cfg["use_view_distribution"] is True
+    with pytest.raises(KeyError):
+        torch.save({"means": raw["means"]}, tmp_path / "bad.th")
+        map_io.load_map(str(tmp_path / "bad.th"))
+
+    class T:
+        pass
+    t = T()
+    for k, v in raw.items():
+        setattr(t, k, v)
+    t.cfg = dict(bound=cfg["bound"], use_view_distribution=True, scale_factor=0.01)
+    t.background = torch.zeros(4)
+    path = map_io.save_map(t, str(tmp_path), 7)
+    assert path.endswith("map_7.th")                                        # f"{save_path}/map_{index}.th"
+    st, ref = torch.load(path), torch.load(os.path.join(gold, "map_ref.th"))
+    assert sorted(st.keys()) == sorted(ref.keys()) == meta["keys"]
+    for k in ("means", "scales", "harmonics", "opacities", "rotations", "view_scores", "view_supports", "view_means"):
+        assert torch.equal(st[k], ref[k]) and st[k].dtype == ref[k].dtype    # what load() assigns as is
+    assert isinstance(st["near"], float) and isinstance(st["far"], float) and isinstance(st["scale_factor"], float)
+    bg = torch.tensor(torch.as_tensor(st["background_color"]).tolist(), dtype=torch.float32)   # load(): torch.tensor(..., float32)
+    assert bg.shape == (4,) and st["use_view_direction"] == ref["use_view_direction"]

@@ -162,3 +162,82 @@ def test_densify_oracle_voxel_rule_and_bilateral_properties():
     d = img.copy(); d[3:6, 4:9] = -1.0
     sm = dor.smooth_depth(d)
     assert np.all(sm[3:6, 4:9] == -1.0) and np.all(sm[d >= 0] >= 0)
+
+
+def test_preprocess_conic_matches_the_reference_tree_ewa_statement():
+    """The only statement of the projection arithmetic INSIDE the reference tree is the (dead) GL splat renderer:
+    /root/reference/visualization/gl_render/shaders/gau_vert.glsl:60-107 (computeCov3D, computeCov2D: Sigma = (SR)^T(SR),
+    J with x/z, y/z clamped to 1.3 tan(fov/2), cov = T^T Sigma^T T with T = W J, +0.3 on the diagonal), :148-160 (conic =
+    inverse) and gau_frag.glsl:20-26 (alpha = min(0.99, a exp(power)), discard power > 0 and alpha < 1/255).  Restated
+    here literally - GLSL mat3(...) fills COLUMNS - and compared with the oracle's per-Gaussian stage: decisions D2 / D4
+    of oracle/surfel_oracle.py are the reference tree's own constants, and a surfel (z-scale 0, gaussian_map.py:373)
+    is that 3-D Gaussian's flat limit."""
+    import numpy as np
+    from oracle.surfel_oracle import ALPHA_MAX, ALPHA_MIN, FRUSTUM_CLAMP, LOWPASS, preprocess
+
+    def glsl_mat3(*cols9):                       # mat3(a,b,c, d,e,f, g,h,i): columns (a,b,c), (d,e,f), (g,h,i)
+        return np.array(cols9, dtype=np.float64).reshape(3, 3).T
+
+    def compute_cov3d(scale, q):                 # gau_vert.glsl:60-80
+        S = np.diag(scale.astype(np.float64))
+        r, x, y, z = [float(v) for v in q]
+        R = glsl_mat3(1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                      2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                      2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y))
+        M = S @ R
+        return M.T @ M
+
+    def compute_cov2d(t, fx, fy, tanx, tany, cov3d, view3):   # gau_vert.glsl:82-107; view3 = mat3(viewmatrix)
+        t = t.astype(np.float64).copy()
+        limx, limy = 1.3 * tanx, 1.3 * tany
+        t[0] = min(limx, max(-limx, t[0] / t[2])) * t[2]
+        t[1] = min(limy, max(-limy, t[1] / t[2])) * t[2]
+        J = glsl_mat3(fx / t[2], 0, -(fx * t[0]) / (t[2] * t[2]), 0, fy / t[2], -(fy * t[1]) / (t[2] * t[2]), 0, 0, 0)
+        W = view3.T
+        T = W @ J
+        cov = T.T @ cov3d.T @ T
+        return cov[0, 0] + 0.3, cov[0, 1], cov[1, 1] + 0.3
+
+    assert (LOWPASS, FRUSTUM_CLAMP, ALPHA_MAX) == (0.3, 1.3, 0.99) and abs(ALPHA_MIN - 1.0 / 255.0) < 1e-12
+    for z_scale in (0.0, 1e-6, 0.4):             # the surfel limit, nearly flat, a genuinely 3-D Gaussian
+        a, S = room_case(300, 96, 128, view=2, seed=5, scale_mult=3.0)
+        a["scales"][:, 2] = z_scale * a["scales"][:, 0]
+        ins = [t.double() for t in oracle_inputs(a, requires_grad=False)]
+        G = preprocess(*ins, S)
+        vis = G["vis"]
+        assert vis.numel() > 40
+        V = S.viewmatrix.double().numpy()        # row-vector convention: t = p @ V[:3, :3] + V[3, :3]
+        A = V[:3, :3].T                          # column-vector rotation (what GLSL's mat3(viewmatrix) holds)
+        fx, fy = S.image_width / (2 * S.tanfovx), S.image_height / (2 * S.tanfovy)
+        worst = 0.0
+        for k, i in enumerate(vis.tolist()):
+            p = ins[0][i].numpy()
+            t = A @ p + V[3, :3]
+            cov3d = compute_cov3d(ins[5][i].numpy(), ins[6][i].numpy())
+            ca, cb, cc = compute_cov2d(t, fx, fy, S.tanfovx, S.tanfovy, cov3d, A)
+            det = ca * cc - cb * cb
+            conic = np.array([cc / det, -cb / det, ca / det])              # gau_vert.glsl:153-155
+            got = G["conic"][k].numpy()
+            worst = max(worst, float(np.abs(got - conic).max() / np.abs(conic).max()))
+        assert worst < 1e-9, (z_scale, worst)
+    # gau_frag.glsl:20-26 against the oracle's blend of ONE surfel over an empty background: opacity image = alpha
+    a, S = room_case(1, 48, 64, view=0, seed=3, scale_mult=8.0)
+    a["means"][0] = torch.tensor([0.0, 0.0, 0.0])
+    from active_gs_amd.synthetic import make_camera
+    from active_gs_amd.camera import camera_matrices
+    ins = [t.double() for t in oracle_inputs(a, requires_grad=False)]
+    c2w = torch.eye(4); c2w[:3, 3] = torch.tensor([0.0, 0.0, -1.0])          # camera 1 m in front of the surfel, looking at it
+    _, K = make_camera(0, 48, 64)
+    cm = camera_matrices(c2w[None], K[None], 0.001, 10.0)
+    S2 = OracleSettings(48, 64, cm["tanfov"][0, 0].item(), cm["tanfov"][0, 1].item(), torch.zeros(4), 1.0,
+                        cm["viewmatrix"][0], cm["projmatrix"][0])
+    out = rasterize(*ins, S2)
+    G = preprocess(*ins, S2)
+    assert G["vis"].numel() == 1
+    m, con, o = G["mean2D"][0].numpy(), G["conic"][0].numpy(), float(ins[2][0])
+    ys, xs = np.mgrid[0:48, 0:64].astype(np.float64)
+    dx, dy = xs - m[0], ys - m[1]
+    power = -0.5 * (con[0] * dx * dx + con[2] * dy * dy) - con[1] * dx * dy
+    alpha = np.minimum(0.99, o * np.exp(power))
+    alpha[(power > 0) | (alpha < 1.0 / 255.0)] = 0.0
+    assert alpha.max() > 0.05 and np.abs(out[3][0].numpy() - alpha).max() < 1e-12

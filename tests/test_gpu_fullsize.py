@@ -81,3 +81,36 @@ def test_mesh_render_1024_forward_matches_oracle(agslib):
     """mesh_generation.py:19,74-82 renders every keyframe at 1024x1024, forward only (rgb + depth feed the TSDF)."""
     err, aux = _compare(200_000, 1024, 1024, room_seed=0, view=3, max_tiles=300, fullest=10, grads=False, focal=512.0)
     assert aux["nonempty"] > 1000
+
+
+def test_reference_checkpoint_renders_at_mesh_resolution(agslib):
+    """f4 end to end: the map the REFERENCE's GaussianMap.save wrote (tests/golden/map_ref.th) is loaded with map_io,
+    activated like GaussianMap.get_attr and rendered forward-only at 1024x1024 through the facade mirror
+    (mesh_generation.py:19,74-82: GaussianRenderer(...).render_view(i) per keyframe camera) - against the oracle."""
+    import os
+    from active_gs_amd import map_io
+    from active_gs_amd.facade import SurfelRenderer
+    from active_gs_amd.synthetic import activate, make_camera
+    from oracle.surfel_oracle import OracleSettings, rasterize
+    from active_gs_amd.camera import camera_matrices
+    dev = torch.device("cuda:0")
+    raw, cfg = map_io.load_map(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "map_ref.th"))
+    raw["scales"] = raw["scales"].clone()
+    raw["scales"][:, :2] += 2.0                                   # visible at 1024x1024 from inside the room
+    raw["confidences"] = torch.ones(raw["means"].shape[0])
+    a = activate(raw)
+    h = w = 1024
+    c2w, K = make_camera(3, h, w, focal_px=512.0)
+    bg = torch.tensor(cfg["background"])
+    attr = tuple(t.to(dev) for t in (a["means"], raw["harmonics"], a["opacities"], a["confidences"], a["scales"], a["rotations"]))
+    r = SurfelRenderer(c2w[None].to(dev), K[None].to(dev), attr, bg.to(dev), cfg["bound"], (h, w), dev)
+    rgb, depth, normal, opacity, d2n, confidence, importance, count, in_view = r.render_view(0)
+    cm = camera_matrices(c2w[None], K[None], *cfg["bound"])
+    S = OracleSettings(h, w, cm["tanfov"][0, 0].item(), cm["tanfov"][0, 1].item(), bg, 1.0, cm["viewmatrix"][0], cm["projmatrix"][0])
+    with torch.no_grad():
+        ref = rasterize(a["means"], torch.zeros_like(a["means"]), a["opacities"][:, None], a["confidences"], a["colors"],
+                        a["scales"], a["rotations"], S)
+    assert float(ref[3].max()) > 0.3                               # the view shows something
+    assert float((rgb.cpu() - ref[0]).abs().mean()) < 1e-4 and float((opacity.cpu() - ref[3]).abs().mean()) < 1e-4
+    assert float((depth.cpu() - ref[2]).abs().mean()) < 1e-3
+    assert torch.equal(in_view.cpu(), ref[7] > 0)
