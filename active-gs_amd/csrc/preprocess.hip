@@ -125,6 +125,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[ic];
     float opacity = in.opacities[ic];
     const float conf = in.confidences[ic];
+    const int was_member = touched.member ? touched.member[ic] : 1;   // requested with the inputs, not behind the projection
     ags_load_rows3x3(in.means3D, in.scales, in.colors, first, rows, rows3, p, sc, col);
     AGS_TL(0, tl_w, 1);
     if (i < in.n) {
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     AGS_TL(0, tl_w, 2);
     if (touched.member) { // sticky row set of the optimisation loop: insert first-time-visible surfels
         // (after the first few steps of a keyframe nothing is new and this is one sparse read)
-        const bool fresh = vis && touched.member[i] == 0 && atomicExch(&touched.member[i], 1) == 0;
+        const bool fresh = vis && was_member == 0 && atomicExch(&touched.member[i], 1) == 0;
         const unsigned long long mask = __ballot(fresh);
         if (mask) { // wave-uniform
             const int lane = threadIdx.x & 63;
