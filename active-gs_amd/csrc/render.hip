@@ -610,10 +610,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 a4 = col[q];
+#ifdef AGS_EXP_NO_MFMA   // experiment: the flush without its matrix instructions (wrong results)
+            d[0] += a4.x * FE[4 * q]; d_odd[1] += a4.y * FE[4 * q + 1]; d[2] += a4.z * FE[4 * q + 2]; d_odd[3] += a4.w * FE[4 * q + 3];
+#else
             d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, FE[4 * q], d, 0, 0, 0);
             d_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, FE[4 * q + 1], d_odd, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, FE[4 * q + 2], d, 0, 0, 0);
             d_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, FE[4 * q + 3], d_odd, 0, 0, 0);
+#endif
         }
         d += d_odd;
         // lane: field fld of rows 4 kgrp + r = (gp, w) of slots 2 kgrp and 2 kgrp + 1
@@ -695,11 +699,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
                 const float koy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_oxy.y), k));
                 slot_sid = mine ? ksid : slot_sid; slot_ox = mine ? kox : slot_ox; slot_oy = mine ? koy : slot_oy;
             }
+#ifdef AGS_EXP_NO_FLUSH   // experiment: the blend loop alone (no reduction, no atomics; wrong results)
+            if (++nb == 8) nb = 0;
+#else
             if (++nb == 8) { flush(); ++tl_flush; }
+#endif
         }
     }
     AGS_TL(3, tl_w, 4);
+#ifndef AGS_EXP_NO_FLUSH
     if (nb) { flush(); ++tl_flush; }
+#endif
     AGS_TL(3, tl_w, 5);
     AGS_TL_VAL(3, tl_w, 6, tl_iters | ((unsigned long long)tl_flush << 32));
     AGS_TL_VAL(3, tl_w, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32));

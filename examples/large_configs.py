@@ -22,7 +22,11 @@ def run(tag, n, h, w, views, room, steps, warmup):
     from active_gs_amd.trainer import SurfelTrainer
     dev = torch.device("cuda:0")
     raw = {k: v.to(dev) for k, v in make_room_scene(n, room=room, seed=0).items()}
-    trainer = SurfelTrainer(raw)
+    # AGS_FREEZE=1 (kernel A/B experiments): learning rates of zero - the scene stays what it is whatever a variant's
+    # gradients are, so per-kernel times of different builds can be compared
+    import os
+    lrs = dict(mean=0.0, scale=0.0, rotation=0.0, opacity=0.0, harmonic=0.0) if os.environ.get("AGS_FREEZE") == "1" else None
+    trainer = SurfelTrainer(raw, lrs=lrs)
     cams = []
     for v in range(views):
         c2w, K = make_camera(v, h, w)
