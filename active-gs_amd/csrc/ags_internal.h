@@ -6,6 +6,12 @@
 #include "../../include/ags_raster.h"
 #include "surfel_math.h"
 
+// AGS_BIN_DIRECT: words between two tiles' key-slot counters.  Device atomics are served per cache LINE: with the
+// counters dense, 32 tiles share a 128-byte line and the ~30 slot requests per tile of a 1200x680 view queue up
+// behind each other (~900 per line).
+#ifndef AGS_TC_STRIDE
+#define AGS_TC_STRIDE 1
+#endif
 #define AGS_SORT_THREADS 256
 #define AGS_SORT_ITEMS 16
 #define AGS_SORT_TILE (AGS_SORT_THREADS * AGS_SORT_ITEMS) // keys per block per pass
@@ -55,7 +61,7 @@ static inline AgsLayout ags_make_layout(int n, int h, int w, int64_t cap) {
     L.status = o; o += 256;
     L.totals = o; o += (size_t)AGS_SORT_MAX_PASSES * 256 * 4;
     L.ranges = o; o += ags_align256((size_t)L.num_tiles * 8);
-    L.tile_count = o; o += ags_align256((size_t)L.num_tiles * 4);
+    L.tile_count = o; o += ags_align256((size_t)L.num_tiles * 4 * AGS_TC_STRIDE);
     L.tile_fill = o; o += ags_align256((size_t)L.num_tiles * 4);
     L.clear_bytes = o;
     L.geom = o; o += ags_align256((size_t)n * sizeof(AgsGeom));

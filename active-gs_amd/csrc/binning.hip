@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict_
     __shared__ uint32_t rank_part[4];
     if (threadIdx.x < 64) AGS_TL(5, blockIdx.x, 0);
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
-    const uint32_t cnt = tile_count[tile];
+    const uint32_t cnt = tile_count[(size_t)tile * AGS_TC_STRIDE];
     const uint32_t K = cnt < tile_cap ? cnt : tile_cap;
     // the tile's slot: band start + number of band tiles with a longer list (ties: lower index first) - exact,
     // deterministic, no counters to reset; <= T/8 counts read per workgroup
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict_
     const int band0 = ags_xcd_band(blockIdx.x & 7, num_tiles, band_size);
     uint32_t ahead = 0;
     for (int j = threadIdx.x; j < band_size; j += 256) {
-        const uint32_t c = tile_count[band0 + j];
+        const uint32_t c = tile_count[(size_t)(band0 + j) * AGS_TC_STRIDE];
         ahead += (c > cnt || (c == cnt && band0 + j < tile)) ? 1u : 0u;
     }
     ahead = ags_wave_sum_u32(ahead);

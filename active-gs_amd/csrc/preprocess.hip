@@ -177,7 +177,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
         const uint32_t wave_first = (uint32_t)(first + (threadIdx.x & ~63));
         ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, rx0, ry0, rwd, __float_as_uint(g.dc), g, F.tiles_x,
                                 [&](bool hit, uint32_t t, uint32_t depth_bits, int owner_lane) {
-                                    const uint32_t got = ags_wave_agg_inc<AGG, true>(tile_count, t, hit);
+                                    const uint32_t got = ags_wave_agg_inc<AGG, true>(tile_count, t * AGS_TC_STRIDE, hit);
                                     if (hit && got < direct.tile_cap)
                                         direct.keys[(size_t)t * direct.tile_cap + got] =
                                             ((uint64_t)depth_bits << 32) | (wave_first + (uint32_t)owner_lane);

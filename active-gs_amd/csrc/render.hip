@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
     const float bx0 = (float)(tx * AGS_TILE), by0 = (float)(ty * AGS_TILE);
     const uint32_t my_strips = ((1u << SLOTS) - 1u) << strip0;
     // last consumer of this tile's binning counters: leave them zero for the next forward pass
-    if (wave == 0 && lane == 0) { tile_count[tile] = 0u; tile_fill[tile] = 0u; }
+    if (wave == 0 && lane == 0) { tile_count[(size_t)tile * (tile_cap ? AGS_TC_STRIDE : 1)] = 0u; tile_fill[tile] = 0u; }
     // the lane's pixel relative to the centre of its quadrant - the same in every quadrant the wave owns
     const float qx = (float)(lane & 7) - 3.5f, qy = (float)(lane >> 3) - 3.5f;
     AgsPix pix[SLOTS];
@@ -472,10 +472,35 @@ typedef float ags_f32x4 __attribute__((ext_vector_type(4)));
 #ifndef AGS_MFMA_STAGE
 #define AGS_MFMA_STAGE 32   // records staged per round: 32 keeps a wave at 6.4 KB of LDS = 6 waves per SIMD
 #endif
+// The per-surfel reduction of the blend backward on the bf16 matrix pipe (default) or in exact f32 (-DAGS_BWD_F32_MFMA).
+// An f32 matrix instruction (v_mfma_f32_16x16x4_f32, 1024 multiply-adds in ~37 cycles) runs at the vector ALUs' rate and
+// does not overlap with other waves' vector instructions on its SIMD (profiles/experiments/mfma_valu_overlap.cpp: a
+// VALU stream and an f32-MFMA stream on one SIMD take the SUM of their times): the sixteen of a flush cost as much as
+// 32 vector instructions per pixel and surfel, 38 % of the kernel on config 5.  v_mfma_f32_16x16x32_bf16 does 8192 in
+// ~28 cycles.  Both operands are split x = hi + lo (bf16 each, by truncation: hi = the upper 16 bits, lo = the upper 16
+// bits of x - hi) and the product is formed as hi.hi + lo.hi + hi.lo with f32 accumulation (the dropped lo.lo term is
+// 2^-16 relative; every term's truncation error is below 2^-16 of the term): six matrix instructions per flush instead
+// of sixteen, four more vector instructions per pixel and surfel for the split.  Gradients move by ~1e-5 relative
+// (tolerance 1e-3); the accumulator leaves the matrix pipe in the same layout, so the rest of the flush is unchanged.
+#ifndef AGS_BWD_F32_MFMA
+#define AGS_BWD_BF16 1
+#endif
 struct AgsWaveBatch {       // one per wave, in LDS: 2048 + 4352 = 6400 B = five 1280-byte granules -> 25 waves per CU
     AgsStagedRec<1> sg[AGS_MFMA_STAGE];
+#ifdef AGS_BWD_BF16
+    unsigned short gh[16][68];   // bf16 hi parts: row 2 i = gp of slot i, row 2 i + 1 = its w; [row][pixel], 136-byte rows
+    unsigned short gl[16][68];   // bf16 lo parts
+#else
     float gw[16][68];       // row 2 i: gp of slot i, row 2 i + 1: its w; 68 floats: 16-byte row reads of 16 lanes hit 64 banks
+#endif
 };
+typedef __bf16 ags_bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned int ags_u4 __attribute__((ext_vector_type(4)));
+// two floats -> one register of two truncated bf16 (lo half = a, hi half = b)
+__device__ __forceinline__ uint32_t ags_pack_bf16_trunc(float a, float b) {
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float ags_bf16_residual(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
 
 #ifndef AGS_MFMA_WAVES
 #define AGS_MFMA_WAVES 6      // register budget: 512 / 6 -> 80 VGPRs
@@ -568,6 +593,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
     // ---- B operands: field (lane & 15) of the 16 pixels t + 16 (lane >> 4) --------------------------
     const int fld = lane & 15, kgrp = lane >> 4;
     const float qx = (float)(lane & 7) - 3.5f, qy = (float)(lane >> 3) - 3.5f;   // the lane's pixel about the quadrant centre
+#ifdef AGS_BWD_BF16
+    // B operands of v_mfma_f32_16x16x32_bf16: lane = (feature fld, k-group kgrp) holds the feature of pixels
+    // 32 b + 8 kgrp .. + 7 for the two K blocks b, as bf16 hi and lo parts: 2 x 4 + 2 x 4 registers
+    ags_u4 BH[2], BL[2];
+    {
+        float* ex = reinterpret_cast<float*>(&wb.gh[0][0]);       // [feature][pixel] f32, rows of 68 floats: 4080 B of the 4352
+        const float feat[16] = {qx, qy, qx * qx, qx * qy, qy * qy, 1.f, pg.dDn, pg.dDn * qx, pg.dDn * qy,
+                                pg.dC0, pg.dC1, pg.dC2, pg.dN0, pg.dN1, pg.dN2, 0.f};
+        static_assert(sizeof(wb.gh) + sizeof(wb.gl) >= (14 * 68 + 64) * 4, "feature exchange fits the batch buffer");
+#pragma unroll
+        for (int f = 0; f < 15; ++f) ex[f * 68 + lane] = feat[f];
+        ags_wave_lds_sync();
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float4* row = reinterpret_cast<const float4*>(ex + fld * 68 + 32 * b + 8 * kgrp);
+            float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+            if (fld < 15) { u = row[0]; v = row[1]; }
+            BH[b] = ags_u4{ags_pack_bf16_trunc(u.x, u.y), ags_pack_bf16_trunc(u.z, u.w), ags_pack_bf16_trunc(v.x, v.y),
+                           ags_pack_bf16_trunc(v.z, v.w)};
+            BL[b] = ags_u4{ags_pack_bf16_trunc(ags_bf16_residual(u.x), ags_bf16_residual(u.y)),
+                           ags_pack_bf16_trunc(ags_bf16_residual(u.z), ags_bf16_residual(u.w)),
+                           ags_pack_bf16_trunc(ags_bf16_residual(v.x), ags_bf16_residual(v.y)),
+                           ags_pack_bf16_trunc(ags_bf16_residual(v.z), ags_bf16_residual(v.w))};
+        }
+        ags_wave_lds_sync();
+    }
+#else
     float FE[16];
     {
         // every pixel lane publishes its 16 feature values ([field][pixel], rows of 68 floats: the
@@ -588,6 +640,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
         }
         ags_wave_lds_sync();
     }
+#endif
     // per-lane constants of the shift to the surfel's mean (see flush): which of ox, oy and their products
     // this lane's field takes
     const float gx1 = fld == 0 ? 1.f : 0.f, gy1 = fld == 1 ? 1.f : 0.f;                     // gp rows: m1x, m1y
@@ -606,6 +659,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
     auto flush = [&]() {
         ags_wave_lds_sync();
         ags_f32x4 d = {0.f, 0.f, 0.f, 0.f}, d_odd = {0.f, 0.f, 0.f, 0.f}; // two chains: a dependent MFMA waits 40 cycles, an independent one 32
+#ifdef AGS_BWD_BF16
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            // A operand: row fld, pixels 32 b + 8 kgrp .. + 7 as eight bf16 = two 8-byte reads (136-byte rows are 8-byte aligned)
+            const uint2* ph = reinterpret_cast<const uint2*>(&wb.gh[fld][32 * b + 8 * kgrp]);
+            const uint2* pl = reinterpret_cast<const uint2*>(&wb.gl[fld][32 * b + 8 * kgrp]);
+            const uint2 h0 = ph[0], h1 = ph[1], l0 = pl[0], l1 = pl[1];
+            const ags_bf8 ah = __builtin_bit_cast(ags_bf8, ags_u4{h0.x, h0.y, h1.x, h1.y});
+            const ags_bf8 al = __builtin_bit_cast(ags_bf8, ags_u4{l0.x, l0.y, l1.x, l1.y});
+            const ags_bf8 bh = __builtin_bit_cast(ags_bf8, BH[b]), bl = __builtin_bit_cast(ags_bf8, BL[b]);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
+            d_odd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d_odd, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
+        }
+#else
         const float4* col = reinterpret_cast<const float4*>(&wb.gw[fld][16 * kgrp]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -619,6 +687,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             d_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, FE[4 * q + 3], d_odd, 0, 0, 0);
 #endif
         }
+#endif
         d += d_odd;
         // lane: field fld of rows 4 kgrp + r = (gp, w) of slots 2 kgrp and 2 kgrp + 1
 #pragma unroll
@@ -690,8 +759,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             const float dalpha = pg.T * gsum - pg.S * iom;
             pg.S += w * gsum;
             const float gp = (alpha < AGS_ALPHA_MAX) ? alpha * dalpha : 0.f;
+#ifdef AGS_BWD_BF16
+            // park the two factors as bf16 hi + lo (truncations: the stores take the registers' upper halves)
+            wb.gh[2 * nb][lane] = (unsigned short)(__float_as_uint(gp) >> 16);
+            wb.gh[2 * nb + 1][lane] = (unsigned short)(__float_as_uint(w) >> 16);
+            wb.gl[2 * nb][lane] = (unsigned short)(__float_as_uint(ags_bf16_residual(gp)) >> 16);
+            wb.gl[2 * nb + 1][lane] = (unsigned short)(__float_as_uint(ags_bf16_residual(w)) >> 16);
+#else
             wb.gw[2 * nb][lane] = gp;
             wb.gw[2 * nb + 1][lane] = w;
+#endif
             {
                 const bool mine = lane == 16 * (nb >> 1) + (nb & 1);
                 const uint32_t ksid = (uint32_t)__builtin_amdgcn_readlane((int)my_gid, k);
