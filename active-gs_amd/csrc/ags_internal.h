@@ -225,6 +225,13 @@ void ags_launch_prune_keep(int n, const float* prune_mask, const float* raw_opac
 // ---- experiment builds only (-DAGS_TIMELINE, profiles/experiments/timeline.py): every wave notes the shader clock
 // (s_memtime) at a few phase boundaries into a caller-provided buffer [kernel][wave][8]; compiled out otherwise.
 #define AGS_TL_WAVES 16384
+// -DAGS_TL_REALTIME: stamps from the chip-wide 100 MHz reference counter (s_memrealtime: 10 ns steps, the same on
+// every CU) instead of the shader clock, which every CU counts on its own: for launch ramps and kernel-to-kernel gaps
+#ifdef AGS_TL_REALTIME
+#define AGS_TL_CLOCK() __builtin_amdgcn_s_memrealtime()
+#else
+#define AGS_TL_CLOCK() __builtin_readcyclecounter()
+#endif
 #if defined(AGS_TIMELINE) && defined(__HIPCC__)
 #define AGS_TL_DEFINE(tu)                                                                                          \
     static __device__ unsigned long long* ags_tl_buf = nullptr;                                                    \
@@ -232,7 +239,7 @@ void ags_launch_prune_keep(int n, const float* prune_mask, const float* raw_opac
 #define AGS_TL(kid, wave_id, phase)                                                                                \
     do {                                                                                                           \
         if ((threadIdx.x & 63) == 0 && ags_tl_buf && (unsigned)(wave_id) < AGS_TL_WAVES)                           \
-            ags_tl_buf[(((size_t)(kid) * AGS_TL_WAVES) + (wave_id)) * 8 + (phase)] = __builtin_readcyclecounter(); \
+            ags_tl_buf[(((size_t)(kid) * AGS_TL_WAVES) + (wave_id)) * 8 + (phase)] = AGS_TL_CLOCK();               \
     } while (0)
 #define AGS_TL_VAL(kid, wave_id, phase, v)                                                                         \
     do {                                                                                                           \

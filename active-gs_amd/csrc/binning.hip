@@ -527,10 +527,109 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict_
     }
     ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS, false>(keys_in + (size_t)tile * tile_cap, K, sk, threadIdx.x,
                                                        keys_out + (size_t)slot * tile_cap);
-    if (threadIdx.x < 64) { AGS_TL(5, blockIdx.x, 1); AGS_TL_VAL(5, blockIdx.x, 6, K); }
+    if (threadIdx.x < 64) { AGS_TL(5, blockIdx.x, 1); AGS_TL_VAL(5, blockIdx.x, 6, K); AGS_TL_VAL(5, blockIdx.x, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32)); }
+}
+
+// The same for views whose tile lists cannot exceed 64 R keys (tile_cap <= 128: the 1200x680 view of 200 k surfels has
+// 51 at most): ONE wave per tile, R keys per lane, four tiles per workgroup.  The general form holds 16 KiB of LDS and
+// four wave slots per tile, so a CU takes 8 tiles at a time and the 12.6 tiles per CU of that view need two rounds (2048
+// tiles start at once, the rest when those end: per-CU span 6.3 us for wave lives of 2.7 us,
+// profiles/experiments/timeline.py); with a wave per tile all tiles are resident at once.
+template <int R>
+__global__ __launch_bounds__(256) void ags_k_tile_sort_direct_wave(uint2* __restrict__ ranges, const uint64_t* __restrict__ keys_in,
+                                                                   uint64_t* __restrict__ keys_out,
+                                                                   const uint32_t* __restrict__ tile_count, uint32_t tile_cap,
+                                                                   uint32_t* __restrict__ partial, int num_tiles, AgsViewStride vs) {
+    { // (offsets are 0 for a single view)
+        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
+        AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(keys_in, wo); AGS_WS_SHIFT(keys_out, wo); AGS_WS_SHIFT(tile_count, wo);
+        AGS_WS_SHIFT(partial, wo);
+    }
+    // workgroup b serves FOUR tiles of XCD band b % 8 (tiles 4 (b / 8) .. + 3 of the band), one per wave: the band's
+    // counts are read once per workgroup (every thread holds <= 2 of them) and compared with the four tiles' counts
+    __shared__ uint32_t part[4][4];      // [wave that counted][tile of the workgroup]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int band_size;
+    const int band0 = ags_xcd_band(blockIdx.x & 7, num_tiles, band_size);
+    const int j0 = 4 * (int)(blockIdx.x >> 3);
+    if (j0 >= band_size) return;                                   // workgroup-uniform
+    const int mine_j = j0 + wave;
+    const bool live = mine_j < band_size;                          // wave-uniform
+    const int tile = band0 + (live ? mine_j : j0);
+    [[maybe_unused]] const int tl_w = tile;
+    if (live) AGS_TL(5, tl_w, 0);
+    // the tile's keys are requested before its count is here (key 64 r + lane in register r; stale keys beyond the
+    // count are masked below)
+    const uint64_t* src = keys_in + (size_t)tile * tile_cap;
+    uint64_t mine[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) mine[r] = ((uint32_t)(64 * r + lane) < tile_cap) ? src[64 * r + lane] : ~0ull;
+    uint32_t tc[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) tc[w] = (j0 + w < band_size) ? tile_count[(size_t)(band0 + j0 + w) * AGS_TC_STRIDE] : 0u;
+    uint32_t ahead[4] = {0u, 0u, 0u, 0u};
+    for (int j = threadIdx.x; j < band_size; j += 256) {
+        const uint32_t c = tile_count[(size_t)(band0 + j) * AGS_TC_STRIDE];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) ahead[w] += (c > tc[w] || (c == tc[w] && j < j0 + w)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t a = ags_wave_sum_u32(ahead[w]);
+        if (lane == 0) part[wave][w] = a;
+    }
+    __syncthreads();
+    if (!live) return;
+    const uint32_t cnt = tc[wave];
+    const uint32_t K = cnt < tile_cap ? cnt : tile_cap;
+    const uint32_t slot = (uint32_t)band0 + part[0][wave] + part[1][wave] + part[2][wave] + part[3][wave];
+    if (lane == 0) {
+        ranges[slot] = make_uint2((uint32_t)tile, K);
+#ifndef AGS_EXP_NO_PARTIALS
+        if (cnt) {
+            atomicAdd(&partial[AGS_PART(tile, AGS_PART_SUM)], cnt);
+            atomicMax(&partial[AGS_PART(tile, AGS_PART_MAX)], cnt);
+        }
+#endif
+    }
+    uint32_t lo[R], hi[R], rank[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if ((uint32_t)(64 * r + lane) >= K) mine[r] = ~0ull;
+        lo[r] = (uint32_t)mine[r]; hi[r] = (uint32_t)(mine[r] >> 32); rank[r] = 0;
+    }
+    // keys are unique: rank = number of smaller keys; every key of the list is broadcast through SGPRs (v_readlane)
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        if (K <= (uint32_t)(64 * q)) break;                       // wave-uniform
+        const uint32_t nq = (K - 64u * q) < 64u ? (K - 64u * q) : 64u;
+        for (uint32_t j = 0; j < nq; ++j) {
+            const uint64_t other = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi[q], j) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int)lo[q], j);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (r == 0 || K > (uint32_t)(64 * r)) rank[r] += (other < mine[r]) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if ((uint32_t)(64 * r + lane) < K) keys_out[(size_t)slot * tile_cap + rank[r]] = mine[r];
+    AGS_TL(5, tl_w, 1); AGS_TL_VAL(5, tl_w, 6, K);
+    AGS_TL_VAL(5, tl_w, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32));
 }
 
 void ags_launch_direct_sort(char* ws, const AgsLayout& L, const AgsViewStride& vs, hipStream_t s) {
+    static const bool no_wave = getenv("AGS_TSORT_NO_WAVE") != nullptr;   // experiment knob: always the 256-thread form
+    const uint32_t tile_cap = ags_direct_tile_cap(L);
+    if (tile_cap <= 128u && !no_wave) {
+#define AGS_LAUNCH_TSORT_WAVE(R)                                                                                          \
+    hipLaunchKernelGGL(ags_k_tile_sort_direct_wave<R>, dim3(8 * ((((L.num_tiles + 7) / 8) + 3) / 4), vs.views), dim3(256), 0, s, (uint2*)(ws + L.ranges), \
+                       (const uint64_t*)(ws + L.keys0), (uint64_t*)(ws + L.keys1), (const uint32_t*)(ws + L.tile_count),    \
+                       tile_cap, (uint32_t*)(ws + L.totals), L.num_tiles, vs)
+        if (tile_cap <= 64u) AGS_LAUNCH_TSORT_WAVE(1); else AGS_LAUNCH_TSORT_WAVE(2);
+#undef AGS_LAUNCH_TSORT_WAVE
+        return;
+    }
     hipLaunchKernelGGL(ags_k_tile_sort_direct, dim3(L.num_tiles, vs.views), dim3(256), 0, s, (uint2*)(ws + L.ranges),
                        (uint64_t*)(ws + L.keys0), (uint64_t*)(ws + L.keys1), (const uint32_t*)(ws + L.tile_count),
                        ags_direct_tile_cap(L), (uint32_t*)(ws + L.totals), L.num_tiles, vs);

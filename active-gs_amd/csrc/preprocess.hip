@@ -203,6 +203,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     }
     AGS_TL(0, tl_w, 5);
     AGS_TL_VAL(0, tl_w, 6, ws | ((unsigned long long)wv << 32));
+    AGS_TL_VAL(0, tl_w, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32));
 }
 
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
@@ -514,6 +515,7 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
     }
     AGS_TL(4, blockIdx.x, 1);
     AGS_TL_VAL(4, blockIdx.x, 6, count);
+    AGS_TL_VAL(4, blockIdx.x, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32));
 }
 
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,

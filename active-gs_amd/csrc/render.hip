@@ -494,6 +494,13 @@ struct AgsWaveBatch {       // one per wave, in LDS: 2048 + 4352 = 6400 B = five
     float gw[16][68];       // row 2 i: gp of slot i, row 2 i + 1: its w; 68 floats: 16-byte row reads of 16 lanes hit 64 banks
 #endif
 };
+// the 8 bytes behind the 64 pixels of batch row `row` (hi rows of the bf16 form / the f32 rows): where a slot's
+// (mean - quadrant centre) [even row] and surfel id [odd row] ride along
+#ifdef AGS_BWD_BF16
+#define AGS_BWD_PAD(row) wb.gh[(row)][64]
+#else
+#define AGS_BWD_PAD(row) wb.gw[(row)][64]
+#endif
 typedef __bf16 ags_bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned int ags_u4 __attribute__((ext_vector_type(4)));
 // two floats -> one register of two truncated bf16 (lo half = a, hi half = b)
@@ -648,16 +655,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
     const float mYx = fld == 2 ? 2.f : 0.f, mYy = fld == 3 ? 1.f : 0.f, mZx = fld == 3 ? 1.f : 0.f, mZy = fld == 4 ? 2.f : 0.f;
     const float wx1 = fld == 7 ? 1.f : 0.f, wy1 = fld == 8 ? 1.f : 0.f;                     // w rows: dgx, dgy
     int nb = 0; // filled slots (wave-uniform)
-    // id and (mean - quadrant centre) of the surfel in batch slot j live in lane 16 (j >> 1) + (j & 1) - the first two
-    // lanes of the 16-lane row whose accumulator rows hold that slot - so the flush fetches them with two DPP row
-    // broadcasts; they are taken from the stage when the slot is filled (a batch may outlive its staging round)
-    uint32_t slot_sid = 0;
-    float slot_ox = 0.f, slot_oy = 0.f;
+    // id and (mean - quadrant centre) of the surfel in batch slot j travel with the slot's parked factors: the staging
+    // lane itself writes them into the 8 unused bytes at the end of the slot's two hi rows (one exec-masked 8-byte and
+    // one 4-byte LDS write - two vector instructions per pair where copying them into "slot lanes" through v_readlane
+    // and selects took ten), and the flush reads them back with the lane's row address
     AGS_TL(3, tl_w, 2);
     [[maybe_unused]] uint32_t tl_iters = 0, tl_flush = 0;
 
     auto flush = [&]() {
         ags_wave_lds_sync();
+        // the lane's two slots (2 kgrp, 2 kgrp + 1): offsets to the mean and ids, requested ahead of the matrix instructions
+        float2 slot_oxy[2];
+        uint32_t slot_sid[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            slot_oxy[h] = *reinterpret_cast<const float2*>(&AGS_BWD_PAD(4 * kgrp + 2 * h));
+            slot_sid[h] = *reinterpret_cast<const uint32_t*>(&AGS_BWD_PAD(4 * kgrp + 2 * h + 1));
+        }
         ags_f32x4 d = {0.f, 0.f, 0.f, 0.f}, d_odd = {0.f, 0.f, 0.f, 0.f}; // two chains: a dependent MFMA waits 40 cycles, an independent one 32
 #ifdef AGS_BWD_BF16
 #pragma unroll
@@ -669,9 +683,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             const ags_bf8 ah = __builtin_bit_cast(ags_bf8, ags_u4{h0.x, h0.y, h1.x, h1.y});
             const ags_bf8 al = __builtin_bit_cast(ags_bf8, ags_u4{l0.x, l0.y, l1.x, l1.y});
             const ags_bf8 bh = __builtin_bit_cast(ags_bf8, BH[b]), bl = __builtin_bit_cast(ags_bf8, BL[b]);
+#ifdef AGS_EXP_NO_MFMA   // experiment: the flush without its matrix instructions (wrong results)
+            d[0] += __uint_as_float(h0.x) * __uint_as_float(BH[b][0]); d_odd[1] += __uint_as_float(l0.x) * __uint_as_float(BH[b][1]);
+            d[2] += __uint_as_float(h1.x) * __uint_as_float(BL[b][0]); d_odd[3] += __uint_as_float(l1.y) * __uint_as_float(BL[b][1]);
+            (void)ah; (void)al; (void)bh; (void)bl;
+#else
             d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
             d_odd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d_odd, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
+#endif
         }
 #else
         const float4* col = reinterpret_cast<const float4*>(&wb.gw[fld][16 * kgrp]);
@@ -693,9 +713,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int slot = 2 * kgrp + h;
-            const float ox = h ? ags_dpp_f<0x151>(slot_ox) : ags_dpp_f<0x150>(slot_ox);
-            const float oy = h ? ags_dpp_f<0x151>(slot_oy) : ags_dpp_f<0x150>(slot_oy);
-            const uint32_t sid = (uint32_t)(h ? ags_dpp_i<0x151>((int)slot_sid) : ags_dpp_i<0x150>((int)slot_sid));
+            const float ox = slot_oxy[h].x, oy = slot_oxy[h].y;
+            const uint32_t sid = slot_sid[h];
             float* rec = dgeom + (size_t)sid * 16 + fld;
             // gp row: raw moments about the quadrant centre -> about the surfel's mean
             const float gpv = d[2 * h];
@@ -769,12 +788,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             wb.gw[2 * nb][lane] = gp;
             wb.gw[2 * nb + 1][lane] = w;
 #endif
-            {
-                const bool mine = lane == 16 * (nb >> 1) + (nb & 1);
-                const uint32_t ksid = (uint32_t)__builtin_amdgcn_readlane((int)my_gid, k);
-                const float kox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_oxy.x), k));
-                const float koy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_oxy.y), k));
-                slot_sid = mine ? ksid : slot_sid; slot_ox = mine ? kox : slot_ox; slot_oy = mine ? koy : slot_oy;
+            if (lane == k) {   // the surfel's staging lane (k is wave-uniform: one exec-masked pair of LDS writes)
+                *reinterpret_cast<float2*>(&AGS_BWD_PAD(2 * nb)) = my_oxy;
+                *reinterpret_cast<uint32_t*>(&AGS_BWD_PAD(2 * nb + 1)) = my_gid;
             }
 #ifdef AGS_EXP_NO_FLUSH   // experiment: the blend loop alone (no reduction, no atomics; wrong results)
             if (++nb == 8) nb = 0;

@@ -60,7 +60,7 @@ torch.cuda.synchronize()
 lib.ags_debug_timeline(None)
 t = buf.cpu().numpy().reshape(8, NW, 8).astype(np.int64)
 if os.environ.get("AGS_TL_DUMP"):
-    np.savez_compressed(os.environ["AGS_TL_DUMP"], t=t[[2, 3]])
+    np.savez_compressed(os.environ["AGS_TL_DUMP"], t=t)
 print(f"workload: n={args.n} {args.h}x{args.w} visible={info['num_visible']} instances={info['num_instances']}")
 GHZ = 2.4
 KERNELS = {0: ("preprocess", ["rows loaded", "math+stores", "row set", "emit(count)", "block sums"]),
@@ -97,6 +97,20 @@ for kid, (name, phases) in KERNELS.items():
     for p, label in enumerate(phases):
         d = full[:, p + 1] - full[:, p]
         print(f"   {label:18s} p50 {pct(d, 50):8.0f} cyc  p90 {pct(d, 90):8.0f}  max {d.max() if len(d) else 0:8.0f}   (p50 {pct(d, 50) / GHZ / 1e3:.2f} us)")
+    if kid in (0, 4, 5):
+        # workgroups go to the XCDs round-robin and every XCD has its own clock: per XCD, when waves start and end
+        # relative to the XCD's first wave (the launch ramp and the tail of the one-round kernels)
+        xcd = (a[:, 7] >> 32) & 15          # XCC_ID noted by the wave
+        rel_s, rel_e, spans = [], [], []
+        for x in range(8):
+            sel = xcd == x
+            if not sel.any():
+                continue
+            s0 = a[sel, 0].min()
+            rel_s.append(a[sel, 0] - s0); rel_e.append(end[sel] - s0); spans.append((end[sel].max() - s0) / GHZ / 1e3)
+        rs, re = np.concatenate(rel_s) / GHZ / 1e3, np.concatenate(rel_e) / GHZ / 1e3
+        print(f"   per XCD (own clock): span first start -> last end {min(spans):.2f} .. {max(spans):.2f} us; wave start after the XCD's first "
+              f"p50 {pct(rs, 50):.2f} p90 {pct(rs, 90):.2f} max {rs.max():.2f} us; wave end p50 {pct(re, 50):.2f} p90 {pct(re, 90):.2f} max {re.max():.2f} us")
     if kid in (2, 3):
         # where each wave ran (HW_REG_HW_ID | XCC_ID << 32, noted by the wave): per SIMD, how many waves were resident
         # on average between the SIMD's first start and last end, and how long that span was (one clock per XCD)
