@@ -41,13 +41,30 @@ def _hipcc() -> str:
     return exe
 
 
+STAMP = LIB + ".srchash"
+
+
+def source_digest() -> str:
+    """SHA-256 over the contents of every source, header and this file (the compile flags live here): what the
+    library was built from, independent of file times (a checkout can give a stale .so a newer mtime than its sources)."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, x)) for x in HEADERS]
+    deps.append(os.path.abspath(__file__))
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB):
+    """True unless the library exists and was built from exactly the current sources and flags (content digest kept
+    next to it; the digest file travels with the .so)."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
-    deps.append(os.path.abspath(__file__))  # the compile flags live here
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_digest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -77,6 +94,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     os.replace(tmp, LIB)
+    with open(STAMP, "w") as f:
+        f.write(source_digest() + "\n")
     return LIB
 
 

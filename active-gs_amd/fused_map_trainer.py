@@ -16,7 +16,7 @@ from . import raster_api as api
 from .camera import camera_matrices
 from .dist_util import all_reduce_
 from .fused_loss import FusedLoss
-from .map_trainer import GaussianMapTrainer, WeightedFrameSampler
+from .map_trainer import GaussianMapTrainer, make_frame_sampler
 from .optimizer import FusedAdam
 from .trainer import GradSlab
 
@@ -163,7 +163,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         rows = api.RowSet(n, self.device) if self.world == 1 else None
         optim.touched = rows
         slab.flat.zero_()
-        sampler = WeightedFrameSampler(self.frames, self.cfg["batch_size"], self.cfg["active_size"])
+        sampler = make_frame_sampler(self.cfg, self.frames)
         self.last_losses = []
         self._cap = max(self._cap, 1 << 16, 2 * n)
         for it in range(self.cfg["optimization_steps"] if steps is None else steps):
@@ -358,7 +358,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         slab = GradSlab(n, dev)
         rows = api.RowSet(n, dev)
         optim.touched = rows
-        sampler = WeightedFrameSampler(self.frames, self.cfg["batch_size"], self.cfg["active_size"])
+        sampler = make_frame_sampler(self.cfg, self.frames)
         K = len(self.frames)
         h, w = self.frames[0]["rgb"].shape[-2:]
         cam0, fx, fy = self._camera(0)
@@ -429,7 +429,8 @@ class FusedMapTrainer(GaussianMapTrainer):
 
         graph = None
         self._loss.accum.zero_()           # from here on ags_loss_finish leaves it zeroed
-        device_sampler = self.cfg.get("sampler", "host") == "device"
+        # (the device draw is the weighted one; the uniform sampler keeps torch.randperm's host stream)
+        device_sampler = self.cfg.get("sampler", "host") == "device" and self.cfg.get("sampler_type", "weighted") == "weighted"
         n_active, n_random = len(sampler.active_ids), sampler.num_random
         for it in range(total):
             if device_sampler:
@@ -511,7 +512,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         dev = self.device
         optim = FusedAdam(params, [lrs["mean"], lrs["scale"], lrs["rotation"], lrs["opacity"], lrs["harmonic"]], eps=1e-15)
         slab = GradSlab(n, dev)
-        sampler = WeightedFrameSampler(self.frames, self.cfg["batch_size"], self.cfg["active_size"])
+        sampler = make_frame_sampler(self.cfg, self.frames)
         K = len(self.frames)
         h, w = self.frames[0]["rgb"].shape[-2:]
         cam0, fx, fy = self._camera(0)

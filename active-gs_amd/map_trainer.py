@@ -22,7 +22,7 @@ DEFAULT_CFG = dict(bound=(0.001, 10.0), scale_factor=0.01, optimization_steps=10
                    background=(0.0, 0.0, 0.0, 0.0), batch_size=8, active_size=3, use_view_distribution=True,
                    # "host": the reference's np.random.choice on the host (reads the per-frame errors back every
                    # iteration); "device" (FusedMapTrainer.train_batched): the same distribution drawn on the GPU
-                   sampler="host",
+                   sampler="host", sampler_type="weighted",
                    lrs=dict(mean=5e-4, scale=1e-2, rotation=5e-4, opacity=1e-2, harmonic=1e-4))
 
 
@@ -47,6 +47,43 @@ class WeightedFrameSampler:
             sel = np.append(sel, self.older_ids[picked])  # the reference indexes by the drawn values
         st = lambda k: torch.stack([self.frames[i][k] for i in sel])
         return st("rgb"), st("depth"), st("extrinsic"), st("intrinsic"), sel
+
+
+class UniformFrameSampler:
+    """Mirror of ``UniformSampler`` (/root/reference/mapping/utils.py:231-261): the newest ``active_size`` frames plus
+    ``batch_size - active_size`` older ones drawn with ``torch.randperm`` (torch's global stream).  ``frames`` is
+    a dict keyed by frame id, as there (a list is taken as ``{0: f0, 1: f1, ...}``).  The reference's ``train()``
+    calls ``next_frames(weight)`` on whichever sampler the config names (gaussian_map.py:81), which this class's
+    original does not accept - ``sampler_type: uniform`` is dead there; here the weight is accepted and ignored so
+    that ``cfg["sampler_type"] = "uniform"`` works in the train loops."""
+
+    def __init__(self, frames, batch_size: int, active_size: int):
+        self.frames = frames if isinstance(frames, dict) else dict(enumerate(frames))
+        ids = list(self.frames.keys())
+        assert len(ids) >= active_size
+        self.active_ids = np.array(ids[-active_size:])
+        self.older_ids = np.array(ids[:-active_size])
+        self.num_random = min(len(self.older_ids), batch_size - active_size)
+        self.v = len(self.active_ids) + self.num_random
+
+    def next_frames(self, weight: Optional[torch.Tensor] = None):
+        sel = self.active_ids.copy()
+        if self.num_random > 0:
+            picked = torch.randperm(len(self.older_ids))[: self.num_random]
+            sel = np.append(sel, self.older_ids[picked.numpy()])
+        st = lambda k: torch.stack([self.frames[i][k] for i in sel])
+        return st("rgb"), st("depth"), st("extrinsic"), st("intrinsic"), sel
+
+
+def make_frame_sampler(cfg: dict, frames):
+    """``cfg["sampler_type"]``: "weighted" (the reference's default, incremental.yaml:23) or "uniform"
+    (gaussian_map.py:253-256)."""
+    kind = cfg.get("sampler_type", "weighted")
+    if kind == "uniform":
+        return UniformFrameSampler(frames, cfg["batch_size"], min(cfg["active_size"], len(frames)))
+    if kind != "weighted":
+        raise ValueError(f"unknown sampler_type {kind!r}")
+    return WeightedFrameSampler(frames, cfg["batch_size"], cfg["active_size"])
 
 
 def _default_optimizer(params, lrs):
@@ -106,7 +143,7 @@ class GaussianMapTrainer:
         lrs = self.cfg["lrs"]
         optim = self.optimizer_factory(params, [lrs["mean"], lrs["scale"], lrs["rotation"], lrs["opacity"],
                                                 lrs["harmonic"]])  # fresh state per train(), :259-292
-        sampler = WeightedFrameSampler(self.frames, self.cfg["batch_size"], self.cfg["active_size"])
+        sampler = make_frame_sampler(self.cfg, self.frames)
         self.last_losses = []
         dist = torch.distributed
         for _ in range(self.cfg["optimization_steps"] if steps is None else steps):

@@ -20,16 +20,23 @@ STAGE = [("ags_k_preprocess_bwd", "preprocess_bwd"), ("ags_k_preprocess", "prepr
          ("ags_k_bucket", "binning"), ("ags_k_tile_sort", "binning"), ("ags_k_render_fwd", "render_fwd"),
          ("ags_k_render_bwd", "render_bwd")]
 stages = collections.defaultdict(lambda: collections.defaultdict(float))
+def stage_of(k):
+    for pat, st in STAGE:
+        if k.startswith(pat): return st
+# per STEP: a kernel counts by its launches per step (launches / the stage's most-launched kernel), so the one-off
+# launches outside the steps (the workspace probe's general tile sort) are not a second kernel of the stage
+steps = collections.defaultdict(int)
+for k, d in acc.items():
+    if stage_of(k): steps[stage_of(k)] = max(steps[stage_of(k)], max(v[1] for v in d.values()))
 for k, d in acc.items():
     print("| `%s` | " % k + " | ".join("%.3g" % (d[n][0] / max(d[n][1], 1)) if n in d else "-" for n in names) + " |")
-    for pat, st in STAGE:
-        if k.startswith(pat):
-            for n in names:
-                if n in d: stages[st][n] += d[n][0] / max(d[n][1], 1)
-            break
+    st = stage_of(k)
+    if st:
+        for n in names:
+            if n in d: stages[st][n] += d[n][0] / steps[st]
 out = {k: dict(v) for k, v in stages.items()}
 out["_session"] = tag
-out["_note"] = "per launch, summed over the kernels of a bench stage; SQ_ACTIVE_INST_VALU is in quad-cycles summed over the SIMDs"
+out["_note"] = "per step, summed over the kernels of a bench stage weighted by their launches per step; SQ_ACTIVE_INST_VALU is in quad-cycles summed over the SIMDs"
 json.dump(out, open("gpurun_out/sq_counters.json", "w"), indent=1)
 PY
 rm -rf gpurun_out/pmc_sq

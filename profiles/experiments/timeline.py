@@ -21,6 +21,7 @@ ap.add_argument("--w", type=int, default=1200)
 ap.add_argument("--room", default="office0")
 ap.add_argument("--mult", type=float, default=1.0)
 ap.add_argument("--binning", default="direct")
+ap.add_argument("--graph", type=int, default=0, help="stamp the LAST step of a hipGraph of this many steps (0: one eager step)")
 args = ap.parse_args()
 
 from active_gs_amd import _lib, raster_api as api  # noqa: E402
@@ -54,8 +55,14 @@ torch.cuda.synchronize()
 NW = 16384
 buf = torch.zeros(8 * NW * 8, dtype=torch.int64, device=dev)
 lib.ags_debug_timeline.argtypes = [C.c_void_p]
+if args.graph:
+    replay = tr.capture([cam], fn, cap, repeat=args.graph)
+    replay(); torch.cuda.synchronize()
 lib.ags_debug_timeline(buf.data_ptr())
-tr.step([cam], fn, cap)
+if args.graph:
+    replay()            # every step of the graph stamps the same slots: the last one's stamps survive
+else:
+    tr.step([cam], fn, cap)
 torch.cuda.synchronize()
 lib.ags_debug_timeline(None)
 t = buf.cpu().numpy().reshape(8, NW, 8).astype(np.int64)

@@ -20,6 +20,7 @@ STAGE = {"ags_k_preprocess<": "preprocess", "ags_k_scan_tiles": "binning", "ags_
 
 
 def load(path, counter):
+    """kernel -> (bytes per launch, launches)"""
     acc = defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
@@ -27,29 +28,43 @@ def load(path, counter):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[k][0] += float(r["Counter_Value"])
         acc[k][1] += 1
-    return {k: v[0] / v[1] * 1024.0 for k, v in acc.items()}
+    return {k: (v[0] / v[1] * 1024.0, v[1]) for k, v in acc.items()}
+
+
+def stage_of(k):
+    for pat, st in STAGE.items():
+        if k.startswith(pat.rstrip("<")) and (pat != "ags_k_preprocess<" or "bwd" not in k):
+            return st
+    return None
 
 
 fetch = load(sys.argv[1], "FETCH_SIZE")
 write = load(sys.argv[2], "WRITE_SIZE")
-print("| kernel | FETCH raw (MB) | FETCH x2 (MB) | WRITE (MB) |")
-print("|---|---:|---:|---:|")
+print("| kernel | launches | FETCH raw (MB) | FETCH x2 (MB) | WRITE (MB) |")
+print("|---|---:|---:|---:|---:|")
+# A stage's bytes per STEP: every kernel of the stage weighted by how often it ran per step (launches / the stage's
+# most-launched kernel): the one-off launches outside the steps (the bench's workspace probe runs the general tile
+# sort once) do not count as a second kernel of the stage.
+steps = defaultdict(int)
+for k, (_, n) in fetch.items():
+    if stage_of(k):
+        steps[stage_of(k)] = max(steps[stage_of(k)], n)
 stage_bytes = defaultdict(lambda: [0.0, 0.0])
-for k in sorted(fetch, key=lambda k: -fetch[k]):
+for k in sorted(fetch, key=lambda k: -fetch[k][0]):
     if not k.startswith("ags_k"):
         continue
-    w = write.get(k, 0.0)
-    print(f"| `{k}` | {fetch[k] / 1e6:.3f} | {2 * fetch[k] / 1e6:.3f} | {w / 1e6:.3f} |")
-    for pat, st in STAGE.items():
-        if k.startswith(pat.rstrip("<")) and (pat != "ags_k_preprocess<" or "bwd" not in k):
-            stage_bytes[st][0] += fetch[k]
-            stage_bytes[st][1] += w
-            break
+    f, n = fetch[k]
+    w = write.get(k, (0.0, 0))[0]
+    print(f"| `{k}` | {n} | {f / 1e6:.3f} | {2 * f / 1e6:.3f} | {w / 1e6:.3f} |")
+    st = stage_of(k)
+    if st:
+        stage_bytes[st][0] += f * n / steps[st]
+        stage_bytes[st][1] += w * n / steps[st]
 if len(sys.argv) > 3:
     out = {k: {"fetch_raw": round(v[0]), "write": round(v[1]), "traffic": round(2 * v[0] + v[1])}
            for k, v in stage_bytes.items()}
     out["_session"] = sys.argv[4] if len(sys.argv) > 4 else "?"
-    out["_note"] = ("bytes per launch, summed over the kernels of a bench stage (bench.py --eager under rocprofv3 --pmc, "
+    out["_note"] = ("bytes per step, summed over the kernels of a bench stage weighted by their launches per step (bench.py --eager under rocprofv3 --pmc, "
                     "FETCH_SIZE and WRITE_SIZE in separate passes); traffic = 2*fetch_raw + write (gfx950 FETCH_SIZE "
                     "counts 128-B requests of wide streaming reads at 64 B: MI355X_MICROARCH.md, HBM section)")
     json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -267,3 +267,31 @@ def test_reference_written_checkpoint_loads_and_ours_has_what_its_load_reads(tmp
     assert isinstance(st["near"], float) and isinstance(st["far"], float) and isinstance(st["scale_factor"], float)
     bg = torch.tensor(torch.as_tensor(st["background_color"]).tolist(), dtype=torch.float32)   # load(): torch.tensor(..., float32)
     assert bg.shape == (4,) and st["use_view_direction"] == ref["use_view_direction"]
+
+
+def test_frame_samplers_pick_the_reference_frames():
+    """tests/golden/sampler.pt: frames picked by the reference's UniformSampler (torch.randperm) and WeightedSampler
+    (np.random.choice), /root/reference/mapping/utils.py:190-261, on seeded inputs - three draws in a row each."""
+    from active_gs_amd.map_trainer import UniformFrameSampler, WeightedFrameSampler, make_frame_sampler
+    cases = torch.load(os.path.join(GOLD, "sampler.pt"), weights_only=False)
+    for c in cases:
+        frames = c["frames"]
+        torch.manual_seed(c["seed"])
+        us = UniformFrameSampler({10 * i: f for i, f in enumerate(frames)}, c["batch"], c["active"])
+        assert us.v == c["uniform_v"]
+        for want in c["uniform"]:
+            rgb, depth, extr, intr, ids = us.next_frames()
+            assert rgb.shape[0] == want["n"] and len(ids) == want["n"]
+            assert torch.equal(rgb.sum(dim=(1, 2, 3)), want["rgb_sum"]) and torch.equal(extr[:, 0, 0], want["extr0"])
+        np.random.seed(c["seed"])
+        ws = WeightedFrameSampler(frames, c["batch"], c["active"])
+        for want in c["weighted"]:
+            rgb, depth, extr, intr, ids = ws.next_frames(c["weight"].clone())
+            assert torch.equal(torch.as_tensor(np.asarray(ids)), want["ids"])
+            assert torch.equal(rgb.sum(dim=(1, 2, 3)), want["rgb_sum"])
+    # the config switch of gaussian_map.py:253-256
+    assert isinstance(make_frame_sampler(dict(sampler_type="uniform", batch_size=8, active_size=3), cases[0]["frames"]),
+                      UniformFrameSampler)
+    assert isinstance(make_frame_sampler(dict(batch_size=8, active_size=3), cases[0]["frames"]), WeightedFrameSampler)
+    with pytest.raises(ValueError):
+        make_frame_sampler(dict(sampler_type="nope", batch_size=8, active_size=3), cases[0]["frames"])
