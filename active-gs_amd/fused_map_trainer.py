@@ -459,8 +459,12 @@ class FusedMapTrainer(GaussianMapTrainer):
                 known_fit = self._last_need is not None and 1.5 * self._last_need * (n / max(self._last_need_n, 1)) <= self._cap
                 while state["batch"] is None or (it == 0 and not known_fit and not fits()):
                     keep["batch"] = None               # release the old buffers before the larger ones are made
-                    ncap = int(n * 1.3) + 4096
-                    self._cap = max(self._cap, 2 * ncap)
+                    # head-room for a map that doubles and for tile lists four times the average (one-pass binning
+                    # needs tiles x the LONGEST list): a re-allocation is ~4 ms of hipMalloc + workspace set-up, and
+                    # with 30 % head-room the mapper loop paid it on two of three keyframes (memory is not the
+                    # constraint on a 288 GB part: ~0.1 GB per view at 512x512 and 260 k surfels)
+                    ncap = max(2 * n + 4096, 1 << 18)
+                    self._cap = max(self._cap, 4 * ncap)
                     state["batch"] = keep["batch"] = api.ViewBatch(
                         g, Bmax, h, w, cam0.tanfovx, cam0.tanfovy, self.background, self._cap,
                         binning_mode=self.binning_mode, capacity_n=ncap)
