@@ -96,7 +96,7 @@ class AgsCandidates(C.Structure):
 
 
 EXPORTS = ["ags_workspace_bytes", "ags_workspace_init", "ags_forward", "ags_forward_batch",
-           "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_read_status", "ags_adam_step",
+           "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_backward_fused_next", "ags_forward_resume", "ags_read_status", "ags_adam_step",
            "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_rows_index", "ags_adam_step_gathered", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_smooth_depth", "ags_densify_candidates",
            "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_compact_plan_bytes", "ags_compact_plan",
            "ags_compact_rows", "ags_profile_enable", "ags_profile_read",
@@ -137,6 +137,14 @@ def load() -> C.CDLL:
     lib.ags_backward.argtypes = [C.POINTER(AgsCamera), C.POINTER(AgsGaussians), C.POINTER(AgsImages),
                                  C.POINTER(AgsPerGaussian), C.POINTER(AgsImageGrads), C.POINTER(AgsGaussianGrads),
                                  C.POINTER(AgsWorkspace), C.c_void_p]
+    lib.ags_backward_fused_next.restype = C.c_int
+    lib.ags_backward_fused_next.argtypes = [C.POINTER(AgsCamera), C.POINTER(AgsGaussians), C.POINTER(AgsImages),
+                                            C.POINTER(AgsPerGaussian), C.POINTER(AgsImageGrads), C.POINTER(AgsGaussianGrads),
+                                            C.POINTER(AgsWorkspace), C.POINTER(AgsCamera), C.POINTER(AgsPerGaussian),
+                                            C.POINTER(AgsWorkspace), C.c_int32, C.c_void_p]
+    lib.ags_forward_resume.restype = C.c_int
+    lib.ags_forward_resume.argtypes = [C.POINTER(AgsCamera), C.POINTER(AgsGaussians), C.POINTER(AgsImages),
+                                       C.POINTER(AgsPerGaussian), C.POINTER(AgsWorkspace), C.c_void_p]
     lib.ags_backward_batch.restype = C.c_int
     lib.ags_backward_batch.argtypes = [C.POINTER(AgsCamera), C.c_int32, C.POINTER(AgsGaussians), C.POINTER(AgsImages),
                                        C.POINTER(AgsPerGaussian), C.POINTER(AgsImageGrads), C.POINTER(AgsGaussianGrads),

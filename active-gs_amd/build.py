@@ -25,7 +25,11 @@ HEADERS = ["ags_internal.h", "surfel_math.h", os.path.join("..", "..", "include"
 # the correctly rounded ~10-instruction expansions: 34 divisions in the per-Gaussian backward alone.
 EXTRA_FLAGS = {"loss.hip": ["-ffp-contract=off"], "densify.hip": ["-ffp-contract=off"],
                "render.hip": ["-fno-signed-zeros"],
-               "preprocess.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt"],
+               # -ffp-contract=on: multiply-adds are fused where the SOURCE writes a * b + c in one expression and
+               # nowhere else, so the per-Gaussian stage rounds the same in every kernel it is inlined into (the
+               # pipelined step runs it from ags_k_rows_adam_preprocess: with the default cross-statement fusion the
+               # two kernels' records differed in the last bit of a few fields)
+               "preprocess.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=on"],
                "adam.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]}
 # -fno-slp-vectorize everywhere: hipcc's SLP pass packs pairs of scalar fp32 ops into v_pk_* at the
 # price of register-pair shuffles (25 % v_mov in render_bwd) and VGPRs; scalar code measured

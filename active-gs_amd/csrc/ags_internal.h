@@ -110,7 +110,11 @@ struct AgsAdamArgs {
     float* st;        // AgsAdamTensors.state_rows: (n, 28) interleaved moments, or nullptr (then m / v)
 };
 // "advance this Adam clock on the side" request carried by a backward launch (clock == nullptr: off)
-struct AgsTick { AgsAdamClock* clock; float lr[5]; float beta1, beta2; };
+// (`rows_count` / `count_snap`: the same thread also notes how many rows the optimiser's row set holds right now in the
+// workspace's status block - AgsStatus.reserved[0] - for the software-pipelined per-Gaussian kernel that follows, whose
+// own workgroups append to the list while others walk it)
+struct AgsTick { AgsAdamClock* clock; float lr[5]; float beta1, beta2; const int* rows_count; uint32_t* count_snap; };
+#define AGS_STATUS_COUNT_SNAP 8   // word index of AgsStatus.reserved[0]
 inline AgsAdamArgs ags_adam_args(const AgsAdamTensors& t) {
     AgsAdamArgs a;
     long long run = 0;
@@ -167,6 +171,10 @@ AgsIdList ags_sorted_ids(char* ws, const AgsLayout& L, int binning_mode);
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs,
                            bool direct, hipStream_t s);
+void ags_launch_rows_adam_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
+                                     const AgsLayout& L, const int* radii, const AgsGaussianGrads& din,
+                                     const AgsFrame& F2, const AgsCamera& cam2, char* ws2, const AgsLayout& L2, int* radii2,
+                                     int rows_hint, hipStream_t s);
 void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick,
                            const AgsViewStride& vs, bool direct, hipStream_t s);

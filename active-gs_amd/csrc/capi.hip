@@ -124,11 +124,16 @@ static int ags_adam_check(const AgsAdamTensors* t, bool need_grad = true) {
     return AGS_OK;
 }
 
-int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* fwd,
-                 const AgsPerGaussian* pg, const AgsImageGrads* dout, const AgsGaussianGrads* din,
-                 const AgsWorkspace* ws, ags_stream_t stream) {
+} // extern "C"
+
+// ags_backward and its software-pipelined form (next_* != NULL: the per-Gaussian kernel also runs the per-Gaussian
+// stage of the NEXT forward pass)
+static int ags_backward_impl(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* fwd,
+                             const AgsPerGaussian* pg, const AgsImageGrads* dout, const AgsGaussianGrads* din,
+                             const AgsWorkspace* ws, const AgsCamera* next_cam, const AgsPerGaussian* next_pg,
+                             const AgsWorkspace* next_ws, int32_t rows_hint, ags_stream_t stream) {
     if (!cam || !in || !fwd || !pg || !dout || !din || !ws || !ws->ptr) return AGS_E_INVALID;
-    if (in->n == 0) return AGS_OK;
+    if (in->n == 0) return next_cam ? AGS_E_INVALID : AGS_OK;
     if (!pg->radii || !fwd->depth || !fwd->opacity) return AGS_E_INVALID;
     {   // all five gradient arrays, or - fused optimiser step, overwrite mode - none at all
         const int have = (din->d_means3D != nullptr) + (din->d_scales != nullptr) + (din->d_rotations != nullptr) +
@@ -148,6 +153,10 @@ int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* 
         tick.clock = (AgsAdamClock*)din->adam_clock;
         for (int k = 0; k < 5; ++k) tick.lr[k] = din->adam_lr[k];
         tick.beta1 = din->adam_beta1; tick.beta2 = din->adam_beta2;
+        if (next_cam && din->touched.count) {   // the pipelined per-Gaussian kernel reads the member count of NOW
+            tick.rows_count = din->touched.count;
+            tick.count_snap = (uint32_t*)(base + L.status) + AGS_STATUS_COUNT_SNAP;
+        }
     }
     if (din->fused_adam) {
         if (!din->touched.rows || !din->touched.count || !din->adam_clock || din->accumulate == 2) return AGS_E_INVALID;
@@ -160,7 +169,63 @@ int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* 
                               din->pack_capacity < 0)) return AGS_E_INVALID;
     { StageScope t(AGS_STAGE_RENDER_BWD, s);
       ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, tick, kOneView, ws->binning_mode == AGS_BIN_DIRECT, s); }
+    if (next_cam) {
+        // pipelined: single view, single rank, fused Adam on raw parameters, one-pass binning on both workspaces
+        if (!next_pg || !next_ws || !next_ws->ptr || !next_pg->radii || !din->fused_adam || !in->raw_params) return AGS_E_INVALID;
+        if (!din->fused_adam->state_rows) return AGS_E_INVALID;   // the pipelined kernel reads the interleaved moments
+        if (!next_cam->viewmatrix || !next_cam->projmatrix || next_cam->image_height <= 0 || next_cam->image_width <= 0) return AGS_E_INVALID;
+        if (ws->binning_mode != AGS_BIN_DIRECT || next_ws->binning_mode != AGS_BIN_DIRECT) return AGS_E_INVALID;
+        if (next_ws->max_instances < 1 || next_ws->max_instances > 0xFFFFFFFFll) return AGS_E_INVALID;
+        if (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences) return AGS_E_INVALID;
+        // the next pass's row set is the optimiser's (new members are appended while this step's rows are walked)
+        if (next_pg->touched.member != din->touched.member || next_pg->touched.rows != din->touched.rows ||
+            next_pg->touched.count != din->touched.count) return AGS_E_INVALID;
+        const AgsLayout L2 = ags_make_layout(in->n, next_cam->image_height, next_cam->image_width, next_ws->max_instances);
+        if (next_ws->bytes < L2.total) return AGS_E_WORKSPACE;
+        if (ags_direct_tile_cap(L2) < 1) return AGS_E_WORKSPACE;
+        const AgsFrame F2 = ags_make_frame(next_cam);
+        StageScope t(AGS_STAGE_PREPROCESS_BWD, s);
+        ags_launch_rows_adam_preprocess(F, *cam, *in, base, L, pg->radii, *din, F2, *next_cam, (char*)next_ws->ptr, L2,
+                                        next_pg->radii, rows_hint, s);
+        return ags_check_launch();
+    }
     { StageScope t(AGS_STAGE_PREPROCESS_BWD, s); ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, kOneView, s); }
+    return ags_check_launch();
+}
+
+extern "C" {
+
+int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* fwd,
+                 const AgsPerGaussian* pg, const AgsImageGrads* dout, const AgsGaussianGrads* din,
+                 const AgsWorkspace* ws, ags_stream_t stream) {
+    return ags_backward_impl(cam, in, fwd, pg, dout, din, ws, nullptr, nullptr, nullptr, 0, stream);
+}
+
+int ags_backward_fused_next(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* fwd,
+                            const AgsPerGaussian* pg, const AgsImageGrads* dout, const AgsGaussianGrads* din,
+                            const AgsWorkspace* ws, const AgsCamera* next_cam, const AgsPerGaussian* next_pg,
+                            const AgsWorkspace* next_ws, int32_t rows_hint, ags_stream_t stream) {
+    if (!next_cam || !next_pg || !next_ws || rows_hint < 0) return AGS_E_INVALID;
+    return ags_backward_impl(cam, in, fwd, pg, dout, din, ws, next_cam, next_pg, next_ws, rows_hint, stream);
+}
+
+int ags_forward_resume(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* out,
+                       const AgsPerGaussian* pg, const AgsWorkspace* ws, ags_stream_t stream) {
+    if (!cam || !in || !out || !pg || !ws || !ws->ptr) return AGS_E_INVALID;
+    if (in->n <= 0 || cam->image_height <= 0 || cam->image_width <= 0) return AGS_E_INVALID;
+    if (!cam->viewmatrix || !cam->projmatrix || !cam->bg || !pg->radii) return AGS_E_INVALID;
+    if (!out->rgb || !out->normal || !out->depth || !out->opacity || !out->confidence) return AGS_E_INVALID;
+    if (cam->want_stats && (!pg->importance || !pg->count)) return AGS_E_INVALID;
+    if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll || ws->binning_mode != AGS_BIN_DIRECT) return AGS_E_INVALID;
+    const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
+    if (ws->bytes < L.total) return AGS_E_WORKSPACE;
+    if (ags_direct_tile_cap(L) < 1) return AGS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* base = (char*)ws->ptr;
+    const AgsFrame F = ags_make_frame(cam);
+    { StageScope t(AGS_STAGE_BINNING, s); ags_launch_direct_sort(base, L, kOneView, s); }
+    { StageScope t(AGS_STAGE_RENDER_FWD, s);
+      ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, kOneView, true, s); }
     return ags_check_launch();
 }
 

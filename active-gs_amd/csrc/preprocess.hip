@@ -89,30 +89,25 @@ struct AgsDirectEmit { uint64_t* keys; uint32_t tile_cap; uint32_t* partial; };
 
 // EMIT: 0 = nothing, 1 = count the tiles a surfel reaches (tile-sort binning), 2 = AGS_BIN_DIRECT: take a slot in
 // the tile's own key range with ONE returning atomic and write the (depth | id) key at once
-template <int EMIT, bool AGG>
-__global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
-    AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
+// Body of the forward per-Gaussian kernel for workgroup `bx` of the pass (pointers already moved to the view).
+// SKIP_MEMBERS (the software-pipelined optimisation step, ags_k_rows_adam_preprocess): rows that are already members of
+// the row set are left alone - the lane that applied their Adam update runs this stage for them from its registers.
+template <int EMIT, bool AGG, bool SKIP_MEMBERS>
+__device__ __forceinline__ void ags_preprocess_block(
+    const AgsFrame& F, const float* __restrict__ Vp, const float* __restrict__ Pp, const AgsGaussians& in,
     AgsGeom* __restrict__ geom, uint32_t* __restrict__ tiles, ushort4* __restrict__ rect,
     int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_vis,
-    uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom, AgsRowSet touched, AgsDirectEmit direct,
-    AgsViewStride vs) {
-    { // batched forward: this workgroup's view // (offsets are 0 for a single view)
-        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
-        Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
-        radii += (size_t)blockIdx.y * (size_t)vs.n;
-        AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(tiles, wo); AGS_WS_SHIFT(rect, wo); AGS_WS_SHIFT(block_sums, wo);
-        AGS_WS_SHIFT(block_vis, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(dgeom, wo);
-        if (EMIT == 2) { AGS_WS_SHIFT(direct.keys, wo); AGS_WS_SHIFT(direct.partial, wo); }
-    }
+    uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom, const AgsRowSet& touched, const AgsDirectEmit& direct,
+    const int bx) {
     __shared__ uint32_t wsum[AGS_PRE_THREADS / 64], wvis[AGS_PRE_THREADS / 64];
     __shared__ AgsEmitRec emit[EMIT ? AGS_PRE_THREADS : 1];
     __shared__ __attribute__((aligned(16))) float rows3[9 * AGS_PRE_THREADS];
     float V[16], P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
-    [[maybe_unused]] const int tl_w = blockIdx.x * (AGS_PRE_THREADS / 64) + (threadIdx.x >> 6);
+    [[maybe_unused]] const int tl_w = bx * (AGS_PRE_THREADS / 64) + (threadIdx.x >> 6);
     AGS_TL(0, tl_w, 0);
-    const int first = blockIdx.x * AGS_PRE_THREADS;
+    const int first = bx * AGS_PRE_THREADS;
     const int i = first + threadIdx.x;
     const int rows = min(AGS_PRE_THREADS, in.n - first);
     uint32_t cnt = 0, vis = 0;
@@ -128,7 +123,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     const int was_member = touched.member ? touched.member[ic] : 1;   // requested with the inputs, not behind the projection
     ags_load_rows3x3(in.means3D, in.scales, in.colors, first, rows, rows3, p, sc, col);
     AGS_TL(0, tl_w, 1);
-    if (i < in.n) {
+    if (i < in.n && !(SKIP_MEMBERS && was_member != 0)) {
         float q[4] = {q4.x, q4.y, q4.z, q4.w};
         if (in.raw_params) { float rv[3], qi; ags_activate_inplace(in, sc, q, opacity, rv, qi); }
         int radius = 0, rc[4];
@@ -187,7 +182,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
     if (EMIT == 2) { // no block-level reduction (and no barrier): one spread atomic per wave that shows anything
 #ifndef AGS_EXP_NO_PARTIALS
-        if ((threadIdx.x & 63) == 0 && wv) atomicAdd(&direct.partial[AGS_PART(blockIdx.x, AGS_PART_VIS)], wv);
+        if ((threadIdx.x & 63) == 0 && wv) atomicAdd(&direct.partial[AGS_PART(bx, AGS_PART_VIS)], wv);
 #endif
     } else {
         const int wave = threadIdx.x >> 6;
@@ -197,13 +192,32 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
             uint32_t a = 0, b = 0;
 #pragma unroll
             for (int k = 0; k < AGS_PRE_THREADS / 64; ++k) { a += wsum[k]; b += wvis[k]; }
-            block_sums[blockIdx.x] = a;
-            block_vis[blockIdx.x] = b;  // summed by the (single-workgroup) scan kernel: no fan-in atomics
+            block_sums[bx] = a;
+            block_vis[bx] = b;  // summed by the (single-workgroup) scan kernel: no fan-in atomics
         }
     }
     AGS_TL(0, tl_w, 5);
     AGS_TL_VAL(0, tl_w, 6, ws | ((unsigned long long)wv << 32));
     AGS_TL_VAL(0, tl_w, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32));
+}
+
+template <int EMIT, bool AGG>
+__global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
+    AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
+    AgsGeom* __restrict__ geom, uint32_t* __restrict__ tiles, ushort4* __restrict__ rect,
+    int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_vis,
+    uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom, AgsRowSet touched, AgsDirectEmit direct,
+    AgsViewStride vs) {
+    { // batched forward: this workgroup's view // (offsets are 0 for a single view)
+        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
+        Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
+        radii += (size_t)blockIdx.y * (size_t)vs.n;
+        AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(tiles, wo); AGS_WS_SHIFT(rect, wo); AGS_WS_SHIFT(block_sums, wo);
+        AGS_WS_SHIFT(block_vis, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(dgeom, wo);
+        if (EMIT == 2) { AGS_WS_SHIFT(direct.keys, wo); AGS_WS_SHIFT(direct.partial, wo); }
+    }
+    ags_preprocess_block<EMIT, AGG, false>(F, Vp, Pp, in, geom, tiles, rect, radii, block_sums, block_vis, tile_count, dgeom,
+                                           touched, direct, (int)blockIdx.x);
 }
 
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
@@ -308,37 +322,142 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
 // MODE 2 (AgsGaussianGrads.pack_segment): the data-parallel step's last view per rank - the row's
 // totals go straight into the rank's exchange segment (record = the row's position in the list: one
 // 64-byte store per lane, see ags_rows_pack in adam.hip for the layout) and the slab is left zeroed.
-template <int MODE>
-__global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
-    AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
-    const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsAdamArgs adam,
-    AgsViewStride vs) {
-    { // (offsets are 0 for a single view)
-        Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
-        radii += (size_t)blockIdx.y * (size_t)vs.n;
-        AGS_WS_SHIFT(dgeom, (size_t)blockIdx.y * (size_t)vs.ws);
+// a row's exp_avg / exp_avg_sq (14 + 14 floats)
+__device__ __forceinline__ void ags_load_moments(const AgsAdamArgs& adam, int i, float am[14], float av[14]) {
+    if (adam.st) { // interleaved moments: the row's 28 floats as seven 16-byte accesses of one 112-byte piece
+        const float4* sr = reinterpret_cast<const float4*>(adam.st + (size_t)i * 28);
+        float mv[28];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { const float4 x = sr[q]; mv[4 * q] = x.x; mv[4 * q + 1] = x.y; mv[4 * q + 2] = x.z; mv[4 * q + 3] = x.w; }
+#pragma unroll
+        for (int e = 0; e < 14; ++e) { am[e] = mv[e]; av[e] = mv[14 + e]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            am[k] = adam.m[0][3 * i + k]; av[k] = adam.v[0][3 * i + k];
+            am[3 + k] = adam.m[1][3 * i + k]; av[3 + k] = adam.v[1][3 * i + k];
+            am[11 + k] = adam.m[4][3 * i + k]; av[11 + k] = adam.v[4][3 * i + k];
+        }
+        const float4 m4 = reinterpret_cast<const float4*>(adam.m[2])[i], v4 = reinterpret_cast<const float4*>(adam.v[2])[i];
+        am[6] = m4.x; am[7] = m4.y; am[8] = m4.z; am[9] = m4.w;
+        av[6] = v4.x; av[7] = v4.y; av[8] = v4.z; av[9] = v4.w;
+        am[10] = adam.m[3][i]; av[10] = adam.v[3][i];
     }
+}
+
+// What the software-pipelined optimisation step (ags_backward_fused_next) hands the per-Gaussian kernel besides the
+// backward's own arguments: the NEXT forward pass's camera and where its per-Gaussian stage writes.
+struct AgsNextPre {
+    AgsFrame F;
+    const float* V; const float* P;           // next view: view / projection matrices
+    AgsGeom* geom; float4* dgeom; int* radii; // next pass's workspace records and radii
+    uint32_t* tile_count;
+    AgsDirectEmit direct;
+    const uint32_t* count_snap;               // members of the row set when this launch started (noted by render_bwd)
+};
+
+// Body of the row-set per-Gaussian backward for wave `wave_index` of `num_waves` (pointers already moved to the view).
+// NEXT (with MODE 1): once a row's Adam update is applied the same lane runs the forward per-Gaussian stage of the
+// next view for it, from the updated parameters it holds in registers (emit_wave: 64 AgsEmitRec of LDS for the wave).
+// (NEXT: AGS_NEXT_ROWS member rows per wave instead of 64.  The member list is COMPACT - every lane's row is visible and
+// its tile rect holds ~12 candidate tiles - so a full wave would emit in a dozen rounds of 64 candidates, each with a
+// search through the wave's records in LDS and a returning atomic: measured 29 us per wave.  The kernel is a latency
+// chain and idle lanes cost nothing, but every wave holds a wave slot that the forward workgroups of the same launch
+// need too.  Measured on the 1200x680 view (step time, five-launch form 78.5 us): 4 rows per wave 76.1, 6: 73.8,
+// 8: 74.4, 12: 75.7, 16: 76.0, 32: 82.6, 64: 109.)
+#ifndef AGS_NEXT_ROWS
+#define AGS_NEXT_ROWS 8
+#endif
+
+// Key emission of a wave whose lanes hold (surfel, tile rect) records, AGS_EMIT_ROUNDS rounds of 64 (surfel, tile)
+// candidates per iteration with ALL those rounds' slot atomics in flight before the first key is stored (the plain loop of
+// ags_emit_tiles_balanced waits for every round's returning atomic: ~2 us each).  One atomic per lane (no same-tile
+// grouping: for images of more than AGS_AGG_MAX_TILES tiles).  row_of_lane: the surfel id a lane's record belongs to.
+#ifndef AGS_EMIT_ROUNDS
+#define AGS_EMIT_ROUNDS 2     // eight surfels of a compact list have ~100 candidate tiles: one iteration
+#endif
+__device__ __forceinline__ void ags_emit_keys_rounds(AgsEmitRec* wave_lds, uint32_t cnt, uint32_t x0, uint32_t y0, uint32_t wd,
+                                                         uint32_t depth_bits, const AgsGeom& g, int tiles_x, int row_of_lane,
+                                                         uint32_t* __restrict__ tile_count, const AgsDirectEmit& direct) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t incl = ags_wave_incl_scan_u32(cnt);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total == 0) return; // wave-uniform
+    AgsEmitRec me;
+    me.excl = incl - cnt; me.xy = x0 | (y0 << 16); me.wd = wd; me.pa = depth_bits;
+    me.mx = g.mx; me.my = g.my; me.ca = g.ca; me.cb = g.cb; me.cc = g.cc; me.o = g.o;
+    wave_lds[lane] = me;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int NR = AGS_EMIT_ROUNDS;
+    for (uint32_t base = 0; base < total; base += 64u * NR) {
+        bool hit[NR];
+        uint32_t tile[NR], owner_depth[NR], got[NR];
+        int lo[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { hit[r] = false; tile[r] = owner_depth[r] = got[r] = 0u; lo[r] = 0; }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (base + 64u * r >= total) break;   // wave-uniform
+            const uint32_t j = base + 64u * r + lane;
+            if (j < total) {
+                int l = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1)
+                    if (wave_lds[l + step].excl <= j) l += step; // largest lane with excl <= j
+                const AgsEmitRec rec = wave_lds[l];
+                const uint32_t t = j - rec.excl;
+                const uint32_t tx = (rec.xy & 0xFFFF) + t % rec.wd, ty = (rec.xy >> 16) + t / rec.wd;
+                AgsGeom og;
+                og.mx = rec.mx; og.my = rec.my; og.ca = rec.ca; og.cb = rec.cb; og.cc = rec.cc; og.o = rec.o;
+                const float bx = (float)(tx * AGS_TILE), by = (float)(ty * AGS_TILE);
+                hit[r] = ags_reaches_box(og, bx, bx + (AGS_TILE - 1), by, by + (AGS_TILE - 1));
+                tile[r] = ty * tiles_x + tx; owner_depth[r] = rec.pa; lo[r] = l;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (hit[r]) got[r] = atomicAdd(&tile_count[(size_t)tile[r] * AGS_TC_STRIDE], 1u);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (base + 64u * r >= total) break;   // wave-uniform
+            const uint32_t owner_row = (uint32_t)__shfl(row_of_lane, lo[r]);
+            if (hit[r] && got[r] < direct.tile_cap)
+                direct.keys[(size_t)tile[r] * direct.tile_cap + got[r]] = ((uint64_t)owner_depth[r] << 32) | owner_row;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+template <int MODE, bool NEXT, bool AGG>
+__device__ __forceinline__ void ags_rows_body(
+    const AgsFrame& F, const float* __restrict__ Vp, const float* __restrict__ Pp, const AgsGaussians& in,
+    const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, const AgsGaussianGrads& out, const AgsAdamArgs& adam,
+    const int wave_index, const int num_waves, const AgsNextPre* nx, AgsEmitRec* emit_wave) {
     constexpr bool FUSED_ADAM = MODE == 1, PACK = MODE == 2;
+    static_assert(!NEXT || FUSED_ADAM, "the pipelined form continues from the fused Adam update");
     float V[16], P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
-    const int lane = threadIdx.x;
-    AGS_TL(4, blockIdx.x, 0);
+    const int lane = threadIdx.x & 63;
+    AGS_TL(4, wave_index, 0);
     // This kernel is a short chain of dependent loads on few rows (latency, not bandwidth), so every
     // load that can be issued early is: the first batch of row ids is fetched while the member count
     // is still in flight (the list is zero-filled past `count`, so any slot holds a valid row), and
     // a row's inputs are fetched together with its radius instead of behind the visibility test.
-    const int slot0 = min(blockIdx.x * AGS_ROWS_THREADS + lane, in.n - 1);
+    constexpr int RPW = NEXT ? AGS_NEXT_ROWS : 64;    // member rows per wave and pass
+    const int slot0 = min(wave_index * RPW + min(lane, RPW - 1), in.n - 1);
     int i_next = out.touched.rows[slot0];
-    const int count = *out.touched.count;
-    if (PACK && blockIdx.x == 0 && lane < 16) // segment header: rows shipped, rows the set holds
+    // (pipelined form: this launch's other workgroups may be appending to the list - the rows of THIS step are the
+    // ones that were members when the launch started)
+    const int count = NEXT ? (int)*nx->count_snap : *out.touched.count;
+    if (PACK && wave_index == 0 && lane < 16) // segment header: rows shipped, rows the set holds
         out.pack_segment[lane] = __int_as_float(lane == 0 ? min(count, out.pack_capacity) : lane == 1 ? count : 0);
-    for (int base = blockIdx.x * AGS_ROWS_THREADS; base < count; base += gridDim.x * AGS_ROWS_THREADS) { // wave-uniform
-        const bool valid = base + lane < count;
+    for (int base = wave_index * RPW; base < count; base += num_waves * RPW) { // wave-uniform
+        const bool valid = lane < RPW && base + lane < count;
         const int i = valid ? i_next : 0;
         {
-            const int nb = base + gridDim.x * AGS_ROWS_THREADS;
-            if (nb < count) i_next = out.touched.rows[min(nb + lane, in.n - 1)];
+            const int nb = base + num_waves * RPW;
+            if (nb < count) i_next = out.touched.rows[min(nb + min(lane, RPW - 1), in.n - 1)];
         }
         const int rad = radii[i];
         float p[3], sc[3];
@@ -346,6 +465,7 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
         for (int k = 0; k < 3; ++k) { p[k] = in.means3D[3 * i + k]; sc[k] = in.scales[3 * i + k]; }
         const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
         float opacity = in.opacities[i];
+        [[maybe_unused]] const float conf_next = NEXT ? in.confidences[i] : 0.f;   // requested with the row's other inputs
         float4* src = reinterpret_cast<float4*>(dgeom + i);
         const float4 a = src[0], b = src[1], c = src[2], d = src[3];
         float am[14], av[14], ap[14]; // FUSED_ADAM: the row's exp_avg / exp_avg_sq / parameters, requested now
@@ -357,25 +477,7 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
             const float4 p4 = reinterpret_cast<const float4*>(adam.p[2])[i];
             ap[6] = p4.x; ap[7] = p4.y; ap[8] = p4.z; ap[9] = p4.w;
             ap[10] = adam.p[3][i];
-            if (adam.st) { // interleaved moments: the row's 28 floats as seven 16-byte accesses of one 112-byte piece
-                const float4* sr = reinterpret_cast<const float4*>(adam.st + (size_t)i * 28);
-                float mv[28];
-#pragma unroll
-                for (int q = 0; q < 7; ++q) { const float4 x = sr[q]; mv[4 * q] = x.x; mv[4 * q + 1] = x.y; mv[4 * q + 2] = x.z; mv[4 * q + 3] = x.w; }
-#pragma unroll
-                for (int e = 0; e < 14; ++e) { am[e] = mv[e]; av[e] = mv[14 + e]; }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    am[k] = adam.m[0][3 * i + k]; av[k] = adam.v[0][3 * i + k];
-                    am[3 + k] = adam.m[1][3 * i + k]; av[3 + k] = adam.v[1][3 * i + k];
-                    am[11 + k] = adam.m[4][3 * i + k]; av[11 + k] = adam.v[4][3 * i + k];
-                }
-                const float4 m4 = reinterpret_cast<const float4*>(adam.m[2])[i], v4 = reinterpret_cast<const float4*>(adam.v[2])[i];
-                am[6] = m4.x; am[7] = m4.y; am[8] = m4.z; am[9] = m4.w;
-                av[6] = v4.x; av[7] = v4.y; av[8] = v4.z; av[9] = v4.w;
-                am[10] = adam.m[3][i]; av[10] = adam.v[3][i];
-            }
+            if (!NEXT) ags_load_moments(adam, i, am, av);
         }
         const bool vis = valid && rad > 0;
         float dm[3] = {0, 0, 0}, ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0}, dm2[2] = {0, 0};
@@ -470,6 +572,18 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
                 out.d_opacities[i] = dop;
             }
         }
+        if (NEXT) AGS_TL(4, wave_index, 2);
+        // (pipelined form: the moments are requested only now - 28 registers less across the chain rule keeps the launch
+        // at three waves per SIMD without spills, which the forward workgroups of the same launch need; one load level
+        // more on the member rows' chain)
+        if (NEXT && FUSED_ADAM && valid) {   // (interleaved moments only: ags_backward_fused_next requires state_rows)
+            const float4* sr = reinterpret_cast<const float4*>(adam.st + (size_t)i * 28);
+            float mv[28];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) { const float4 x = sr[q]; mv[4 * q] = x.x; mv[4 * q + 1] = x.y; mv[4 * q + 2] = x.z; mv[4 * q + 3] = x.w; }
+#pragma unroll
+            for (int e = 0; e < 14; ++e) { am[e] = mv[e]; av[e] = mv[14 + e]; }
+        }
         if (FUSED_ADAM && valid) {
             // the row's Adam state was requested together with its inputs (am / av / ap above), so it is
             // here by now: update in the owning lane and store each tensor's 3-4 floats as one access
@@ -512,10 +626,100 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
                 adam.m[3][i] = am[10]; adam.v[3][i] = av[10];
             }
         }
+        if constexpr (NEXT) {
+            AGS_TL(4, wave_index, 3);
+            // ---- the next view's per-Gaussian stage for this row (what ags_k_preprocess<2> does for non-member rows),
+            // from the parameters the Adam update above left in registers
+            float V2[16], P2[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { V2[k] = nx->V[k]; P2[k] = nx->P[k]; }
+            uint32_t cnt = 0, vis2 = 0, rx0 = 0, ry0 = 0, rwd = 1;
+            AgsGeom g2;
+            g2.mx = g2.my = g2.ca = g2.cb = g2.cc = g2.o = 0.f; g2.dc = 0.f;
+            if (valid) {
+                float p2[3] = {ap[0], ap[1], ap[2]}, sc2[3] = {ap[3], ap[4], ap[5]}, q2[4] = {ap[6], ap[7], ap[8], ap[9]};
+                float op2 = ap[10];
+                const float col2[3] = {ap[11], ap[12], ap[13]};
+                if (in.raw_params) { float rv[3], qi; ags_activate_inplace(in, sc2, q2, op2, rv, qi); }
+                int radius = 0, rc[4];
+                if (ags_preprocess_fwd(nx->F, V2, P2, p2, sc2, q2, op2, col2, conf_next, 0.f, 0.f, g2, radius, rc)) {
+                    float4* dst = reinterpret_cast<float4*>(nx->geom + i);
+                    dst[0] = make_float4(g2.mx, g2.my, g2.ca, g2.cb);
+                    dst[1] = make_float4(g2.cc, g2.o, g2.dc, g2.gx);
+                    dst[2] = make_float4(g2.gy, g2.r, g2.g, g2.b);
+                    dst[3] = make_float4(g2.nx, g2.ny, g2.nz, g2.conf);
+                    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    nx->dgeom[4 * (size_t)i + 0] = z4; nx->dgeom[4 * (size_t)i + 1] = z4;
+                    nx->dgeom[4 * (size_t)i + 2] = z4; nx->dgeom[4 * (size_t)i + 3] = z4;
+                    cnt = (uint32_t)((rc[2] - rc[0]) * (rc[3] - rc[1]));
+                    rx0 = (uint32_t)rc[0]; ry0 = (uint32_t)rc[1]; rwd = (uint32_t)(rc[2] - rc[0]);
+                    vis2 = 1;
+                }
+                nx->radii[i] = radius;
+            }
+            AGS_TL(4, wave_index, 4);
+            const int my_row = i;
+            if constexpr (AGG)   // images of few tiles: same-tile lanes share an atomic (ags_wave_agg_inc), round by round
+                ags_emit_tiles_balanced(emit_wave, cnt, rx0, ry0, rwd, __float_as_uint(g2.dc), g2, nx->F.tiles_x,
+                                        [&](bool hit, uint32_t t, uint32_t depth_bits, int owner_lane) {
+                                            const uint32_t got = ags_wave_agg_inc<AGG, true>(nx->tile_count, t * AGS_TC_STRIDE, hit);
+                                            const uint32_t owner_row = (uint32_t)__shfl(my_row, owner_lane);
+                                            if (hit && got < nx->direct.tile_cap)
+                                                nx->direct.keys[(size_t)t * nx->direct.tile_cap + got] = ((uint64_t)depth_bits << 32) | owner_row;
+                                        });
+            else
+                ags_emit_keys_rounds(emit_wave, cnt, rx0, ry0, rwd, __float_as_uint(g2.dc), g2, nx->F.tiles_x, my_row,
+                                     nx->tile_count, nx->direct);
+            const uint32_t wv = ags_wave_sum_u32(vis2);
+            if (lane == 0 && wv) atomicAdd(&nx->direct.partial[AGS_PART(wave_index, AGS_PART_VIS)], wv);
+            AGS_TL(4, wave_index, 5);
+        }
     }
-    AGS_TL(4, blockIdx.x, 1);
-    AGS_TL_VAL(4, blockIdx.x, 6, count);
-    AGS_TL_VAL(4, blockIdx.x, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32));
+    AGS_TL(4, wave_index, 1);
+    AGS_TL_VAL(4, wave_index, 6, count);
+    AGS_TL_VAL(4, wave_index, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
+    AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
+    const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsAdamArgs adam,
+    AgsViewStride vs) {
+    { // (offsets are 0 for a single view)
+        Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
+        radii += (size_t)blockIdx.y * (size_t)vs.n;
+        AGS_WS_SHIFT(dgeom, (size_t)blockIdx.y * (size_t)vs.ws);
+    }
+    ags_rows_body<MODE, false, false>(F, Vp, Pp, in, radii, dgeom, out, adam, (int)blockIdx.x, (int)gridDim.x, nullptr, nullptr);
+}
+
+// The software-pipelined optimisation step's per-Gaussian kernel (single view, single rank, one-pass binning): ONE
+// launch does what ags_k_preprocess_bwd_rows<1> of step k and ags_k_preprocess<2> of step k + 1 do in two.  The two
+// are consecutive kernels of the training loop, both are one generation of waves that live for a chain of dependent
+// loads, and the second depends on the first only ROW BY ROW (a surfel's projection needs that surfel's updated
+// parameters and nothing else), so:
+//   * workgroups [0, rows_blocks): one lane per MEMBER row - the gradient chain rule and the Adam update as before, then
+//     the next view's per-Gaussian stage for that row from the registers the update left (no reload);
+//   * workgroups [rows_blocks, ...): the forward kernel's body over all rows, skipping member rows.
+// Every row is projected exactly once; no workgroup waits for another.  Saved per step: one kernel boundary (~2.5 us
+// inside a replayed graph), one launch ramp and drain (~4 us), and the shorter of the two latency chains.
+template <bool AGG>
+#ifndef AGS_FUSED_WAVES
+#define AGS_FUSED_WAVES 3     // register budget: 3 waves per SIMD (168 VGPRs)
+#endif
+__global__ __launch_bounds__(AGS_PRE_THREADS) __attribute__((amdgpu_waves_per_eu(AGS_FUSED_WAVES, AGS_FUSED_WAVES))) void ags_k_rows_adam_preprocess(
+    AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
+    const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsAdamArgs adam,
+    AgsNextPre nx, int rows_blocks) {
+    __shared__ AgsEmitRec emit_rows[AGS_PRE_THREADS];
+    if ((int)blockIdx.x < rows_blocks) {
+        const int wave = threadIdx.x >> 6;
+        ags_rows_body<1, true, AGG>(F, Vp, Pp, in, radii, dgeom, out, adam, (int)blockIdx.x * (AGS_PRE_THREADS / 64) + wave,
+                                    rows_blocks * (AGS_PRE_THREADS / 64), &nx, emit_rows + (threadIdx.x & ~63));
+        return;
+    }
+    ags_preprocess_block<2, AGG, true>(nx.F, nx.V, nx.P, in, nx.geom, nullptr, nullptr, nx.radii, nullptr, nullptr,
+                                       nx.tile_count, nx.dgeom, out.touched, nx.direct, (int)blockIdx.x - rows_blocks);
 }
 
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
@@ -532,6 +736,32 @@ void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGau
     else if (emit == 1) { if (agg) AGS_LAUNCH_PRE(1, true); else AGS_LAUNCH_PRE(1, false); }
     else { if (agg) AGS_LAUNCH_PRE(2, true); else AGS_LAUNCH_PRE(2, false); }
 #undef AGS_LAUNCH_PRE
+}
+
+void ags_launch_rows_adam_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
+                                     const AgsLayout& L, const int* radii, const AgsGaussianGrads& din,
+                                     const AgsFrame& F2, const AgsCamera& cam2, char* ws2, const AgsLayout& L2, int* radii2,
+                                     int rows_hint, hipStream_t s) {
+    AgsNextPre nx;
+    nx.F = F2; nx.V = cam2.viewmatrix; nx.P = cam2.projmatrix;
+    nx.geom = (AgsGeom*)(ws2 + L2.geom); nx.dgeom = (float4*)(ws2 + L2.dgeom); nx.radii = radii2;
+    nx.tile_count = (uint32_t*)(ws2 + L2.tile_count);
+    nx.direct = AgsDirectEmit{(uint64_t*)(ws2 + L2.keys0), ags_direct_tile_cap(L2), (uint32_t*)(ws2 + L2.totals)};
+    nx.count_snap = (const uint32_t*)(ws + L.status) + AGS_STATUS_COUNT_SNAP;
+    // the member count lives on the device: the member workgroups stride over the list, so any number of them is
+    // correct; `rows_hint` (what the caller last saw, 0 = no idea) sizes them for one pass
+    constexpr int rows_per_block = (AGS_PRE_THREADS / 64) * AGS_NEXT_ROWS;
+    const long long want = rows_hint > 0 ? (long long)rows_hint : (long long)in.n;
+    int rows_blocks = (int)((want + rows_per_block - 1) / rows_per_block);
+    if (rows_blocks < 1) rows_blocks = 1;
+    if (rows_blocks > 4096) rows_blocks = 4096;
+    const dim3 grid(rows_blocks + L2.n_blocks), block(AGS_PRE_THREADS);
+    if (L2.num_tiles <= AGS_AGG_MAX_TILES)
+        hipLaunchKernelGGL(ags_k_rows_adam_preprocess<true>, grid, block, 0, s, F, cam.viewmatrix, cam.projmatrix, in, radii,
+                           (AgsGeomGrad*)(ws + L.dgeom), din, ags_adam_args(*din.fused_adam), nx, rows_blocks);
+    else
+        hipLaunchKernelGGL(ags_k_rows_adam_preprocess<false>, grid, block, 0, s, F, cam.viewmatrix, cam.projmatrix, in, radii,
+                           (AgsGeomGrad*)(ws + L.dgeom), din, ags_adam_args(*din.fused_adam), nx, rows_blocks);
 }
 
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,

@@ -370,7 +370,10 @@ __global__ __launch_bounds__(64) AGS_BWD_ATTR void ags_k_render_bwd(
     if (!ags_wave_block(blockIdx.x, num_tiles, 4 / SLOTS, slot, wave)) return;
     // side job of a step's last backward: advance the Adam device clock.  Nothing in this launch
     // reads it; the per-Gaussian kernel that follows (fused step) or ags_adam_step_device does.
-    if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2);
+    if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2);
+        if (tick.count_snap) *tick.count_snap = (uint32_t)*tick.rows_count;
+    }
     uint2 rg;
     const int tile = ags_slot_tile(ranges, slot, tile_cap, rg);
     if (rg.y <= rg.x) return;
@@ -536,7 +539,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
     if (!ags_wave_block(blockIdx.x, num_tiles, 4, slot, wave)) return;
     AgsWaveStageQ<1, AGS_MFMA_STAGE, false>& st = *reinterpret_cast<AgsWaveStageQ<1, AGS_MFMA_STAGE, false>*>(&wb.sg[0]);
     static_assert(sizeof(AgsWaveBatch) <= 6400, "the blend backward's LDS per wave: five 1280-byte granules");
-    if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2);
+    if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2);
+        if (tick.count_snap) *tick.count_snap = (uint32_t)*tick.rows_count;
+    }
     [[maybe_unused]] const int tl_w = slot * 4 + wave;
     AGS_TL(3, tl_w, 0);
     AGS_PRIO_HIGH();

@@ -171,11 +171,13 @@ def alloc_outputs(n: int, h: int, w: int, device, workspace: torch.Tensor, max_i
 
 
 def forward(cam: Camera, g: Gaussians, state: ForwardState, stream: Optional[int] = None, checked: bool = False,
-            touched: Optional[RowSet] = None) -> ForwardState:
+            touched: Optional[RowSet] = None, resume: bool = False) -> ForwardState:
     """Enqueue one forward pass into ``state`` (see ``alloc_state``). Asynchronous.
     ``touched``: a ``RowSet`` the visible surfels are inserted into (training loops).
     ``stream``: raw HIP stream handle (default: torch's current stream); ``checked``: the caller
-    vouches for contiguous float32 GPU inputs (hot loops skip the per-call validation)."""
+    vouches for contiguous float32 GPU inputs (hot loops skip the per-call validation).
+    ``resume``: the per-Gaussian stage of this pass has already run (``backward(..., next_view=(cam, state))`` of the
+    previous optimisation step): only the tile sort and the blend are launched (``ags_forward_resume``)."""
     lib = _lib.load()
     if not checked:
         for name in ("means3D", "scales", "rotations", "opacities", "colors", "confidences"):
@@ -185,6 +187,10 @@ def forward(cam: Camera, g: Gaussians, state: ForwardState, stream: Optional[int
         state.count.zero_()
     cs, gs = cam.c_struct(), g.c_struct()
     im, pg, ws = state.images_struct(), state.per_gaussian_struct(touched), state.ws_struct()
+    if resume:
+        _lib.check(lib.ags_forward_resume(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(ws),
+                                          _stream() if stream is None else stream), "ags_forward_resume")
+        return state
     _lib.check(lib.ags_forward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(ws),
                                _stream() if stream is None else stream), "ags_forward")
     return state
@@ -221,14 +227,17 @@ def alloc_grads(n: int, device, with_means2d: bool = False, zero: bool = False) 
 def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_normal=None, d_depth=None,
              d_opacity=None, d_confidence=None, grads: Optional[GaussianGrads] = None,
              accumulate: bool = False, adam_tick=None, stream: Optional[int] = None,
-             touched: Optional[RowSet] = None, fused_adam=None, pack=None) -> GaussianGrads:
+             touched: Optional[RowSet] = None, fused_adam=None, pack=None, next_view=None) -> GaussianGrads:
     """Enqueue the backward pass of the view held in ``state``. Asynchronous.
     ``adam_tick`` = (device_clock_tensor, lrs, beta1, beta2): also advance that Adam clock.
     ``touched``: the ``RowSet`` given to this view's ``forward``: only its rows are written.
     ``fused_adam`` = (AgsAdamTensors struct, eps): the launch also performs the optimiser step for
     the member rows (last view of a single-GPU step; needs ``touched`` and ``adam_tick``).
     ``pack`` = (segment tensor, capacity): the member rows' totals leave as the rank's exchange segment
-    (last view of a rank's data-parallel step; needs ``touched``), the gradient rows are left zeroed."""
+    (last view of a rank's data-parallel step; needs ``touched``), the gradient rows are left zeroed.
+    ``next_view`` = (Camera, ForwardState[, rows_hint]) with ``fused_adam``: software-pipelined step - the per-Gaussian launch also
+    runs the per-Gaussian stage of the NEXT forward pass (``ags_backward_fused_next``); render that view with
+    ``forward(..., resume=True)``."""
     lib = _lib.load()
     if grads is None:
         grads = alloc_grads(g.n, g.means3D.device)
@@ -257,6 +266,14 @@ def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_norma
         segment, capacity = pack
         din.pack_segment = ptr(segment)
         din.pack_capacity = int(capacity)
+    if next_view is not None:
+        cam2, state2 = next_view[:2]
+        rows_hint = int(next_view[2]) if len(next_view) > 2 else 0
+        cs2, pg2, ws2 = cam2.c_struct(), state2.per_gaussian_struct(touched), state2.ws_struct()
+        _lib.check(lib.ags_backward_fused_next(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(dout), C.byref(din),
+                                               C.byref(ws), C.byref(cs2), C.byref(pg2), C.byref(ws2), rows_hint,
+                                               _stream() if stream is None else stream), "ags_backward_fused_next")
+        return grads
     _lib.check(lib.ags_backward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(dout), C.byref(din),
                                 C.byref(ws), _stream() if stream is None else stream), "ags_backward")
     return grads

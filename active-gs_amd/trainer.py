@@ -194,6 +194,10 @@ class SurfelTrainer:
         # overflow), with what is needed to repeat them: see check_overflow()
         self._pending = []
         self.exchange_regrowths = 0
+        # software-pipelined steps (step(..., next_cam=...)): (ForwardState, Camera) whose per-Gaussian stage the
+        # previous step's last launch has already run, or None
+        self._prepared = None
+        self._rows_hint = 0      # members of the row set when last looked at (+ slack): sizes the pipelined launch
 
     CHECK_EVERY = 16     # optimisation steps between two reads of the overflow notes (one 64-byte D2H each)
 
@@ -202,6 +206,7 @@ class SurfelTrainer:
         gaussian_map.py:259-292): a fresh Adam.  Moments, step counter, gradient slab and the sticky
         row set are cleared together (the row set's losslessness rests on exactly that)."""
         self.check_overflow()              # settle the previous optimiser's steps first
+        self._drop_prepared()              # a prepared pass has inserted its surfels into the row set that is cleared below
         for t in self.optim.exp_avg + self.optim.exp_avg_sq:
             t.zero_()
         self.optim.step_count = 0
@@ -254,30 +259,50 @@ class SurfelTrainer:
                                  scale_factor=self.scale_factor, max_scale=self.max_scale)
         return self.activate()
 
-    def _local_pass(self, cams, image_grads, max_instances, tick: bool = False, fuse_adam: bool = False) -> bool:
+    def _drop_prepared(self) -> None:
+        """Leave the pipeline: the prepared pass has taken key slots in its workspace - clear them."""
+        if self._prepared is not None:
+            st, _ = self._prepared
+            api.init_workspace(st, self.n, st.rgb.shape[-2], st.rgb.shape[-1])
+            self._prepared = None
+
+    def _local_pass(self, cams, image_grads, max_instances, tick: bool = False, fuse_adam: bool = False,
+                    next_cam: Optional[api.Camera] = None) -> bool:
         """Forward+backward of this rank's views; with ``tick`` the last backward also advances
         the Adam device clock (returns whether it did); with ``fuse_adam`` that last backward
-        performs the optimiser step itself (``self.adam_fused`` says whether it did)."""
+        performs the optimiser step itself (``self.adam_fused`` says whether it did).  ``next_cam`` (with a fused
+        optimiser step and one-pass binning): that launch also runs the per-Gaussian stage of the NEXT step's first
+        view, which then starts at its tile sort (software pipelining across steps)."""
         g = self.gaussians()
         ticked = False
         self.adam_fused = False
         fuse_adam = fuse_adam and tick and self.rows is not None and self.fused_activations
+        pipeline = next_cam is not None and fuse_adam and self.binning_mode == api.BIN_DIRECT and len(cams) > 0
         # data-parallel step with an agreed segment size: the rank's last backward writes the exchange segment itself
         x = self.exchange
         pack = (x.send, x.capacity) if (x is not None and x.capacity and self.fused_activations and len(cams) > 0) else None
         self._packed = pack is not None
         for v, cam in enumerate(cams):
             st = self.state_for(cam.image_height, cam.image_width, max_instances)
-            api.forward(cam, g, st, touched=self.rows)
+            resume = self._prepared is not None and self._prepared[0] is st and self._prepared[1] is cam and v == 0
+            if not resume:
+                self._drop_prepared()
+            self._prepared = None
+            api.forward(cam, g, st, touched=self.rows, resume=resume)
             d = image_grads(v, st)
             final = v == len(cams) - 1
             last = tick and final
             fused = (self.optim.tensors_struct(self.slab.as_list()), self.optim.eps) if (last and fuse_adam) else None
             # a fused step over ONE view: the gradient never leaves the registers (no slab rows written at all)
             grads = self._no_grads if (fused is not None and v == 0) else self.slab.grads
+            nxt = None
+            if pipeline and fused is not None:
+                nxt = (next_cam, self.state_for(next_cam.image_height, next_cam.image_width, max_instances), self._rows_hint)
             api.backward(cam, g, st, *d, grads=grads, accumulate=(v > 0),
                          adam_tick=self.optim.tick_args() if last else None, touched=self.rows, fused_adam=fused,
-                         pack=pack if final else None)
+                         pack=pack if final else None, next_view=nxt)
+            if nxt is not None:
+                self._prepared = (nxt[1], nxt[0])
             ticked |= last
             self.adam_fused |= fused is not None
         if len(cams) == 0:
@@ -287,22 +312,26 @@ class SurfelTrainer:
         return ticked
 
     def step(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int,
-             device_clock: bool = True) -> None:
+             device_clock: bool = True, next_cam: Optional[api.Camera] = None) -> None:
         """``cams``: this rank's views. ``image_grads(view_index, state)`` returns the five
         image gradients (d_rgb, d_normal, d_depth, d_opacity, d_confidence; None = zero)
         for that view, already divided by the GLOBAL number of views where the loss is a
         batch mean.  Asynchronous except for the collective and, every ``CHECK_EVERY`` steps, one small
         read-back (``check_overflow``).  ``device_clock`` (default): the Adam step counter lives on the GPU,
-        the same clock ``capture()`` replays on; False = the host-side counter of ``ags_adam_step``."""
+        the same clock ``capture()`` replays on; False = the host-side counter of ``ags_adam_step``.
+        ``next_cam`` (single rank): the first view of the NEXT step, its matrices already in place - this step's
+        last launch then also runs that view's per-Gaussian stage (``ags_backward_fused_next``) and the next
+        ``step`` whose first camera is that object starts at its tile sort."""
         self.optim.use_clock(device_clock)
-        self._step_once(cams, image_grads, max_instances, device_clock)
+        self._step_once(cams, image_grads, max_instances, device_clock, next_cam)
         self._pending.append((cams, image_grads, max_instances, device_clock))
         if len(self._pending) >= self.CHECK_EVERY:
             self.check_overflow()
 
-    def _step_once(self, cams, image_grads, max_instances, device_clock) -> None:
+    def _step_once(self, cams, image_grads, max_instances, device_clock, next_cam=None) -> None:
         dist_on = self._distributed()
-        ticked = self._local_pass(cams, image_grads, max_instances, tick=device_clock, fuse_adam=not dist_on)
+        ticked = self._local_pass(cams, image_grads, max_instances, tick=device_clock, fuse_adam=not dist_on,
+                                  next_cam=None if dist_on else next_cam)
         if dist_on:
             self._exchange_gradients(device_clock)
         self._optimizer_step(device_clock, ticked)
@@ -350,6 +379,8 @@ class SurfelTrainer:
           agreeing on a larger one - no gradient row is dropped, the replicas never diverge.
         Returns the number of repeated steps."""
         pending, self._pending = self._pending, []
+        if self.rows is not None:
+            self._rows_hint = int(int(self.rows.count.item()) * 1.25) + 1024
         bad = self.workspace_overflows()
         if bad:
             raise RuntimeError(f"a view outgrew its rasterizer workspace {bad} (view size -> overflowed passes, "
@@ -455,7 +486,8 @@ class SurfelTrainer:
         self._capturable = bool(flag.item())
         return self._capturable
 
-    def capture(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int, repeat: int = 1) -> Callable:
+    def capture(self, cams: Sequence[api.Camera], image_grads: Callable, max_instances: int, repeat: int = 1,
+                pipeline: bool = False) -> Callable:
         """Capture one optimisation step into hipGraphs and return a ``replay()`` callable.
 
         The library never allocates or synchronises and every per-view input that changes
@@ -467,10 +499,18 @@ class SurfelTrainer:
         graph).  Call after at least one eager ``step`` so every buffer exists.  ``repeat`` > 1
         records that many consecutive optimisation steps in ONE graph, so a replay pays the
         graph-launch latency once per ``repeat`` steps; ``replay.steps`` says how many steps a call
-        performs."""
+        performs.  ``pipeline`` (single rank, one-pass binning): every recorded step's last launch also runs the
+        per-Gaussian stage of the step that follows it (the same views again: ``cams[0]``), so a step is FOUR launches
+        (tile sort, blend, blend backward, [Adam of this step + per-Gaussian stage of the next]); one eager pipelined
+        step is taken here to prime the first replay, and ``cams[0]``'s matrices must not change between replays
+        (or call ``step`` without ``next_cam`` once to leave the pipeline)."""
         self.check_overflow()              # settle the eager steps first: a capture bakes the segment size in
         self.optim.use_clock(True)
         dist_on = self._distributed()
+        pipeline = pipeline and not dist_on and self.binning_mode == api.BIN_DIRECT and len(cams) > 0
+        if pipeline:
+            self.step(cams, image_grads, max_instances, next_cam=cams[0])      # primes: cams[0] is prepared from here on
+            self.check_overflow()
         rows_x = dist_on and self._row_exchange_on()
         in_graph = dist_on and self._collectives_capturable()
         repeat = max(1, int(repeat)) if (not dist_on or in_graph) else 1
@@ -503,12 +543,22 @@ class SurfelTrainer:
             elif not dist_on:
                 with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
                     for _ in range(repeat):
-                        ticked = self._local_pass(cams, image_grads, max_instances, tick=True, fuse_adam=True)
+                        ticked = self._local_pass(cams, image_grads, max_instances, tick=True, fuse_adam=True,
+                                                  next_cam=cams[0] if pipeline else None)
                         if not self.adam_fused:
                             self.optim.step(self.slab.as_list(), device_clock=True, pre_ticked=ticked)
         torch.cuda.current_stream().wait_stream(side)
 
+        prepared_for = (self.state_for(cams[0].image_height, cams[0].image_width, max_instances), cams[0]) if pipeline else None
+
         def replay():
+            if pipeline:
+                # a pipelined graph starts at the tile sort of a pass whose per-Gaussian stage the previous step ran
+                if self._prepared is None or self._prepared[0] is not prepared_for[0] or self._prepared[1] is not prepared_for[1]:
+                    raise RuntimeError("pipelined replay: the prepared pass is gone (an un-pipelined step or reset_optimizer() "
+                                       "ran in between) - capture again")
+            else:
+                self._drop_prepared()      # (no-op unless a pipelined step ran in between)
             g_local.replay()
             if dist_on and not in_graph:
                 if rows_x:
@@ -518,6 +568,7 @@ class SurfelTrainer:
                 g_opt.replay()
 
         replay.collective_in_graph = in_graph
+        replay.pipelined = pipeline
         self._graphs = (g_local, g_opt)
         replay.steps = repeat
         # After some replays: ``trainer.regrow_exchange()`` (collective, host-synchronous) returns the number of

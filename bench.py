@@ -161,6 +161,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--binning", choices=["direct", "tile_sort", "radix"], default="direct")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="single GPU: five launches per step (the per-Gaussian backward + Adam of step k and the per-Gaussian "
+                         "forward stage of step k+1 as two kernels) instead of the software-pipelined four "
+                         "(ags_backward_fused_next: both in ONE kernel, -4 %% step time)")
     ap.add_argument("--graph-steps", type=int, default=int(os.environ.get("AGS_BENCH_GRAPH_STEPS", "25")),
                     help="optimisation steps recorded per hipGraph (single GPU); K steps = K/this replays")
     args = ap.parse_args()
@@ -249,7 +253,8 @@ def main():
     many_steps, per_replay = None, 1
     if not args.eager:
         try:
-            one_step = trainer.capture([cam], grads_fn, cap)
+            pipe = not dist_on and not args.no_pipeline and args.binning == "direct"
+            one_step = trainer.capture([cam], grads_fn, cap, pipeline=pipe)
             in_graph = getattr(one_step, "collective_in_graph", False)
             if dist_on:
                 launch_mode = ("hipGraph replay, gradient exchange recorded in the graph" if in_graph
@@ -258,9 +263,13 @@ def main():
             # whole replays of ONE graph and this string describes exactly what was timed
             rep = max(d for d in range(1, max(1, args.graph_steps) + 1) if args.steps % d == 0)
             if rep > 1 and (not dist_on or in_graph):
-                many_steps = trainer.capture([cam], grads_fn, cap, repeat=rep)
+                many_steps = trainer.capture([cam], grads_fn, cap, repeat=rep, pipeline=pipe)
                 per_replay = many_steps.steps
             launch_mode += f", {per_replay} step(s) per graph, {args.steps // per_replay} replay(s) timed"
+            if getattr(one_step, "pipelined", False):
+                launch_mode += ("; software-pipelined: 4 launches per step - tile sort, blend, blend backward, [chain rule + Adam "
+                                "of this step and the per-Gaussian stage (cull, project, key emission) of the next step] - every "
+                                "step still does one of each stage")
         except Exception as e:  # never lose the measurement to a capture problem
             launch_mode = f"eager (graph capture failed: {type(e).__name__})"
             many_steps, per_replay = None, 1
@@ -406,8 +415,10 @@ def main():
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                        "stage_mean_ms": {k: round(v, 4) for k, v in stage_mean_ms.items()},
                        "stage_timing": f"HIP events on the launch stream around every stage of {args.steps} eager steps "
-                                       "run right after the timed region (medians); an event pair reads ~3 us more than "
-                                       "rocprofv3's kernel duration"},
+                                       "run right after the timed region (medians; the un-pipelined five-launch form of "
+                                       "the step: `preprocess` and `preprocess_bwd` are separate kernels there, one "
+                                       "launch in the timed region); an event pair reads ~3 us more than rocprofv3's "
+                                       "kernel duration"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": sb[dom],

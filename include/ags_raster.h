@@ -237,6 +237,29 @@ int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* 
                  const AgsPerGaussian* per_gaussian, const AgsImageGrads* dout,
                  const AgsGaussianGrads* din, const AgsWorkspace* ws, ags_stream_t stream);
 
+/* Software-pipelined optimisation step (single view per step, single rank, AGS_BIN_DIRECT): the per-Gaussian kernels
+ * of consecutive steps in ONE launch.  The last kernel of step k (chain rule + Adam over the row set's members) and the
+ * first kernel of step k + 1 (cull + project + key emission over all surfels) are neighbours in a training loop
+ * (gaussian_map.py:77-127: optimizer.step() of one iteration, render of the next) and the second needs the first only
+ * row by row, so
+ *   ags_backward_fused_next  = ags_backward with din->fused_adam (required, with state_rows; in->raw_params required), whose per-Gaussian
+ *                              launch also runs the per-Gaussian stage of the NEXT forward pass: camera `next_cam` into
+ *                              workspace `next_ws` (may be `ws` itself: the blend backward is done with it by then) and
+ *                              `next_per_gaussian->radii`; `next_per_gaussian->touched` must be din->touched;
+ *   ags_forward_resume       = the rest of that forward pass (tile sort + blend) - call it INSTEAD of ags_forward for
+ *                              the view that was handed to ags_backward_fused_next, with the same camera contents.
+ * The next view's matrices must be in place when ags_backward_fused_next runs.  To leave the pipeline (the prepared
+ * pass is not wanted after all) re-initialise `next_ws` with ags_workspace_init before its next ags_forward - the
+ * prepared pass has already taken key slots in it.  `rows_hint`: about how many rows the row set holds (it lives on the
+ * device; 0 = unknown) - sizes the part of the launch that walks the list, any value is correct.  Results are identical
+ * to ags_backward + ags_forward. */
+int ags_backward_fused_next(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* fwd,
+                            const AgsPerGaussian* per_gaussian, const AgsImageGrads* dout, const AgsGaussianGrads* din,
+                            const AgsWorkspace* ws, const AgsCamera* next_cam, const AgsPerGaussian* next_per_gaussian,
+                            const AgsWorkspace* next_ws, int32_t rows_hint, ags_stream_t stream);
+int ags_forward_resume(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* out,
+                       const AgsPerGaussian* per_gaussian, const AgsWorkspace* ws, ags_stream_t stream);
+
 /* Copies the status block to host memory: enqueues a D2H copy and waits for the stream. */
 int ags_read_status(const AgsWorkspace* ws, AgsStatus* host_out, ags_stream_t stream);
 

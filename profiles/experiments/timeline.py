@@ -21,6 +21,7 @@ ap.add_argument("--w", type=int, default=1200)
 ap.add_argument("--room", default="office0")
 ap.add_argument("--mult", type=float, default=1.0)
 ap.add_argument("--binning", default="direct")
+ap.add_argument("--pipeline", action="store_true", help="software-pipelined steps (4 launches)")
 ap.add_argument("--graph", type=int, default=0, help="stamp the LAST step of a hipGraph of this many steps (0: one eager step)")
 args = ap.parse_args()
 
@@ -49,20 +50,21 @@ P = args.h * args.w
 gen = torch.Generator().manual_seed(1234)
 d_img = [(torch.randn(c, args.h, args.w, generator=gen) / P).to(dev) for c in (3, 3, 1)]
 fn = lambda v, st: (d_img[0], d_img[1], d_img[2], None, None)
+nxt = cam if args.pipeline else None
 for _ in range(30):
-    tr.step([cam], fn, cap)
+    tr.step([cam], fn, cap, next_cam=nxt)
 torch.cuda.synchronize()
 NW = 16384
 buf = torch.zeros(8 * NW * 8, dtype=torch.int64, device=dev)
 lib.ags_debug_timeline.argtypes = [C.c_void_p]
 if args.graph:
-    replay = tr.capture([cam], fn, cap, repeat=args.graph)
+    replay = tr.capture([cam], fn, cap, repeat=args.graph, pipeline=args.pipeline)
     replay(); torch.cuda.synchronize()
 lib.ags_debug_timeline(buf.data_ptr())
 if args.graph:
     replay()            # every step of the graph stamps the same slots: the last one's stamps survive
 else:
-    tr.step([cam], fn, cap)
+    tr.step([cam], fn, cap, next_cam=nxt)
 torch.cuda.synchronize()
 lib.ags_debug_timeline(None)
 t = buf.cpu().numpy().reshape(8, NW, 8).astype(np.int64)

@@ -1,0 +1,160 @@
+"""Software-pipelined optimisation step (``ags_backward_fused_next`` + ``ags_forward_resume``): the per-Gaussian launch
+of step k (chain rule + Adam over the row set) also runs the per-Gaussian stage of step k + 1.  Must give what
+``ags_backward`` + ``ags_forward`` give - the reference's loop is optimizer.step() then the next render
+(/root/reference/mapping/gaussian_map.py:77-127)."""
+import pytest
+import torch
+
+from _scenes import room_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n=9000, h=136, w=240, views=4, seed=5):
+    from active_gs_amd import raster_api as api
+    dev = torch.device("cuda:0")
+    cams = []
+    for view in range(views):
+        _, S = room_case(n, h, w, view=view, seed=seed)
+        cams.append(api.Camera(S.image_height, S.image_width, S.tanfovx, S.tanfovy, S.viewmatrix.to(dev),
+                               S.projmatrix.to(dev), S.bg.to(dev)))
+    gen = torch.Generator().manual_seed(6)
+    d = [(torch.randn(c, h, w, generator=gen) / (h * w)).to(dev) for c in (3, 3, 1)]
+    return dev, cams, (lambda v, st: (d[0], d[1], d[2], None, None))
+
+
+def _trainer(n, dev, seed=5, scale_boost=0.0):
+    from active_gs_amd.synthetic import make_room_scene
+    from active_gs_amd.trainer import SurfelTrainer
+    raw = {k: v.to(dev) for k, v in make_room_scene(n, seed=seed).items()}
+    raw["scales"][:, :2] += scale_boost
+    return SurfelTrainer(raw)
+
+
+@pytest.mark.parametrize("n,h,w,boost", [(9000, 136, 240, 0.0), (3000, 96, 128, 1.2), (40000, 340, 600, 0.0)])
+def test_prepared_pass_is_bitwise_the_plain_forward(agslib, n, h, w, boost):
+    """After a pipelined step the prepared view, resumed, must be bit for bit the plain forward of the same parameters
+    (same records, same keys up to their order inside a tile, which the sort removes), with the same radii, status
+    and row set."""
+    from active_gs_amd import raster_api as api
+    dev, cams, fn = _setup(n, h, w)
+    tr = _trainer(n, dev, scale_boost=boost)
+    cap = 1 << 21
+    tr.step([cams[0]], fn, cap)                              # plain step: fills the row set with view 0
+    tr.step([cams[1]], fn, cap, next_cam=cams[2])            # pipelined: view 2 is prepared
+    assert tr._prepared is not None
+    st = tr.state_for(h, w, cap)
+    g = tr.gaussians()
+    count_before = int(tr.rows.count.item())
+    api.forward(cams[2], g, st, touched=tr.rows, resume=True)
+    torch.cuda.synchronize()
+    got = dict(rgb=st.rgb.clone(), normal=st.normal.clone(), depth=st.depth.clone(), opacity=st.opacity.clone(),
+               confidence=st.confidence.clone(), radii=st.radii.clone())
+    info_a = api.read_status(st)
+    api.init_workspace(st, n, h, w)
+    api.forward(cams[2], g, st, touched=tr.rows)
+    torch.cuda.synchronize()
+    info_b = api.read_status(st)
+    for k in ("rgb", "normal", "depth", "opacity", "confidence", "radii"):
+        assert torch.equal(got[k], getattr(st, k)), k
+    for k in ("num_instances", "num_visible", "max_tile_instances", "overflow"):
+        assert info_a[k] == info_b[k], (k, info_a, info_b)
+    assert info_a["num_visible"] > 0 and not info_a["overflow"]
+    # the plain forward found nothing new to insert; the list holds every member once
+    count = int(tr.rows.count.item())
+    assert count == count_before
+    listed = tr.rows.rows[:count].long()
+    assert listed.unique().numel() == count
+    assert torch.equal(torch.sort(listed).values, torch.nonzero(tr.rows.member.bool()).flatten())
+    assert bool((tr.rows.member.bool() | (st.radii <= 0)).all())      # every visible surfel is a member
+
+
+def test_pipelined_training_matches_plain_training(agslib):
+    from active_gs_amd import raster_api as api
+    n, h, w = 9000, 136, 240
+    dev, cams, fn = _setup(n, h, w)
+    schedule = [0, 1, 2, 3, 0, 2, 1, 1, 3]
+    out = {}
+    for mode in ("plain", "pipelined"):
+        tr = _trainer(n, dev)
+        for k, v in enumerate(schedule):
+            nxt = cams[schedule[k + 1]] if (mode == "pipelined" and k + 1 < len(schedule)) else None
+            tr.step([cams[v]], fn, 1 << 20, next_cam=nxt)
+        torch.cuda.synchronize()
+        assert tr._prepared is None
+        count = int(tr.rows.count.item())
+        out[mode] = dict(params=[p.clone() for p in tr.params], members=torch.sort(tr.rows.rows[:count]).values.clone(),
+                         m=[x.clone() for x in tr.optim.exp_avg], steps=int(tr.optim.device_clock[0].item()))
+    assert out["plain"]["steps"] == out["pipelined"]["steps"] == len(schedule)
+    assert torch.equal(out["plain"]["members"], out["pipelined"]["members"])
+    # (float atomics in the blend backward: two runs differ in the last bits whatever the launch structure)
+    for a, b in zip(out["plain"]["m"], out["pipelined"]["m"]):
+        assert float((a - b).abs().sum()) <= 1e-3 * float(a.abs().sum()) + 1e-12
+    for a, b in zip(out["plain"]["params"], out["pipelined"]["params"]):
+        diff = (a - b).abs()
+        assert float(diff.mean()) < 2e-6 and float((diff > 1e-4).float().mean()) < 0.01
+
+
+def test_pipelined_graph_replay_and_leaving_the_pipeline(agslib):
+    from active_gs_amd import raster_api as api
+    n, h, w = 9000, 136, 240
+    dev, cams, fn = _setup(n, h, w)
+    cap = 1 << 20
+    out = {}
+    for mode in ("plain", "pipelined"):
+        tr = _trainer(n, dev)
+        tr.step([cams[0]], fn, cap)
+        replay = tr.capture([cams[0]], fn, cap, repeat=3, pipeline=(mode == "pipelined"))
+        assert replay.pipelined == (mode == "pipelined") and replay.steps == 3
+        replay(); replay()
+        tr.step([cams[1]], fn, cap)                  # an un-pipelined step: drops the prepared pass
+        assert tr._prepared is None
+        torch.cuda.synchronize()
+        assert not api.read_status(tr.state_for(h, w, cap))["overflow"]
+        if mode == "pipelined":
+            with pytest.raises(RuntimeError):
+                replay()                             # the graph starts at a tile sort: nothing is prepared any more
+        out[mode] = dict(params=[p.clone() for p in tr.params], steps=int(tr.optim.device_clock[0].item()))
+    # pipelined capture takes one eager priming step
+    assert out["pipelined"]["steps"] == out["plain"]["steps"] + 1 == 1 + 1 + 6 + 1
+    # one more step of the same view moves the parameters a little: compare against a plain run with that step too
+    tr = _trainer(n, dev)
+    for v in [0, 0, 0, 0, 0, 0, 0, 0, 1]:
+        tr.step([cams[v]], fn, cap)
+    torch.cuda.synchronize()
+    for a, b in zip(tr.params, out["pipelined"]["params"]):
+        diff = (a - b).abs()
+        assert float(diff.mean()) < 2e-6 and float((diff > 1e-4).float().mean()) < 0.01
+
+
+def test_fused_next_argument_checks(agslib):
+    """ags_backward_fused_next refuses what it cannot do: no fused Adam, another binning mode, a foreign row set."""
+    from active_gs_amd import raster_api as api
+    from active_gs_amd import _lib
+    n, h, w = 3000, 96, 128
+    dev, cams, fn = _setup(n, h, w)
+    tr = _trainer(n, dev)
+    st = tr.state_for(h, w, 1 << 18)
+    g = tr.gaussians()
+    api.forward(cams[0], g, st, touched=tr.rows)
+    d = fn(0, st)
+    with pytest.raises(RuntimeError):       # no fused optimiser step
+        api.backward(cams[0], g, st, *d, grads=tr.slab.grads, touched=tr.rows, next_view=(cams[1], st))
+    other = api.RowSet(n, dev)
+    fused = (tr.optim.tensors_struct(tr.slab.as_list()), tr.optim.eps)
+    with pytest.raises(RuntimeError):       # the next pass must insert into the optimiser's row set
+        lib = _lib.load()
+        cs, gs = cams[0].c_struct(), g.c_struct()
+        im, pg, ws = st.images_struct(), st.per_gaussian_struct(), st.ws_struct()
+        import ctypes as C
+        dout = _lib.AgsImageGrads(_lib.ptr(d[0]), _lib.ptr(d[1]), _lib.ptr(d[2]), None, None)
+        din = _lib.AgsGaussianGrads(None, None, None, None, None, None, 0)
+        clock, lrs, b1, b2 = tr.optim.tick_args()
+        din.adam_clock = _lib.ptr(clock)
+        din.touched = tr.rows.c_struct()
+        din.fused_adam = C.cast(C.pointer(fused[0]), C.c_void_p)
+        cs2, pg2, ws2 = cams[1].c_struct(), st.per_gaussian_struct(other), st.ws_struct()
+        _lib.check(lib.ags_backward_fused_next(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(dout), C.byref(din),
+                                               C.byref(ws), C.byref(cs2), C.byref(pg2), C.byref(ws2), 0,
+                                               torch.cuda.current_stream().cuda_stream), "ags_backward_fused_next")
+    torch.cuda.synchronize()
