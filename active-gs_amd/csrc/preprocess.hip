@@ -704,13 +704,16 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
 // Every row is projected exactly once; no workgroup waits for another.  Saved per step: one kernel boundary (~2.5 us
 // inside a replayed graph), one launch ramp and drain (~4 us), and the shorter of the two latency chains.
 template <bool AGG>
+#ifndef AGS_FUSED_SUB
+#define AGS_FUSED_SUB 1       // (2 and 4 measured the same step time: the launch's ramp and drain, not its waves, are the rest)
+#endif
 #ifndef AGS_FUSED_WAVES
 #define AGS_FUSED_WAVES 3     // register budget: 3 waves per SIMD (168 VGPRs)
 #endif
 __global__ __launch_bounds__(AGS_PRE_THREADS) __attribute__((amdgpu_waves_per_eu(AGS_FUSED_WAVES, AGS_FUSED_WAVES))) void ags_k_rows_adam_preprocess(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsAdamArgs adam,
-    AgsNextPre nx, int rows_blocks) {
+    AgsNextPre nx, int rows_blocks, int n_blocks) {
     __shared__ AgsEmitRec emit_rows[AGS_PRE_THREADS];
     if ((int)blockIdx.x < rows_blocks) {
         const int wave = threadIdx.x >> 6;
@@ -718,8 +721,17 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) __attribute__((amdgpu_waves_per_eu
                                     rows_blocks * (AGS_PRE_THREADS / 64), &nx, emit_rows + (threadIdx.x & ~63));
         return;
     }
-    ags_preprocess_block<2, AGG, true>(nx.F, nx.V, nx.P, in, nx.geom, nullptr, nullptr, nx.radii, nullptr, nullptr,
-                                       nx.tile_count, nx.dgeom, out.touched, nx.direct, (int)blockIdx.x - rows_blocks);
+    // AGS_FUSED_SUB blocks of 256 rows per forward workgroup, one after the other: the member-row waves hold most wave
+    // slots for the whole launch, so the forward rows want FEW waves (in steady state their lanes are all culled - every
+    // visible surfel is a member - and a pass over 256 rows is ~4.5 us)
+    const int fb = ((int)blockIdx.x - rows_blocks) * AGS_FUSED_SUB;
+#pragma unroll 1
+    for (int sub = 0; sub < AGS_FUSED_SUB; ++sub) {
+        if (fb + sub >= n_blocks) break;       // workgroup-uniform
+        if (sub) __syncthreads();              // the body's LDS is reused
+        ags_preprocess_block<2, AGG, true>(nx.F, nx.V, nx.P, in, nx.geom, nullptr, nullptr, nx.radii, nullptr, nullptr,
+                                           nx.tile_count, nx.dgeom, out.touched, nx.direct, fb + sub);
+    }
 }
 
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
@@ -755,13 +767,13 @@ void ags_launch_rows_adam_preprocess(const AgsFrame& F, const AgsCamera& cam, co
     int rows_blocks = (int)((want + rows_per_block - 1) / rows_per_block);
     if (rows_blocks < 1) rows_blocks = 1;
     if (rows_blocks > 4096) rows_blocks = 4096;
-    const dim3 grid(rows_blocks + L2.n_blocks), block(AGS_PRE_THREADS);
+    const dim3 grid(rows_blocks + (L2.n_blocks + AGS_FUSED_SUB - 1) / AGS_FUSED_SUB), block(AGS_PRE_THREADS);
     if (L2.num_tiles <= AGS_AGG_MAX_TILES)
         hipLaunchKernelGGL(ags_k_rows_adam_preprocess<true>, grid, block, 0, s, F, cam.viewmatrix, cam.projmatrix, in, radii,
-                           (AgsGeomGrad*)(ws + L.dgeom), din, ags_adam_args(*din.fused_adam), nx, rows_blocks);
+                           (AgsGeomGrad*)(ws + L.dgeom), din, ags_adam_args(*din.fused_adam), nx, rows_blocks, L2.n_blocks);
     else
         hipLaunchKernelGGL(ags_k_rows_adam_preprocess<false>, grid, block, 0, s, F, cam.viewmatrix, cam.projmatrix, in, radii,
-                           (AgsGeomGrad*)(ws + L.dgeom), din, ags_adam_args(*din.fused_adam), nx, rows_blocks);
+                           (AgsGeomGrad*)(ws + L.dgeom), din, ags_adam_args(*din.fused_adam), nx, rows_blocks, L2.n_blocks);
 }
 
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
