@@ -53,7 +53,12 @@ def candidates(frame: dict, depth_smooth: torch.Tensor, pred: Optional[dict], er
     dev = rgb.device
     h, w = rgb.shape[-2:]
     P = h * w
-    kinv = torch.linalg.inv(frame["intrinsic"].to(dev).float()).contiguous()
+    # 3x3 inverse on the HOST (9 floats down, 9 up): on the GPU torch.linalg.inv is a rocSOLVER LU - a handful of tiny
+    # launches (~0.9 ms per keyframe in the mapper loop) and, the first time in a process, the load of that library
+    kinv = frame.get("intrinsic_inv")
+    if kinv is None:
+        kinv = torch.linalg.inv(frame["intrinsic"].detach().float().cpu())
+    kinv = kinv.to(dev).float().contiguous()
     ext = frame["extrinsic"].to(dev).float().contiguous()
     f = _lib.AgsKeyframe(h, w, ptr(rgb), ptr(depth), ptr(kinv), ptr(ext))
     keep_alive = [rgb, depth, kinv, ext]
