@@ -31,8 +31,9 @@ def _trainer(n, dev, seed=5, scale_boost=0.0):
     return SurfelTrainer(raw)
 
 
-@pytest.mark.parametrize("n,h,w,boost", [(9000, 136, 240, 0.0), (3000, 96, 128, 1.2), (40000, 340, 600, 0.0)])
-def test_prepared_pass_is_bitwise_the_plain_forward(agslib, n, h, w, boost):
+@pytest.mark.parametrize("n,h,w,boost,hint", [(9000, 136, 240, 0.0, 0), (3000, 96, 128, 1.2, 0), (40000, 340, 600, 0.0, 0),
+                                              (9000, 136, 240, 0.0, 1), (40000, 340, 600, 0.0, 40)])
+def test_prepared_pass_is_bitwise_the_plain_forward(agslib, n, h, w, boost, hint):
     """After a pipelined step the prepared view, resumed, must be bit for bit the plain forward of the same parameters
     (same records, same keys up to their order inside a tile, which the sort removes), with the same radii, status
     and row set."""
@@ -41,6 +42,7 @@ def test_prepared_pass_is_bitwise_the_plain_forward(agslib, n, h, w, boost):
     tr = _trainer(n, dev, scale_boost=boost)
     cap = 1 << 21
     tr.step([cams[0]], fn, cap)                              # plain step: fills the row set with view 0
+    tr._rows_hint = hint       # 0: sized for the whole map; tiny: the member workgroups stride over the list in many passes
     tr.step([cams[1]], fn, cap, next_cam=cams[2])            # pipelined: view 2 is prepared
     assert tr._prepared is not None
     st = tr.state_for(h, w, cap)
