@@ -415,10 +415,11 @@ def main():
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                        "stage_mean_ms": {k: round(v, 4) for k, v in stage_mean_ms.items()},
                        "stage_timing": f"HIP events on the launch stream around every stage of {args.steps} eager steps "
-                                       "run right after the timed region (medians; the un-pipelined five-launch form of "
-                                       "the step: `preprocess` and `preprocess_bwd` are separate kernels there, one "
-                                       "launch in the timed region); an event pair reads ~3 us more than rocprofv3's "
-                                       "kernel duration"},
+                                       "run right after the timed region (medians"
+                                       + ("; the un-pipelined five-launch form of the step: `preprocess` and "
+                                          "`preprocess_bwd` are separate kernels there, one launch in the timed region"
+                                          if getattr(one_step, "pipelined", False) else "")
+                                       + "); an event pair reads ~3 us more than rocprofv3's kernel duration"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": sb[dom],
