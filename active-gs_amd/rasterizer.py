@@ -18,6 +18,38 @@ import torch.nn as nn
 from . import raster_api as api
 
 SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+         1.445305721320277, -0.5900435899266435)
+
+
+def eval_sh(degree: int, sh: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+    """Real spherical harmonics of degree 0..3 evaluated along unit directions: ``sh`` (N, >= (degree+1)^2, 3),
+    ``dirs`` (N, 3) -> (N, 3), before the +0.5 offset.  The basis, its ordering and signs are the ones the reference tree
+    itself evaluates in its viewer (/root/reference/visualization/gl_render/shaders/gau_vert.glsl:3-18,173-205; the
+    3DGS convention).  Plain torch on whatever device the inputs live on: autograd carries the gradients to the
+    coefficients and, through the direction, to the means - the reference's mapper never takes this branch (it passes
+    ``colors_precomp``, operations.py:709), so there is no kernel for it."""
+    if not 0 <= degree <= 3:
+        raise ValueError("sh_degree must be 0..3")
+    if sh.shape[1] < (degree + 1) ** 2:
+        raise ValueError(f"degree {degree} needs {(degree + 1) ** 2} coefficients per channel, got {sh.shape[1]}")
+    out = SH_C0 * sh[:, 0]
+    if degree > 0:
+        x, y, z = dirs[:, 0:1], dirs[:, 1:2], dirs[:, 2:3]
+        out = out - SH_C1 * y * sh[:, 1] + SH_C1 * z * sh[:, 2] - SH_C1 * x * sh[:, 3]
+        if degree > 1:
+            xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+            out = (out + SH_C2[0] * xy * sh[:, 4] + SH_C2[1] * yz * sh[:, 5] + SH_C2[2] * (2.0 * zz - xx - yy) * sh[:, 6]
+                   + SH_C2[3] * xz * sh[:, 7] + SH_C2[4] * (xx - yy) * sh[:, 8])
+            if degree > 2:
+                out = (out + SH_C3[0] * y * (3.0 * xx - yy) * sh[:, 9] + SH_C3[1] * xy * z * sh[:, 10]
+                       + SH_C3[2] * y * (4.0 * zz - xx - yy) * sh[:, 11]
+                       + SH_C3[3] * z * (2.0 * zz - 3.0 * xx - 3.0 * yy) * sh[:, 12]
+                       + SH_C3[4] * x * (4.0 * zz - xx - yy) * sh[:, 13] + SH_C3[5] * z * (xx - yy) * sh[:, 14]
+                       + SH_C3[6] * x * (xx - 3.0 * yy) * sh[:, 15])
+    return out
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -168,8 +200,12 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is not None:
             raise NotImplementedError("surfels need scale+rotation (the normal is R[:,2]); cov3D_precomp is unsupported")
         if shs is not None:
-            if int(self.raster_settings.sh_degree) != 0:
-                raise NotImplementedError("only SH degree 0 is supported (the reference uses colors_precomp)")
-            colors_precomp = torch.clamp_min(SH_C0 * shs[:, 0, :] + 0.5, 0.0)
+            # view-dependent colour from SH coefficients (N, K, 3): direction = mean - camera centre, normalised; the
+            # result + 0.5 is clamped at 0 (the clamp passes no gradient where it is active, as upstream's `clamped` flag)
+            deg = int(self.raster_settings.sh_degree)
+            campos = self.raster_settings.campos.to(means3D.device, means3D.dtype).reshape(1, 3)
+            dirs = means3D - campos
+            dirs = dirs / dirs.norm(dim=1, keepdim=True).clamp_min(1e-20)
+            colors_precomp = torch.clamp_min(eval_sh(deg, shs, dirs) + 0.5, 0.0)
         return _RasterizeSurfels.apply(means3D, means2D, opacities, confidences, colors_precomp, scales, rotations,
                                        self.raster_settings)

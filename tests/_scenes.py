@@ -35,7 +35,7 @@ def product_settings(S, dev):
     return GaussianRasterizationSettings(
         image_height=S.image_height, image_width=S.image_width, tanfovx=S.tanfovx, tanfovy=S.tanfovy,
         bg=S.bg.to(dev), scale_modifier=S.scale_modifier, viewmatrix=S.viewmatrix.to(dev),
-        projmatrix=S.projmatrix.to(dev), sh_degree=0, campos=(S.campos if S.campos is not None else torch.zeros(3)).to(dev),
+        projmatrix=S.projmatrix.to(dev), sh_degree=int(S.sh_degree), campos=(S.campos if S.campos is not None else torch.zeros(3)).to(dev),
         prefiltered=False, render_mask=mask.to(dev), weight_thres=S.weight_thres, debug=False,
         config=S.config.to(dev))
 

@@ -295,3 +295,40 @@ def test_frame_samplers_pick_the_reference_frames():
     assert isinstance(make_frame_sampler(dict(batch_size=8, active_size=3), cases[0]["frames"]), WeightedFrameSampler)
     with pytest.raises(ValueError):
         make_frame_sampler(dict(sampler_type="nope", batch_size=8, active_size=3), cases[0]["frames"])
+
+
+def test_spherical_harmonics_follow_the_reference_viewer_shader():
+    """eval_sh (the drop-in module's `shs=` branch) against a literal transcription of the SH block of the reference
+    tree's own viewer shader, /root/reference/visualization/gl_render/shaders/gau_vert.glsl:3-18,173-205 - the only
+    statement of the basis the reference holds (its mapper passes colors_precomp)."""
+    from active_gs_amd.rasterizer import eval_sh
+    C0, C1 = 0.28209479177387814, 0.4886025119029199
+    C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+    C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+          1.445305721320277, -0.5900435899266435]
+    rng = np.random.default_rng(3)
+    n = 257
+    sh = rng.standard_normal((n, 16, 3))
+    d = rng.standard_normal((n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for deg in range(4):
+        want = np.zeros((n, 3))
+        for i in range(n):     # the shader, statement by statement (render_mod >= deg, sh_dim = 48)
+            x, y, z = d[i]
+            g = lambda k: sh[i, k]
+            color = C0 * g(0)
+            if deg >= 1:
+                color = color - C1 * y * g(1) + C1 * z * g(2) - C1 * x * g(3)
+                if deg >= 2:
+                    xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+                    color = (color + C2[0] * xy * g(4) + C2[1] * yz * g(5) + C2[2] * (2.0 * zz - xx - yy) * g(6)
+                             + C2[3] * xz * g(7) + C2[4] * (xx - yy) * g(8))
+                    if deg >= 3:
+                        color = (color + C3[0] * y * (3.0 * xx - yy) * g(9) + C3[1] * xy * z * g(10)
+                                 + C3[2] * y * (4.0 * zz - xx - yy) * g(11) + C3[3] * z * (2.0 * zz - 3.0 * xx - 3.0 * yy) * g(12)
+                                 + C3[4] * x * (4.0 * zz - xx - yy) * g(13) + C3[5] * z * (xx - yy) * g(14)
+                                 + C3[6] * x * (xx - 3.0 * yy) * g(15))
+            want[i] = color
+        got = eval_sh(deg, torch.from_numpy(sh), torch.from_numpy(d)).numpy()
+        assert np.abs(got - want).max() < 1e-12, deg
+    with pytest.raises(ValueError):
+        eval_sh(2, torch.zeros(4, 4, 3), torch.zeros(4, 3))
