@@ -88,6 +88,7 @@ def main():
 
     t_grow = t_train = 0.0
     sizes, added = [], []
+    ms0 = torch.cuda.memory_stats(dev)
     t_all0 = time.perf_counter()
     for k, f in enumerate(frames):
         n_add, dt = timed(lambda: tr.add_gaussians(f))
@@ -110,7 +111,11 @@ def main():
         train_ms_per_keyframe=round(1e3 * t_train / args.keyframes, 3),
         final_surfels=sizes[-1], surfels_after_10=sizes[min(9, len(sizes) - 1)],
         added_first=added[0], added_last=added[-1],
-        mean_frame_error=round(float(tr.training_performance.mean()), 5), last_loss=round(tr.last_losses[-1], 5))))
+        mean_frame_error=round(float(tr.training_performance.mean()), 5), last_loss=round(tr.last_losses[-1], 5),
+        # hipMalloc / hipFree calls of torch's caching allocator inside the timed loop (each is a host stall of ~0.1-1 ms)
+        device_mallocs=int(torch.cuda.memory_stats(dev)["num_device_alloc"] - ms0["num_device_alloc"]),
+        device_frees=int(torch.cuda.memory_stats(dev)["num_device_free"] - ms0["num_device_free"]),
+        overflow_retries=int(getattr(tr, "overflow_retries", 0)))))
 
 
 if __name__ == "__main__":
