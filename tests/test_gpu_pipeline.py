@@ -160,3 +160,42 @@ def test_fused_next_argument_checks(agslib):
                                                C.byref(ws), C.byref(cs2), C.byref(pg2), C.byref(ws2), 0,
                                                torch.cuda.current_stream().cuda_stream), "ags_backward_fused_next")
     torch.cuda.synchronize()
+
+
+def test_prepared_pass_in_another_workspace(agslib):
+    """The next view may be of another size: its per-Gaussian stage then goes into that size's own workspace
+    (``next_ws`` != ``ws``) - resumed, it is bit for bit the plain forward."""
+    from active_gs_amd import raster_api as api
+    n = 6000
+    dev, cams_a, fn = _setup(n, 136, 240)
+    _, cams_b, _ = _setup(n, 96, 128)
+    tr = _trainer(n, dev)
+    cap = 1 << 20
+    tr.step([cams_a[0]], fn, cap)
+    tr.step([cams_a[1]], fn, cap, next_cam=cams_b[2])
+    st_b = tr.state_for(96, 128, cap)
+    assert tr._prepared is not None and tr._prepared[0] is st_b and st_b is not tr.state_for(136, 240, cap)
+    g = tr.gaussians()
+    api.forward(cams_b[2], g, st_b, touched=tr.rows, resume=True)
+    torch.cuda.synchronize()
+    got = {k: getattr(st_b, k).clone() for k in ("rgb", "normal", "depth", "opacity", "confidence", "radii")}
+    api.init_workspace(st_b, n, 96, 128)
+    api.forward(cams_b[2], g, st_b, touched=tr.rows)
+    torch.cuda.synchronize()
+    for k, v in got.items():
+        assert torch.equal(v, getattr(st_b, k)), k
+    assert int((st_b.radii > 0).sum()) > 0
+
+
+def test_pipelined_step_reports_an_outgrown_workspace(agslib):
+    """A prepared pass whose tile lists do not fit the workspace is flagged like any other pass (sticky status words):
+    ``check_overflow`` raises instead of training on truncated lists."""
+    n, h, w = 9000, 136, 240
+    dev, cams, fn = _setup(n, h, w)
+    tr = _trainer(n, dev, scale_boost=1.5)
+    tiles = ((h + 15) // 16) * ((w + 15) // 16)
+    cap = 4 * tiles                 # four key slots per tile: far too few
+    tr.step([cams[0]], fn, cap, next_cam=cams[1])
+    tr.step([cams[1]], fn, cap, next_cam=cams[1])
+    with pytest.raises(RuntimeError, match="outgrew"):
+        tr.check_overflow()
