@@ -242,8 +242,12 @@ def main():
     d_img = [(torch.randn(c, H, W, generator=gen) * scale).to(dev) for c in (3, 3, 1)]
     grads_fn = lambda v, st: (d_img[0], d_img[1], d_img[2], None, None)
 
+    # (AGS_BENCH_EAGER_PIPELINE=1: the eager steps are software-pipelined too - for counter passes over the fused
+    # per-Gaussian kernel; the per-stage event profile wants the five-launch form, so it is not the default)
+    eager_next = cam if os.environ.get("AGS_BENCH_EAGER_PIPELINE") == "1" else None
+
     def eager_step():
-        trainer.step([cam], grads_fn, cap)
+        trainer.step([cam], grads_fn, cap, next_cam=eager_next)
 
     for _ in range(3):
         eager_step()  # creates every buffer before capture
