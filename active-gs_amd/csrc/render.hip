@@ -282,10 +282,11 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
                     const float4 gs = ags_lds_read16(&g.slot[s]);         // E0, E1, E2, D0
                     const AgsQuadCoef qc = {gs.x, gs.y, gs.z, gs.w};
                     const float a = ags_alpha_quad(sh, qc, qx, qy);
-                    al[s] = (a >= AGS_ALPHA_MIN && !pix[s].done) ? a : 0.f;
+                    const bool take = a >= AGS_ALPHA_MIN && !pix[s].done;   // (alpha >= 1/255 > 0 when taken: the mask is the test)
+                    al[s] = take ? a : 0.f;
                     d0[s] = gs.w;
+                    any |= take;
                 }
-                any |= al[s] > 0.f;
             }
             if (!__any(any)) continue;
             const uint32_t pos1 = base - rg.x + k + 1;
@@ -771,8 +772,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             const AgsQuadShared sh = {ga.x, ga.y, ga.z};
             const AgsQuadCoef qc = {gs.x, gs.y, gs.z, gs.w};
             const float a = ags_alpha_quad(sh, qc, qx, qy);
-            const float alpha = (a >= AGS_ALPHA_MIN && pos1 <= pg.last) ? a : 0.f;
-            if (!__any(alpha > 0.f)) continue;
+            const bool take = a >= AGS_ALPHA_MIN && pos1 <= pg.last;   // (alpha >= 1/255 > 0 when taken: the mask is the test)
+            if (!__any(take)) continue;
+            const float alpha = take ? a : 0.f;
             // the blend recurrence (ags_blend_bwd_apply without its accumulation)
             const float iom = ags_rcp(1.f - alpha);
             pg.T = pg.T * iom;
