@@ -329,8 +329,12 @@ def main():
     _lib.check(lib.ags_profile_enable(args.steps), "ags_profile_enable")
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        eager_step()
+    profile_note = None
+    try:
+        for _ in range(args.steps):
+            eager_step()
+    except RuntimeError as e:     # e.g. a very long run whose drifting synthetic scene outgrew the workspace sized at its start
+        profile_note = f"per-stage pass stopped early: {e}"
     torch.cuda.synchronize()
     eager_elapsed = time.perf_counter() - t1
 
@@ -402,6 +406,7 @@ def main():
                        "gaussians": N_GAUSS, "image": [H, W], "views_per_gpu": 1, "visible": V,
                        "tile_instances": I, "parallelism": f"view-parallel dp{world}",
                        "overflow": bool(info["overflow"]) or bool(info["overflow_passes"]) or refused > 0,
+                       "overflow_passes": int(info["overflow_passes"]), "profile_note": profile_note,
                        "binning": args.binning,
                        "launch": launch_mode,
                        "optimizer": ("row-set Adam fused into the per-Gaussian backward (exact: untouched rows "
