@@ -20,7 +20,7 @@ class AgsCamera(C.Structure):
                 ("tanfovy", C.c_float), ("scale_modifier", C.c_float), ("weight_thres", C.c_float),
                 ("normalize_depth", C.c_int32), ("perpix_depth", C.c_int32), ("want_stats", C.c_int32),
                 ("front_only", C.c_int32), ("viewmatrix", c_f32p), ("projmatrix", c_f32p), ("bg", c_f32p),
-                ("render_mask", c_f32p)]
+                ("render_mask", c_f32p), ("config", c_f32p)]
 
 
 class AgsGaussians(C.Structure):
@@ -95,8 +95,8 @@ class AgsCandidates(C.Structure):
     _fields_ = [("means", c_f32p), ("rotations", c_f32p), ("harmonics", c_f32p), ("select", C.c_void_p)]
 
 
-EXPORTS = ["ags_workspace_bytes", "ags_workspace_init", "ags_forward", "ags_forward_batch",
-           "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_backward_fused_next", "ags_forward_resume", "ags_read_status", "ags_adam_step",
+EXPORTS = ["ags_workspace_bytes", "ags_workspace_region", "ags_workspace_init", "ags_workspace_discard_pass", "ags_forward", "ags_forward_batch",
+           "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_backward_fused_next", "ags_forward_resume", "ags_read_status", "ags_read_status_async", "ags_adam_step",
            "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_rows_index", "ags_adam_step_gathered", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_smooth_depth", "ags_densify_candidates",
            "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_compact_plan_bytes", "ags_compact_plan",
            "ags_compact_rows", "ags_profile_enable", "ags_profile_read",
@@ -123,8 +123,13 @@ def load() -> C.CDLL:
     lib = C.CDLL(path)
     lib.ags_workspace_bytes.restype = C.c_size_t
     lib.ags_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64]
+    lib.ags_workspace_region.restype = C.c_int
+    lib.ags_workspace_region.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.ags_workspace_init.restype = C.c_int
     lib.ags_workspace_init.argtypes = [C.POINTER(AgsWorkspace), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.ags_workspace_discard_pass.restype = C.c_int
+    lib.ags_workspace_discard_pass.argtypes = [C.POINTER(AgsWorkspace), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.ags_forward.restype = C.c_int
     lib.ags_forward.argtypes = [C.POINTER(AgsCamera), C.POINTER(AgsGaussians), C.POINTER(AgsImages),
                                 C.POINTER(AgsPerGaussian), C.POINTER(AgsWorkspace), C.c_void_p]
@@ -151,6 +156,8 @@ def load() -> C.CDLL:
                                        C.POINTER(AgsWorkspace), C.c_void_p]
     lib.ags_read_status.restype = C.c_int
     lib.ags_read_status.argtypes = [C.POINTER(AgsWorkspace), C.POINTER(AgsStatus), C.c_void_p]
+    lib.ags_read_status_async.restype = C.c_int
+    lib.ags_read_status_async.argtypes = [C.POINTER(AgsWorkspace), C.c_void_p, C.c_void_p]
     lib.ags_adam_step.restype = C.c_int
     lib.ags_adam_step.argtypes = [C.POINTER(AgsAdamTensors), C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]
     lib.ags_adam_step_device.restype = C.c_int

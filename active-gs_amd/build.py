@@ -71,18 +71,37 @@ def is_stale() -> bool:
         return f.read().strip() != source_digest()
 
 
+# A second build of the same library whose blend backward forms its per-surfel sums with EXACT f32 matrix instructions
+# (render.hip -DAGS_BWD_F32_MFMA: 16 v_mfma_f32_16x16x4_f32 per flush instead of 6 bf16 ones on hi/lo splits).  Not used
+# by the product; bench.py times it beside the default (`ms_per_step_f32_exact`, a child process with AGS_LIB_PATH) so
+# that what the bf16 split buys is on the record next to the headline.
+LIB_F32 = os.path.join(LIBDIR, "libags_raster_f32exact.so")
+VARIANT_FLAGS = {"f32exact": {"render.hip": ["-DAGS_BWD_F32_MFMA"]}}
+
+
+def _link(hipcc, objs, out):
+    tmp = out + ".tmp"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    os.replace(tmp, out)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 and link libags_raster.so. Returns its path."""
-    if not force and not is_stale():
+    """Compile every HIP source for gfx950 and link libags_raster.so (and the f32-exact variant, see LIB_F32).
+    Returns the product library's path."""
+    if not force and not is_stale() and os.path.exists(LIB_F32):
         return LIB
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
 
-    def compile_one(src):
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+    def compile_one(job):
+        src, extra, suffix = job
+        obj = os.path.join(objdir, src.replace(".hip", suffix + ".o"))
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
@@ -90,14 +109,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(r.stderr)
         return obj
 
+    jobs = [(s, [], "") for s in SOURCES] + [(s, fl, "_" + tag) for tag, m in VARIANT_FLAGS.items() for s, fl in m.items()]
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
-    tmp = LIB + ".tmp"
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp],
-                       capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stderr}")
-    os.replace(tmp, LIB)
+        objs = list(ex.map(compile_one, jobs))
+    main_objs = objs[:len(SOURCES)]
+    _link(hipcc, main_objs, LIB)
+    f32_objs = [objs[len(SOURCES)] if s == "render.hip" else o for s, o in zip(SOURCES, main_objs)]
+    _link(hipcc, f32_objs, LIB_F32)
     with open(STAMP, "w") as f:
         f.write(source_digest() + "\n")
     return LIB

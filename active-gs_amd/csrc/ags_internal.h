@@ -89,6 +89,7 @@ static inline AgsFrame ags_make_frame(const AgsCamera* c) {
     F.fx = F.W / (2.0f * c->tanfovx); F.fy = F.H / (2.0f * c->tanfovy);
     F.scale_mod = c->scale_modifier;
     F.perpix_depth = c->perpix_depth; F.front_only = c->front_only;
+    F.cfg = c->config;
     return F;
 }
 
@@ -147,8 +148,9 @@ struct AgsViewStride {
 struct AgsIdList { const uint32_t* ids; int stride; };
 // emit: 0 = nothing (radix mode counts rect tiles only), 1 = count the reachable tiles (tile-sort mode),
 // 2 = AGS_BIN_DIRECT: take a key slot in the tile's own slot range and write the key
+// (cam.config != NULL: the kernel also zero-fills pg.importance / pg.count, see AgsCamera.config)
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
-                           const AgsLayout& L, int* radii, int emit, const AgsRowSet& touched,
+                           const AgsLayout& L, const AgsPerGaussian& pg, int emit,
                            const AgsViewStride& vs, hipStream_t s);
 void ags_launch_direct_sort(char* ws, const AgsLayout& L, const AgsViewStride& vs, hipStream_t s);
 // AGS_BIN_DIRECT bookkeeping, kept in the (otherwise radix-only) digit-total words of the workspace: 64 partial
@@ -262,6 +264,16 @@ void ags_launch_prune_keep(int n, const float* prune_mask, const float* raw_opac
 void ags_tl_set_preprocess(void*); void ags_tl_set_binning(void*); void ags_tl_set_render(void*);
 
 #if defined(__HIPCC__)
+// ---- AgsCamera.config: the reference hands its five configuration floats over as a DEVICE tensor it has just built
+// (operations.py:697-699); reading them back would cost the caller a stream synchronisation per view, so the kernels
+// take them where they are: wave-uniform scalar loads through the kernel-argument pointer.  cfg == nullptr: the host's
+// ints (every other caller).
+__device__ __forceinline__ void ags_frame_flags(AgsFrame& F) {
+    if (F.cfg) { F.perpix_depth = F.cfg[2] > 0.f ? 1 : 0; F.front_only = F.cfg[4] > 0.f ? 1 : 0; }
+}
+__device__ __forceinline__ int ags_cfg_flag(const float* cfg, int k, int host_value) {
+    return cfg ? (cfg[k] > 0.f ? 1 : 0) : host_value;
+}
 // ---- wave64 helpers (gfx950): DPP reductions, no LDS, no ds_bpermute
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ int ags_dpp_i(int v) {

@@ -36,6 +36,35 @@ int ags_workspace_init(const AgsWorkspace* ws, int32_t n, int32_t h, int32_t w, 
     return AGS_OK;
 }
 
+int ags_workspace_region(int32_t n, int32_t h, int32_t w, int64_t max_instances, int32_t binning_mode, int32_t region,
+                         size_t* offset, size_t* bytes) {
+    if (n < 0 || h <= 0 || w <= 0 || max_instances < 1 || !offset || !bytes) return AGS_E_INVALID;
+    const AgsLayout L = ags_make_layout(n, h, w, max_instances);
+    const size_t P = (size_t)h * w;
+    switch (region) {
+        case AGS_REGION_FINAL_T: *offset = L.final_T; *bytes = P * 4; return AGS_OK;
+        case AGS_REGION_N_CONTRIB: *offset = L.n_contrib; *bytes = P * 4; return AGS_OK;
+        case AGS_REGION_GEOM: *offset = L.geom; *bytes = (size_t)n * sizeof(AgsGeom); return AGS_OK;
+        case AGS_REGION_RANGES: *offset = L.ranges; *bytes = (size_t)L.num_tiles * 8; return AGS_OK;
+        case AGS_REGION_KEYS:
+            if (binning_mode == AGS_BIN_RADIX) return AGS_E_INVALID;
+            *offset = binning_mode == AGS_BIN_DIRECT ? L.keys1 : L.keys0; *bytes = (size_t)L.cap * 8; return AGS_OK;
+        case AGS_REGION_IDS:
+            if (binning_mode != AGS_BIN_RADIX) return AGS_E_INVALID;
+            *offset = (ags_sort_passes(L.num_tiles) & 1) ? L.vals1 : L.vals0; *bytes = (size_t)L.cap * 4; return AGS_OK;
+        default: return AGS_E_INVALID;
+    }
+}
+
+int ags_workspace_discard_pass(const AgsWorkspace* ws, int32_t n, int32_t h, int32_t w, ags_stream_t stream) {
+    if (!ws || !ws->ptr || n < 0 || h <= 0 || w <= 0 || ws->max_instances < 1) return AGS_E_INVALID;
+    const AgsLayout L = ags_make_layout(n, h, w, ws->max_instances);
+    if (ws->bytes < L.total) return AGS_E_WORKSPACE;
+    // everything behind the status block: partial sums / digit totals, tile ranges, tile counters, tile fills
+    if (hipMemsetAsync((char*)ws->ptr + L.totals, 0, L.clear_bytes - L.totals, (hipStream_t)stream) != hipSuccess) return AGS_E_LAUNCH;
+    return AGS_OK;
+}
+
 static const AgsViewStride kOneView = {0, 0, 0, 1};
 
 int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* out,
@@ -45,7 +74,7 @@ int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* o
     if (!cam->viewmatrix || !cam->projmatrix || !cam->bg) return AGS_E_INVALID;
     if (in->n > 0 && !pg->radii) return AGS_E_INVALID;
     if (!out->rgb || !out->normal || !out->depth || !out->opacity || !out->confidence) return AGS_E_INVALID;
-    if (in->n > 0 && cam->want_stats && (!pg->importance || !pg->count)) return AGS_E_INVALID;
+    if (in->n > 0 && (cam->want_stats || cam->config) && (!pg->importance || !pg->count)) return AGS_E_INVALID;
     if (in->n > 0 && (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences))
         return AGS_E_INVALID;
     if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll) return AGS_E_INVALID;
@@ -67,7 +96,7 @@ int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* o
     }
     if (in->n > 0) {
         { StageScope t(AGS_STAGE_PREPROCESS, s);
-          ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, radix ? 0 : direct ? 2 : 1, pg->touched, kOneView, s); }
+          ags_launch_preprocess(F, *cam, *in, base, L, *pg, radix ? 0 : direct ? 2 : 1, kOneView, s); }
         { StageScope t(AGS_STAGE_BINNING, s);
           if (radix) ags_launch_binning(F, *in, base, L, s);
           else if (direct) ags_launch_direct_sort(base, L, kOneView, s);
@@ -90,7 +119,7 @@ int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* i
     if (in->n <= 0 || cam->image_height <= 0 || cam->image_width <= 0) return AGS_E_INVALID;
     if (!cam->viewmatrix || !cam->projmatrix || !cam->bg || !pg->radii) return AGS_E_INVALID;
     if (!out->rgb || !out->normal || !out->depth || !out->opacity || !out->confidence) return AGS_E_INVALID;
-    if (cam->want_stats && (!pg->importance || !pg->count)) return AGS_E_INVALID;
+    if ((cam->want_stats || cam->config) && (!pg->importance || !pg->count)) return AGS_E_INVALID;
     if (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences) return AGS_E_INVALID;
     if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll) return AGS_E_INVALID;
     if (ws->binning_mode != AGS_BIN_TILE_SORT && ws->binning_mode != AGS_BIN_DIRECT) return AGS_E_INVALID;
@@ -103,7 +132,7 @@ int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* i
     const AgsFrame F = ags_make_frame(cam);
     AgsViewStride vs;
     vs.ws = (long long)L.total; vs.px = (long long)cam->image_height * cam->image_width; vs.n = in->n; vs.views = views;
-    ags_launch_preprocess(F, *cam, *in, base, L, pg->radii, direct ? 2 : 1, pg->touched, vs, s);
+    ags_launch_preprocess(F, *cam, *in, base, L, *pg, direct ? 2 : 1, vs, s);
     if (direct) ags_launch_direct_sort(base, L, vs, s); else ags_launch_tile_binning(F, *in, base, L, vs, s);
     ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, vs, direct, s);
     return ags_check_launch();
@@ -167,10 +196,10 @@ static int ags_backward_impl(const AgsCamera* cam, const AgsGaussians* in, const
     }
     if (din->pack_segment && (!din->touched.rows || !din->touched.count || din->fused_adam || din->accumulate == 2 ||
                               din->pack_capacity < 0)) return AGS_E_INVALID;
-    { StageScope t(AGS_STAGE_RENDER_BWD, s);
-      ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, tick, kOneView, ws->binning_mode == AGS_BIN_DIRECT, s); }
     if (next_cam) {
         // pipelined: single view, single rank, fused Adam on raw parameters, one-pass binning on both workspaces
+        // (all of this is checked BEFORE the blend backward is enqueued: a refused call must leave dgeom and the Adam
+        // clock exactly as they were)
         if (!next_pg || !next_ws || !next_ws->ptr || !next_pg->radii || !din->fused_adam || !in->raw_params) return AGS_E_INVALID;
         if (!din->fused_adam->state_rows) return AGS_E_INVALID;   // the pipelined kernel reads the interleaved moments
         if (!next_cam->viewmatrix || !next_cam->projmatrix || next_cam->image_height <= 0 || next_cam->image_width <= 0) return AGS_E_INVALID;
@@ -183,6 +212,11 @@ static int ags_backward_impl(const AgsCamera* cam, const AgsGaussians* in, const
         const AgsLayout L2 = ags_make_layout(in->n, next_cam->image_height, next_cam->image_width, next_ws->max_instances);
         if (next_ws->bytes < L2.total) return AGS_E_WORKSPACE;
         if (ags_direct_tile_cap(L2) < 1) return AGS_E_WORKSPACE;
+    }
+    { StageScope t(AGS_STAGE_RENDER_BWD, s);
+      ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, tick, kOneView, ws->binning_mode == AGS_BIN_DIRECT, s); }
+    if (next_cam) {
+        const AgsLayout L2 = ags_make_layout(in->n, next_cam->image_height, next_cam->image_width, next_ws->max_instances);
         const AgsFrame F2 = ags_make_frame(next_cam);
         StageScope t(AGS_STAGE_PREPROCESS_BWD, s);
         ags_launch_rows_adam_preprocess(F, *cam, *in, base, L, pg->radii, *din, F2, *next_cam, (char*)next_ws->ptr, L2,
@@ -215,7 +249,7 @@ int ags_forward_resume(const AgsCamera* cam, const AgsGaussians* in, const AgsIm
     if (in->n <= 0 || cam->image_height <= 0 || cam->image_width <= 0) return AGS_E_INVALID;
     if (!cam->viewmatrix || !cam->projmatrix || !cam->bg || !pg->radii) return AGS_E_INVALID;
     if (!out->rgb || !out->normal || !out->depth || !out->opacity || !out->confidence) return AGS_E_INVALID;
-    if (cam->want_stats && (!pg->importance || !pg->count)) return AGS_E_INVALID;
+    if ((cam->want_stats || cam->config) && (!pg->importance || !pg->count)) return AGS_E_INVALID;
     if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll || ws->binning_mode != AGS_BIN_DIRECT) return AGS_E_INVALID;
     const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
     if (ws->bytes < L.total) return AGS_E_WORKSPACE;
@@ -261,6 +295,12 @@ int ags_read_status(const AgsWorkspace* ws, AgsStatus* host_out, ags_stream_t st
     hipStream_t s = (hipStream_t)stream;
     if (hipMemcpyAsync(host_out, ws->ptr, sizeof(AgsStatus), hipMemcpyDeviceToHost, s) != hipSuccess) return AGS_E_LAUNCH;
     if (hipStreamSynchronize(s) != hipSuccess) return AGS_E_LAUNCH;
+    return AGS_OK;
+}
+
+int ags_read_status_async(const AgsWorkspace* ws, AgsStatus* host_out, ags_stream_t stream) {
+    if (!ws || !ws->ptr || !host_out) return AGS_E_INVALID;
+    if (hipMemcpyAsync(host_out, ws->ptr, sizeof(AgsStatus), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return AGS_E_LAUNCH;
     return AGS_OK;
 }
 

@@ -207,11 +207,19 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     AgsGeom* __restrict__ geom, uint32_t* __restrict__ tiles, ushort4* __restrict__ rect,
     int* __restrict__ radii, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_vis,
     uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom, AgsRowSet touched, AgsDirectEmit direct,
-    AgsViewStride vs) {
+    float* __restrict__ zero_importance, int* __restrict__ zero_count, AgsViewStride vs) {
+    ags_frame_flags(F);
     { // batched forward: this workgroup's view // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
         Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
         radii += (size_t)blockIdx.y * (size_t)vs.n;
+        if (zero_importance) { // device-side configuration (AgsCamera.config): the statistics start at zero without a caller-side memset
+            const int i = blockIdx.x * AGS_PRE_THREADS + threadIdx.x;
+            if (i < in.n) {
+                zero_importance[(size_t)blockIdx.y * (size_t)vs.n + i] = 0.f;
+                zero_count[(size_t)blockIdx.y * (size_t)vs.n + i] = 0;
+            }
+        }
         AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(tiles, wo); AGS_WS_SHIFT(rect, wo); AGS_WS_SHIFT(block_sums, wo);
         AGS_WS_SHIFT(block_vis, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(dgeom, wo);
         if (EMIT == 2) { AGS_WS_SHIFT(direct.keys, wo); AGS_WS_SHIFT(direct.partial, wo); }
@@ -223,6 +231,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsViewStride vs) {
+    ags_frame_flags(F);
     { // batched backward (accumulate == 2): this workgroup's view // (offsets are 0 for a single view)
         Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
         radii += (size_t)blockIdx.y * (size_t)vs.n;
@@ -685,6 +694,7 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsAdamArgs adam,
     AgsViewStride vs) {
+    ags_frame_flags(F);
     { // (offsets are 0 for a single view)
         Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
         radii += (size_t)blockIdx.y * (size_t)vs.n;
@@ -714,6 +724,8 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) __attribute__((amdgpu_waves_per_eu
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
     const int* __restrict__ radii, AgsGeomGrad* __restrict__ dgeom, AgsGaussianGrads out, AgsAdamArgs adam,
     AgsNextPre nx, int rows_blocks, int n_blocks) {
+    ags_frame_flags(F);
+    ags_frame_flags(nx.F);
     __shared__ AgsEmitRec emit_rows[AGS_PRE_THREADS];
     if ((int)blockIdx.x < rows_blocks) {
         const int wave = threadIdx.x >> 6;
@@ -735,14 +747,19 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) __attribute__((amdgpu_waves_per_eu
 }
 
 void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
-                           const AgsLayout& L, int* radii, int emit, const AgsRowSet& touched,
+                           const AgsLayout& L, const AgsPerGaussian& pg, int emit,
                            const AgsViewStride& vs, hipStream_t s) {
+    int* radii = pg.radii;
+    const AgsRowSet& touched = pg.touched;
+    float* zero_importance = cam.config ? pg.importance : nullptr;
+    int* zero_count = cam.config ? pg.count : nullptr;
     const AgsDirectEmit direct = {(uint64_t*)(ws + L.keys0), ags_direct_tile_cap(L), (uint32_t*)(ws + L.totals)};
 #define AGS_LAUNCH_PRE(EMIT, AGG)                                                                                        \
     hipLaunchKernelGGL((ags_k_preprocess<EMIT, AGG>), dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, F,          \
                        cam.viewmatrix, cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),             \
                        (ushort4*)(ws + L.rect), radii, (uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.block_vis),      \
-                       (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched, direct, vs)
+                       (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched, direct, zero_importance,         \
+                       zero_count, vs)
     const bool agg = L.num_tiles <= AGS_AGG_MAX_TILES;
     if (emit == 0) AGS_LAUNCH_PRE(0, false);
     else if (emit == 1) { if (agg) AGS_LAUNCH_PRE(1, true); else AGS_LAUNCH_PRE(1, false); }

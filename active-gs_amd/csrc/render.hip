@@ -215,6 +215,10 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
     const int lane = threadIdx.x;
     int slot, wave;   // blockIdx-derived: SGPRs, strip masks become scalar tests
     if (!ags_wave_block(blockIdx.x, num_tiles, 4 / SLOTS, slot, wave)) return;
+    // device-side configuration (AgsCamera.config): the STATS kernel is launched and config[3] says whether the
+    // statistics are wanted at all (wave-uniform: scalar branches around the per-surfel reductions)
+    normalize_depth = ags_cfg_flag(F.cfg, 1, normalize_depth);
+    const bool stats_on = STATS && ags_cfg_flag(F.cfg, 3, 1) != 0;
     [[maybe_unused]] const int tl_w = slot * (4 / SLOTS) + wave;
     AGS_TL(2, tl_w, 0);
     AGS_PRIO_HIGH();
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
         const bool inside = (AGS_PX(s) < F.W) && (AGS_PY(s) < F.H);
         ags_pix_init(pix[s], inside);
         mk[s] = inside ? 1.f : 0.f;
-        if (STATS && mask != nullptr && inside) mk[s] = mask[(size_t)AGS_PY(s) * F.W + AGS_PX(s)] > 0.f ? 1.f : 0.f;
+        if (STATS && stats_on && mask != nullptr && inside) mk[s] = mask[(size_t)AGS_PY(s) * F.W + AGS_PX(s)] > 0.f ? 1.f : 0.f;
         alldone &= pix[s].done;
     }
     AGS_TL(2, tl_w, 1);
@@ -298,10 +302,10 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
             for (int s = 0; s < SLOTS; ++s) {
                 if (SLOTS == 1 || __any(al[s] > 0.f)) { // wave-uniform; lanes that do not take the surfel blend alpha = 0
                     const float w = ags_blend_apply_q(pix[s], gb.y, gb.z, gb.w, gc.x, gc.y, gc.z, gc.w, d0[s] + dq, al[s], pos1);
-                    if (STATS) { const float wm = w * mk[s]; wsum += wm; wcnt += (wm > weight_thres) ? 1u : 0u; }
+                    if (STATS && stats_on) { const float wm = w * mk[s]; wsum += wm; wcnt += (wm > weight_thres) ? 1u : 0u; }
                 }
             }
-            if (STATS) {
+            if (STATS && stats_on) {
                 const float ts = ags_wave_sum(wsum);
                 const uint32_t tc = ags_wave_sum_u32(wcnt);
                 if constexpr (STATS) {
@@ -369,6 +373,7 @@ __global__ __launch_bounds__(64) AGS_BWD_ATTR void ags_k_render_bwd(
     const int lane = threadIdx.x;
     int slot, wave;
     if (!ags_wave_block(blockIdx.x, num_tiles, 4 / SLOTS, slot, wave)) return;
+    normalize_depth = ags_cfg_flag(F.cfg, 1, normalize_depth);
     // side job of a step's last backward: advance the Adam device clock.  Nothing in this launch
     // reads it; the per-Gaussian kernel that follows (fused step) or ags_adam_step_device does.
     if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -538,6 +543,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
     const int lane = threadIdx.x;
     int slot, wave;
     if (!ags_wave_block(blockIdx.x, num_tiles, 4, slot, wave)) return;
+    normalize_depth = ags_cfg_flag(F.cfg, 1, normalize_depth);
     AgsWaveStageQ<1, AGS_MFMA_STAGE, false>& st = *reinterpret_cast<AgsWaveStageQ<1, AGS_MFMA_STAGE, false>*>(&wb.sg[0]);
     static_assert(sizeof(AgsWaveBatch) <= 6400, "the blend backward's LDS per wave: five 1280-byte granules");
     if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -846,7 +852,7 @@ static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
     float* fT = (float*)(ws + L.final_T);
     uint32_t* nc = (uint32_t*)(ws + L.n_contrib);
     const dim3 block(64), grid(8 * ags_wave_blocks_per_xcd(L.num_tiles, 4 / SLOTS), vs.views);
-    if (cam.want_stats)
+    if (cam.want_stats || cam.config)   // (device-side configuration: config[3] decides inside the kernel)
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, true>), grid, block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),

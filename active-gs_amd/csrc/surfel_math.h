@@ -53,6 +53,9 @@ struct AgsFrame {
     float tanfovx, tanfovy, fx, fy;
     float scale_mod;
     int perpix_depth, front_only;
+    // AgsCamera.config (device, 5 floats) or nullptr: when set, the kernels take the flags from config[1..4] on the
+    // device (ags_frame_flags, ags_internal.h) and the two ints above are only what the host knew
+    const float* cfg;
 };
 
 AGS_HD float ags_rcp(float x) {

@@ -82,7 +82,8 @@ class FusedMapTrainer(GaussianMapTrainer):
 
     def _state(self, slot: int, n: int, h: int, w: int) -> api.ForwardState:
         st = self._states.get(slot)
-        if st is None or st.max_instances < self._cap or st.radii.shape[0] != n or st.rgb.shape[-2:] != (h, w):
+        if (st is None or st.max_instances < self._cap or st.radii.shape[0] != n or st.rgb.shape[-2:] != (h, w)
+                or st.binning_mode != self.binning_mode):
             st = api.alloc_state(n, h, w, self._cap, self.device, self.binning_mode)
             self._states[slot] = st
         return st
@@ -93,10 +94,30 @@ class FusedMapTrainer(GaussianMapTrainer):
                              self.confidences().contiguous(), raw_params=True, scale_factor=self.cfg["scale_factor"],
                              max_scale=0.05)
 
+    # One-pass binning needs tiles x the LONGEST tile list of key slots; with badly skewed lists (a distant or
+    # zoomed-out camera: most surfels in a few tiles) that is far above the instance total, which is all the scan-based
+    # binning needs - same images.  Past these thresholds the trainer goes on with AGS_BIN_TILE_SORT.
+    SKEW_FACTOR, DIRECT_BUDGET_BYTES = 8, 1 << 30
+
+    def _grow_cap(self, need: int, instances: int = 0) -> None:
+        """A view needed ``need`` key slots (``AgsStatus.needed_instances``; ``instances`` = its instance total when
+        known): raise the capacity new workspaces are made with - or leave one-pass binning when its need is skew."""
+        if (self.binning_mode == api.BIN_DIRECT and instances > 0 and need > self.SKEW_FACTOR * max(instances, 1 << 16)
+                and need * 24 > self.DIRECT_BUDGET_BYTES):
+            self.binning_mode = api.BIN_TILE_SORT
+            self.mode_switches = getattr(self, "mode_switches", 0) + 1
+            self._states.clear()
+            if getattr(self, "_batched_cache", None):
+                self._batched_cache["batch"] = None
+            need = instances
+            self._cap = 0
+        self._cap = min(max(int(need * 1.5) + 4096, self._cap + 1), 0xFFFFFFFF)
+
     def _check_capacity(self, slots) -> bool:
-        need = max((api.read_status(self._states[s])["needed"] for s in slots), default=0)
+        infos = [api.read_status(self._states[s]) for s in slots]
+        need = max((i["needed"] for i in infos), default=0)
         if need > self._cap:
-            self._cap = int(need * 1.5) + 4096
+            self._grow_cap(need, max((i["num_instances"] for i in infos), default=0))
             return False
         return True
 
@@ -104,16 +125,16 @@ class FusedMapTrainer(GaussianMapTrainer):
         """After a loop: did ANY pass on these workspaces since they were initialised need more tile instances
         than they hold (``AgsStatus.peak_instances / overflow_passes``)?  Raises ``_cap`` if so.  With several
         ranks the answer is agreed (MAX) so that all of them repeat the call together."""
-        peak, bad = 0, 0
+        peak, bad, inst = 0, 0, 0
         for s in slots:
             info = api.read_status(self._states[s])
-            peak, bad = max(peak, info["peak_instances"]), bad + info["overflow_passes"]
+            peak, bad, inst = max(peak, info["peak_instances"]), bad + info["overflow_passes"], max(inst, info["num_instances"])
         if self.world > 1:
-            t = torch.tensor([peak, bad], device=self.device, dtype=torch.int64)
+            t = torch.tensor([peak, bad, inst], device=self.device, dtype=torch.int64)
             all_reduce_(t, torch.distributed.ReduceOp.MAX, self.pg)
-            peak, bad = int(t[0]), int(t[1])
+            peak, bad, inst = int(t[0]), int(t[1]), int(t[2])
         if bad:
-            self._cap = max(int(peak * 1.5) + 4096, self._cap + 1)
+            self._grow_cap(peak, inst)      # (inst: the LAST pass's total - a proxy for the pass that peaked)
             return False
         return True
 
@@ -125,6 +146,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         snap = {k: getattr(self, k).clone() for k in ("means", "scales", "rotations", "opacities", "harmonics",
                                                      "training_performance")}
         snap["np_rng"] = np.random.get_state()           # the reference's sampler draws from numpy's global stream
+        snap["torch_rng"] = torch.get_rng_state()        # sampler_type "uniform": torch.randperm on the CPU generator
         snap["cuda_rng"] = torch.cuda.get_rng_state(self.device)   # cfg["sampler"] = "device"
         return snap
 
@@ -133,6 +155,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         for k in ("means", "scales", "rotations", "opacities", "harmonics", "training_performance"):
             getattr(self, k).copy_(snap[k])
         np.random.set_state(snap["np_rng"])
+        torch.set_rng_state(snap["torch_rng"])
         torch.cuda.set_rng_state(snap["cuda_rng"], self.device)
 
     def _all_or_nothing(self, run, steps) -> None:
@@ -269,10 +292,11 @@ class FusedMapTrainer(GaussianMapTrainer):
                                       want_stats=True, front_only=True, render_masks=masks,
                                       binning_mode=self.binning_mode)
                 batch.render(vm, pm)
-                need = int(batch.statuses()[:, 7].max())
+                stw = batch.statuses()
+                need = int(stw[:, 7].max())
                 if need <= self._cap:
                     return batch.count.clone()
-                self._cap = int(need * 1.5) + 4096
+                self._grow_cap(need, int(stw[:, 0].max()))
         out = []
         for k, fid in enumerate(frame_ids):
             cam0, _, _ = self._camera(int(fid))
@@ -385,7 +409,8 @@ class FusedMapTrainer(GaussianMapTrainer):
         loss_now = torch.zeros((), device=dev)
         state = dict(batch=None, idx=None, B=0)
         cached = keep["batch"]
-        if cached is not None and cached.capacity_n >= n and cached.max_instances >= self._cap:
+        if (cached is not None and cached.capacity_n >= n and cached.max_instances >= self._cap
+                and cached.binning_mode == self.binning_mode):
             cached.bind(g)
             state["batch"] = cached
             self._cap = cached.max_instances
@@ -421,10 +446,13 @@ class FusedMapTrainer(GaussianMapTrainer):
             torch.index_select(all_view, 0, idx, out=batch.viewmats[:B])
             torch.index_select(all_proj, 0, idx, out=batch.projmats[:B])
             batch.forward(B)
-            need = int(batch.statuses(B)[:, 7].max())
+            stw = batch.statuses(B)
+            need = int(stw[:, 7].max())
             if need <= self._cap:
                 return True
-            self._cap = int(need * 1.5) + 4096
+            self._grow_cap(need, int(stw[:, 0].max()))
+            if state["batch"] is not None and state["batch"].binning_mode != self.binning_mode:
+                state["batch"] = None          # one-pass binning was left: the batch is rebuilt in the other mode
             return False
 
         graph = None
@@ -487,7 +515,7 @@ class FusedMapTrainer(GaussianMapTrainer):
             status = batch.statuses()                     # every slot, sticky words: any pass of any iteration
             self._last_need, self._last_need_n = int(status[:, 4].max()), n
             if bool(status[:, 5].any()):
-                self._cap = max(int(self._last_need * 1.5) + 4096, self._cap + 1)
+                self._grow_cap(self._last_need, int(status[:, 0].max()))
                 self._last_need = None
                 keep["batch"] = None                      # too small: the repeat allocates a larger one
                 return False

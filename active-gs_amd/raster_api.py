@@ -34,6 +34,9 @@ class Camera:
     want_stats: bool = False
     front_only: bool = False
     render_mask: Optional[torch.Tensor] = None
+    # the reference's `config` tensor itself (device, 5 floats): the kernels read the four flags above from it on the
+    # device (AgsCamera.config) - what the drop-in module passes so that it never has to read the tensor back
+    config: Optional[torch.Tensor] = None
 
     def c_struct(self) -> _lib.AgsCamera:
         m = self.render_mask
@@ -44,7 +47,7 @@ class Camera:
         return _lib.AgsCamera(self.image_height, self.image_width, self.tanfovx, self.tanfovy,
                               self.scale_modifier, self.weight_thres, int(self.normalize_depth),
                               int(self.perpix_depth), int(self.want_stats), int(self.front_only),
-                              ptr(self.viewmatrix), ptr(self.projmatrix), ptr(self.bg), ptr(m))
+                              ptr(self.viewmatrix), ptr(self.projmatrix), ptr(self.bg), ptr(m), ptr(self.config))
 
 
 @dataclass
@@ -132,6 +135,42 @@ def workspace_bytes(n: int, h: int, w: int, max_instances: int) -> int:
 
 
 BIN_TILE_SORT, BIN_RADIX, BIN_DIRECT = 0, 1, 2
+REGION_FINAL_T, REGION_N_CONTRIB, REGION_GEOM, REGION_RANGES, REGION_KEYS, REGION_IDS = range(6)
+
+
+def workspace_region(state: "ForwardState", n: int, h: int, w: int, region: int, dtype) -> torch.Tensor:
+    """A typed view of one region of ``state.workspace`` (``ags_workspace_region``: the per-pixel blend state, the
+    projected records, the tile ranges, the sorted keys) - diagnostics and parity tests."""
+    off, nbytes = C.c_size_t(), C.c_size_t()
+    _lib.check(_lib.load().ags_workspace_region(n, h, w, state.max_instances, int(state.binning_mode), int(region),
+                                                C.byref(off), C.byref(nbytes)), "ags_workspace_region")
+    return state.workspace[off.value:off.value + nbytes.value].view(dtype)
+
+
+def last_contributor(state: "ForwardState", n: int, h: int, w: int) -> torch.Tensor:
+    """(H, W) int64: id of the last surfel every pixel blended (-1: none), from the forward pass's per-pixel list
+    position (``n_contrib``), the tile ranges and the sorted ids - comparable across binning modes and with a
+    rasterizer whose tile lists are longer (every tile of a surfel's rect) but in the same order."""
+    tx, ty = (w + 15) // 16, (h + 15) // 16
+    T = tx * ty
+    last = workspace_region(state, n, h, w, REGION_N_CONTRIB, torch.int32).view(h, w).long()
+    rg = workspace_region(state, n, h, w, REGION_RANGES, torch.int32).view(T, 2).long() & 0xFFFFFFFF
+    mode = int(state.binning_mode)
+    if mode == BIN_RADIX:
+        ids = workspace_region(state, n, h, w, REGION_IDS, torch.int32).long() & 0xFFFFFFFF
+        begin = rg[:, 0]
+    else:
+        ids = workspace_region(state, n, h, w, REGION_KEYS, torch.int64) & 0xFFFFFFFF
+        if mode == BIN_DIRECT:     # rg[slot] = {tile, count}; the list of slot s starts at s * tile_cap
+            tile_cap = state.max_instances // T
+            begin = torch.zeros(T, dtype=torch.long, device=rg.device)
+            begin[rg[:, 0]] = torch.arange(T, device=rg.device) * tile_cap
+        else:
+            begin = rg[:, 0]
+    ys, xs = torch.meshgrid(torch.arange(h, device=last.device), torch.arange(w, device=last.device), indexing="ij")
+    tile = (ys // 16) * tx + xs // 16
+    pos = (begin[tile] + last - 1).clamp_min(0)
+    return torch.where(last > 0, ids[pos.clamp_max(ids.numel() - 1)], torch.full_like(last, -1))
 
 
 def alloc_state(n: int, h: int, w: int, max_instances: int, device, binning_mode: int = BIN_DIRECT) -> ForwardState:
@@ -155,6 +194,13 @@ def init_workspace(state: ForwardState, n: int, h: int, w: int) -> None:
     """``ags_workspace_init`` on a freshly allocated workspace (once per allocation: forwards leave it clean)."""
     ws = state.ws_struct()
     _lib.check(_lib.load().ags_workspace_init(C.byref(ws), n, h, w, _stream()), "ags_workspace_init")
+
+
+def discard_pass(state: ForwardState, n: int, h: int, w: int) -> None:
+    """``ags_workspace_discard_pass``: forget a prepared per-Gaussian stage (leaving the software pipeline) without
+    touching the status block's sticky overflow notes."""
+    ws = state.ws_struct()
+    _lib.check(_lib.load().ags_workspace_discard_pass(C.byref(ws), n, h, w, _stream()), "ags_workspace_discard_pass")
 
 
 def alloc_outputs(n: int, h: int, w: int, device, workspace: torch.Tensor, max_instances: int,
@@ -182,7 +228,7 @@ def forward(cam: Camera, g: Gaussians, state: ForwardState, stream: Optional[int
     if not checked:
         for name in ("means3D", "scales", "rotations", "opacities", "colors", "confidences"):
             _require_cuda(getattr(g, name), name)
-    if cam.want_stats:
+    if cam.want_stats and cam.config is None:     # (device-side configuration: the per-Gaussian kernel clears them)
         state.importance.zero_()
         state.count.zero_()
     cs, gs = cam.c_struct(), g.c_struct()

@@ -260,10 +260,11 @@ class SurfelTrainer:
         return self.activate()
 
     def _drop_prepared(self) -> None:
-        """Leave the pipeline: the prepared pass has taken key slots in its workspace - clear them."""
+        """Leave the pipeline: the prepared pass has taken key slots in its workspace - clear them (the status block's
+        sticky overflow notes stay: ``check_overflow`` has not looked at the last steps yet)."""
         if self._prepared is not None:
             st, _ = self._prepared
-            api.init_workspace(st, self.n, st.rgb.shape[-2], st.rgb.shape[-1])
+            api.discard_pass(st, self.n, st.rgb.shape[-2], st.rgb.shape[-1])
             self._prepared = None
 
     def _local_pass(self, cams, image_grads, max_instances, tick: bool = False, fuse_adam: bool = False,
@@ -507,7 +508,9 @@ class SurfelTrainer:
         self.check_overflow()              # settle the eager steps first: a capture bakes the segment size in
         self.optim.use_clock(True)
         dist_on = self._distributed()
-        pipeline = pipeline and not dist_on and self.binning_mode == api.BIN_DIRECT and len(cams) > 0
+        # (the pipelined kernel continues from the fused Adam update on raw parameters: _local_pass's own conditions)
+        pipeline = (pipeline and not dist_on and self.binning_mode == api.BIN_DIRECT and len(cams) > 0
+                    and self.rows is not None and self.fused_activations)
         if pipeline:
             self.step(cams, image_grads, max_instances, next_cam=cams[0])      # primes: cams[0] is prepared from here on
             self.check_overflow()

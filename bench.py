@@ -7,13 +7,22 @@ activation backward -> [exchange of the gradient rows when N>1] -> fused Adam.
 Workload at every N: BASELINE.json configs[1] per GPU (office0 stand-in, 200k surfels,
 1200x680, one view per rank, weak scaling).  Prints ONE JSON line on rank 0.
 
+Timing: after W warm-up steps the K steps are timed R times (R >= 21, >= 0.25 s in total), every sample bracketed
+by barrier + torch.cuda.synchronize() on both sides and the MAX taken over the ranks; `ms_per_step` / `value` are the
+MEDIAN sample, min / max are printed beside it.  Everything else in the line (stage times, the un-pipelined and the
+exact-f32 forms of the same step, the drop-in module's call path, the larger configurations, the CPU oracle) is
+measured AFTER that region and labelled.
+
 ``python bench.py --gpus N`` with N > 1 and no RANK in the environment launches the N ranks itself
 (``python -m torch.distributed.run``, one process per GPU, RCCL) BEFORE this process touches the GPU and
 relays rank 0's line; under ``torch.distributed.run`` (RANK set) it is one of the ranks.
+``--check`` (with --gpus N): only initialise the process group, run one all-gather and the captured-collective probe
+and print which exchange path every rank would take - a readiness check that costs seconds.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,13 +36,18 @@ H, W = 680, 1200
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PMC_HBM_FILE = "pmc_hbm_bytes.json"   # per-stage HBM bytes per launch of this command (rocprofv3 --pmc, committed)
 PMC_SQ_FILE = "sq_counters.json"      # per-stage SQ instruction counters per launch of this command
+DTYPE = ("f32 (the blend backward forms its 15 per-surfel sums on the bf16 matrix pipe from hi/lo splits of both "
+         "operands - hi.hi + lo.hi + hi.lo, f32 accumulate, every dropped term < 2^-16 of its product; "
+         "ms_per_step_f32_exact is the same step with exact f32 matrix instructions)")
 
 
-def stage_bytes(N, V, I, P, T, rows=None, direct=True, fused_single_view=True):
+def stage_bytes(N, V, I, P, T, rows=None, direct=True, fused_single_view=True, bwd_extra_images=0):
     """ALGORITHMIC bytes per launch of each stage: every logical
     array moved once.  ``rows``: member rows of the sticky row set when the per-Gaussian backward
     runs in its row-set form with the Adam step fused in (single rank), else None.  ``direct``: one-pass
-    binning (the per-Gaussian kernel writes the keys, the sort stage copies them into slot order)."""
+    binning (the per-Gaussian kernel writes the keys, the sort stage copies them into slot order).
+    ``bwd_extra_images``: how many of d_opacity / d_confidence the backward is given (0 in the bench step, whose
+    image gradients are d_rgb, d_normal, d_depth - like the reference's loss, gaussian_map.py:106-124)."""
     if rows is not None:
         # per member row: id 4 + radius 4 + parameters read 56 (the four geometry tensors 44 + harmonics 12) + gradient
         # record read 64 / re-zeroed 64 (visible rows) + interleaved Adam moments 112 read + 112 written + parameters
@@ -51,12 +65,163 @@ def stage_bytes(N, V, I, P, T, rows=None, direct=True, fused_single_view=True):
         "preprocess": pre,
         "binning": binning,
         "render_fwd": 8 * T + 68 * I + 44 * P,                  # headers; id 4 + record 64; 9 ch + T + n_contrib
-        "render_bwd": 8 * T + 68 * I + 52 * P + 64 * V,         # + 9 grads, depth, opac, T, n; accumulate dgeom
+        # headers; id 4 + record 64; per pixel n_contrib 4 + final_T 4 + depth 4 + opacity 4 + d_rgb 12 + d_normal 12 +
+        # d_depth 4 = 44 (+ 4 per extra image gradient); one 64-byte gradient record per visible surfel
+        "render_bwd": 8 * T + 68 * I + (44 + 4 * bwd_extra_images) * P + 64 * V,
         "preprocess_bwd": pbwd,
     }
 
 
 STAGE_IDS = {"preprocess": 0, "binning": 1, "render_fwd": 2, "render_bwd": 3, "preprocess_bwd": 4}
+
+
+def time_samples(run_k, samples, dist_on, dev):
+    """`samples` timings of one call of run_k(), each bracketed by barrier + synchronize on both sides; -> list of
+    seconds, the MAX over the ranks per sample."""
+    out = []
+    for _ in range(samples):
+        if dist_on:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_k()
+        torch.cuda.synchronize()
+        if dist_on:
+            torch.distributed.barrier()
+        out.append(time.perf_counter() - t0)
+    if dist_on:
+        from active_gs_amd.dist_util import all_reduce_
+        t = torch.tensor(out, device=dev, dtype=torch.float64)
+        all_reduce_(t, torch.distributed.ReduceOp.MAX)
+        out = t.tolist()
+    return out
+
+
+def summarise(samples_s, k):
+    per = sorted(s / k * 1e3 for s in samples_s)
+    return dict(median=statistics.median(per), min=per[0], max=per[-1], samples=len(per))
+
+
+def read_stage_times(lib):
+    import ctypes as C
+    from active_gs_amd import _lib
+    med, mean = {}, {}
+    for name, sid in STAGE_IDS.items():
+        ms, md, cnt = C.c_float(), C.c_float(), C.c_int32()
+        _lib.check(lib.ags_profile_read(sid, C.byref(ms), C.byref(md), C.byref(cnt)), "ags_profile_read")
+        med[name], mean[name] = md.value, ms.value      # median over the eager steps (robust to host stalls)
+    return med, mean
+
+
+def measure_dropin(dev, n, h, w, views, iters=30, focal=None):
+    """The path an UNMODIFIED caller takes (operations.py:682-713, :854): ``GaussianRasterizer(settings)(...)`` per view
+    under autograd + one backward through all of them - the module alone (no facade post-processing, no loss head,
+    no optimiser).  -> (ms per view, host synchronisations the module itself issued per view)."""
+    from active_gs_amd.camera import camera_matrices
+    from active_gs_amd.synthetic import activate, make_camera, make_room_scene
+    import active_gs_amd.rasterizer as R
+    from diff_gaussian_rasterization_2d import GaussianRasterizationSettings, GaussianRasterizer, check_overflow
+    raw = make_room_scene(n, seed=0)
+    c2w, K = zip(*[make_camera(v, h, w, focal_px=focal) for v in range(views)])
+    cm0 = camera_matrices(torch.stack(c2w), torch.stack(K), 0.001, 10.0)
+    a = {k: v.to(dev) for k, v in activate(raw).items()}
+    leaves = [a["means"].clone().requires_grad_(True), torch.zeros(n, 3, device=dev, requires_grad=True),
+              a["opacities"][:, None].clone().requires_grad_(True), a["confidences"], a["colors"].clone().requires_grad_(True),
+              a["scales"].clone().requires_grad_(True), a["rotations"].clone().requires_grad_(True)]
+    gen = torch.Generator().manual_seed(0)
+    gimg = [torch.randn(c, h, w, generator=gen).to(dev) / (h * w) for c in (3, 3, 1)]
+    settings = [GaussianRasterizationSettings(
+        image_height=h, image_width=w, tanfovx=float(cm0["tanfov"][v, 0]), tanfovy=float(cm0["tanfov"][v, 1]),
+        bg=torch.zeros(4, device=dev), scale_modifier=1.0, viewmatrix=cm0["viewmatrix"][v].to(dev),
+        projmatrix=cm0["projmatrix"][v].to(dev), sh_degree=0, campos=cm0["campos"][v].to(dev), prefiltered=False,
+        render_mask=torch.tensor([], device=dev), weight_thres=0.03, debug=False,
+        config=torch.tensor([1.0, 1, 1, 0, 0]).to(dev)) for v in range(views)]
+
+    def iteration():
+        outs = [GaussianRasterizer(s)(leaves[0], leaves[1], leaves[2], leaves[3], None, leaves[4], leaves[5], leaves[6], None)
+                for s in settings]
+        # rgb, normal, depth carry gradients (gaussian_map.py:106-124); opacity / confidence are used detached
+        torch.autograd.backward([o[k] for o in outs for k in range(3)], [gimg[k] for _ in outs for k in range(3)])
+        for t in leaves:
+            t.grad = None
+
+    for _ in range(3):
+        iteration()
+    torch.cuda.synchronize()
+    check_overflow()
+    syncs0 = R.counters["status_syncs"]
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        iteration()
+    host_s = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    check_overflow()
+    return dict(ms_per_view=dt / (iters * views) * 1e3, host_enqueue_ms_per_view=host_s / (iters * views) * 1e3,
+                module_syncs_per_view=(R.counters["status_syncs"] - syncs0) / (iters * views))
+
+
+def measure_config(tag, n, h, w, views, room, steps, dev, lrs=None, binning_mode=None):
+    """One GPU's optimisation step on a synthetic scene of another size (BASELINE.json configs 4 and 5: the per-GPU
+    share), same step as the headline: hipGraph replay timed over samples, then the per-stage eager pass."""
+    from active_gs_amd import _lib, raster_api as api
+    from active_gs_amd.camera import camera_matrices
+    from active_gs_amd.synthetic import make_camera, make_room_scene
+    from active_gs_amd.trainer import SurfelTrainer
+    lib = _lib.load()
+    raw = {k: v.to(dev) for k, v in make_room_scene(n, room=room, seed=0).items()}
+    trainer = SurfelTrainer(raw, lrs=lrs, binning_mode=api.BIN_DIRECT if binning_mode is None else binning_mode)
+    cams = []
+    for v in range(views):
+        c2w, K = make_camera(v, h, w)
+        cm = camera_matrices(c2w[None].to(dev), K[None].to(dev), 0.001, 10.0)
+        tan = cm["tanfov"][0].cpu()
+        cams.append(api.Camera(h, w, float(tan[0]), float(tan[1]), cm["viewmatrix"][0].contiguous(),
+                               cm["projmatrix"][0].contiguous(), torch.zeros(4, device=dev)))
+    gen = torch.Generator().manual_seed(4)
+    d_img = [(torch.randn(c, h, w, generator=gen) / (h * w * views)).to(dev) for c in (3, 3, 1)]
+    fn = lambda v, st: (d_img[0], d_img[1], d_img[2], None, None)
+    cap = 1 << 22
+    V = I = 0
+    while True:                                     # size the workspace: grow until no view overflows
+        trainer.step(cams, fn, cap, device_clock=True)
+        need, V, I = 0, 0, 0
+        for cam in cams:
+            st = trainer.state_for(h, w, cap)
+            api.forward(cam, trainer.gaussians(), st)
+            info = api.read_status(st)
+            need = max(need, info["needed"]); V += info["num_visible"]; I += info["num_instances"]
+        if need <= cap:
+            break
+        cap = int(need * 1.25)
+    replay = trainer.capture(cams, fn, cap)
+    for _ in range(5):
+        replay()
+    torch.cuda.synchronize()
+    s = summarise(time_samples(lambda: [replay() for _ in range(steps)], 5, False, dev), steps)
+    _lib.check(lib.ags_profile_enable(steps * views), "ags_profile_enable")
+    for _ in range(steps):
+        trainer.step(cams, fn, cap)
+    torch.cuda.synchronize()
+    med, _ = read_stage_times(lib)
+    lib.ags_profile_enable(0)
+    trainer.check_overflow()
+    P, T = h * w, ((h + 15) // 16) * ((w + 15) // 16)
+    rows = int(trainer.rows.count.item()) if trainer.rows is not None else None
+    # per view: the stage times are medians over all (step, view) launches
+    sb = stage_bytes(n, V / views, I / views, P, T, None if rows is None else rows / 1.0, direct=True, fused_single_view=(views == 1))
+    frac = {k: (sb[k] / (med[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if med[k] > 0 else 0.0) for k in sb}
+    st = trainer.state_for(h, w, cap)
+    out = dict(config=tag, surfels=n, image=[h, w], views_per_step=views, ms_per_step=round(s["median"], 4),
+               ms_per_step_min=round(s["min"], 4), ms_per_step_max=round(s["max"], 4), samples=s["samples"], steps_per_sample=steps,
+               gaussians_per_s=n * views / (s["median"] * 1e-3), visible_per_view=V // views, tile_instances_per_view=I // views,
+               member_rows=rows, workspace_MB=round(st.workspace.numel() / 2**20, 1),
+               stage_ms_per_view={k: round(v, 4) for k, v in med.items()},
+               stage_hbm_frac={k: round(v, 4) for k, v in frac.items()},
+               whole_step_hbm_frac=round(sum(sb.values()) * views / (s["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    del trainer, replay, raw
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(raw_cpu, cam_cpu, d_img_cpu, gpu_check, budget_s=15.0, max_threads=16):
@@ -66,9 +231,12 @@ def cpu_baseline(raw_cpu, cam_cpu, d_img_cpu, gpu_check, budget_s=15.0, max_thre
 
     The images and gradients the oracle computes on the way are not thrown away: ``gpu_check(tile_mask)``
     runs the HIP path on the same (initial) parameters with the same image gradients restricted to the tiles
-    the oracle covered, and the two are compared -> the ``parity`` object of the JSON line."""
+    the oracle covered, and the two are compared -> the ``parity`` object of the JSON line (the same gates as
+    tests/_parity.py: contract mean-L1, largest pixel error, worst-tile mean L1, relative L1 of the gradients)."""
     from active_gs_amd.synthetic import activate
     from oracle.surfel_oracle import OracleSettings, bin_instances, preprocess, render_tiles
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _parity
     cores = min(os.cpu_count() or 1, max_threads)  # many small ops: more threads only add overhead
     torch.set_num_threads(cores)
     a = activate(raw_cpu)
@@ -108,16 +276,21 @@ def cpu_baseline(raw_cpu, cam_cpu, d_img_cpu, gpu_check, budget_s=15.0, max_thre
                       f"1200x680 view ({t_pre:.1f}s) + fwd+bwd of {done} of {len(nonempty)} non-empty tiles "
                       f"({t_tiles:.1f}s), extrapolated to all tiles"}
     # ---- parity of the HIP path against what the oracle just computed (checker role only)
-    gpu_images, gpu_grads = gpu_check(covered)
-    npx = float(covered.sum())
-    l1 = {k: float(((gpu_images[k] - images[k]) * covered).abs().sum() / (npx * images[k].shape[0])) for k in images}
+    gpu_images, gpu_grads, gpu_radii = gpu_check(covered)
+    stats = {k: _parity.image_stats(images[k], gpu_images[k], covered) for k in images}
     ref_grads = {"means3D": ins[0].grad, "opacities": ins[2].grad.reshape(-1), "colors": ins[4].grad, "scales": ins[5].grad,
                  "rotations": ins[6].grad}
-    rel = {k: float((gpu_grads[k] - r).abs().sum() / r.abs().sum().clamp_min(1e-30)) for k, r in ref_grads.items()}
-    parity = {"parity_rgb_L1": l1["rgb"], "parity_grad_rel": max(rel.values()),
-              "image_L1": l1, "grad_rel_L1": rel, "tiles_compared": done, "tiles_nonempty": len(nonempty),
-              "tolerance": {"rgb_L1": 1e-4, "grad_rel": 1e-3},
-              "ok": bool(l1["rgb"] < 1e-4 and max(rel.values()) < 1e-3),
+    rel = _parity.grad_stats(ref_grads, gpu_grads)
+    radii_mismatch = int((gpu_radii != G["radii"]).sum())
+    ok = all(stats[k]["mean"] < _parity.MEAN_L1[k] and stats[k]["max"] < _parity.MAX_ABS[k] and stats[k]["tile"] < _parity.TILE_L1[k]
+             for k in stats) and max(rel.values()) < _parity.GRAD_REL
+    parity = {"parity_rgb_L1": stats["rgb"]["mean"], "parity_grad_rel": max(rel.values()),
+              "image_L1": {k: s["mean"] for k, s in stats.items()}, "image_max_abs": {k: s["max"] for k, s in stats.items()},
+              "image_worst_tile_L1": {k: s["tile"] for k, s in stats.items()}, "grad_rel_L1": rel,
+              "radii_rows_differing": radii_mismatch, "tiles_compared": done, "tiles_nonempty": len(nonempty),
+              "tolerance": {"mean_L1": _parity.MEAN_L1["rgb"], "mean_L1_depth_m": _parity.MEAN_L1["depth"], "max_abs": _parity.MAX_ABS["rgb"],
+                            "worst_tile_L1": _parity.TILE_L1["rgb"], "grad_rel": _parity.GRAD_REL},
+              "ok": bool(ok),
               "what": "HIP forward+backward of the bench view (initial parameters, the bench step's image gradients "
                       "restricted to the compared tiles) against the oracle's fp32 images / autograd gradients"}
     return base, parity
@@ -125,7 +298,8 @@ def cpu_baseline(raw_cpu, cam_cpu, d_img_cpu, gpu_check, budget_s=15.0, max_thre
 
 def launch_ranks(args) -> int:
     """``--gpus N`` without a launcher: start N ranks (one per GPU) as a child job and relay rank 0's JSON line.
-    Runs before anything in this process has touched the GPU (no GPU state to share, no re-exec)."""
+    Runs before anything in this process has touched the GPU (no GPU state to share, no re-exec).  On failure the
+    tail of the job's stderr (every rank's last lines, the watchdog's stacks) is printed."""
     import socket
     import subprocess
     share = os.environ.get("AGS_BENCH_SHARE_GPU") == "1"
@@ -140,12 +314,13 @@ def launch_ranks(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool
     env.setdefault("OMP_NUM_THREADS", "8")
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     other = [l for l in r.stdout.splitlines() if not l.startswith("{")]
     if other:
         print("\n".join(other), file=sys.stderr)
     if r.returncode != 0 or len(lines) != 1:
+        print("\n".join(r.stderr.splitlines()[-120:]), file=sys.stderr)
         print(f"bench.py: the {args.gpus}-rank job exited with code {r.returncode} and {len(lines)} result line(s)",
               file=sys.stderr)
         return r.returncode or 1
@@ -153,12 +328,27 @@ def launch_ranks(args) -> int:
     return 0
 
 
+def rank_identity(dev, world, rank):
+    """what every rank is, gathered on all ranks: (rank, host, device index, device uuid / name)"""
+    import socket
+    p = torch.cuda.get_device_properties(dev)
+    me = dict(rank=rank, host=socket.gethostname(), device_index=dev.index, name=p.name,
+              uuid=str(getattr(p, "uuid", "")) or None, pci_bus_id=getattr(p, "pci_bus_id", None))
+    everyone = [None] * world
+    torch.distributed.all_gather_object(everyone, me)
+    return everyone
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--samples", type=int, default=0, help="timed samples of --steps steps each (0 = automatic: >= 21, >= 0.25 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip what is measured after the timed region besides the stage times: un-pipelined / exact-f32 forms, "
+                         "the drop-in module's call path, configurations 4 and 5")
     ap.add_argument("--binning", choices=["direct", "tile_sort", "radix"], default="direct")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -167,18 +357,23 @@ def main():
                          "(ags_backward_fused_next: both in ONE kernel, -4 %% step time)")
     ap.add_argument("--graph-steps", type=int, default=int(os.environ.get("AGS_BENCH_GRAPH_STEPS", "25")),
                     help="optimisation steps recorded per hipGraph (single GPU); K steps = K/this replays")
+    ap.add_argument("--check", action="store_true", help="multi-GPU readiness check only (see the module docstring)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "RANK" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
-    if os.environ.get("AGS_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack and exit after N s
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["AGS_BENCH_WATCHDOG"]), exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # A rank that hangs (a collective that never completes) must not hang the job until the driver's timeout: with more
+    # than one rank every rank dumps all its threads' stacks and exits non-zero after AGS_BENCH_WATCHDOG seconds
+    # (default 600; 0 = off); the launcher above then prints the tail of the job's stderr.
+    wd = int(os.environ.get("AGS_BENCH_WATCHDOG", "600" if world > 1 else "0"))
+    if wd > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
@@ -194,6 +389,7 @@ def main():
     # test-only hook: AGS_DP_FORCE=1 runs the data-parallel step (exchange, union Adam, collectives in the graph)
     # in a one-rank RCCL group - the overhead of that path without any wire time, measurable on a 1-GPU box
     dist_on = world > 1 or os.environ.get("AGS_DP_FORCE") == "1"
+    identity = None
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
@@ -205,6 +401,13 @@ def main():
         else:
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # test transport, ranks on one host: never pick a NIC by hostname
             dist.init_process_group(backend)
+        if dist.get_world_size() != world:
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, WORLD_SIZE says {world}")
+        identity = rank_identity(dev, world, rank)
+        if not share_gpu and world > 1:
+            seen = {(e["host"], e["uuid"] or e["pci_bus_id"] or e["device_index"]) for e in identity}
+            if len(seen) != world:
+                raise SystemExit(f"bench.py: {world} ranks but {len(seen)} distinct devices: {identity}")
 
     from active_gs_amd import _lib, raster_api as api
     from active_gs_amd.camera import camera_matrices
@@ -252,47 +455,74 @@ def main():
     for _ in range(3):
         eager_step()  # creates every buffer before capture
     torch.cuda.synchronize()
-    launch_mode = "eager" if args.eager else "hipGraph replay"
-    one_step = eager_step
-    many_steps, per_replay = None, 1
-    if not args.eager:
-        try:
-            pipe = not dist_on and not args.no_pipeline and args.binning == "direct"
-            one_step = trainer.capture([cam], grads_fn, cap, pipeline=pipe)
-            in_graph = getattr(one_step, "collective_in_graph", False)
-            if dist_on:
-                launch_mode = ("hipGraph replay, gradient exchange recorded in the graph" if in_graph
-                               else "hipGraph replay: graph | collective | graph")
-            # steps per graph: the largest divisor of K that is <= --graph-steps, so that the timed region is
-            # whole replays of ONE graph and this string describes exactly what was timed
-            rep = max(d for d in range(1, max(1, args.graph_steps) + 1) if args.steps % d == 0)
-            if rep > 1 and (not dist_on or in_graph):
-                many_steps = trainer.capture([cam], grads_fn, cap, repeat=rep, pipeline=pipe)
-                per_replay = many_steps.steps
-            launch_mode += f", {per_replay} step(s) per graph, {args.steps // per_replay} replay(s) timed"
-            if getattr(one_step, "pipelined", False):
-                launch_mode += ("; software-pipelined: 4 launches per step - tile sort, blend, blend backward, [chain rule + Adam "
-                                "of this step and the per-Gaussian stage (cull, project, key emission) of the next step] - every "
-                                "step still does one of each stage")
-        except Exception as e:  # never lose the measurement to a capture problem
-            launch_mode = f"eager (graph capture failed: {type(e).__name__})"
-            many_steps, per_replay = None, 1
-            torch.cuda.synchronize()
 
-    def run_steps(k):
-        """exactly k optimisation steps"""
-        if many_steps is not None:
-            for _ in range(k // per_replay):
-                many_steps()
-            k = k % per_replay
-        for _ in range(k):
-            one_step()
-
-    def barrier():
+    if args.check:
+        # readiness: the process group is up, the ranks are distinct devices, one eager data-parallel step (all-gather
+        # of the rows or all-reduce of the slab) has run, and the captured-collective probe says which form a captured
+        # step would take
+        path = None
+        if dist_on:
+            in_graph = trainer._collectives_capturable()
+            rows_x = trainer._row_exchange_on()
+            path = ("rows" if rows_x else "dense") + (" in graph" if in_graph else ": graph | collective | graph")
+            paths = [None] * world
+            torch.distributed.all_gather_object(paths, path)
+            if len(set(paths)) != 1:
+                raise SystemExit(f"bench.py --check: ranks disagree on the exchange path: {paths}")
+        if rank == 0:
+            print(json.dumps({"check": "ok", "n_gpus": world, "backend": backend if dist_on else None, "exchange_path": path,
+                              "ranks": identity, "refused_steps": trainer.refused_steps() if dist_on else 0}))
         if dist_on:
             torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
 
-    # bring the GPU to its sustained clock before the W warm-up steps (a step is ~0.2 ms:
+    def capture(pipe):
+        """-> (one_step, many_steps, steps per replay of many_steps, description)"""
+        mode = "hipGraph replay"
+        one = trainer.capture([cam], grads_fn, cap, pipeline=pipe)
+        in_graph = getattr(one, "collective_in_graph", False)
+        if dist_on:
+            mode = ("hipGraph replay, gradient exchange recorded in the graph" if in_graph
+                    else "hipGraph replay: graph | collective | graph")
+        # steps per graph: the largest divisor of K that is <= --graph-steps, so that a sample is whole replays of ONE graph
+        rep = max(d for d in range(1, max(1, args.graph_steps) + 1) if args.steps % d == 0)
+        many, per = None, 1
+        if rep > 1 and (not dist_on or in_graph):
+            many = trainer.capture([cam], grads_fn, cap, repeat=rep, pipeline=pipe)
+            per = many.steps
+        mode += f", {per} step(s) per graph, {args.steps // per} replay(s) per sample"
+        if getattr(one, "pipelined", False):
+            mode += ("; software-pipelined: 4 launches per step - tile sort, blend, blend backward, [chain rule + Adam "
+                     "of this step and the per-Gaussian stage (cull, project, key emission) of the next step] - every "
+                     "step still does one of each stage")
+        return one, many, per, mode
+
+    launch_mode = "eager" if args.eager else "hipGraph replay"
+    one_step, many_steps, per_replay = eager_step, None, 1
+    pipe = not dist_on and not args.no_pipeline and args.binning == "direct"
+    if not args.eager:
+        try:
+            one_step, many_steps, per_replay, launch_mode = capture(pipe)
+        except Exception as e:  # never lose the measurement to a capture problem
+            launch_mode = f"eager (graph capture failed: {type(e).__name__}: {e})"
+            one_step, many_steps, per_replay = eager_step, None, 1
+            torch.cuda.synchronize()
+
+    def make_runner(one, many, per):
+        def run_steps(k):
+            """exactly k optimisation steps"""
+            if many is not None:
+                for _ in range(k // per):
+                    many()
+                k = k % per
+            for _ in range(k):
+                one()
+        return run_steps
+
+    run_steps = make_runner(one_step, many_steps, per_replay)
+
+    # bring the GPU to its sustained clock before the W warm-up steps (a step is ~0.1 ms:
     # W of them alone finish before DVFS has settled)
     t_pre = time.perf_counter()
     while True:
@@ -308,43 +538,51 @@ def main():
             break
     run_steps(args.warmup)
     torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
+    # one untimed sample tells how many samples make >= 0.25 s; every rank must take the same number
+    est = time_samples(lambda: run_steps(args.steps), 1, dist_on, dev)[0]
+    n_samples = args.samples if args.samples > 0 else int(min(201, max(21, 0.25 / max(est, 1e-6) + 1)))
+    # ---------------------------------------------------------------- the timed region
     t0 = time.perf_counter()
     run_steps(args.steps)
     enqueue_s = time.perf_counter() - t0
     torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        all_reduce_(t, torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
+    samples = time_samples(lambda: run_steps(args.steps), n_samples, dist_on, dev)
+    # ----------------------------------------------------------------
+    timing = summarise(samples, args.steps)
     st = trainer.state_for(H, W, cap)
     info = api.read_status(st)
     refused = trainer.refused_steps() if dist_on else 0      # steps the row exchange refused (segment outgrown)
 
-    # per-stage kernel time: the same K steps launched eagerly with library-owned HIP events
+    extras = {}
+    if not dist_on and not args.eager and not args.no_extras and pipe and getattr(one_step, "pipelined", False):
+        # the same step un-pipelined (five launches): what a loop that cannot name its next view one step early gets
+        try:
+            trainer.step([cam], grads_fn, cap)      # an un-pipelined step consumes the prepared pass: the pipeline is left
+            o2, m2, p2, _ = capture(False)
+            r2 = make_runner(o2, m2, p2)
+            r2(args.warmup)
+            extras["ms_per_step_no_pipeline"] = summarise(time_samples(lambda: r2(args.steps), max(5, n_samples // 3), False, dev),
+                                                           args.steps)["median"]
+        except Exception as e:
+            extras["ms_per_step_no_pipeline"] = None
+            extras["no_pipeline_note"] = f"{type(e).__name__}: {e}"
+            torch.cuda.synchronize()
+
+    # per-stage kernel time: K steps launched eagerly with library-owned HIP events
     # around every stage (events cannot be timed inside a replayed graph)
-    _lib.check(lib.ags_profile_enable(args.steps), "ags_profile_enable")
+    k_prof = min(args.steps, 200)
+    _lib.check(lib.ags_profile_enable(k_prof), "ags_profile_enable")
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     profile_note = None
     try:
-        for _ in range(args.steps):
+        for _ in range(k_prof):
             eager_step()
     except RuntimeError as e:     # e.g. a very long run whose drifting synthetic scene outgrew the workspace sized at its start
         profile_note = f"per-stage pass stopped early: {e}"
     torch.cuda.synchronize()
     eager_elapsed = time.perf_counter() - t1
-
-    import ctypes as C
-    stage_ms, stage_mean_ms = {}, {}
-    for name, sid in STAGE_IDS.items():
-        ms, med, cnt = C.c_float(), C.c_float(), C.c_int32()
-        _lib.check(lib.ags_profile_read(sid, C.byref(ms), C.byref(med), C.byref(cnt)), "ags_profile_read")
-        stage_ms[name] = med.value       # median over the K eager steps (robust to host stalls)
-        stage_mean_ms[name] = ms.value
+    stage_ms, stage_mean_ms = read_stage_times(lib)
     lib.ags_profile_enable(0)
 
     if rank == 0:
@@ -359,18 +597,25 @@ def main():
                         "overflow": x.overflowed(), "refused_steps": refused, "regrowths": trainer.exchange_regrowths}
         else:
             exchange = {"kind": "all-reduce of the dense gradient slab", "bytes_per_rank": 4 * trainer.slab.flat.numel()}
+        if exchange is not None:
+            exchange["world_size"] = torch.distributed.get_world_size()
+            exchange["backend"] = backend
+            exchange["ranks"] = identity
         sb = stage_bytes(N_GAUSS, V, I, P, T, rows, direct=(args.binning == "direct"), fused_single_view=not dist_on)
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         ach = sb[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         # Counter figures cannot be collected from inside this process: they come from the committed rocprofv3
         # --pmc runs of THIS command on this build (profiles/, made by profiles/experiments/pmc_run.sh) and are
         # labelled as such; per-launch instruction counts and HBM bytes of a fixed workload do not depend on the run.
-        traffic, traffic_src, valu = None, None, None
+        traffic = traffic_src = traffic_read = traffic_write = valu = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", PMC_HBM_FILE)))
             traffic = pm.get(dom, {}).get("traffic")
+            traffic_read = 2 * pm.get(dom, {}).get("fetch_raw", 0) or None
+            traffic_write = pm.get(dom, {}).get("write")
             traffic_src = f"profiles/{PMC_HBM_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
-                          f"session {pm.get('_session', '?')}; not collected in this run)"
+                          f"session {pm.get('_session', '?')}; not collected in this run; read = 2 x FETCH_SIZE, the gfx950 " \
+                          "correction for wide reads)"
         except Exception:
             pass
         try:
@@ -390,19 +635,23 @@ def main():
                                   "not collected in this run) / this run's HIP-event stage times"}
         except Exception:
             pass
-        ms_per_step = elapsed / args.steps * 1e3
-        step_s = elapsed / args.steps
+        ms_per_step = timing["median"]
+        step_s = ms_per_step * 1e-3
         out = {
             "metric": "splatted-Gaussians/s (fwd+bwd) @1200x680; achieved HBM GB/s vs peak",
             "value": N_GAUSS * world / step_s,
             "unit": "Gaussians/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step_min": timing["min"], "ms_per_step_max": timing["max"], "samples": timing["samples"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE,
             "data": "synthetic",
             "config": {"workload": "office0 stand-in (seeded box room), 200k surfels, 1200x680, 1 view per GPU (rank r: "
                                    "view 0 mirrored through the room's symmetry planes = equal work per rank), "
                                    "step = activations + fwd + bwd (fed fixed random image gradients d_rgb, d_normal, "
                                    "d_depth: no loss head in the step) + gradient-row exchange (N>1) + Adam",
+                       "timing": f"{timing['samples']} samples of exactly {args.steps} steps each, every sample bracketed by "
+                                 "barrier + torch.cuda.synchronize() on both sides, max over ranks per sample; ms_per_step "
+                                 "and value are the MEDIAN sample",
                        "gaussians": N_GAUSS, "image": [H, W], "views_per_gpu": 1, "visible": V,
                        "tile_instances": I, "parallelism": f"view-parallel dp{world}",
                        "overflow": bool(info["overflow"]) or bool(info["overflow_passes"]) or refused > 0,
@@ -420,24 +669,72 @@ def main():
                                          "tile_instances_per_s": I * world / step_s,
                                          "visible_fraction": V / N_GAUSS},
                        "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
-                       "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
+                       "eager_ms_per_step": round(eager_elapsed / max(k_prof, 1) * 1e3, 4),
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                        "stage_mean_ms": {k: round(v, 4) for k, v in stage_mean_ms.items()},
-                       "stage_timing": f"HIP events on the launch stream around every stage of {args.steps} eager steps "
+                       "stage_timing": f"HIP events on the launch stream around every stage of {k_prof} eager steps "
                                        "run right after the timed region (medians"
                                        + ("; the un-pipelined five-launch form of the step: `preprocess` and "
                                           "`preprocess_bwd` are separate kernels there, one launch in the timed region"
                                           if getattr(one_step, "pipelined", False) else "")
                                        + "); an event pair reads ~3 us more than rocprofv3's kernel duration"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_read": traffic_read,
+                         "traffic_write": traffic_write, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": sb[dom],
+                         "algorithmic_note": "render_bwd: 8 T + 68 I + 44 P + 64 V (the step passes d_rgb, d_normal, d_depth; "
+                                             "d_opacity / d_confidence are not given and not read).  The kernel adds one "
+                                             "64-byte gradient record per (surfel, wave that blended it) with atomics, not "
+                                             "one per surfel: its WRITE traffic exceeds the algorithmic 64 V by that factor "
+                                             "(traffic_write), its READ traffic matches the algorithmic reads",
                          "all_stages_GBps": {k: (sb[k] / (stage_ms[k] * 1e-3) / 1e9 if stage_ms[k] > 0 else 0.0)
+                                             for k in sb},
+                         "all_stages_frac": {k: (sb[k] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if stage_ms[k] > 0 else 0.0)
                                              for k in sb},
                          "whole_step_GBps": sum(sb.values()) / step_s / 1e9},
         }
+        out.update(extras)
         if valu is not None:
             out["roofline_valu"] = valu
+        if not dist_on and not args.no_extras and not args.eager:
+            # -- the same step with the blend backward's per-surfel sums in exact f32 (a second build of the library,
+            #    loaded by a CHILD process through AGS_LIB_PATH; this process keeps the GPU, the child runs beside it)
+            try:
+                import subprocess
+                from active_gs_amd import build as B
+                env = dict(os.environ, AGS_LIB_PATH=B.LIB_F32)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                    "--no-cpu-baseline", "--no-extras"] + (["--no-pipeline"] if args.no_pipeline else []),
+                                   env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                out["ms_per_step_f32_exact"] = json.loads(line[-1])["ms_per_step"] if (r.returncode == 0 and line) else None
+                if out["ms_per_step_f32_exact"] is None:
+                    out["f32_exact_note"] = (r.stderr or "")[-300:]
+            except Exception as e:
+                out["ms_per_step_f32_exact"] = None
+                out["f32_exact_note"] = f"{type(e).__name__}: {e}"
+            # -- the path an UNMODIFIED caller takes: the drop-in module under autograd, per view
+            try:
+                d1 = measure_dropin(dev, N_GAUSS, H, W, 1, iters=100)
+                d2 = measure_dropin(dev, N_GAUSS, 512, 512, 8, iters=25, focal=0.5 * 512 / 0.57735)
+                out["config"]["dropin_ms_per_view"] = round(d1["ms_per_view"], 4)
+                out["config"]["dropin"] = {"c2_1200x680_1_view": d1, "reference_shape_512x512_8_views": d2,
+                                           "what": "diff_gaussian_rasterization_2d.GaussianRasterizer under autograd, forward + "
+                                                   "backward per view (no facade, no loss head, no optimiser), measured after "
+                                                   "the timed region"}
+            except Exception as e:
+                out["config"]["dropin_ms_per_view"] = None
+                out["config"]["dropin"] = f"{type(e).__name__}: {e}"
+            # -- one GPU's share of BASELINE.json's configurations 4 and 5
+            try:
+                del trainer, one_step, many_steps
+                torch.cuda.empty_cache()
+                sec = {"c4_share": measure_config("c4: one GPU's 4 of 32 views, 1.5 M surfels @1200x680", 1_500_000, 680, 1200, 4,
+                                                  "room0", 20, dev),
+                       "c5": measure_config("c5: 5 M surfels @2048x2048, 1 view", 5_000_000, 2048, 2048, 1, "office0", 20, dev)}
+                out["config"]["secondary"] = {"c4_share_ms": sec["c4_share"]["ms_per_step"], "c5_ms": sec["c5"]["ms_per_step"], **sec}
+            except Exception as e:
+                out["config"]["secondary"] = f"{type(e).__name__}: {e}"
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only (contract)
             d_cpu = [t.cpu() for t in d_img]
 
@@ -457,7 +754,7 @@ def main():
                 assert not api.read_status(s0)["overflow"]
                 imgs = {"rgb": s0.rgb.cpu(), "normal": s0.normal.cpu(), "depth": s0.depth.cpu(), "opacity": s0.opacity.cpu()}
                 grads = {k: getattr(gr, k).cpu() for k in ("means3D", "opacities", "colors", "scales", "rotations")}
-                return imgs, grads
+                return imgs, grads, s0.radii.cpu()
 
             out["cpu_baseline"], out["parity"] = cpu_baseline(
                 raw_cpu, dict(tanx=tanx, tany=tany, bg=bg, view=cm["viewmatrix"][0], proj=cm["projmatrix"][0]), d_cpu, gpu_check)

@@ -60,6 +60,13 @@ typedef struct AgsCamera {
     const float* projmatrix; /* projmatrix, 16 floats */
     const float* bg;         /* bg, >= 3 floats (the reference passes 4) */
     const float* render_mask;/* render_mask: H*W floats {0,1}, or NULL when unused */
+    /* Optional (NULL = off): `config` itself, the DEVICE tensor of 5 floats the reference builds per call
+     * (operations.py:697-699: [1, 1, 1, importance?, front_only?]).  When given, the kernels read
+     * normalize_depth = config[1] > 0, perpix_depth = config[2] > 0, want_stats = config[3] > 0 and
+     * front_only = config[4] > 0 ON THE DEVICE and the four ints above are ignored - the caller does not have to
+     * read the tensor back (a stream synchronisation per view).  In this mode per_gaussian->importance / count must
+     * always be given and need NOT be zero-filled by the caller: the per-Gaussian kernel clears them. */
+    const float* config;
 } AgsCamera;
 
 /* Replaces the tensor kwargs of GaussianRasterizer.__call__ (operations.py:703-713).
@@ -200,11 +207,35 @@ typedef struct AgsStatus {
  * The forward pass leaves its state there; the backward pass of the same view reads it. */
 size_t ags_workspace_bytes(int32_t n, int32_t h, int32_t w, int64_t max_instances);
 
+/* Where the forward pass leaves the parts of its state a caller may want to look at (diagnostics, parity tests):
+ * byte offset and size of a region inside a workspace of this geometry.  Returns AGS_E_INVALID for an unknown region.
+ *   FINAL_T    (H*W) float    transmittance left behind each pixel (= 1 - the opacity image)
+ *   N_CONTRIB  (H*W) uint32   1-based position, in the pixel's tile list, of the last surfel the pixel blended (0: none)
+ *   GEOM       (n) x 16 float the projected surfel records
+ *   RANGES     (tiles) x 2 uint32   AGS_BIN_TILE_SORT / AGS_BIN_RADIX: [begin, end) of tile t's list in the id array;
+ *                                   AGS_BIN_DIRECT: {tile, count} of SLOT s, whose list starts at s * (max_instances / tiles)
+ *   KEYS       sorted (depth_bits << 32 | id) keys: AGS_BIN_TILE_SORT (list order = RANGES); AGS_BIN_DIRECT (slot order)
+ *   IDS        AGS_BIN_RADIX: the sorted ids (uint32) */
+#define AGS_REGION_FINAL_T 0
+#define AGS_REGION_N_CONTRIB 1
+#define AGS_REGION_GEOM 2
+#define AGS_REGION_RANGES 3
+#define AGS_REGION_KEYS 4
+#define AGS_REGION_IDS 5
+int ags_workspace_region(int32_t n, int32_t h, int32_t w, int64_t max_instances, int32_t binning_mode, int32_t region,
+                         size_t* offset, size_t* bytes);
+
 /* Must be called ONCE on a freshly allocated (or otherwise scribbled-on) workspace before its
  * first ags_forward: clears the counters the forward pass relies on.  Every ags_forward leaves
  * them clean again (each tile's workgroup resets its own counters), so there is no per-pass
  * memset in the default binning mode. */
 int ags_workspace_init(const AgsWorkspace* ws, int32_t n, int32_t h, int32_t w, ags_stream_t stream);
+
+/* Forgets a per-Gaussian stage that has run into this workspace without the rest of its pass (the prepared pass of
+ * ags_backward_fused_next when the caller leaves the pipeline: it has taken key slots and added to the partial sums):
+ * clears the binning counters like ags_workspace_init but KEEPS the status block, whose sticky words
+ * (AgsStatus.peak_instances / overflow_passes) a loop has not read yet. */
+int ags_workspace_discard_pass(const AgsWorkspace* ws, int32_t n, int32_t h, int32_t w, ags_stream_t stream);
 
 /* Forward: cull+project, tile binning, depth sort, per-tile blend. */
 int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* out,
@@ -249,7 +280,7 @@ int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* 
  *   ags_forward_resume       = the rest of that forward pass (tile sort + blend) - call it INSTEAD of ags_forward for
  *                              the view that was handed to ags_backward_fused_next, with the same camera contents.
  * The next view's matrices must be in place when ags_backward_fused_next runs.  To leave the pipeline (the prepared
- * pass is not wanted after all) re-initialise `next_ws` with ags_workspace_init before its next ags_forward - the
+ * pass is not wanted after all) call ags_workspace_discard_pass on `next_ws` before its next ags_forward - the
  * prepared pass has already taken key slots in it.  `rows_hint`: about how many rows the row set holds (it lives on the
  * device; 0 = unknown) - sizes the part of the launch that walks the list, any value is correct.  Results are identical
  * to ags_backward + ags_forward. */
@@ -262,6 +293,11 @@ int ags_forward_resume(const AgsCamera* cam, const AgsGaussians* in, const AgsIm
 
 /* Copies the status block to host memory: enqueues a D2H copy and waits for the stream. */
 int ags_read_status(const AgsWorkspace* ws, AgsStatus* host_out, ags_stream_t stream);
+/* The same without the wait: enqueues the copy and returns.  `host_out` should be page-locked host memory (else the
+ * runtime may stage and block); the caller finds out that the copy has landed with an event it records behind this
+ * call on the same stream.  Lets a per-view caller (the drop-in module) look at a view's overflow flag / capacity
+ * need one call LATE instead of stalling the stream after every forward pass. */
+int ags_read_status_async(const AgsWorkspace* ws, AgsStatus* host_out, ags_stream_t stream);
 
 /* Fused Adam over the five parameter tensors of gaussian_map.py:259-292
  * (means 3n, scales 3n, rotations 4n, opacities n, harmonics 3n), torch.optim.Adam

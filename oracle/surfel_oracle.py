@@ -230,6 +230,10 @@ def preprocess(means3D, means2D, opacities, confidences, colors, scales, rotatio
         conf=confidences.reshape(-1)[vis],
         rect=torch.stack([x0, y0, x1, y1], -1)[sel],
         ntiles=ntiles[sel],
+        # diagnostics for the parity tests' boundary analysis (every surfel that passed the near cull, detached):
+        # which rows, 3*sqrt(lambda_max) before the ceil, the pixel-space mean, the determinant, the facing test
+        diag=dict(keep=keep, rad_raw=(3.0 * torch.sqrt(lam)).detach(), mid=mid.detach(), mx=mx.detach(),
+                  my=my.detach(), det=det.detach(), dotnc=dotnc.detach()),
     )
     return out
 

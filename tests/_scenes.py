@@ -65,6 +65,7 @@ def oracle_on_tiles(ins, S, image_grads, tiles=None, max_tiles=None, batch=32, f
     covered = torch.zeros(H, W)
     names = ("rgb", "normal", "depth", "opacity", "confidence")
     images = {k: torch.zeros(3 if k in ("rgb", "normal") else 1, H, W) for k in names}
+    n_contrib = torch.zeros(H, W, dtype=torch.int32)
     for b0 in range(0, len(tiles), batch):
         sample = tiles[b0:b0 + batch]
         m = torch.zeros(H, W)
@@ -78,5 +79,6 @@ def oracle_on_tiles(ins, S, image_grads, tiles=None, max_tiles=None, batch=32, f
         covered += m
         for k in names:
             images[k] += R[k].detach() * m
-    aux = dict(G=G, ranges=ranges, tiles=tiles, nonempty=len(nonempty), max_list=int(lens.max()), instances=int(lens.sum()))
+        n_contrib += R["n_contrib"] * m.to(torch.int32)
+    aux = dict(G=G, ranges=ranges, sorted_owner=so, n_contrib=n_contrib, tiles=tiles, nonempty=len(nonempty), max_list=int(lens.max()), instances=int(lens.sum()))
     return images, covered, aux

@@ -28,7 +28,7 @@ AgsFrame make_frame(int H, int W, float tanfovx, float tanfovy, float scale_mod,
     F.tiles_x = (W + AGS_TILE - 1) / AGS_TILE; F.tiles_y = (H + AGS_TILE - 1) / AGS_TILE;
     F.tanfovx = tanfovx; F.tanfovy = tanfovy;
     F.fx = W / (2.0f * tanfovx); F.fy = H / (2.0f * tanfovy);
-    F.scale_mod = scale_mod; F.perpix_depth = perpix; F.front_only = front_only;
+    F.scale_mod = scale_mod; F.perpix_depth = perpix; F.front_only = front_only; F.cfg = nullptr;
     return F;
 }
 

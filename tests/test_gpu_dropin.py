@@ -1,0 +1,154 @@
+"""The drop-in module's call path itself (active-gs_amd/rasterizer.py): what an unmodified caller of
+``diff_gaussian_rasterization_2d`` gets per call (/root/reference/utils/operations.py:682-713) - the configuration
+read on the device, workspaces checked one call late instead of a stream synchronisation per view, the fallback for
+skewed tile lists."""
+import pytest
+import torch
+
+from _scenes import oracle_inputs, product_settings, room_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _call(S, gin, settings=None, dev=None):
+    from diff_gaussian_rasterization_2d import GaussianRasterizer
+    return GaussianRasterizer(settings or product_settings(S, dev))(gin[0], gin[1], gin[2], gin[3], None, gin[4], gin[5], gin[6], None)
+
+
+@pytest.fixture
+def fresh_module():
+    """every test starts from a module that has seen nothing"""
+    import active_gs_amd.rasterizer as R
+    R.check_overflow()
+    saved = (dict(R._need_seen), dict(R._mode_for), R.STATUS_CHECK, R.SKEW_FACTOR, R.DIRECT_BUDGET_BYTES)
+    R._need_seen.clear(); R._mode_for.clear(); R._workspace_pool.clear()
+    yield R
+    try:
+        R.check_overflow()
+    except RuntimeError:
+        pass
+    R._need_seen.clear(); R._need_seen.update(saved[0]); R._mode_for.clear(); R._mode_for.update(saved[1])
+    R.STATUS_CHECK, R.SKEW_FACTOR, R.DIRECT_BUDGET_BYTES = saved[2:]
+    R._workspace_pool.clear()
+
+
+def test_config_on_the_device_equals_config_on_the_host(agslib, fresh_module):
+    """The reference hands `config` over as a device tensor (operations.py:697-699); the kernels read the four flags
+    there.  A host tensor is decoded on the host (the template / int-flag path).  Same bits out, for every combination
+    the reference uses and the two depth flags."""
+    dev = torch.device("cuda:0")
+    h, w = 96, 128
+    gen = torch.Generator().manual_seed(5)
+    mask = (torch.rand(1, h, w, generator=gen) > 0.3).float()
+    for config in [(1, 1, 1, 0, 0), (1, 1, 1, 1, 1), (1, 0, 0, 0, 0), (1, 1, 0, 1, 0), (1, 0, 1, 0, 1)]:
+        a, S = room_case(2500, h, w, view=4, seed=4, scale_mult=3.0, config=config, mask=mask)
+        ins = oracle_inputs(a)
+        outs, grads = [], []
+        for where in ("device", "host"):
+            gin = [t.detach().clone().to(dev).requires_grad_(t.requires_grad) for t in ins]
+            s = product_settings(S, dev)
+            if where == "host":
+                s = s._replace(config=S.config.clone())         # a CPU tensor
+            out = _call(S, gin, s)
+            (out[0].sum() + out[1].sum() + 2 * out[2].sum()).backward()
+            outs.append([o.detach().cpu() for o in out])
+            grads.append([gin[i].grad.cpu() for i in (0, 2, 4, 5, 6)])
+        for k in range(8):
+            assert torch.equal(outs[0][k], outs[1][k]), (config, k)
+        for ga, gb in zip(*grads):                                # (the backward's atomics: order-dependent last bits)
+            assert float((ga - gb).abs().sum()) <= 1e-5 * float(gb.abs().sum()) + 1e-12
+        if not config[3]:
+            assert int(outs[0][6].abs().sum()) == 0 and float(outs[0][5].abs().sum()) == 0.0
+    fresh_module.check_overflow()
+
+
+def test_no_host_synchronisation_once_a_view_size_is_known(agslib, fresh_module):
+    """A call that finds a pooled workspace does not read anything back: the status block is copied to page-locked
+    memory without waiting and looked at by a later call."""
+    R = fresh_module
+    dev = torch.device("cuda:0")
+    a, S = room_case(3000, 120, 160, view=0, seed=0, scale_mult=3.0)
+    ins = oracle_inputs(a)
+    gin = [t.detach().clone().to(dev).requires_grad_(t.requires_grad) for t in ins]
+    c0 = dict(R.counters)
+    ref = None
+    for it in range(6):
+        out = _call(S, gin, dev=dev)
+        out[0].sum().backward()
+        if ref is None:
+            ref = out[0].detach().clone()
+        else:
+            assert torch.equal(out[0].detach(), ref)
+        for t in gin:
+            t.grad = None
+        del out
+    assert R.counters["forward_calls"] - c0["forward_calls"] == 6
+    assert R.counters["status_syncs"] - c0["status_syncs"] == 1          # the first call made the workspace
+    R.check_overflow()
+    assert R.counters["deferred_checks"] - c0["deferred_checks"] == 5 and R.counters["overflows"] == c0["overflows"]
+    # AGS_DROPIN_STATUS=always: the CUDA extension's behaviour, one read-back per call
+    R.STATUS_CHECK = "always"
+    c1 = dict(R.counters)
+    with torch.no_grad():
+        for _ in range(3):
+            _call(S, gin, dev=dev)
+    assert R.counters["status_syncs"] - c1["status_syncs"] == 3
+
+
+def test_overflow_of_a_pooled_workspace_is_reported_one_call_late_and_repaired(agslib, fresh_module):
+    """Deferred check: a view that outgrows the pooled workspace (here: the same surfels 12x larger) cannot be
+    repaired inside the call that has already returned - the NEXT call / check_overflow() raises, the size is raised,
+    and repeating the call gives the right image."""
+    R = fresh_module
+    from active_gs_amd import raster_api as api
+    dev = torch.device("cuda:0")
+    n, h, w = 4000, 120, 160
+    a, S = room_case(n, h, w, view=1, seed=1, scale_mult=1.0)
+    ins = oracle_inputs(a, requires_grad=False)
+    gin = [t.to(dev) for t in ins]
+    with torch.no_grad():
+        _call(S, gin, dev=dev)                                            # sized for small surfels
+        big = list(gin)
+        big[5] = gin[5] * 12.0
+        bad = _call(S, big, dev=dev)                                      # pooled workspace: not checked yet
+        with pytest.raises(RuntimeError, match="truncated"):
+            R.check_overflow()
+        assert R.counters["overflows"] >= 1
+        good = _call(S, big, dev=dev)                                     # a workspace is made for the size just learnt
+        R.check_overflow()
+    cam = api.Camera(h, w, S.tanfovx, S.tanfovy, S.viewmatrix.to(dev), S.projmatrix.to(dev), S.bg.to(dev))
+    g = api.Gaussians(big[0], big[5].contiguous(), big[6], big[2].reshape(-1).contiguous(), big[4], big[3])
+    st = api.alloc_state(n, h, w, 1 << 22, dev, api.BIN_TILE_SORT)
+    api.forward(cam, g, st)
+    assert not api.read_status(st)["overflow"]
+    assert torch.equal(good[0], st.rgb) and not torch.equal(bad[0], st.rgb)
+    # ... and the error is raised by the next CALL too, before it enqueues anything
+    R._need_seen.clear(); R._workspace_pool.clear()
+    with torch.no_grad():
+        _call(S, gin, dev=dev)
+        _call(S, big, dev=dev)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="repeat the iteration"):
+            _call(S, gin, dev=dev)
+
+
+def test_skewed_tile_lists_fall_back_to_scan_based_binning(agslib, fresh_module):
+    """One-pass binning needs tiles x the LONGEST list of key slots.  When that is far above the instance total (a
+    distant camera: most surfels in a few tiles) the view size moves to the scan-based binning - same image."""
+    R = fresh_module
+    from active_gs_amd import raster_api as api
+    dev = torch.device("cuda:0")
+    n, h, w = 3000, 128, 160
+    a, S = room_case(n, h, w, view=2, seed=2, scale_mult=2.0)
+    a["means"] = a["means"] * 0.05 + torch.tensor([0.0, 0.0, 0.0])       # everything in a small clump
+    ins = oracle_inputs(a, requires_grad=False)
+    gin = [t.to(dev) for t in ins]
+    R.SKEW_FACTOR, R.DIRECT_BUDGET_BYTES = 1e-9, 0                          # (thresholds a test scene can reach)
+    with torch.no_grad():
+        first = _call(S, gin, dev=dev)
+        assert R._mode_for.get((0, h, w)) == api.BIN_TILE_SORT and R.counters["mode_switches"] >= 1
+        second = _call(S, gin, dev=dev)
+        R.check_overflow()
+    assert any(k[-1] == api.BIN_TILE_SORT for k in R._workspace_pool)
+    for k in range(8):
+        assert torch.equal(first[k], second[k]), k
