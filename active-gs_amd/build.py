@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libags_raster.so")
 SOURCES = ["preprocess.hip", "binning.hip", "render.hip", "adam.hip", "loss.hip", "densify.hip", "capi.hip"]
-HEADERS = ["ags_internal.h", "surfel_math.h", os.path.join("..", "..", "include", "ags_raster.h")]
+HEADERS = ["ags_internal.h", "ags_experiments.h", "surfel_math.h", os.path.join("..", "..", "include", "ags_raster.h")]
 # loss.hip must reproduce exact cancellations of the reference's un-fused torch ops (see ags_point)
 # render.hip: -fno-signed-zeros lets the compiler fold the `0 + x` of freshly zeroed accumulators
 # (-2.5 % step time); NaN / inf semantics are left alone.
@@ -140,3 +140,58 @@ def build_demo() -> str:
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on the C ABI demo:\n{r.stderr}")
     return DEMO_BIN
+
+
+# ---- the drop-in module's native host side (csrc/torch_binding.cpp): a torch extension module built in-tree with g++
+# (no device code in it: it calls the C ABI) against the torch of this image; it travels with the repository snapshot
+# like the library does.
+BINDING_SRC = os.path.join(CSRC, "torch_binding.cpp")
+BINDING_NAME = "ags_torch_binding"
+BINDING = os.path.join(LIBDIR, BINDING_NAME + ".so")
+BINDING_STAMP = BINDING + ".srchash"
+
+
+def binding_digest() -> str:
+    import hashlib
+    import torch
+    h = hashlib.sha256()
+    for d in (BINDING_SRC, os.path.normpath(os.path.join(CSRC, "..", "..", "include", "ags_raster.h"))):
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(torch.__version__.encode())
+    h.update(b"flags-v1")
+    return h.hexdigest()
+
+
+def binding_is_stale() -> bool:
+    if not os.path.exists(BINDING) or not os.path.exists(BINDING_STAMP):
+        return True
+    with open(BINDING_STAMP) as f:
+        return f.read().strip() != binding_digest()
+
+
+def build_torch_binding(force: bool = False) -> str:
+    """Compile csrc/torch_binding.cpp into lib/ags_torch_binding.so.  Returns its path."""
+    if not force and not binding_is_stale():
+        return BINDING
+    import sysconfig
+    import torch
+    import torch.utils.cpp_extension as ce
+    os.makedirs(LIBDIR, exist_ok=True)
+    cxx = shutil.which("g++") or "g++"
+    inc = [*ce.include_paths(), sysconfig.get_paths()["include"], "/opt/rocm/include",
+           os.path.normpath(os.path.join(HERE, "..", "include"))]
+    libdirs = ce.library_paths() + ["/opt/rocm/lib"]
+    tmp = BINDING + ".tmp"
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-DTORCH_EXTENSION_NAME={BINDING_NAME}",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-Wno-deprecated-declarations", BINDING_SRC, "-o", tmp,
+           *[f"-I{i}" for i in inc], *[f"-L{d}" for d in libdirs], *[f"-Wl,-rpath,{d}" for d in libdirs],
+           "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python", "-lamdhip64", "-ldl"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed on torch_binding.cpp:\n{r.stderr[-6000:]}")
+    os.replace(tmp, BINDING)
+    with open(BINDING_STAMP, "w") as f:
+        f.write(binding_digest() + "\n")
+    return BINDING

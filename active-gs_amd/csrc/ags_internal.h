@@ -232,36 +232,9 @@ void ags_launch_compact_rows(int n, int width, const int32_t* dst_index, const f
 void ags_launch_prune_keep(int n, const float* prune_mask, const float* raw_opacities, float min_opacity, int32_t* keep,
                            hipStream_t s);
 
-// ---- experiment builds only (-DAGS_TIMELINE, profiles/experiments/timeline.py): every wave notes the shader clock
-// (s_memtime) at a few phase boundaries into a caller-provided buffer [kernel][wave][8]; compiled out otherwise.
-#define AGS_TL_WAVES 16384
-// -DAGS_TL_REALTIME: stamps from the chip-wide 100 MHz reference counter (s_memrealtime: 10 ns steps, the same on
-// every CU) instead of the shader clock, which every CU counts on its own: for launch ramps and kernel-to-kernel gaps
-#ifdef AGS_TL_REALTIME
-#define AGS_TL_CLOCK() __builtin_amdgcn_s_memrealtime()
-#else
-#define AGS_TL_CLOCK() __builtin_readcyclecounter()
-#endif
-#if defined(AGS_TIMELINE) && defined(__HIPCC__)
-#define AGS_TL_DEFINE(tu)                                                                                          \
-    static __device__ unsigned long long* ags_tl_buf = nullptr;                                                    \
-    void ags_tl_set_##tu(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(ags_tl_buf), &p, sizeof(p)); }
-#define AGS_TL(kid, wave_id, phase)                                                                                \
-    do {                                                                                                           \
-        if ((threadIdx.x & 63) == 0 && ags_tl_buf && (unsigned)(wave_id) < AGS_TL_WAVES)                           \
-            ags_tl_buf[(((size_t)(kid) * AGS_TL_WAVES) + (wave_id)) * 8 + (phase)] = AGS_TL_CLOCK();               \
-    } while (0)
-#define AGS_TL_VAL(kid, wave_id, phase, v)                                                                         \
-    do {                                                                                                           \
-        if ((threadIdx.x & 63) == 0 && ags_tl_buf && (unsigned)(wave_id) < AGS_TL_WAVES)                           \
-            ags_tl_buf[(((size_t)(kid) * AGS_TL_WAVES) + (wave_id)) * 8 + (phase)] = (unsigned long long)(v);      \
-    } while (0)
-#else
-#define AGS_TL_DEFINE(tu)
-#define AGS_TL(kid, wave_id, phase) do { } while (0)
-#define AGS_TL_VAL(kid, wave_id, phase, v) do { } while (0)
-#endif
-void ags_tl_set_preprocess(void*); void ags_tl_set_binning(void*); void ags_tl_set_render(void*);
+// instrumentation of experiment builds (per-wave phase timelines, issue-priority and prologue knobs): compiles to nothing
+// in the product build
+#include "ags_experiments.h"
 
 #if defined(__HIPCC__)
 // ---- AgsCamera.config: the reference hands its five configuration floats over as a DEVICE tensor it has just built
@@ -403,9 +376,6 @@ __device__ __forceinline__ void ags_emit_tiles_balanced(AgsEmitRec* wave_lds, ui
                                                         uint32_t wd, uint32_t pa, const AgsGeom& g, int tiles_x,
                                                         Fn&& f) {
     const int lane = threadIdx.x & 63;
-#ifdef AGS_EXP_NO_EMIT
-    if (cnt != 0xFFFFFFFFu) return;
-#endif
     const uint32_t incl = ags_wave_incl_scan_u32(cnt);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (total == 0) return; // wave-uniform

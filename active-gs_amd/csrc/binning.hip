@@ -447,9 +447,6 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
     // same predicate and same inputs as the counting pass in ags_k_preprocess<true>
     ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, x0, y0, wd, (uint32_t)threadIdx.x, g, tiles_x,
                             [&](bool hit, uint32_t t, uint32_t owner_tid, int) {
-#ifdef AGS_EXP_BUCKET_NOATOMIC
-        if (hit && t == 0xFFFFFFFFu) keys[0] = 1;
-#else
         const uint32_t got = ags_wave_agg_inc<AGG, true>(tile_fill, t, hit);
         if (hit) {
             uint32_t b, e;
@@ -459,7 +456,6 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_bucket(
             if (slot < e)
                 keys[slot] = ((uint64_t)depth_bits[owner_tid] << 32) | (uint32_t)(blockIdx.x * AGS_PRE_THREADS + owner_tid);
         }
-#endif
     });
     AGS_TL(1, tl_w, 3);
 }
@@ -518,12 +514,10 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict_
     const uint32_t slot = (uint32_t)band0 + rank_part[0] + rank_part[1] + rank_part[2] + rank_part[3];
     if (threadIdx.x == 0) {
         ranges[slot] = make_uint2((uint32_t)tile, K);
-#ifndef AGS_EXP_NO_PARTIALS
         if (cnt) {
             atomicAdd(&partial[AGS_PART(blockIdx.x, AGS_PART_SUM)], cnt);
             atomicMax(&partial[AGS_PART(blockIdx.x, AGS_PART_MAX)], cnt);
         }
-#endif
     }
     ags_sort_tile_keys<256, AGS_TSORT_LDS_KEYS, false>(keys_in + (size_t)tile * tile_cap, K, sk, threadIdx.x,
                                                        keys_out + (size_t)slot * tile_cap);
@@ -585,12 +579,10 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct_wave(uint2* __rest
     const uint32_t slot = (uint32_t)band0 + part[0][wave] + part[1][wave] + part[2][wave] + part[3][wave];
     if (lane == 0) {
         ranges[slot] = make_uint2((uint32_t)tile, K);
-#ifndef AGS_EXP_NO_PARTIALS
         if (cnt) {
             atomicAdd(&partial[AGS_PART(tile, AGS_PART_SUM)], cnt);
             atomicMax(&partial[AGS_PART(tile, AGS_PART_MAX)], cnt);
         }
-#endif
     }
     uint32_t lo[R], hi[R], rank[R];
 #pragma unroll

@@ -162,11 +162,7 @@ __device__ __forceinline__ void ags_preprocess_block(
     if (EMIT == 1)  // tile-sort binning: how many surfels can reach each tile
         ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, rx0, ry0, rwd, 0u, g, F.tiles_x,
                                 [&](bool hit, uint32_t t, uint32_t, int) {
-#ifdef AGS_EXP_PRE_NOCOUNT
-                                    if (hit && t == 0xFFFFFFFFu) tile_count[0] = 1;
-#else
                                     ags_wave_agg_inc<AGG, false>(tile_count, t, hit);
-#endif
                                 });
     if (EMIT == 2) { // one-pass binning: the tile's counter hands out the slot, the key is written at once
         const uint32_t wave_first = (uint32_t)(first + (threadIdx.x & ~63));
@@ -181,9 +177,7 @@ __device__ __forceinline__ void ags_preprocess_block(
     AGS_TL(0, tl_w, 4);
     const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
     if (EMIT == 2) { // no block-level reduction (and no barrier): one spread atomic per wave that shows anything
-#ifndef AGS_EXP_NO_PARTIALS
         if ((threadIdx.x & 63) == 0 && wv) atomicAdd(&direct.partial[AGS_PART(bx, AGS_PART_VIS)], wv);
-#endif
     } else {
         const int wave = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) { wsum[wave] = ws; wvis[wave] = wv; }

