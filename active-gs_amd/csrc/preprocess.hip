@@ -2,6 +2,8 @@
 // (conic/mean2D/depth/normal gradients -> means3D, scales, rotations, opacity, colour).
 // One lane per Gaussian; the camera matrices are wave-uniform (scalar loads).
 // Counterpart of the preprocess / preprocess-backward stages listed in SURVEY.md §2.3.
+#include <stdlib.h>
+
 #include "ags_internal.h"
 
 AGS_TL_DEFINE(preprocess)
@@ -220,6 +222,199 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
     }
     ags_preprocess_block<EMIT, AGG, false>(F, Vp, Pp, in, geom, tiles, rect, radii, block_sums, block_vis, tile_count, dgeom,
                                            touched, direct, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------
+// The forward per-Gaussian stage for LARGE maps of which a view shows little (one-pass binning, raw parameters: the
+// trainers' configuration 4 / 5 shape - 1.5 M / 5 M surfels, 11-20 % visible, in random order).  In ags_k_preprocess a
+// lane owns a row from load to key emission: with one row in nine visible nearly every wave still has a visible lane and
+// runs the ~900-instruction projection at a tenth of its lanes (config 5: ~110 of the kernel's 215 us are that).  Here
+// the workgroup's 512 rows are CULLED first with the mean alone - view depth, projected centre, and a radius bound that
+// needs no other input (scales are clamped to max_scale, the rotation is normalised in-kernel: lambda_max <=
+// max_scale^2 |J|_F^2 |A|_F^2 + 0.92) - the survivors (the visible rows plus a margin of ~130 px around the image) are
+// compacted, and the exact stage (the same ags_preprocess_fwd: bit-identical records) runs on full waves, gathering
+// the survivors' other inputs by row.  Key emission is balanced over the WORKGROUP's survivors.
+#define AGS_CULL_ROWS 512
+#define AGS_CULL_MIN_N (1 << 20)     // below this the plain kernel's single pass is the shorter chain
+__global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_cull(
+    AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,
+    AgsGeom* __restrict__ geom, int* __restrict__ radii, uint32_t* __restrict__ tile_count, float4* __restrict__ dgeom,
+    AgsRowSet touched, AgsDirectEmit direct, float* __restrict__ zero_importance, int* __restrict__ zero_count,
+    AgsViewStride vs) {
+    ags_frame_flags(F);
+    {
+        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
+        Vp += 16 * blockIdx.y; Pp += 16 * blockIdx.y;
+        radii += (size_t)blockIdx.y * (size_t)vs.n;
+        if (zero_importance) { zero_importance += (size_t)blockIdx.y * (size_t)vs.n; zero_count += (size_t)blockIdx.y * (size_t)vs.n; }
+        AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(dgeom, wo);
+        AGS_WS_SHIFT(direct.keys, wo); AGS_WS_SHIFT(direct.partial, wo);
+    }
+    constexpr int R = AGS_CULL_ROWS, NT = AGS_PRE_THREADS;
+    __shared__ __attribute__((aligned(16))) float lmeans[3 * R];
+    __shared__ unsigned short cand[R];
+    __shared__ AgsEmitRec emit[NT];
+    __shared__ uint32_t wtot[NT / 64], wcnt[2][NT / 64], s_total;
+    float V[16], P[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int first = blockIdx.x * R;
+    const int rows = min(R, in.n - first);
+    {   // the block's means: 6144 contiguous bytes, coalesced, kept in LDS for the exact stage
+        const float* src = in.means3D + (size_t)first * 3;
+        if (rows == R && ((uintptr_t)src & 15) == 0) {
+            for (int k = t; k < R * 3 / 4; k += NT) reinterpret_cast<float4*>(lmeans)[k] = reinterpret_cast<const float4*>(src)[k];
+        } else {
+            for (int k = t; k < rows * 3; k += NT) lmeans[k] = src[k];
+        }
+    }
+    __syncthreads();
+    // ---- the cull: conservative (never drops a row the exact stage would keep)
+    const float limx = AGS_FRUSTUM_CLAMP * F.tanfovx, limy = AGS_FRUSTUM_CLAMP * F.tanfovy;
+    float a2 = 0.f;   // |A|_F^2, A = the view matrix's 3x3 part
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a2 += V[k * 4 + 0] * V[k * 4 + 0] + V[k * 4 + 1] * V[k * 4 + 1] + V[k * 4 + 2] * V[k * 4 + 2];
+    const float smax = in.max_scale * F.scale_mod;
+    const float cb = 1.0001f * smax * smax * a2 * (F.fx * F.fx * (1.f + limx * limx) + F.fy * F.fy * (1.f + limy * limy));
+    bool is_cand[R / NT];
+#pragma unroll
+    for (int u = 0; u < R / NT; ++u) {
+        const int r = t + u * NT, i = first + r;
+        bool c = false;
+        if (r < rows) {
+            const float x = lmeans[3 * r], y = lmeans[3 * r + 1], z = lmeans[3 * r + 2];
+            const float tz = ags_affine(V, 2, x, y, z);
+            if (tz > AGS_NEAR_CULL) {
+                const float phx = ags_affine(P, 0, x, y, z), phy = ags_affine(P, 1, x, y, z), phw = ags_affine(P, 3, x, y, z);
+                const float pw = 1.0f / (phw + 1e-7f);
+                const float mx = ((phx * pw + 1.0f) * F.W - 1.0f) * 0.5f, my = ((phy * pw + 1.0f) * F.H - 1.0f) * 0.5f;
+                const float rb = 3.0f * sqrtf(cb / (tz * tz) + 0.92f) + 2.0f;       // >= ceil(3 sqrt(lambda_max)) + 1
+                // the exact rect [ (m - r) / 16, (m + r + 15) / 16 ) clamped to the grid is empty unless all four hold
+                c = (mx + rb >= 0.f) && (mx - rb < (float)(AGS_TILE * F.tiles_x)) && (my + rb >= 0.f) &&
+                    (my - rb < (float)(AGS_TILE * F.tiles_y));
+                c = c || !(mx == mx) || !(my == my);                                 // (never drop on a NaN: the exact stage decides)
+            }
+            if (!c) radii[i] = 0;
+            if (zero_importance) { zero_importance[i] = 0.f; zero_count[i] = 0; }
+        }
+        is_cand[u] = c;
+    }
+    // ---- compaction: survivors' local row numbers, in row order
+    uint32_t pre[R / NT];
+#pragma unroll
+    for (int u = 0; u < R / NT; ++u) {
+        const unsigned long long m = __ballot(is_cand[u]);
+        pre[u] = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[u][wave] = (uint32_t)__builtin_popcountll(m);
+    }
+    __syncthreads();
+    uint32_t ncand = 0;
+    {
+        uint32_t base = 0;
+#pragma unroll
+        for (int u = 0; u < R / NT; ++u) {
+#pragma unroll
+            for (int k = 0; k < NT / 64; ++k) {
+                if (k == wave && is_cand[u]) cand[base + pre[u]] = (unsigned short)(t + u * NT);
+                base += wcnt[u][k];
+            }
+        }
+        ncand = base;    // workgroup-uniform
+    }
+    __syncthreads();
+    // ---- the exact stage on the survivors + workgroup-balanced key emission, 256 survivors at a time
+    uint32_t vis_total = 0;
+    for (uint32_t c0 = 0; c0 < ncand; c0 += NT) {
+        const bool have = c0 + t < ncand;
+        const int r = have ? (int)cand[c0 + t] : 0, i = first + r;
+        uint32_t cnt = 0, vis = 0, rx0 = 0, ry0 = 0, rwd = 1;
+        AgsGeom g;
+        g.mx = g.my = g.ca = g.cb = g.cc = g.o = 0.f; g.dc = 0.f;
+        int was_member = 1;
+        if (have) {
+            const float p[3] = {lmeans[3 * r], lmeans[3 * r + 1], lmeans[3 * r + 2]};
+            float sc[3] = {in.scales[3 * (size_t)i], in.scales[3 * (size_t)i + 1], in.scales[3 * (size_t)i + 2]};
+            const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
+            float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            float opacity = in.opacities[i];
+            const float col[3] = {in.colors[3 * (size_t)i], in.colors[3 * (size_t)i + 1], in.colors[3 * (size_t)i + 2]};
+            const float conf = in.confidences[i];
+            was_member = touched.member ? touched.member[i] : 1;
+            { float rv[3], qi; ags_activate_inplace(in, sc, q, opacity, rv, qi); }
+            int radius = 0, rc[4];
+            if (ags_preprocess_fwd(F, V, P, p, sc, q, opacity, col, conf, 0.f, 0.f, g, radius, rc)) {
+                float4* dst = reinterpret_cast<float4*>(geom + i);
+                dst[0] = make_float4(g.mx, g.my, g.ca, g.cb);
+                dst[1] = make_float4(g.cc, g.o, g.dc, g.gx);
+                dst[2] = make_float4(g.gy, g.r, g.g, g.b);
+                dst[3] = make_float4(g.nx, g.ny, g.nz, g.conf);
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                dgeom[4 * (size_t)i + 0] = z4; dgeom[4 * (size_t)i + 1] = z4;
+                dgeom[4 * (size_t)i + 2] = z4; dgeom[4 * (size_t)i + 3] = z4;
+                cnt = (uint32_t)((rc[2] - rc[0]) * (rc[3] - rc[1]));
+                rx0 = (uint32_t)rc[0]; ry0 = (uint32_t)rc[1]; rwd = (uint32_t)(rc[2] - rc[0]);
+                vis = 1;
+            }
+            radii[i] = radius;
+        }
+        if (touched.member) { // sticky row set of the optimisation loop: insert first-time-visible surfels
+            const bool fresh = vis && was_member == 0 && atomicExch(&touched.member[i], 1) == 0;
+            const unsigned long long mask = __ballot(fresh);
+            if (mask) { // wave-uniform
+                int base = 0;
+                if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(touched.count, (int)__builtin_popcountll(mask));
+                base = __shfl(base, (int)__builtin_ctzll(mask));
+                if (fresh) touched.rows[base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = i;
+            }
+        }
+        vis_total += ags_wave_sum_u32(vis);
+        // the batch's (surfel, candidate tile) pairs flattened over the whole workgroup
+        const uint32_t incl = ags_wave_incl_scan_u32(cnt);
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();          // (also: the previous batch's emit[] reads are done)
+        uint32_t excl = incl - cnt, total = 0;
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) { if (k < wave) excl += wtot[k]; total += wtot[k]; }
+        AgsEmitRec me;
+        me.excl = excl; me.xy = rx0 | (ry0 << 16); me.wd = rwd; me.pa = __float_as_uint(g.dc);
+        me.mx = g.mx; me.my = g.my; me.ca = g.ca; me.cb = g.cb; me.cc = g.cc; me.o = g.o;
+        emit[t] = me;
+        __syncthreads();
+        constexpr int NR = 2;     // rounds of 256 pairs with their slot atomics in flight together
+        for (uint32_t base = 0; base < total; base += (uint32_t)NT * NR) {
+            bool hit[NR];
+            uint32_t tile[NR], got[NR], owner_depth[NR], owner_row[NR];
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                hit[rr] = false; tile[rr] = got[rr] = owner_depth[rr] = owner_row[rr] = 0u;
+                const uint32_t j = base + (uint32_t)NT * rr + t;
+                if (j < total) {
+                    int l = 0;
+#pragma unroll
+                    for (int step = NT / 2; step > 0; step >>= 1)
+                        if (emit[l + step].excl <= j) l += step;       // largest entry with excl <= j (entries without tiles share their successor's excl and lose to it)
+                    const AgsEmitRec rec = emit[l];
+                    const uint32_t tt = j - rec.excl;
+                    const uint32_t tx = (rec.xy & 0xFFFF) + tt % rec.wd, ty = (rec.xy >> 16) + tt / rec.wd;
+                    AgsGeom og;
+                    og.mx = rec.mx; og.my = rec.my; og.ca = rec.ca; og.cb = rec.cb; og.cc = rec.cc; og.o = rec.o;
+                    const float bx = (float)(tx * AGS_TILE), by = (float)(ty * AGS_TILE);
+                    hit[rr] = ags_reaches_box(og, bx, bx + (AGS_TILE - 1), by, by + (AGS_TILE - 1));
+                    tile[rr] = ty * F.tiles_x + tx; owner_depth[rr] = rec.pa;
+                    owner_row[rr] = (uint32_t)first + (uint32_t)cand[c0 + l];
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr)
+                if (hit[rr]) got[rr] = atomicAdd(&tile_count[(size_t)tile[rr] * AGS_TC_STRIDE], 1u);
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr)
+                if (hit[rr] && got[rr] < direct.tile_cap)
+                    direct.keys[(size_t)tile[rr] * direct.tile_cap + got[rr]] = ((uint64_t)owner_depth[rr] << 32) | owner_row[rr];
+        }
+    }
+    if (lane == 0 && vis_total) atomicAdd(&direct.partial[AGS_PART(blockIdx.x * (NT / 64) + wave, AGS_PART_VIS)], vis_total);
 }
 
 __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_bwd(
@@ -755,6 +950,14 @@ void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGau
                        (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched, direct, zero_importance,         \
                        zero_count, vs)
     const bool agg = L.num_tiles <= AGS_AGG_MAX_TILES;
+    // large maps, raw parameters, one-pass binning: cull with the means first, project the survivors on full waves
+    static const int cull_min_n = [] { const char* e = getenv("AGS_PRE_CULL_MIN_N"); return e ? atoi(e) : AGS_CULL_MIN_N; }();
+    if (emit == 2 && !agg && in.raw_params && in.n >= cull_min_n && in.max_scale > 0.f) {
+        hipLaunchKernelGGL(ags_k_preprocess_cull, dim3((in.n + AGS_CULL_ROWS - 1) / AGS_CULL_ROWS, vs.views), dim3(AGS_PRE_THREADS), 0, s, F,
+                           cam.viewmatrix, cam.projmatrix, in, (AgsGeom*)(ws + L.geom), radii, (uint32_t*)(ws + L.tile_count),
+                           (float4*)(ws + L.dgeom), touched, direct, zero_importance, zero_count, vs);
+        return;
+    }
     if (emit == 0) AGS_LAUNCH_PRE(0, false);
     else if (emit == 1) { if (agg) AGS_LAUNCH_PRE(1, true); else AGS_LAUNCH_PRE(1, false); }
     else { if (agg) AGS_LAUNCH_PRE(2, true); else AGS_LAUNCH_PRE(2, false); }
