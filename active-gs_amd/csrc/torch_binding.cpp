@@ -13,8 +13,8 @@
 //   * inputs are used in place when they are contiguous float32 on the GPU (the reference's always are);
 //   * `config` (operations.py:697-699) stays on the device: the kernels read its four flags there (AgsCamera.config);
 //   * outputs are fresh tensors; the view's workspace (projected records, keys, per-pixel blend state, gradient
-//     records) comes from a pool keyed by (device, surfels, image size, binning mode) and goes back when the autograd
-//     node releases its saved state (after backward, or when the graph is dropped);
+//     records) comes from a pool keyed by (device, image size, binning mode) - a slab laid out for another map size is
+//     re-initialised if it is large enough - and goes back when the autograd node is destroyed (the graph is dropped);
 //   * the workspace check: a call that has to MAKE a workspace reads the status block back and repairs an overflow on
 //     the spot (what the CUDA extension's num_rendered read-back does on every call); a call that finds a pooled one
 //     copies the status block to page-locked memory without waiting and a LATER call (or check_overflow()) looks at
@@ -73,8 +73,10 @@ struct Counters { int64_t forward_calls = 0, status_syncs = 0, deferred_checks =
 
 using SizeKey = std::tuple<int, int, int>;           // device, h, w
 using NeedKey = std::tuple<int, int, int, int>;      // device, h, w, mode
-using PoolKey = std::tuple<int, int, int, int, int>; // device, n, h, w, mode
-struct Pooled { at::Tensor ws; int64_t cap; };
+using PoolKey = std::tuple<int, int, int, int>;      // device, h, w, mode
+// a pooled slab remembers the layout it was initialised for (surfels, key slots): a map that has grown or shrunk since
+// re-initialises a slab that is large enough instead of leaving one set of workspaces per map size behind
+struct Pooled { at::Tensor ws; int64_t cap; int n; };
 std::mutex mu;
 std::map<NeedKey, int64_t> need_seen;
 std::map<SizeKey, int> mode_for;
@@ -149,36 +151,45 @@ void poll_pending(bool block) {
                 "has been raised - repeat the iteration (AGS_DROPIN_STATUS=always checks every call before it returns).");
 }
 
-// a pooled workspace of at least min_cap key slots, or a new one of cap; -> (tensor, slots, newly made)
+// a pooled workspace laid out for n surfels with at least min_cap key slots; else a pooled slab that is large enough,
+// re-initialised for (n, cap); else a new one of cap; -> (tensor, slots, newly made or re-initialised)
 std::tuple<at::Tensor, int64_t, bool> take_workspace(const PoolKey& pk, int n, int h, int w, int64_t min_cap, int64_t cap,
                                                     const at::TensorOptions& bytes_opt, int mode, hipStream_t stream) {
+    const size_t bytes = abi.workspace_bytes(n, h, w, cap);
+    at::Tensor reuse;
     {
         std::lock_guard<std::mutex> g(mu);
         auto it = pool.find(pk);
         if (it != pool.end()) {
             auto& v = it->second;
-            while (!v.empty()) {                 // too-small ones are dropped: the need only grows
-                Pooled p = std::move(v.back());
-                v.pop_back();
-                if (p.cap >= min_cap) return {p.ws, p.cap, false};
+            for (size_t k = v.size(); k-- > 0;) {          // newest first
+                if (v[k].n == n && v[k].cap >= min_cap) {
+                    Pooled p = std::move(v[k]);
+                    v.erase(v.begin() + k);
+                    return {p.ws, p.cap, false};
+                }
             }
+            for (size_t k = v.size(); k-- > 0;) {
+                if ((size_t)v[k].ws.numel() >= bytes) { reuse = std::move(v[k].ws); v.erase(v.begin() + k); break; }
+            }
+            if (!reuse.defined()) v.clear();   // every pooled slab is too small for this map: the need only grows, let them go
         }
     }
-    const size_t bytes = abi.workspace_bytes(n, h, w, cap);
-    at::Tensor ws = at::empty({(int64_t)bytes}, bytes_opt);
-    AgsWorkspace wss{ws.data_ptr(), bytes, cap, mode};
+    at::Tensor ws = reuse.defined() ? reuse : at::empty({(int64_t)bytes}, bytes_opt);
+    AgsWorkspace wss{ws.data_ptr(), (size_t)ws.numel(), cap, mode};
     check_rc(abi.workspace_init(&wss, n, h, w, stream), "ags_workspace_init");
     return {ws, cap, true};
 }
 
 // returns its workspace to the pool when the autograd node lets go of its saved state
 struct Lease : torch::CustomClassHolder {
-    PoolKey key; at::Tensor ws; int64_t cap;
-    Lease(PoolKey k, at::Tensor t, int64_t c) : key(k), ws(std::move(t)), cap(c) {}
+    PoolKey key; at::Tensor ws; int64_t cap; int n;
+    Lease(PoolKey k, at::Tensor t, int64_t c, int n_) : key(k), ws(std::move(t)), cap(c), n(n_) {}
     ~Lease() override {
         std::lock_guard<std::mutex> g(mu);
         auto& v = pool[key];
-        if ((int)v.size() < opt.pool_max_per_key) v.push_back(Pooled{std::move(ws), cap});
+        if ((int)v.size() >= opt.pool_max_per_key) v.erase(v.begin());
+        v.push_back(Pooled{std::move(ws), cap, n});
     }
 };
 
@@ -272,7 +283,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
             const int64_t floor_cap = std::max<int64_t>(1 << 16, 2 * n);
             const int64_t min_cap = std::min(std::max<int64_t>((int64_t)(seen * opt.min_headroom) + 1024, floor_cap), kU32);
             const int64_t new_cap = std::min(std::max<int64_t>((int64_t)(seen * opt.headroom) + 1024, floor_cap), kU32);
-            pk = PoolKey{dev.index(), (int)n, (int)h, (int)w, mode};
+            pk = PoolKey{dev.index(), (int)h, (int)w, mode};
             bool fresh;
             std::tie(ws, ws_cap, fresh) = take_workspace(pk, (int)n, (int)h, (int)w, min_cap, new_cap, fo.dtype(at::kByte), mode, stream);
             AgsWorkspace wss{ws.data_ptr(), (size_t)ws.numel(), ws_cap, mode};
@@ -310,7 +321,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
             // workspace back to the pool when the node releases its saved state
             ctx->save_for_backward({depth, opacity, radii, m3, sc, rot, op, col, conf, V, P, bg,
                                     mask.defined() ? mask : at::Tensor(), cfg.defined() ? cfg : at::Tensor()});
-            ctx->saved_data["lease"] = c10::make_intrusive<Lease>(pk, ws, ws_cap);
+            ctx->saved_data["lease"] = c10::make_intrusive<Lease>(pk, ws, ws_cap, (int)n);
             ctx->saved_data["scalars"] = std::vector<double>{double(h), double(w), tanx, tany, scale_mod, weight_thres,
                                                              double(flags[0]), double(flags[1]), double(flags[2]), double(flags[3]),
                                                              double(ws_cap), double(mode)};
@@ -319,7 +330,8 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         } else {
             std::lock_guard<std::mutex> g(mu);
             auto& v = pool[pk];
-            if ((int)v.size() < opt.pool_max_per_key) v.push_back(Pooled{ws, ws_cap});
+            if ((int)v.size() >= opt.pool_max_per_key) v.erase(v.begin());
+            v.push_back(Pooled{ws, ws_cap, (int)n});
         }
         ctx->set_materialize_grads(false);
         ctx->mark_non_differentiable({importance, count, radii});
@@ -430,14 +442,18 @@ std::map<std::string, int64_t> counters() {
 }
 
 // what the module has learnt: [(device, h, w, mode, largest need seen)], [(device, h, w, mode in use)], pooled workspaces
-// [(device, n, h, w, mode, count)]
+// [(device, h, w, mode, count, bytes)]
 std::tuple<std::vector<std::vector<int64_t>>, std::vector<std::vector<int64_t>>, std::vector<std::vector<int64_t>>> state() {
     std::lock_guard<std::mutex> g(mu);
     std::vector<std::vector<int64_t>> a, b, c;
     for (auto& kv : need_seen) a.push_back({std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first), kv.second});
     for (auto& kv : mode_for) b.push_back({std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), kv.second});
-    for (auto& kv : pool) c.push_back({std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first),
-                                       std::get<4>(kv.first), (int64_t)kv.second.size()});
+    for (auto& kv : pool) {
+        int64_t bytes = 0;
+        for (auto& p : kv.second) bytes += p.ws.numel();
+        c.push_back({std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first),
+                     (int64_t)kv.second.size(), bytes});
+    }
     return {a, b, c};
 }
 

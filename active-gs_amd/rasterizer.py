@@ -118,7 +118,7 @@ def counters() -> dict:
 def state() -> dict:
     need, modes, pooled = _load_binding().state()
     return dict(need_seen={tuple(r[:4]): r[4] for r in need}, mode_for={tuple(r[:3]): r[3] for r in modes},
-                pooled={tuple(r[:5]): r[5] for r in pooled})
+                pooled={tuple(r[:4]): dict(count=r[4], bytes=r[5]) for r in pooled})
 
 
 def reset_state() -> None:

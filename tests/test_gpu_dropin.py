@@ -153,3 +153,28 @@ def test_skewed_tile_lists_fall_back_to_scan_based_binning(agslib, fresh_module)
     assert any(k[-1] == api.BIN_TILE_SORT for k in R.state()["pooled"])
     for k in range(8):
         assert torch.equal(first[k], second[k]), k
+
+
+def test_a_growing_map_does_not_leave_a_set_of_workspaces_per_size_behind(agslib, fresh_module):
+    """The mapper's map changes size at every keyframe (gaussian_map.py:294-468, :234-246).  Pooled workspaces are keyed
+    by image size and binning mode only: a slab laid out for another map size is re-initialised when it is large enough,
+    dropped when it is not - the pool holds a bounded number of slabs however many sizes it has seen."""
+    R = fresh_module
+    dev = torch.device("cuda:0")
+    h, w = 96, 128
+    ref = {}
+    for rnd in range(2):
+        for n in (3000, 1800, 2600, 4100, 2200, 5000, 900):          # grows and shrinks
+            a, S = room_case(n, h, w, view=3, seed=n, scale_mult=3.0)
+            ins = oracle_inputs(a)
+            gin = [t.detach().clone().to(dev).requires_grad_(t.requires_grad) for t in ins]
+            outs = [_call(S, gin, dev=dev) for _ in range(3)]           # three views alive at once, like a training batch
+            sum(o[0].sum() for o in outs).backward()
+            img = outs[0][0].detach().clone()
+            if n in ref:
+                assert torch.equal(img, ref[n])                          # a re-initialised slab renders the same bits
+            ref[n] = img
+            del outs
+    R.check_overflow()
+    pooled = R.state()["pooled"]
+    assert len(pooled) == 1 and next(iter(pooled.values()))["count"] <= 3, pooled
