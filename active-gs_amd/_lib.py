@@ -51,12 +51,17 @@ class AgsGaussianGrads(C.Structure):
                 ("d_colors", c_f32p), ("d_means2D", c_f32p), ("accumulate", C.c_int32), ("adam_clock", C.c_void_p),
                 ("adam_lr", C.c_float * 5), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float),
                 ("touched", AgsRowSet), ("fused_adam", C.c_void_p), ("adam_eps", C.c_float),
-                ("pack_segment", c_f32p), ("pack_capacity", C.c_int32)]
+                ("pack_segment", c_f32p), ("pack_capacity", C.c_int32), ("defer_rows", C.c_int32)]
+
 
 
 class AgsWorkspace(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_size_t), ("max_instances", C.c_int64),
                 ("binning_mode", C.c_int32)]
+
+
+class AgsViewRef(C.Structure):
+    _fields_ = [("cam", C.POINTER(AgsCamera)), ("radii", C.c_void_p), ("ws", C.POINTER(AgsWorkspace))]
 
 
 class AgsStatus(C.Structure):
@@ -96,7 +101,7 @@ class AgsCandidates(C.Structure):
 
 
 EXPORTS = ["ags_workspace_bytes", "ags_workspace_region", "ags_workspace_init", "ags_workspace_discard_pass", "ags_forward", "ags_forward_batch",
-           "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_backward_fused_next", "ags_forward_resume", "ags_read_status", "ags_read_status_async", "ags_adam_step",
+           "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_backward_rows", "ags_backward_fused_next", "ags_forward_resume", "ags_read_status", "ags_read_status_async", "ags_adam_step",
            "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_rows_index", "ags_adam_step_gathered", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_smooth_depth", "ags_densify_candidates",
            "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_compact_plan_bytes", "ags_compact_plan",
            "ags_compact_rows", "ags_profile_enable", "ags_profile_read",
@@ -142,6 +147,9 @@ def load() -> C.CDLL:
     lib.ags_backward.argtypes = [C.POINTER(AgsCamera), C.POINTER(AgsGaussians), C.POINTER(AgsImages),
                                  C.POINTER(AgsPerGaussian), C.POINTER(AgsImageGrads), C.POINTER(AgsGaussianGrads),
                                  C.POINTER(AgsWorkspace), C.c_void_p]
+    lib.ags_backward_rows.restype = C.c_int
+    lib.ags_backward_rows.argtypes = [C.POINTER(AgsViewRef), C.c_int32, C.POINTER(AgsGaussians), C.POINTER(AgsGaussianGrads),
+                                      C.c_void_p]
     lib.ags_backward_fused_next.restype = C.c_int
     lib.ags_backward_fused_next.argtypes = [C.POINTER(AgsCamera), C.POINTER(AgsGaussians), C.POINTER(AgsImages),
                                             C.POINTER(AgsPerGaussian), C.POINTER(AgsImageGrads), C.POINTER(AgsGaussianGrads),

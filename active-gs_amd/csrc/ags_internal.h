@@ -183,6 +183,16 @@ void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
 void ags_launch_preprocess_bwd(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
                                const AgsLayout& L, const int* radii, const AgsGaussianGrads& din,
                                const AgsViewStride& vs, hipStream_t s);
+// ags_backward_rows: per view the frame, the matrices, the gradient records and the radii
+struct AgsRowViews {
+    int views;
+    AgsFrame F[AGS_MAX_ROW_VIEWS];
+    const float* V[AGS_MAX_ROW_VIEWS];
+    const float* P[AGS_MAX_ROW_VIEWS];
+    AgsGeomGrad* dgeom[AGS_MAX_ROW_VIEWS];
+    const int* radii[AGS_MAX_ROW_VIEWS];
+};
+void ags_launch_rows_multi(const AgsRowViews& rv, const AgsGaussians& in, const AgsGaussianGrads& din, hipStream_t s);
 void ags_launch_adam(const AgsAdamTensors& t, float beta1, float beta2, float eps, int step, void* dev_state,
                      bool pre_ticked, hipStream_t s);
 #if defined(__HIPCC__)

@@ -164,10 +164,12 @@ static int ags_backward_impl(const AgsCamera* cam, const AgsGaussians* in, const
     if (!cam || !in || !fwd || !pg || !dout || !din || !ws || !ws->ptr) return AGS_E_INVALID;
     if (in->n == 0) return next_cam ? AGS_E_INVALID : AGS_OK;
     if (!pg->radii || !fwd->depth || !fwd->opacity) return AGS_E_INVALID;
-    {   // all five gradient arrays, or - fused optimiser step, overwrite mode - none at all
+    if (!din->defer_rows) {   // all five gradient arrays, or - fused optimiser step, overwrite mode - none at all
         const int have = (din->d_means3D != nullptr) + (din->d_scales != nullptr) + (din->d_rotations != nullptr) +
                          (din->d_opacities != nullptr) + (din->d_colors != nullptr);
         if (have != 5 && !(have == 0 && din->fused_adam && din->accumulate == 0 && !din->d_means2D)) return AGS_E_INVALID;
+    } else if (next_cam || din->fused_adam || din->pack_segment) {
+        return AGS_E_INVALID;   // a deferred view runs its blend backward only; the optimiser / exchange tail belongs to ags_backward_rows
     }
     const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
     if (ws->bytes < L.total) return AGS_E_WORKSPACE;
@@ -215,6 +217,7 @@ static int ags_backward_impl(const AgsCamera* cam, const AgsGaussians* in, const
     }
     { StageScope t(AGS_STAGE_RENDER_BWD, s);
       ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, tick, kOneView, ws->binning_mode == AGS_BIN_DIRECT, s); }
+    if (din->defer_rows) return ags_check_launch();
     if (next_cam) {
         const AgsLayout L2 = ags_make_layout(in->n, next_cam->image_height, next_cam->image_width, next_ws->max_instances);
         const AgsFrame F2 = ags_make_frame(next_cam);
@@ -268,8 +271,11 @@ int ags_backward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* 
                        const AgsWorkspace* ws, ags_stream_t stream) {
     if (!cam || !in || !fwd || !pg || !dout || !din || !ws || !ws->ptr || views < 1 || views > 65535) return AGS_E_INVALID;
     if (in->n <= 0 || !pg->radii || !fwd->depth || !fwd->opacity) return AGS_E_INVALID;
-    if (!din->d_means3D || !din->d_scales || !din->d_rotations || !din->d_opacities || !din->d_colors) return AGS_E_INVALID;
-    if (din->accumulate != 2 || din->fused_adam || din->pack_segment) return AGS_E_INVALID; // views sum with atomics into a pre-zeroed slab
+    if (!din->defer_rows) {
+        if (!din->d_means3D || !din->d_scales || !din->d_rotations || !din->d_opacities || !din->d_colors) return AGS_E_INVALID;
+        if (din->accumulate != 2) return AGS_E_INVALID;     // views sum with atomics into a pre-zeroed slab
+    }
+    if (din->fused_adam || din->pack_segment) return AGS_E_INVALID;
     if (ws->binning_mode != AGS_BIN_TILE_SORT && ws->binning_mode != AGS_BIN_DIRECT) return AGS_E_INVALID;
     const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
     if (ws->bytes < (size_t)views * L.total) return AGS_E_WORKSPACE;
@@ -286,7 +292,44 @@ int ags_backward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* 
     }
     ags_launch_render_bwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *fwd, *dout, tick, vs,
                           ws->binning_mode == AGS_BIN_DIRECT, s);
-    ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, vs, s);
+    if (!din->defer_rows) ags_launch_preprocess_bwd(F, *cam, *in, base, L, pg->radii, *din, vs, s);
+    return ags_check_launch();
+}
+
+int ags_backward_rows(const AgsViewRef* views, int32_t num_views, const AgsGaussians* in, const AgsGaussianGrads* din,
+                      ags_stream_t stream) {
+    if (!views || !in || !din || num_views < 1 || num_views > AGS_MAX_ROW_VIEWS) return AGS_E_INVALID;
+    if (in->n == 0) return AGS_OK;
+    if (!din->touched.member || !din->touched.rows || !din->touched.count || din->accumulate == 2) return AGS_E_INVALID;
+    if (!in->means3D || !in->scales || !in->rotations || !in->opacities) return AGS_E_INVALID;
+    {
+        const int have = (din->d_means3D != nullptr) + (din->d_scales != nullptr) + (din->d_rotations != nullptr) +
+                         (din->d_opacities != nullptr) + (din->d_colors != nullptr);
+        if (have != 5 && !(have == 0 && (din->fused_adam || din->pack_segment) && !din->d_means2D)) return AGS_E_INVALID;
+        if (din->accumulate != 0 && have != 5) return AGS_E_INVALID;
+    }
+    if (din->fused_adam) {
+        if (!din->adam_clock || din->pack_segment) return AGS_E_INVALID;
+        if (int e = ags_adam_check(din->fused_adam, false)) return e;
+        const int64_t* ne = din->fused_adam->numel;
+        const int64_t n64 = in->n;
+        if (ne[0] != 3 * n64 || ne[1] != 3 * n64 || ne[2] != 4 * n64 || ne[3] != n64 || ne[4] != 3 * n64) return AGS_E_INVALID;
+    }
+    if (din->pack_segment && din->pack_capacity < 0) return AGS_E_INVALID;
+    AgsRowViews rv;
+    rv.views = num_views;
+    for (int v = 0; v < num_views; ++v) {
+        const AgsViewRef& r = views[v];
+        if (!r.cam || !r.radii || !r.ws || !r.ws->ptr || !r.cam->viewmatrix || !r.cam->projmatrix) return AGS_E_INVALID;
+        if (r.cam->image_height <= 0 || r.cam->image_width <= 0) return AGS_E_INVALID;
+        const AgsLayout L = ags_make_layout(in->n, r.cam->image_height, r.cam->image_width, r.ws->max_instances);
+        if (r.ws->bytes < L.total) return AGS_E_WORKSPACE;
+        rv.F[v] = ags_make_frame(r.cam);
+        rv.V[v] = r.cam->viewmatrix; rv.P[v] = r.cam->projmatrix;
+        rv.dgeom[v] = (AgsGeomGrad*)((char*)r.ws->ptr + L.dgeom);
+        rv.radii[v] = r.radii;
+    }
+    { StageScope t(AGS_STAGE_PREPROCESS_BWD, (hipStream_t)stream); ags_launch_rows_multi(rv, *in, *din, (hipStream_t)stream); }
     return ags_check_launch();
 }
 

@@ -878,6 +878,193 @@ __device__ __forceinline__ void ags_rows_body(
     AGS_TL_VAL(4, wave_index, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32));
 }
 
+// ---------------------------------------------------------------------------------------
+// ags_backward_rows: the per-Gaussian backward of ALL the views of an optimisation step in one launch.  One lane per
+// member row; the row's inputs are loaded and activated once; every view that shows the row adds its chain rule (in the
+// space of the ACTIVATED parameters: the activations' own chain rule is view-independent and applied once to the sum);
+// then the tail of the single-view row kernel: MODE 1 fused Adam, MODE 2 exchange segment, MODE 0 gradient arrays.
+template <int MODE>
+__global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_rows_multi(AgsRowViews rv, AgsGaussians in, AgsGaussianGrads out,
+                                                                    AgsAdamArgs adam) {
+    constexpr bool FUSED_ADAM = MODE == 1, PACK = MODE == 2;
+    const int lane = threadIdx.x & 63;
+    const int wave_index = (int)blockIdx.x, num_waves = (int)gridDim.x;
+    const int slot0 = min(wave_index * 64 + lane, in.n - 1);
+    int i_next = out.touched.rows[slot0];
+    const int count = *out.touched.count;
+    if (PACK && wave_index == 0 && lane < 16) // segment header: rows shipped, rows the set holds
+        out.pack_segment[lane] = __int_as_float(lane == 0 ? min(count, out.pack_capacity) : lane == 1 ? count : 0);
+    for (int base = wave_index * 64; base < count; base += num_waves * 64) { // wave-uniform
+        const bool valid = base + lane < count;
+        const int i = valid ? i_next : 0;
+        {
+            const int nb = base + num_waves * 64;
+            if (nb < count) i_next = out.touched.rows[min(nb + lane, in.n - 1)];
+        }
+        float p[3], sc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { p[k] = in.means3D[3 * (size_t)i + k]; sc[k] = in.scales[3 * (size_t)i + k]; }
+        const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
+        float opacity = in.opacities[i];
+        float am[14], av[14], ap[14];
+        if (FUSED_ADAM) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                ap[k] = adam.p[0][3 * (size_t)i + k]; ap[3 + k] = adam.p[1][3 * (size_t)i + k]; ap[11 + k] = adam.p[4][3 * (size_t)i + k];
+            }
+            const float4 p4 = reinterpret_cast<const float4*>(adam.p[2])[i];
+            ap[6] = p4.x; ap[7] = p4.y; ap[8] = p4.z; ap[9] = p4.w;
+            ap[10] = adam.p[3][i];
+        }
+        float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        float raw_v[3] = {0, 0, 0}, qinv = 1.f;
+        if (in.raw_params) ags_activate_inplace(in, sc, q, opacity, raw_v, qinv);
+        float dm[3] = {0, 0, 0}, ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0}, dm2[2] = {0, 0};
+        bool vis_any = false;
+#pragma unroll 1
+        for (int v = 0; v < rv.views; ++v) {
+            const bool vis = valid && rv.radii[v][i] > 0;
+            if (!__any(vis)) continue;      // wave-uniform
+            if (vis) {
+                AgsFrame F = rv.F[v];
+                ags_frame_flags(F);
+                float V[16], P[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { V[k] = rv.V[v][k]; P[k] = rv.P[v][k]; }
+                float4* src = reinterpret_cast<float4*>(rv.dgeom[v] + i);
+                const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                src[0] = z4; src[1] = z4; src[2] = z4; src[3] = z4;
+                AgsGeomGrad dg;
+                dg.m1x = a.x; dg.m1y = a.y; dg.m2xx = a.z; dg.m2xy = a.w;
+                dg.m2yy = b.x; dg.m0 = b.y; dg.ddc = b.z; dg.dgx = b.w;
+                dg.dgy = c.x; dg.dr = c.y; dg.dg = c.z; dg.db = c.w;
+                dg.dnx = d.x; dg.dny = d.y; dg.dnz = d.z; dg.pad = 0.f;
+                float vm[3], vs_[3], vq[4], vop, vcol[3], vm2[2];
+                ags_preprocess_bwd(F, V, P, p, sc, q, opacity, dg, vm, vs_, vq, &vop, vcol, vm2);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { dm[k] += vm[k]; ds[k] += vs_[k]; dcol[k] += vcol[k]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dq[k] += vq[k];
+                dop += vop; dm2[0] += vm2[0]; dm2[1] += vm2[1];
+                vis_any = true;
+            }
+        }
+        // (the moments are requested only now: 28 registers less across the views' chain rules)
+        if (FUSED_ADAM) ags_load_moments(adam, i, am, av);
+        if (in.raw_params && vis_any) { // chain rule through clamp(exp), normalize, sigmoid: linear, applied to the views' sum
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ds[k] = (raw_v[k] >= 0.f && raw_v[k] <= in.max_scale) ? ds[k] * raw_v[k] : 0.f;
+            const float dot = q[0] * dq[0] + q[1] * dq[1] + q[2] * dq[2] + q[3] * dq[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dq[k] = (dq[k] - q[k] * dot) * qinv;
+            dop *= opacity * (1.f - opacity);
+        }
+        if (valid && out.d_means3D && !(PACK && base + lane < out.pack_capacity)) {
+            // the gradient arrays: overwrite, or += what earlier calls of the step left (accumulate 1)
+            if (out.accumulate) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    dm[k] += out.d_means3D[3 * (size_t)i + k]; ds[k] += out.d_scales[3 * (size_t)i + k]; dcol[k] += out.d_colors[3 * (size_t)i + k];
+                }
+                const float4 o = reinterpret_cast<float4*>(out.d_rotations)[i];
+                dq[0] += o.x; dq[1] += o.y; dq[2] += o.z; dq[3] += o.w;
+                dop += out.d_opacities[i];
+            }
+            if (!PACK) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    out.d_means3D[3 * (size_t)i + k] = dm[k]; out.d_scales[3 * (size_t)i + k] = ds[k]; out.d_colors[3 * (size_t)i + k] = dcol[k];
+                }
+                reinterpret_cast<float4*>(out.d_rotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+                out.d_opacities[i] = dop;
+                if (out.d_means2D) { out.d_means2D[3 * (size_t)i] = dm2[0]; out.d_means2D[3 * (size_t)i + 1] = dm2[1]; out.d_means2D[3 * (size_t)i + 2] = 0.f; }
+            }
+        }
+        if (PACK && valid) {
+            if (base + lane < out.pack_capacity) {
+                if (out.d_means3D && out.accumulate) {   // earlier partial sums of the step travel too, and their rows are cleared
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        dm[k] += out.d_means3D[3 * (size_t)i + k]; ds[k] += out.d_scales[3 * (size_t)i + k]; dcol[k] += out.d_colors[3 * (size_t)i + k];
+                        out.d_means3D[3 * (size_t)i + k] = 0.f; out.d_scales[3 * (size_t)i + k] = 0.f; out.d_colors[3 * (size_t)i + k] = 0.f;
+                    }
+                    float4* dr = reinterpret_cast<float4*>(out.d_rotations) + i;
+                    const float4 o = *dr;
+                    dq[0] += o.x; dq[1] += o.y; dq[2] += o.z; dq[3] += o.w;
+                    *dr = make_float4(0.f, 0.f, 0.f, 0.f);
+                    dop += out.d_opacities[i]; out.d_opacities[i] = 0.f;
+                }
+                float4* rec = reinterpret_cast<float4*>(out.pack_segment + 16 + (size_t)(base + lane) * 16);
+                rec[0] = make_float4(dm[0], dm[1], dm[2], ds[0]);
+                rec[1] = make_float4(ds[1], ds[2], dq[0], dq[1]);
+                rec[2] = make_float4(dq[2], dq[3], dop, dcol[0]);
+                rec[3] = make_float4(dcol[1], dcol[2], __int_as_float(i), 0.f);
+            } else if (out.d_means3D) {
+                // the segment is full: like ags_rows_pack, rows that do not travel keep their totals in the gradient arrays
+                // (already += above when accumulate is set)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    out.d_means3D[3 * (size_t)i + k] = dm[k]; out.d_scales[3 * (size_t)i + k] = ds[k]; out.d_colors[3 * (size_t)i + k] = dcol[k];
+                }
+                reinterpret_cast<float4*>(out.d_rotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+                out.d_opacities[i] = dop;
+            }
+        }
+        if (FUSED_ADAM && valid) {
+            const AgsAdamClock* clk = (const AgsAdamClock*)out.adam_clock;
+            const float ib = clk->inv_bc2_sqrt, b1 = out.adam_beta1, b2 = out.adam_beta2, eps = out.adam_eps;
+            const float gr[14] = {dm[0], dm[1], dm[2], ds[0], ds[1], ds[2], dq[0], dq[1], dq[2], dq[3], dop,
+                                  dcol[0], dcol[1], dcol[2]};
+#pragma unroll
+            for (int e = 0; e < 14; ++e) {
+                const int seg = (e >= 3) + (e >= 6) + (e >= 10) + (e >= 11);
+                const float g = gr[e];
+                const float m = am[e] + (1.f - b1) * (g - am[e]);
+                const float vv = av[e] * b2 + (1.f - b2) * g * g;
+                const float denom = sqrtf(vv) * ib + eps;
+                am[e] = m; av[e] = vv;
+                ap[e] -= clk->step_size[seg] * (m / denom);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                adam.p[0][3 * (size_t)i + k] = ap[k]; adam.p[1][3 * (size_t)i + k] = ap[3 + k]; adam.p[4][3 * (size_t)i + k] = ap[11 + k];
+            }
+            reinterpret_cast<float4*>(adam.p[2])[i] = make_float4(ap[6], ap[7], ap[8], ap[9]);
+            adam.p[3][i] = ap[10];
+            if (adam.st) {
+                float4* sr = reinterpret_cast<float4*>(adam.st + (size_t)i * 28);
+                float mv[28];
+#pragma unroll
+                for (int e = 0; e < 14; ++e) { mv[e] = am[e]; mv[14 + e] = av[e]; }
+#pragma unroll
+                for (int qq = 0; qq < 7; ++qq) sr[qq] = make_float4(mv[4 * qq], mv[4 * qq + 1], mv[4 * qq + 2], mv[4 * qq + 3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    adam.m[0][3 * (size_t)i + k] = am[k]; adam.v[0][3 * (size_t)i + k] = av[k];
+                    adam.m[1][3 * (size_t)i + k] = am[3 + k]; adam.v[1][3 * (size_t)i + k] = av[3 + k];
+                    adam.m[4][3 * (size_t)i + k] = am[11 + k]; adam.v[4][3 * (size_t)i + k] = av[11 + k];
+                }
+                reinterpret_cast<float4*>(adam.m[2])[i] = make_float4(am[6], am[7], am[8], am[9]);
+                reinterpret_cast<float4*>(adam.v[2])[i] = make_float4(av[6], av[7], av[8], av[9]);
+                adam.m[3][i] = am[10]; adam.v[3][i] = av[10];
+            }
+        }
+    }
+}
+
+void ags_launch_rows_multi(const AgsRowViews& rv, const AgsGaussians& in, const AgsGaussianGrads& din, hipStream_t s) {
+    int blocks = (in.n + AGS_ROWS_THREADS - 1) / AGS_ROWS_THREADS;
+    if (blocks > 16384) blocks = 16384; // fixed grid (the member count lives on the device): idle blocks exit at once
+    if (din.fused_adam)
+        hipLaunchKernelGGL(ags_k_rows_multi<1>, dim3(blocks), dim3(AGS_ROWS_THREADS), 0, s, rv, in, din, ags_adam_args(*din.fused_adam));
+    else if (din.pack_segment)
+        hipLaunchKernelGGL(ags_k_rows_multi<2>, dim3(blocks), dim3(AGS_ROWS_THREADS), 0, s, rv, in, din, AgsAdamArgs());
+    else
+        hipLaunchKernelGGL(ags_k_rows_multi<0>, dim3(blocks), dim3(AGS_ROWS_THREADS), 0, s, rv, in, din, AgsAdamArgs());
+}
+
 template <int MODE>
 __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_preprocess_bwd_rows(
     AgsFrame F, const float* __restrict__ Vp, const float* __restrict__ Pp, AgsGaussians in,

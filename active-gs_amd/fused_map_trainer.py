@@ -98,6 +98,8 @@ class FusedMapTrainer(GaussianMapTrainer):
     # zoomed-out camera: most surfels in a few tiles) that is far above the instance total, which is all the scan-based
     # binning needs - same images.  Past these thresholds the trainer goes on with AGS_BIN_TILE_SORT.
     SKEW_FACTOR, DIRECT_BUDGET_BYTES = 8, 1 << 30
+    MULTI_VIEW_ROWS = True     # the batched iteration's per-Gaussian backward + Adam as ONE launch (ags_backward_rows)
+    _no_grads = api.GaussianGrads(None, None, None, None, None)
 
     def _grow_cap(self, need: int, instances: int = 0) -> None:
         """A view needed ``need`` key slots (``AgsStatus.needed_instances``; ``instances`` = its instance total when
@@ -435,9 +437,18 @@ class FusedMapTrainer(GaussianMapTrainer):
             images = batch._structs()[0]
             self._loss.stage1_batch(images, gt_rgb, gt_depth, bufs, B)
             self._loss.stage2_batch(images, gt_depth, bufs, B)
-            batch.backward(B, bufs.d_rgb, bufs.d_normal, bufs.d_depth, slab.grads, touched=rows,
-                           adam_tick=optim.tick_args())
-            optim.step(slab.as_list(), device_clock=True, pre_ticked=True)
+            if self.MULTI_VIEW_ROWS and B <= 16:
+                # the blend backward of all views, then ONE per-Gaussian launch over the member rows: the views' chain rules
+                # meet in registers and the Adam update follows in the same lane (no gradient slab, no atomics into it, no
+                # separate optimiser kernel)
+                batch.backward(B, bufs.d_rgb, bufs.d_normal, bufs.d_depth, self._no_grads, adam_tick=optim.tick_args(),
+                               defer_rows=True)
+                api.backward_rows([(batch.cams[v], batch.states[v]) for v in range(B)], batch.g, self._no_grads, rows,
+                                  adam_clock=optim.tick_args(), fused_adam=(optim.tensors_struct(slab.as_list()), optim.eps))
+            else:
+                batch.backward(B, bufs.d_rgb, bufs.d_normal, bufs.d_depth, slab.grads, touched=rows,
+                               adam_tick=optim.tick_args())
+                optim.step(slab.as_list(), device_clock=True, pre_ticked=True)
             self._loss.finish(B, idx, self.training_performance, loss_out)
 
         def fits() -> bool:

@@ -273,7 +273,8 @@ def alloc_grads(n: int, device, with_means2d: bool = False, zero: bool = False) 
 def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_normal=None, d_depth=None,
              d_opacity=None, d_confidence=None, grads: Optional[GaussianGrads] = None,
              accumulate: bool = False, adam_tick=None, stream: Optional[int] = None,
-             touched: Optional[RowSet] = None, fused_adam=None, pack=None, next_view=None) -> GaussianGrads:
+             touched: Optional[RowSet] = None, fused_adam=None, pack=None, next_view=None,
+             defer_rows: bool = False) -> GaussianGrads:
     """Enqueue the backward pass of the view held in ``state``. Asynchronous.
     ``adam_tick`` = (device_clock_tensor, lrs, beta1, beta2): also advance that Adam clock.
     ``touched``: the ``RowSet`` given to this view's ``forward``: only its rows are written.
@@ -283,8 +284,12 @@ def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_norma
     (last view of a rank's data-parallel step; needs ``touched``), the gradient rows are left zeroed.
     ``next_view`` = (Camera, ForwardState[, rows_hint]) with ``fused_adam``: software-pipelined step - the per-Gaussian launch also
     runs the per-Gaussian stage of the NEXT forward pass (``ags_backward_fused_next``); render that view with
-    ``forward(..., resume=True)``."""
+    ``forward(..., resume=True)``.
+    ``defer_rows``: run the blend backward only; ``backward_rows`` later turns the gradient records of all the step's views
+    into parameter gradients in one launch (every such view needs its own ``state`` until then)."""
     lib = _lib.load()
+    if defer_rows:
+        grads = grads or GaussianGrads(None, None, None, None, None)
     if grads is None:
         grads = alloc_grads(g.n, g.means3D.device)
         accumulate = False
@@ -304,6 +309,7 @@ def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_norma
             din.adam_lr[k] = float(lrs[k])
         din.adam_beta1, din.adam_beta2 = float(b1), float(b2)
     din.touched = _rowset_struct(touched)
+    din.defer_rows = int(defer_rows)
     if fused_adam is not None:
         tensors, eps = fused_adam
         din.fused_adam = C.cast(C.pointer(tensors), C.c_void_p)
@@ -322,6 +328,44 @@ def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_norma
         return grads
     _lib.check(lib.ags_backward(C.byref(cs), C.byref(gs), C.byref(im), C.byref(pg), C.byref(dout), C.byref(din),
                                 C.byref(ws), _stream() if stream is None else stream), "ags_backward")
+    return grads
+
+
+def backward_rows(views: Sequence, g: Gaussians, grads: GaussianGrads, touched: RowSet, accumulate: bool = False,
+                  adam_clock=None, fused_adam=None, pack=None, stream: Optional[int] = None) -> GaussianGrads:
+    """``ags_backward_rows``: the per-Gaussian backward of ALL the views of a step (``views`` = [(Camera, ForwardState)],
+    each rendered and taken through ``backward(..., defer_rows=True)``) in one launch over the member rows of ``touched``:
+    the views' gradients are summed in registers, then written to ``grads`` / packed as the rank's exchange segment
+    (``pack``) / consumed by the fused Adam step (``fused_adam`` = (AgsAdamTensors, eps), ``adam_clock`` = the optimiser's
+    ``tick_args()`` whose clock one of the views' ``backward`` calls has already advanced)."""
+    lib = _lib.load()
+    n = len(views)
+    refs = (_lib.AgsViewRef * n)()
+    keep = []
+    for k, (cam, state) in enumerate(views):
+        cs, ws = cam.c_struct(), state.ws_struct()
+        keep.append((cs, ws))
+        refs[k].cam, refs[k].radii, refs[k].ws = C.pointer(cs), ptr(state.radii), C.pointer(ws)
+    gs = g.c_struct()
+    din = _lib.AgsGaussianGrads(ptr(grads.means3D), ptr(grads.scales), ptr(grads.rotations), ptr(grads.opacities),
+                                ptr(grads.colors), ptr(grads.means2D), int(accumulate))
+    din.touched = _rowset_struct(touched)
+    if adam_clock is not None:
+        clock, lrs, b1, b2 = adam_clock
+        din.adam_clock = ptr(clock)
+        for k in range(5):
+            din.adam_lr[k] = float(lrs[k])
+        din.adam_beta1, din.adam_beta2 = float(b1), float(b2)
+    if fused_adam is not None:
+        tensors, eps = fused_adam
+        din.fused_adam = C.cast(C.pointer(tensors), C.c_void_p)
+        din.adam_eps = float(eps)
+    if pack is not None:
+        segment, capacity = pack
+        din.pack_segment = ptr(segment)
+        din.pack_capacity = int(capacity)
+    _lib.check(lib.ags_backward_rows(refs, n, C.byref(gs), C.byref(din), _stream() if stream is None else stream),
+               "ags_backward_rows")
     return grads
 
 
@@ -463,10 +507,11 @@ class ViewBatch:
         self._enqueue_batched(views, touched)
 
     def backward(self, views: int, d_rgb, d_normal, d_depth, grads: "GaussianGrads", touched: Optional[RowSet] = None,
-                 adam_tick=None) -> None:
+                 adam_tick=None, defer_rows: bool = False) -> None:
         """Backward of the first ``views`` views of the last ``forward``: image-gradient batches
         ``(views,C,H,W)`` (None = zeros), gradients of all views SUMMED atomically into the pre-zeroed
-        ``grads``."""
+        ``grads``.  ``defer_rows``: the blend backward only; ``backward_rows([(batch.cams[v], batch.states[v]) ...])``
+        then does the per-Gaussian backward of all the views (and the optimiser step) in one launch."""
         lib = _lib.load()
         cs, gs = self.cam.c_struct(), self.g.c_struct()
         im, pg, ws = self._structs()
@@ -480,6 +525,7 @@ class ViewBatch:
                 din.adam_lr[k] = float(lrs[k])
             din.adam_beta1, din.adam_beta2 = float(b1), float(b2)
         din.touched = _rowset_struct(touched)
+        din.defer_rows = int(defer_rows)
         _lib.check(lib.ags_backward_batch(C.byref(cs), int(views), C.byref(gs), C.byref(im), C.byref(pg), C.byref(dout),
                                           C.byref(din), C.byref(ws), _stream()), "ags_backward_batch")
 

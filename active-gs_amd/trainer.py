@@ -200,6 +200,7 @@ class SurfelTrainer:
         self._rows_hint = 0      # members of the row set when last looked at (+ slack): sizes the pipelined launch
 
     CHECK_EVERY = 16     # optimisation steps between two reads of the overflow notes (one 64-byte D2H each)
+    MULTI_VIEW_ROWS = True   # several views per step: one per-Gaussian backward launch for all of them (ags_backward_rows)
 
     def reset_optimizer(self) -> None:
         """What the reference does at the start of every ``train()`` call (``init_training``,
@@ -283,6 +284,28 @@ class SurfelTrainer:
         x = self.exchange
         pack = (x.send, x.capacity) if (x is not None and x.capacity and self.fused_activations and len(cams) > 0) else None
         self._packed = pack is not None
+        # several views per step on the row-set path: every view keeps its gradient records in its own workspace and ONE
+        # launch (ags_backward_rows) turns them all into parameter gradients - the member list is walked once, a row's
+        # inputs are loaded once, the views' gradients meet in registers (no read-modify-write of the gradient rows per
+        # view), and the optimiser step / exchange segment is its tail
+        if len(cams) > 1 and len(cams) <= 16 and self.rows is not None and self.MULTI_VIEW_ROWS:
+            self._drop_prepared()
+            done = []
+            for v, cam in enumerate(cams):
+                st = self.state_for(cam.image_height, cam.image_width, max_instances, slot=v)
+                api.forward(cam, g, st, touched=self.rows)
+                d = image_grads(v, st)
+                last = tick and v == len(cams) - 1
+                api.backward(cam, g, st, *d, adam_tick=self.optim.tick_args() if last else None, defer_rows=True)
+                done.append((cam, st))
+                ticked |= last
+            fused = (self.optim.tensors_struct(self.slab.as_list()), self.optim.eps) if (ticked and fuse_adam) else None
+            api.backward_rows(done, g, self._no_grads if fused is not None else self.slab.grads, self.rows,
+                              adam_clock=self.optim.tick_args() if fused is not None else None, fused_adam=fused, pack=pack)
+            self.adam_fused = fused is not None
+            if not self.fused_activations:
+                self.activate_backward()
+            return ticked
         for v, cam in enumerate(cams):
             st = self.state_for(cam.image_height, cam.image_width, max_instances)
             resume = self._prepared is not None and self._prepared[0] is st and self._prepared[1] is cam and v == 0

@@ -209,7 +209,11 @@ def measure_config(tag, n, h, w, views, room, steps, dev, lrs=None, binning_mode
     P, T = h * w, ((h + 15) // 16) * ((w + 15) // 16)
     rows = int(trainer.rows.count.item()) if trainer.rows is not None else None
     # per view: the stage times are medians over all (step, view) launches
-    sb = stage_bytes(n, V / views, I / views, P, T, None if rows is None else rows / 1.0, direct=True, fused_single_view=(views == 1))
+    sb = stage_bytes(n, V / views, I / views, P, T, None if rows is None else rows / 1.0, direct=True, fused_single_view=True)
+    if views > 1 and rows is not None:
+        # several views per step: ONE per-Gaussian backward launch for all of them (ags_backward_rows): every member row
+        # once (id, parameters, moments in and out) + every view's gradient records of the rows it shows (read + re-zeroed)
+        sb["preprocess_bwd"] = (8 + 56 + 224 + 56) * rows + 128 * V
     frac = {k: (sb[k] / (med[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if med[k] > 0 else 0.0) for k in sb}
     st = trainer.state_for(h, w, cap)
     out = dict(config=tag, surfels=n, image=[h, w], views_per_step=views, ms_per_step=round(s["median"], 4),
@@ -217,8 +221,12 @@ def measure_config(tag, n, h, w, views, room, steps, dev, lrs=None, binning_mode
                gaussians_per_s=n * views / (s["median"] * 1e-3), visible_per_view=V // views, tile_instances_per_view=I // views,
                member_rows=rows, workspace_MB=round(st.workspace.numel() / 2**20, 1),
                stage_ms_per_view={k: round(v, 4) for k, v in med.items()},
+               stage_note=("per view, except preprocess_bwd: ONE launch per step for all views (ags_backward_rows)" if views > 1 and rows is not None
+                           else "per view"),
                stage_hbm_frac={k: round(v, 4) for k, v in frac.items()},
-               whole_step_hbm_frac=round(sum(sb.values()) * views / (s["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+               whole_step_hbm_frac=round((sum(v for k, v in sb.items() if k != "preprocess_bwd") * views +
+                                          sb["preprocess_bwd"] * (1 if (views > 1 and rows is not None) else views))
+                                         / (s["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     del trainer, replay, raw
     torch.cuda.empty_cache()
     return out

@@ -169,6 +169,10 @@ typedef struct AgsGaussianGrads {
      * travel and KEEP their totals in the gradient arrays (header word 1 > pack_capacity tells). */
     float* pack_segment;   /* ags_rows_segment_floats(pack_capacity) floats */
     int32_t pack_capacity;
+    /* != 0: ags_backward / ags_backward_batch run the blend backward ONLY - the view's per-surfel gradient records stay in
+     * its workspace - and ags_backward_rows later turns the records of ALL the step's views into parameter gradients in
+     * one launch.  The five d_* pointers are not used by such a call (they may be NULL); adam_clock still works. */
+    int32_t defer_rows;
 } AgsGaussianGrads;
 
 #define AGS_BIN_TILE_SORT 0 /* tile counting + bucket scatter + per-tile LDS bitonic sort */
@@ -267,6 +271,25 @@ int ags_backward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* 
 int ags_backward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* fwd,
                  const AgsPerGaussian* per_gaussian, const AgsImageGrads* dout,
                  const AgsGaussianGrads* din, const AgsWorkspace* ws, ags_stream_t stream);
+
+/* The per-Gaussian backward of ALL the views of an optimisation step in ONE launch (views whose ags_backward /
+ * ags_backward_batch ran with din->defer_rows).  One lane per member row of din->touched (required): the row's inputs
+ * are loaded and activated once, every view that shows the row contributes its chain rule from that view's gradient
+ * record (which is re-zeroed), the views' gradients are summed in registers, and the tail is the one of ags_backward's
+ * row kernel: din->fused_adam (single rank: the optimiser step, needs adam_clock already advanced by a view's
+ * ags_backward), din->pack_segment (the rank's exchange segment), or the gradient arrays (accumulate 0: overwrite, member
+ * rows no view shows get zeros).  Against per-view per-Gaussian launches this saves, per extra view, a walk over the member
+ * list, a reload of the row's inputs and a read-modify-write of its 56-byte gradient row.  All views: the same `in`, the
+ * same image size is NOT required; 1 <= num_views <= AGS_MAX_ROW_VIEWS; every view needs its own workspace (and radii)
+ * until this call. */
+#define AGS_MAX_ROW_VIEWS 16
+typedef struct AgsViewRef {
+    const AgsCamera* cam;      /* the view's camera (matrices in place) */
+    const int32_t* radii;      /* the view's radii output (n) */
+    const AgsWorkspace* ws;    /* the view's workspace */
+} AgsViewRef;
+int ags_backward_rows(const AgsViewRef* views, int32_t num_views, const AgsGaussians* in, const AgsGaussianGrads* din,
+                      ags_stream_t stream);
 
 /* Software-pipelined optimisation step (single view per step, single rank, AGS_BIN_DIRECT): the per-Gaussian kernels
  * of consecutive steps in ONE launch.  The last kernel of step k (chain rule + Adam over the row set's members) and the
