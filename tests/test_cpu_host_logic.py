@@ -112,6 +112,21 @@ def test_workspace_size_and_argument_checks(agslib):
     assert agslib.ags_forward(C.byref(cam), C.byref(g), C.byref(im), C.byref(pg), C.byref(ws), None) == -1
     assert agslib.ags_adam_step(None, 0.9, 0.999, 1e-15, 1, None) == -1
     assert agslib.ags_error_string(-2).decode().startswith("workspace")
+    # round-3 entry points: argument checks come before any HIP call too
+    assert agslib.ags_backward_rows(None, 1, None, None, None) == -1
+    refs = (_lib.AgsViewRef * 1)()
+    gg = _lib.AgsGaussianGrads()
+    g.n = 4
+    assert agslib.ags_backward_rows(refs, 0, C.byref(g), C.byref(gg), None) == -1          # no views
+    assert agslib.ags_backward_rows(refs, 17, C.byref(g), C.byref(gg), None) == -1         # more than AGS_MAX_ROW_VIEWS
+    assert agslib.ags_backward_rows(refs, 1, C.byref(g), C.byref(gg), None) == -1          # no row set
+    assert agslib.ags_workspace_discard_pass(C.byref(ws), 10, 32, 32, None) == -1          # no pointer
+    assert agslib.ags_read_status_async(C.byref(ws), None, None) == -1
+    off, nb = C.c_size_t(), C.c_size_t()
+    assert agslib.ags_workspace_region(100, 64, 64, 1 << 16, 2, 1, C.byref(off), C.byref(nb)) == 0
+    assert nb.value == 64 * 64 * 4 and off.value % 256 == 0 and off.value + nb.value <= agslib.ags_workspace_bytes(100, 64, 64, 1 << 16)
+    assert agslib.ags_workspace_region(100, 64, 64, 1 << 16, 2, 99, C.byref(off), C.byref(nb)) == -1
+    assert agslib.ags_workspace_region(100, 64, 64, 1 << 16, 1, 4, C.byref(off), C.byref(nb)) == -1    # no key array in radix mode
 
 
 def test_product_refuses_cpu_tensors(agslib):
