@@ -884,7 +884,7 @@ __device__ __forceinline__ void ags_rows_body(
 // space of the ACTIVATED parameters: the activations' own chain rule is view-independent and applied once to the sum);
 // then the tail of the single-view row kernel: MODE 1 fused Adam, MODE 2 exchange segment, MODE 0 gradient arrays.
 template <int MODE>
-__global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_rows_multi(AgsRowViews rv, AgsGaussians in, AgsGaussianGrads out,
+__global__ __launch_bounds__(AGS_ROWS_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void ags_k_rows_multi(AgsRowViews rv, AgsGaussians in, AgsGaussianGrads out,
                                                                     AgsAdamArgs adam) {
     constexpr bool FUSED_ADAM = MODE == 1, PACK = MODE == 2;
     const int lane = threadIdx.x & 63;
@@ -894,20 +894,34 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_rows_multi(AgsRowViews
     const int count = *out.touched.count;
     if (PACK && wave_index == 0 && lane < 16) // segment header: rows shipped, rows the set holds
         out.pack_segment[lane] = __int_as_float(lane == 0 ? min(count, out.pack_capacity) : lane == 1 ? count : 0);
-    for (int base = wave_index * 64; base < count; base += num_waves * 64) { // wave-uniform
-        const bool valid = base + lane < count;
-        const int i = valid ? i_next : 0;
-        {
+    // When most of the map is listed (a room seen from inside: config 4's four views list 73 % of the rows) walking the
+    // MAP in row order with a membership test beats walking the list: every access of a wave is then a stream instead
+    // of 64 scattered 12-16-byte pieces per array (six sectors per row for 52 useful bytes).  Not for the exchange
+    // segment, whose record positions are list positions.
+    const bool dense = !PACK && 2 * (long long)count > (long long)in.n;
+    const int total = dense ? in.n : count;
+    for (int base = wave_index * 64; base < total; base += num_waves * 64) { // wave-uniform
+        bool valid = base + lane < total;
+        int i = dense ? min(base + lane, in.n - 1) : (valid ? i_next : 0);
+        if (dense) {
+            valid = valid && out.touched.member[i] != 0;
+            if (!__any(valid)) continue;            // wave-uniform
+            if (!valid) i = 0;
+        } else {
             const int nb = base + num_waves * 64;
             if (nb < count) i_next = out.touched.rows[min(nb + lane, in.n - 1)];
         }
-        float p[3], sc[3];
+        float p[3] = {0, 0, 0}, sc[3] = {0, 0, 0};
+        float4 q4 = make_float4(1.f, 0.f, 0.f, 0.f);
+        float opacity = 0.f;
+        if (valid || !dense) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { p[k] = in.means3D[3 * (size_t)i + k]; sc[k] = in.scales[3 * (size_t)i + k]; }
-        const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[i];
-        float opacity = in.opacities[i];
+            for (int k = 0; k < 3; ++k) { p[k] = in.means3D[3 * (size_t)i + k]; sc[k] = in.scales[3 * (size_t)i + k]; }
+            q4 = reinterpret_cast<const float4*>(in.rotations)[i];
+            opacity = in.opacities[i];
+        }
         float am[14], av[14], ap[14];
-        if (FUSED_ADAM) {
+        if (FUSED_ADAM && (valid || !dense)) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 ap[k] = adam.p[0][3 * (size_t)i + k]; ap[3 + k] = adam.p[1][3 * (size_t)i + k]; ap[11 + k] = adam.p[4][3 * (size_t)i + k];
@@ -951,7 +965,7 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) void ags_k_rows_multi(AgsRowViews
             }
         }
         // (the moments are requested only now: 28 registers less across the views' chain rules)
-        if (FUSED_ADAM) ags_load_moments(adam, i, am, av);
+        if (FUSED_ADAM && (valid || !dense)) ags_load_moments(adam, i, am, av);
         if (in.raw_params && vis_any) { // chain rule through clamp(exp), normalize, sigmoid: linear, applied to the views' sum
 #pragma unroll
             for (int k = 0; k < 3; ++k) ds[k] = (raw_v[k] >= 0.f && raw_v[k] <= in.max_scale) ? ds[k] * raw_v[k] : 0.f;
