@@ -8,7 +8,9 @@
 
 // ---- experiment builds only (-DAGS_TIMELINE, profiles/experiments/timeline.py): every wave notes the shader clock
 // (s_memtime) at a few phase boundaries into a caller-provided buffer [kernel][wave][8]; compiled out otherwise.
+#ifndef AGS_TL_WAVES
 #define AGS_TL_WAVES 16384
+#endif
 // -DAGS_TL_REALTIME: stamps from the chip-wide 100 MHz reference counter (s_memrealtime: 10 ns steps, the same on
 // every CU) instead of the shader clock, which every CU counts on its own: for launch ramps and kernel-to-kernel gaps
 #ifdef AGS_TL_REALTIME

@@ -54,7 +54,7 @@ nxt = cam if args.pipeline else None
 for _ in range(30):
     tr.step([cam], fn, cap, next_cam=nxt)
 torch.cuda.synchronize()
-NW = 16384
+NW = int(os.environ.get("AGS_TL_WAVES", 16384))      # (-DAGS_TL_WAVES=65536 for 2048x2048: 4 waves x 16 384 tiles)
 buf = torch.zeros(8 * NW * 8, dtype=torch.int64, device=dev)
 lib.ags_debug_timeline.argtypes = [C.c_void_p]
 if args.graph:
