@@ -199,3 +199,44 @@ def test_pipelined_step_reports_an_outgrown_workspace(agslib):
     tr.step([cams[1]], fn, cap, next_cam=cams[1])
     with pytest.raises(RuntimeError, match="outgrew"):
         tr.check_overflow()
+
+
+def test_every_binning_mode_replays_from_a_graph(agslib):
+    """A forward + backward recorded into a hipGraph gives the eager pass's results on EVERY replay, in every binning
+    mode: the workspace's counters are left clean by the kernels themselves (nothing a replay could find stale).  (Found
+    while building: a hipMemsetAsync NODE wrote garbage patterns from the second replay on - ROCm 7.0.)"""
+    from active_gs_amd import raster_api as api
+    dev = torch.device("cuda:0")
+    a, S = room_case(6000, 136, 240, view=2, seed=12, scale_mult=2.0)
+    cam = api.Camera(S.image_height, S.image_width, S.tanfovx, S.tanfovy, S.viewmatrix.to(dev), S.projmatrix.to(dev),
+                     S.bg.to(dev))
+    g = api.Gaussians(*(a[k].to(dev).contiguous() for k in ("means", "scales", "rotations", "opacities", "colors",
+                                                              "confidences")))
+    gen = torch.Generator().manual_seed(3)
+    d = [(torch.randn(c, cam.image_height, cam.image_width, generator=gen) / (cam.image_height * cam.image_width)).to(dev)
+         for c in (3, 3, 1)]
+    for mode in (api.BIN_TILE_SORT, api.BIN_RADIX, api.BIN_DIRECT):
+        st = api.alloc_state(g.n, cam.image_height, cam.image_width, 1 << 20, dev, mode)
+        api.forward(cam, g, st)
+        ref_grads = api.backward(cam, g, st, d[0], d[1], d[2])
+        ref = [t.clone() for t in (st.rgb, st.depth, st.radii, ref_grads.means3D, ref_grads.scales, ref_grads.colors)]
+        info = api.read_status(st)
+        assert not info["overflow"] and info["num_instances"] > 0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                api.forward(cam, g, st)
+                grads = api.backward(cam, g, st, d[0], d[1], d[2])
+        torch.cuda.synchronize()
+        for replay in range(4):
+            graph.replay()
+            torch.cuda.synchronize()
+            got = (st.rgb, st.depth, st.radii, grads.means3D, grads.scales, grads.colors)
+            for k in range(3):
+                assert torch.equal(got[k], ref[k]), (mode, replay, k)
+            for k in range(3, 6):          # (float atomics: order-dependent last bits)
+                assert float((got[k] - ref[k]).abs().sum()) <= 1e-5 * float(ref[k].abs().sum()) + 1e-12, (mode, replay, k)
+            again = api.read_status(st)
+            assert again["num_instances"] == info["num_instances"] and again["overflow_passes"] == 0
