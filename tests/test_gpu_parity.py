@@ -745,3 +745,41 @@ def test_one_backward_rows_launch_equals_per_view_backwards(agslib, fused_activa
     if not fused_activations:          # (the fused single-rank step keeps no gradient slab)
         for a, b in zip(ga, gb):
             assert float((a - b).abs().sum()) <= 1e-3 * float(b.abs().sum()) + 1e-12
+
+
+_SWEEP = [  # (n, h, w, view, mult, config, masked): odd image sizes (ragged last tiles), one-tile images, sparse and dense
+    (60, 16, 16, 0, 8.0, (1, 1, 1, 0, 0), False), (25, 17, 33, 1, 6.0, (1, 1, 1, 1, 0), False),
+    (40, 31, 250, 2, 5.0, (1, 0, 1, 0, 0), False), (300, 49, 47, 3, 4.0, (1, 1, 0, 1, 1), True),
+    (900, 130, 70, 4, 3.0, (1, 1, 1, 1, 1), True), (1500, 97, 161, 5, 2.5, (1, 0, 0, 1, 0), False),
+    (2500, 75, 203, 6, 2.0, (1, 1, 1, 0, 1), False), (4000, 144, 176, 7, 1.5, (1, 1, 1, 1, 0), True),
+    (6000, 33, 400, 8, 3.5, (1, 0, 1, 1, 1), False), (350, 200, 24, 9, 6.0, (1, 1, 0, 0, 0), False),
+]
+
+
+@pytest.mark.parametrize("case", range(len(_SWEEP)))
+def test_sweep_of_sizes_flags_and_masks_matches_oracle(agslib, case):
+    """A seeded sweep over what the other cases fix: image sizes that are not tile multiples (down to one tile), one to
+    a few thousand surfels, every combination class of the reference's config flags (operations.py:697-699), with and
+    without a render mask - images, statistics, radii and all six gradients against the oracle with the same gates."""
+    n, h, w, view, mult, config, masked = _SWEEP[case]
+    mask = None
+    if masked:
+        gen = torch.Generator().manual_seed(100 + case)
+        mask = (torch.rand(1, h, w, generator=gen) > 0.4).float()
+    a, S = room_case(n, h, w, view=view, seed=50 + case, scale_mult=mult, config=config, mask=mask,
+                     bg=(0.05 * case, 0.3, 1.0 - 0.08 * case, 0.0))
+    ins, ref, gin, out = _run_both(a, S, seed=case)
+    what = f"sweep {case}: {n} surfels {w}x{h} config {config} mask {masked}"
+    _check_images(ref, out, what)
+    from oracle.surfel_oracle import preprocess
+    with torch.no_grad():
+        G = preprocess(*[t.detach() for t in ins], S)
+    _parity.radii_report(out[7], G, ins, S, what)
+    if config[3]:
+        ref_imp = float(ref[5].abs().sum())
+        assert float((out[5].cpu() - ref[5]).abs().sum()) <= 1e-4 * ref_imp + 1e-7, what
+        _parity.count_report(out[6], ref[6], what)
+    else:
+        assert int(out[6].abs().sum()) == 0 and float(out[5].abs().sum()) == 0.0
+    if any(float(t.grad.abs().sum()) > 0 for t in ins if t.grad is not None):
+        _check_grads(ins, gin, what)
