@@ -747,6 +747,51 @@ def test_one_backward_rows_launch_equals_per_view_backwards(agslib, fused_activa
             assert float((a - b).abs().sum()) <= 1e-3 * float(b.abs().sum()) + 1e-12
 
 
+
+def test_views_of_a_step_on_several_streams_equal_one_stream(agslib):
+    """SurfelTrainer.VIEW_STREAMS: the views of a multi-view step are enqueued on several streams (nothing a view's
+    four launches read is produced by another view of the step; the row set's members are claimed with atomicExch) and
+    joined in front of the one per-Gaussian backward - same parameters and moments as on one stream, stepped eagerly
+    and replayed from a captured graph (whose capture forks and joins the streams)."""
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.synthetic import make_room_scene
+    from active_gs_amd.trainer import SurfelTrainer
+    dev = torch.device("cuda:0")
+    h, w, n = 136, 240, 6000
+    cams = []
+    for v in (0, 3, 5, 6, 2):
+        _, S = room_case(n, h, w, view=v, seed=3)
+        cams.append(api.Camera(h, w, S.tanfovx, S.tanfovy, S.viewmatrix.to(dev), S.projmatrix.to(dev), S.bg.to(dev)))
+    gen = torch.Generator().manual_seed(4)
+    d = [[(torch.randn(c, h, w, generator=gen) / (h * w * len(cams))).to(dev) for c in (3, 3, 1)] for _ in cams]
+    fn = lambda v, st: (d[v][0], d[v][1], d[v][2], None, None)
+    res = []
+    for streams, graph in ((1, False), (4, False), (3, True)):
+        raw = {k: v.to(dev) for k, v in make_room_scene(n, seed=3).items()}
+        raw["scales"][:, :2] += 1.0
+        tr = SurfelTrainer(raw)
+        tr.VIEW_STREAMS = streams
+        tr.step(cams, fn, 1 << 20)
+        if graph:
+            replay = tr.capture(cams, fn, 1 << 20)
+            for _ in range(3):
+                replay()
+        else:
+            for _ in range(3):
+                tr.step(cams, fn, 1 << 20)
+        tr.check_overflow()
+        torch.cuda.synchronize()
+        assert (len(tr._lanes) == 0) == (streams == 1)
+        res.append(([p.clone() for p in tr.params], [m.clone() for m in tr.optim.exp_avg], int(tr.rows.count.item())))
+    for (pa, ma, ca) in res[1:]:
+        assert ca == res[0][2] > 500
+        for a, b in zip(pa, res[0][0]):
+            diff = (a - b).abs()
+            assert float(diff.mean()) < 2e-6 and float((diff > 1e-4).float().mean()) < 0.01, (float(diff.mean()), float(diff.max()))
+        for a, b in zip(ma, res[0][1]):
+            assert float((a - b).abs().sum()) <= 1e-3 * float(b.abs().sum()) + 1e-12
+
+
 _SWEEP = [  # (n, h, w, view, mult, config, masked): odd image sizes (ragged last tiles), one-tile images, sparse and dense
     (60, 16, 16, 0, 8.0, (1, 1, 1, 0, 0), False), (25, 17, 33, 1, 6.0, (1, 1, 1, 1, 0), False),
     (40, 31, 250, 2, 5.0, (1, 0, 1, 0, 0), False), (300, 49, 47, 3, 4.0, (1, 1, 0, 1, 1), True),
