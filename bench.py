@@ -198,7 +198,11 @@ def measure_config(tag, n, h, w, views, room, steps, dev, lrs=None, binning_mode
     for _ in range(5):
         replay()
     torch.cuda.synchronize()
-    s = summarise(time_samples(lambda: [replay() for _ in range(steps)], 5, False, dev), steps)
+    s = summarise(time_samples(lambda: [replay() for _ in range(steps)], 9, False, dev), steps)
+    # per-stage times: the same step with its views on ONE stream (on several, the stages of different views overlap
+    # and an event pair around one of them also times its neighbours)
+    view_streams = min(int(trainer.VIEW_STREAMS), views) if views > 1 else 1
+    trainer.VIEW_STREAMS = 1
     _lib.check(lib.ags_profile_enable(steps * views), "ags_profile_enable")
     for _ in range(steps):
         trainer.step(cams, fn, cap)
@@ -221,8 +225,10 @@ def measure_config(tag, n, h, w, views, room, steps, dev, lrs=None, binning_mode
                gaussians_per_s=n * views / (s["median"] * 1e-3), visible_per_view=V // views, tile_instances_per_view=I // views,
                member_rows=rows, workspace_MB=round(st.workspace.numel() / 2**20, 1),
                stage_ms_per_view={k: round(v, 4) for k, v in med.items()},
-               stage_note=("per view, except preprocess_bwd: ONE launch per step for all views (ags_backward_rows)" if views > 1 and rows is not None
-                           else "per view"),
+               view_streams=view_streams,
+               stage_note=("per view, except preprocess_bwd: ONE launch per step for all views (ags_backward_rows); measured with the views "
+                           "on one stream - the timed step spreads them over view_streams streams, so the stages do not add up to it"
+                           if views > 1 and rows is not None else "per view"),
                stage_hbm_frac={k: round(v, 4) for k, v in frac.items()},
                whole_step_hbm_frac=round((sum(v for k, v in sb.items() if k != "preprocess_bwd") * views +
                                           sb["preprocess_bwd"] * (1 if (views > 1 and rows is not None) else views))
