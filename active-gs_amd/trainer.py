@@ -363,7 +363,9 @@ class SurfelTrainer:
         """``cams``: this rank's views. ``image_grads(view_index, state)`` returns the five
         image gradients (d_rgb, d_normal, d_depth, d_opacity, d_confidence; None = zero)
         for that view, already divided by the GLOBAL number of views where the loss is a
-        batch mean.  Asynchronous except for the collective and, every ``CHECK_EVERY`` steps, one small
+        batch mean.  With several views per step it is called under the stream that view runs on
+        (``VIEW_STREAMS``): what it enqueues for different views may overlap, so it must not share
+        scratch buffers between views.  Asynchronous except for the collective and, every ``CHECK_EVERY`` steps, one small
         read-back (``check_overflow``).  ``device_clock`` (default): the Adam step counter lives on the GPU,
         the same clock ``capture()`` replays on; False = the host-side counter of ``ags_adam_step``.
         ``next_cam`` (single rank): the first view of the NEXT step, its matrices already in place - this step's
