@@ -444,6 +444,25 @@ int ags_loss_stage2(const AgsLossConfig* cfg, const AgsImages* fwd, const float*
     return ags_check_launch();
 }
 
+int ags_facade_post(int32_t h, int32_t w, float tanfov_x, float tanfov_y, const float* normal_raw, const float* depth,
+                    const float* opacity, float* normal_out, float* d2n_out, ags_stream_t stream) {
+    if (h <= 0 || w <= 0 || !(tanfov_x > 0.f) || !(tanfov_y > 0.f) || !depth || !opacity || !d2n_out) return AGS_E_INVALID;
+    if ((normal_raw == nullptr) != (normal_out == nullptr)) return AGS_E_INVALID;
+    ags_launch_facade_post(h, w, tanfov_x, tanfov_y, normal_raw, depth, opacity, normal_out, d2n_out, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_facade_post_backward(int32_t h, int32_t w, float tanfov_x, float tanfov_y, const float* normal_raw,
+                             const float* depth, const float* opacity, const float* g_normal, const float* g_d2n,
+                             float* d_normal_raw, float* d_depth, ags_stream_t stream) {
+    if (h <= 0 || w <= 0 || !(tanfov_x > 0.f) || !(tanfov_y > 0.f) || !depth || !opacity) return AGS_E_INVALID;
+    if (g_d2n && !d_depth) return AGS_E_INVALID;
+    if (d_normal_raw && g_normal && !normal_raw) return AGS_E_INVALID;
+    ags_launch_facade_post_bwd(h, w, tanfov_x, tanfov_y, normal_raw, depth, opacity, g_normal, g_d2n, d_normal_raw, d_depth,
+                               (hipStream_t)stream);
+    return ags_check_launch();
+}
+
 int ags_stage_frames(int32_t views, int32_t h, int32_t w, const int64_t* frame_index, const float* all_view,
                      const float* all_proj, const float* all_rgb, const float* all_depth, float* dst_view, float* dst_proj,
                      float* dst_rgb, float* dst_depth, int32_t* msum, ags_stream_t stream) {

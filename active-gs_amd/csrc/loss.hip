@@ -247,6 +247,110 @@ __global__ __launch_bounds__(256) void ags_k_loss_finish(AgsLossDev c, float* __
                       c.w_tv * sums[3] / (b * 4.f * hw);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The facade's post-processing on its own (render_cuda_core, /root/reference/utils/operations.py:714-718 with
+// depth2normal :172-219), for callers that keep the reference's loss head in torch: n = normalize(N) * (opacity > 1e-2)
+// and d2n = depth2normal(depth, that mask, fov) in one launch, and their backward in one launch (what ~35 torch ops
+// and their autograd nodes do per view).  Same arithmetic as the fused loss stages above.
+struct AgsPostDev { int H, W; float fxq, fyq; };
+
+struct AgsD2n {          // everything the backward needs again
+    float3 ray_c, ray_u, ray_b, ray_l, ray_r, pu, pl, pb, pr, m;
+    float Mu, Mb, Ml, Mr, mn, ml;
+    int iu, ib, il, ir;
+};
+__device__ __forceinline__ AgsD2n ags_d2n_at(const AgsPostDev& c, const float* __restrict__ depth,
+                                             const float* __restrict__ opacity, int x, int y, int p) {
+    AgsD2n r;
+    const int H = c.H, W = c.W;
+    r.mn = opacity[p] > 1e-2f ? 1.f : 0.f;
+    const int yu = max(y - 1, 0), yb = min(y + 1, H - 1), xl = max(x - 1, 0), xr = min(x + 1, W - 1);
+    r.iu = yu * W + x; r.ib = yb * W + x; r.il = y * W + xl; r.ir = y * W + xr;
+    const float rx = ((float)x - 0.5f * (float)W) / c.fxq, ry = ((float)y - 0.5f * (float)H) / c.fyq;
+    const float rxl = ((float)xl - 0.5f * (float)W) / c.fxq, rxr = ((float)xr - 0.5f * (float)W) / c.fxq;
+    const float ryu = ((float)yu - 0.5f * (float)H) / c.fyq, ryb = ((float)yb - 0.5f * (float)H) / c.fyq;
+    r.Mu = opacity[r.iu] > 1e-2f ? 1.f : 0.f; r.Mb = opacity[r.ib] > 1e-2f ? 1.f : 0.f;
+    r.Ml = opacity[r.il] > 1e-2f ? 1.f : 0.f; r.Mr = opacity[r.ir] > 1e-2f ? 1.f : 0.f;
+    r.ray_c = f3(rx, ry, 1.f); r.ray_u = f3(rx, ryu, 1.f); r.ray_b = f3(rx, ryb, 1.f);
+    r.ray_l = f3(rxl, ry, 1.f); r.ray_r = f3(rxr, ry, 1.f);
+    const float3 pc = ags_point(r.ray_c, depth[p]) * r.mn;
+    r.pu = (ags_point(r.ray_u, depth[r.iu]) - pc) * r.Mu; r.pl = (ags_point(r.ray_l, depth[r.il]) - pc) * r.Ml;
+    r.pb = (ags_point(r.ray_b, depth[r.ib]) - pc) * r.Mb; r.pr = (ags_point(r.ray_r, depth[r.ir]) - pc) * r.Mr;
+    r.m = cross3(r.pu, r.pl) + cross3(r.pr, r.pu) + cross3(r.pb, r.pr) + cross3(r.pl, r.pb);
+    r.ml = fmaxf(sqrtf(dot3(r.m, r.m)), 1e-12f);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void ags_k_facade_post(AgsPostDev c, const float* __restrict__ normal_raw,
+                                                         const float* __restrict__ depth, const float* __restrict__ opacity,
+                                                         float* __restrict__ normal_out, float* __restrict__ d2n_out) {
+    const int HW = c.H * c.W, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / c.W, x = p - y * c.W;
+    const AgsD2n r = ags_d2n_at(c, depth, opacity, x, y, p);
+    if (normal_raw && normal_out) {
+        const float nx = normal_raw[p], ny = normal_raw[HW + p], nz = normal_raw[2 * HW + p];
+        const float inv = r.mn / fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-12f);
+        normal_out[p] = nx * inv; normal_out[HW + p] = ny * inv; normal_out[2 * HW + p] = nz * inv;
+    }
+    const float3 d2n = r.m * (r.mn / r.ml);
+    d2n_out[p] = d2n.x; d2n_out[HW + p] = d2n.y; d2n_out[2 * HW + p] = d2n.z;
+}
+
+__global__ __launch_bounds__(256) void ags_k_facade_post_bwd(AgsPostDev c, const float* __restrict__ normal_raw,
+                                                             const float* __restrict__ depth, const float* __restrict__ opacity,
+                                                             const float* __restrict__ g_normal, const float* __restrict__ g_d2n,
+                                                             float* __restrict__ d_normal_raw, float* __restrict__ d_depth) {
+    const int HW = c.H * c.W, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / c.W, x = p - y * c.W;
+    const float mn = opacity[p] > 1e-2f ? 1.f : 0.f;
+    if (d_normal_raw) {   // n = normalize(N) * mask
+        float3 dN = f3(0.f, 0.f, 0.f);
+        if (g_normal && normal_raw) {
+            const float3 N = f3(normal_raw[p], normal_raw[HW + p], normal_raw[2 * HW + p]);
+            const float3 gn = f3(g_normal[p], g_normal[HW + p], g_normal[2 * HW + p]);
+            const float Nl = sqrtf(dot3(N, N));
+            if (mn > 0.f && Nl > 1e-12f) {
+                const float3 nh = N * (1.f / Nl);
+                dN = (gn - nh * dot3(nh, gn)) * (1.f / Nl);
+            }
+        }
+        d_normal_raw[p] = dN.x; d_normal_raw[HW + p] = dN.y; d_normal_raw[2 * HW + p] = dN.z;
+    }
+    if (!g_d2n || !d_depth || mn == 0.f) return;
+    const float3 G = f3(g_d2n[p], g_d2n[HW + p], g_d2n[2 * HW + p]);
+    if (G.x == 0.f && G.y == 0.f && G.z == 0.f) return;
+    const AgsD2n r = ags_d2n_at(c, depth, opacity, x, y, p);
+    if (sqrtf(dot3(r.m, r.m)) <= 1e-12f) return;
+    const float3 mh = r.m * (1.f / r.ml);
+    const float3 Gm = (G - mh * dot3(mh, G)) * (1.f / r.ml);
+    const float3 gpu = cross3(r.pl, Gm) + cross3(Gm, r.pr);
+    const float3 gpl = cross3(Gm, r.pu) + cross3(r.pb, Gm);
+    const float3 gpr = cross3(r.pu, Gm) + cross3(Gm, r.pb);
+    const float3 gpb = cross3(r.pr, Gm) + cross3(Gm, r.pl);
+    const float3 gpc = (gpu * r.Mu + gpl * r.Ml + gpr * r.Mr + gpb * r.Mb) * -1.f;
+    atomicAdd(&d_depth[p], dot3(gpc, r.ray_c) * r.mn);
+    atomicAdd(&d_depth[r.iu], dot3(gpu, r.ray_u) * r.Mu);
+    atomicAdd(&d_depth[r.il], dot3(gpl, r.ray_l) * r.Ml);
+    atomicAdd(&d_depth[r.ir], dot3(gpr, r.ray_r) * r.Mr);
+    atomicAdd(&d_depth[r.ib], dot3(gpb, r.ray_b) * r.Mb);
+}
+
+void ags_launch_facade_post(int h, int w, float tanx, float tany, const float* normal_raw, const float* depth,
+                            const float* opacity, float* normal_out, float* d2n_out, hipStream_t s) {
+    const AgsPostDev c = {h, w, (float)h / (2.0f * tanx), (float)w / (2.0f * tany)};   // the reference pairs fov_x with H (sic)
+    hipLaunchKernelGGL(ags_k_facade_post, dim3((h * w + 255) / 256), dim3(256), 0, s, c, normal_raw, depth, opacity,
+                       normal_out, d2n_out);
+}
+void ags_launch_facade_post_bwd(int h, int w, float tanx, float tany, const float* normal_raw, const float* depth,
+                                const float* opacity, const float* g_normal, const float* g_d2n, float* d_normal_raw,
+                                float* d_depth, hipStream_t s) {
+    const AgsPostDev c = {h, w, (float)h / (2.0f * tanx), (float)w / (2.0f * tany)};
+    hipLaunchKernelGGL(ags_k_facade_post_bwd, dim3((h * w + 255) / 256), dim3(256), 0, s, c, normal_raw, depth, opacity,
+                       g_normal, g_d2n, d_normal_raw, d_depth);
+}
+
 static AgsLossDev make_dev(const AgsLossConfig& cfg) {
     AgsLossDev c;
     c.H = cfg.image_height; c.W = cfg.image_width; c.B = cfg.batch_total;

@@ -25,10 +25,59 @@ def _default_module():
     return m
 
 
+class _FacadePost(torch.autograd.Function):
+    """normalize(normal) * mask and depth2normal on the GPU: one launch forward, one backward
+    (``ags_facade_post[_backward]``, csrc/loss.hip) instead of ~35 torch ops and their autograd nodes per view."""
+
+    @staticmethod
+    def forward(ctx, normal_raw, depth, opacity, tanx, tany):
+        import ctypes as C
+        from . import _lib
+        from ._lib import ptr
+        _, H, W = depth.shape
+        depth_c, op_c = depth.detach().float().contiguous(), opacity.detach().float().contiguous()
+        nr_c = None if normal_raw is None else normal_raw.detach().float().contiguous()
+        d2n = torch.empty(3, H, W, device=depth.device, dtype=torch.float32)
+        n_out = None if nr_c is None else torch.empty_like(d2n)
+        _lib.check(_lib.load().ags_facade_post(H, W, float(tanx), float(tany), ptr(nr_c), ptr(depth_c), ptr(op_c), ptr(n_out),
+                                               ptr(d2n), torch.cuda.current_stream().cuda_stream), "ags_facade_post")
+        ctx.save_for_backward(*([depth_c, op_c] + ([nr_c] if nr_c is not None else [])))
+        ctx.geom = (H, W, float(tanx), float(tany), nr_c is not None)
+        if n_out is None:
+            return d2n
+        return n_out, d2n
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from . import _lib
+        from ._lib import ptr
+        H, W, tanx, tany, has_normal = ctx.geom
+        saved = ctx.saved_tensors
+        depth_c, op_c = saved[0], saved[1]
+        nr_c = saved[2] if has_normal else None
+        g_n, g_d = (grads[0], grads[1]) if has_normal else (None, grads[0])
+        g_n = None if g_n is None else g_n.float().contiguous()
+        g_d = None if g_d is None else g_d.float().contiguous()
+        d_nr = torch.empty_like(nr_c) if (has_normal and ctx.needs_input_grad[0]) else None
+        d_depth = torch.zeros(1, H, W, device=depth_c.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        _lib.check(_lib.load().ags_facade_post_backward(H, W, tanx, tany, ptr(nr_c), ptr(depth_c), ptr(op_c), ptr(g_n),
+                                                        ptr(g_d if d_depth is not None else None), ptr(d_nr), ptr(d_depth),
+                                                        torch.cuda.current_stream().cuda_stream), "ags_facade_post_backward")
+        return d_nr, d_depth, None, None, None
+
+
 def depth_to_normal(depth: torch.Tensor, mask: torch.Tensor, fov) -> torch.Tensor:
     """(1,H,W) depth, (1,H,W) bool mask -> (3,H,W) unit normals from the four neighbouring
     back-projected points.  Quirk kept from the reference: the x focal is derived from
-    fov[0] and the image HEIGHT, the y focal from fov[1] and the WIDTH."""
+    fov[0] and the image HEIGHT, the y focal from fov[1] and the WIDTH.  Device tensors take the one-launch
+    kernel (and its one-launch backward); host tensors (the CPU tests) the torch statement below."""
+    if depth.is_cuda:
+        return _FacadePost.apply(None, depth, mask.to(torch.float32), math.tan(float(fov[0]) / 2.0),
+                                 math.tan(float(fov[1]) / 2.0))
+    return _depth_to_normal_torch(depth, mask, fov)
+
+
+def _depth_to_normal_torch(depth: torch.Tensor, mask: torch.Tensor, fov) -> torch.Tensor:
     _, H, W = depth.shape
     d = depth[0]
     m = mask[0].to(d.dtype)
@@ -52,24 +101,33 @@ def depth_to_normal(depth: torch.Tensor, mask: torch.Tensor, fov) -> torch.Tenso
 
 def render_core(module, cam_pos, fov, view_matrix, projection_matrix, render_mask, image_shape, background_color,
                 means, harmonics, opacities, confidences, scales, rotations, front_only=False,
-                require_importance=False, weight_thres=0.03):
+                require_importance=False, weight_thres=0.03, tan_fov_host=None, config=None):
     """One view through the rasterizer + the facade's post-processing; returns the 9-tuple
-    (rgb, depth, normal, opacity, d2n, confidence, importance, count, radii)."""
+    (rgb, depth, normal, opacity, d2n, confidence, importance, count, radii).
+    ``tan_fov_host`` (two Python floats) / ``config`` (the 5-float device tensor): what the reference derives per call
+    with two ``.item()`` read-backs and one host-to-device copy (operations.py:682-699), handed in by a caller that
+    has them already (SurfelRenderer: once per batch)."""
     device = means.device
-    tan_fov = (0.5 * fov).tan()
+    if tan_fov_host is None:
+        tan_fov = (0.5 * fov).tan()
+        tan_fov_host = (tan_fov[0].item(), tan_fov[1].item())
+    if config is None:
+        config = torch.tensor([1.0, 1.0, 1.0, 1.0 if require_importance else 0.0, 1.0 if front_only else 0.0]).to(device)
     means_2d = torch.zeros_like(means, requires_grad=True)
     settings = module.GaussianRasterizationSettings(
-        image_height=image_shape[0], image_width=image_shape[1], tanfovx=tan_fov[0].item(),
-        tanfovy=tan_fov[1].item(), bg=background_color, scale_modifier=1.0, viewmatrix=view_matrix,
+        image_height=image_shape[0], image_width=image_shape[1], tanfovx=tan_fov_host[0],
+        tanfovy=tan_fov_host[1], bg=background_color, scale_modifier=1.0, viewmatrix=view_matrix,
         projmatrix=projection_matrix, sh_degree=0, campos=cam_pos, prefiltered=False, render_mask=render_mask,
-        weight_thres=weight_thres, debug=False,
-        config=torch.tensor([1.0, 1.0, 1.0, 1.0 if require_importance else 0.0, 1.0 if front_only else 0.0]).to(device))
+        weight_thres=weight_thres, debug=False, config=config)
     rgb, normal, depth, opacity, confidence, importance, count, radii = module.GaussianRasterizer(settings)(
         means3D=means, means2D=means_2d, opacities=opacities[..., None], confidences=confidences, shs=None,
         colors_precomp=harmonics[:, 0, :], scales=scales, rotations=rotations, cov3D_precomp=None)
-    mask = opacity.detach() > 1e-2
-    normal = F.normalize(normal, dim=0) * mask
-    d2n = depth_to_normal(depth, mask, fov)
+    if depth.is_cuda:      # (the same two statements as one launch, one more for their backward)
+        normal, d2n = _FacadePost.apply(normal, depth, opacity, settings.tanfovx, settings.tanfovy)
+    else:
+        mask = opacity.detach() > 1e-2
+        normal = F.normalize(normal, dim=0) * mask
+        d2n = depth_to_normal(depth, mask, fov)
     return rgb, depth, normal, opacity, d2n, confidence, importance, count, radii
 
 
@@ -88,6 +146,8 @@ class SurfelRenderer:
         self.view_matrices = cm["viewmatrix"]
         self.projection_matrices = cm["projmatrix"]
         self.fovs = 2.0 * torch.atan(cm["tanfov"])
+        self._tan_host = [(float(a), float(b)) for a, b in (0.5 * self.fovs).tan().cpu().tolist()]   # one read-back per batch
+        self._configs = {}
         if render_masks is None:
             self.render_masks = [torch.tensor([], device=device) for _ in range(self.batch_size)]
         else:
@@ -98,11 +158,16 @@ class SurfelRenderer:
          self.gaussian_scales, self.gaussian_rotations) = gaussians_attr
 
     def _core(self, i, front_only, require_importance):
+        key = (bool(require_importance), bool(front_only))
+        if key not in self._configs:
+            self._configs[key] = torch.tensor([1.0, 1.0, 1.0, 1.0 if require_importance else 0.0,
+                                               1.0 if front_only else 0.0]).to(self.gaussian_means.device)
         return render_core(self.module, self.cam_pos[i], self.fovs[i], self.view_matrices[i],
                            self.projection_matrices[i], self.render_masks[i], (self.h, self.w),
                            self.background_color, self.gaussian_means, self.gaussian_harmonics,
                            self.gaussian_opacities, self.gaussian_confidences, self.gaussian_scales,
-                           self.gaussian_rotations, front_only=front_only, require_importance=require_importance)
+                           self.gaussian_rotations, front_only=front_only, require_importance=require_importance,
+                           tan_fov_host=self._tan_host[i], config=self._configs[key])
 
     def render_view(self, i=0, require_grad=False, require_importance=False, front_only=False):
         with torch.set_grad_enabled(require_grad):

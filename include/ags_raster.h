@@ -447,6 +447,22 @@ int ags_loss_stage2(const AgsLossConfig* cfg, const AgsImages* fwd, const float*
                     const int32_t* msum, float* d_normal, float* d_depth /* += */, float* accum,
                     ags_stream_t stream);
 
+/* The facade's post-processing alone (render_cuda_core, /root/reference/utils/operations.py:714-718, and
+ * depth2normal, :172-219), for callers that keep the reference's loss head in torch:
+ *   normal_out = normalize(normal_raw, dim 0, eps 1e-12) * (opacity > 1e-2)
+ *   d2n_out    = depth2normal(depth, opacity > 1e-2, fov)   - four-neighbour cross products of the back-projected
+ *                points, replicate padding, x focal = H / (2 tan(fov_x / 2)), y focal = W / (2 tan(fov_y / 2)) (the
+ *                reference's pairing, kept)
+ * in one launch.  Images are (C,H,W) float; tanfov_* = tan(fov / 2).  normal_raw and normal_out may both be NULL
+ * (depth -> normal only). */
+int ags_facade_post(int32_t h, int32_t w, float tanfov_x, float tanfov_y, const float* normal_raw, const float* depth,
+                    const float* opacity, float* normal_out, float* d2n_out, ags_stream_t stream);
+/* Its backward in one launch: g_normal / g_d2n are the gradients wrt normal_out / d2n_out (either may be NULL = zero);
+ * d_normal_raw (3,H,W) is written (may be NULL), d_depth (H,W) is ADDED to with atomics - zero it first. */
+int ags_facade_post_backward(int32_t h, int32_t w, float tanfov_x, float tanfov_y, const float* normal_raw,
+                             const float* depth, const float* opacity, const float* g_normal, const float* g_d2n,
+                             float* d_normal_raw, float* d_depth, ags_stream_t stream);
+
 /* ---- Map growth and pruning (replaces the torch/cv2 code of GaussianMap.add_gaussians, cal_mask,
  * prune and voxel_downsample: /root/reference/mapping/gaussian_map.py:234-246,294-489,
  * /root/reference/utils/operations.py:161-169,603-625).  Same rules as everything above: device

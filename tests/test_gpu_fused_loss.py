@@ -14,7 +14,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def test_fused_loss_matches_torch_autograd(agslib):
     from active_gs_amd import raster_api as api
-    from active_gs_amd.facade import depth_to_normal, training_losses
+    from active_gs_amd.facade import _depth_to_normal_torch as depth_to_normal, training_losses   # (the torch statement)
     from active_gs_amd.fused_loss import FusedLoss
     dev = torch.device("cuda:0")
     n, h, w, B = 6000, 96, 128, 3
@@ -189,3 +189,51 @@ def test_stage_frames_and_loss_finish_match_torch(agslib):
     assert torch.allclose(perf[idx2], want_err, rtol=1e-5) and float(perf[1]) == 10.0
     assert torch.allclose(total[0], want_total, rtol=1e-5)
     assert float(loss.accum.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("h,w", [(64, 96), (97, 51), (16, 16)])
+def test_facade_post_kernel_matches_the_torch_statements(agslib, h, w):
+    """render_cuda_core's two post-processing statements (operations.py:714-718: normalize(normal) * (opacity > 1e-2),
+    depth2normal with replicate padding and the fov/H pairing) as ONE launch and ONE backward launch
+    (ags_facade_post[_backward]) against their torch statement, values and gradients wrt the raw normal and the depth;
+    holes in the opacity (masked centres and masked neighbours), non-square and one-tile images."""
+    import math
+    import torch.nn.functional as F
+    from active_gs_amd.facade import _FacadePost, _depth_to_normal_torch, depth_to_normal
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(h * 1000 + w)
+    ys, xs = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
+    depth = (1.5 + 0.8 * xs + 0.3 * torch.sin(6 * ys) + 0.003 * torch.randn(h, w, generator=gen))[None]
+    normal = torch.randn(3, h, w, generator=gen)
+    opacity = torch.rand(1, h, w, generator=gen)
+    opacity[:, h // 3: h // 3 + 3, :] = 0.0                      # a masked band, masked borders
+    opacity[:, :, 0] = 0.005
+    opacity[0, -1, -1] = 0.0
+    fov = torch.tensor([math.radians(70.0), math.radians(50.0)])
+    tan = [math.tan(float(f) / 2) for f in fov]
+    g_n, g_d = torch.randn(3, h, w, generator=gen), torch.randn(3, h, w, generator=gen)
+    res = []
+    for native in (False, True):
+        # the torch statement in float64: in float32 its own (padded point - centre) cancellations cost it 2.5e-4 of the
+        # depth gradient (relative L1 against float64, 22 of 228 at the worst pixel); the kernel's rounded products
+        # keep 8e-7
+        dt = torch.float32 if native else torch.float64
+        N = normal.clone().to(dev, dt).requires_grad_(True)
+        D = depth.clone().to(dev, dt).requires_grad_(True)
+        O = opacity.to(dev)
+        if native:
+            n_out, d2n = _FacadePost.apply(N, D, O, tan[0], tan[1])
+            alone = depth_to_normal(D.detach(), O > 1e-2, fov)         # the public function takes the kernel too
+            assert torch.equal(alone, d2n.detach())
+        else:
+            mask = O > 1e-2
+            n_out = F.normalize(N, dim=0) * mask
+            d2n = _depth_to_normal_torch(D, mask, fov.to(dev, dt))
+        ((n_out * g_n.to(dev, dt)).sum() + (d2n * g_d.to(dev, dt)).sum()).backward()
+        res.append([t.detach().cpu().double() for t in (n_out, d2n, N.grad, D.grad)])
+    for k, name in enumerate(("normal", "d2n", "d_normal_raw", "d_depth")):
+        a, b = res[1][k], res[0][k]
+        scale = float(b.abs().max()) + 1e-12
+        diff = (a - b).abs()
+        assert float(diff.max()) <= 5e-5 * scale + 1e-6, (name, float(diff.max()), scale)
+        assert float(diff.sum()) <= 1e-5 * float(b.abs().sum()) + 1e-6, (name, float(diff.sum()), float(b.abs().sum()))
