@@ -15,11 +15,11 @@ import torch
 def fov_from_intrinsics(K: torch.Tensor) -> torch.Tensor:
     """(B,3,3) normalised intrinsics -> (B,2) [fov_x, fov_y]: the angle between the
     rays through the mid-points of opposite image edges (operations.py:628-642)."""
-    Kinv = torch.linalg.inv(K)
+    Kinv = torch.linalg.inv_ex(K).inverse     # (inv() reads an error flag back from the device: a stream synchronisation)
 
     def ray(v):
-        v = torch.tensor(v, dtype=torch.float32, device=K.device)
-        d = torch.einsum("bij,j->bi", Kinv, v)
+        # Kinv @ v without bringing v to the device (four small host-to-device copies per batch otherwise)
+        d = Kinv[:, :, 0] * v[0] + Kinv[:, :, 1] * v[1] + Kinv[:, :, 2] * v[2]
         return d / d.norm(dim=-1, keepdim=True)
 
     fov_x = (ray([0.0, 0.5, 1.0]) * ray([1.0, 0.5, 1.0])).sum(-1).acos()
@@ -47,6 +47,6 @@ def camera_matrices(c2w: torch.Tensor, K: torch.Tensor, near: float, far: float)
     row-vector convention the rasterizer takes (operations.py:749-762)."""
     fov = fov_from_intrinsics(K)
     P = projection_matrix(near, far, fov[:, 0], fov[:, 1])
-    view = torch.linalg.inv(c2w).transpose(1, 2).contiguous()
+    view = torch.linalg.inv_ex(c2w).inverse.transpose(1, 2).contiguous()
     proj = (view @ P.transpose(1, 2)).contiguous()
     return dict(viewmatrix=view, projmatrix=proj, tanfov=(0.5 * fov).tan(), campos=c2w[:, :3, 3].contiguous())
