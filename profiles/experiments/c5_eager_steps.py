@@ -1,5 +1,7 @@
+"""Config 5 (5 M surfels @2048x2048, one view) stepped eagerly, 3 x 20 timed steps (AGS_FREEZE=1: learning rates 0).
+Used for A/B runs of library builds: AGS_LIB_PATH=scratch/libags_<tag>.so python profiles/experiments/c5_eager_steps.py"""
 import sys, os, torch
-R = os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."); sys.path.insert(0, R)
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, R)
 from active_gs_amd import raster_api as api
 from active_gs_amd.camera import camera_matrices
 from active_gs_amd.synthetic import make_camera, make_room_scene

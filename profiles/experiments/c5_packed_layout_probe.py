@@ -1,5 +1,8 @@
+"""Probe: config 5 with scales / rotation / opacity / colour as strided views of ONE (N,16) buffer
+(PACK=1, needs a probe build whose cull-first and member-row kernels index with stride 16) against the separate arrays
+(PACK=0, product build); prints the per-stage medians.  The probe build is not kept: the layout was not adopted."""
 import sys, os, torch, time
-R = os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."); sys.path.insert(0, R)
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, R)
 from active_gs_amd import raster_api as api, _lib
 from active_gs_amd.camera import camera_matrices
 from active_gs_amd.synthetic import make_camera, make_room_scene
