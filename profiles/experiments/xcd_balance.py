@@ -1,3 +1,6 @@
+"""Per-XCD work of the blend backward under other band partitions, from the same kind of dump as xcd_residency.py (the
+build must also stamp tile / list length / maxlast per wave - see r03_xcd_work_stealing.patch's session notes):
+    python profiles/experiments/xcd_balance.py x.npz <number of tiles>"""
 import numpy as np, sys
 t = np.load(sys.argv[1])["t"]
 a = t[3]; m = t[6]

@@ -1,3 +1,6 @@
+"""Resident waves per SIMD over the blend launches and per-XCD end times / wave-time, from a timeline dump made with a
+-DAGS_TIMELINE -DAGS_TL_REALTIME -DAGS_TL_WAVES=65536 build (AGS_TL_DUMP=x.npz AGS_TL_WAVES=65536 python timeline.py ...):
+    python profiles/experiments/xcd_residency.py x.npz"""
 import numpy as np, sys
 t = np.load(sys.argv[1])["t"]
 NS = 10.0
