@@ -54,12 +54,43 @@ class FusedMapTrainer(GaussianMapTrainer):
         self.num_streams = max(1, int(num_streams))
         self._streams = None
         self._cams = {}          # frame index -> (api.Camera, fov_x, fov_y)
+        self._store = None       # _frame_store()
+        self._count_batch = None # _render_counts(): the chunk of views the prune pass renders at a time
         self._states = {}        # view slot -> ForwardState
         self._loss = None
         self._loss_bufs = []
         self._cap = 0
         self._last_need, self._last_need_n = None, 0   # most tile instances a view of the last train() call needed, and the map size then
         self.is_init = len(frames) > 0 and self.means.shape[0] > 0   # gaussian_map.py:35,130
+
+    # ---- the keyframes' images and matrices as ONE growing set of arrays the sampled batch is gathered from on the
+    # device.  Stacking all K frames at every train() call (as round 2 did) is K x 4 MB of copies and a fresh
+    # allocation a size larger than the last per call: 63 ms per call at 300 keyframes against 9 ms at 50.
+    def _frame_store(self):
+        """(all_view (K,4,4), all_proj (K,4,4), all_rgb (K,3,H,W), all_depth (K,1,H,W)) of self.frames, appended to
+        as frames arrive (capacity doubles); the frames must share one image size (_uniform_frames)."""
+        K = len(self.frames)
+        st = self._store
+        h, w = self.frames[0]["rgb"].shape[-2:]
+        ids = [id(f) for f in self.frames]
+        if st is not None and (st["hw"] != (h, w) or st["n"] > K or st["ids"] != ids[:st["n"]]):
+            st = None                                   # another image size, or the list was edited: rebuild
+        if st is None or st["cap"] < K:
+            cap = max(16, 2 * K)
+            f = dict(device=self.device, dtype=torch.float32)
+            new = dict(hw=(h, w), cap=cap, n=0, ids=[], view=torch.empty(cap, 4, 4, **f), proj=torch.empty(cap, 4, 4, **f),
+                       rgb=torch.empty(cap, 3, h, w, **f), depth=torch.empty(cap, 1, h, w, **f))
+            if st is not None:
+                for k in ("view", "proj", "rgb", "depth"):
+                    new[k][:st["n"]] = st[k][:st["n"]]
+                new["n"], new["ids"] = st["n"], st["ids"]
+            st = self._store = new
+        for i in range(st["n"], K):
+            cam = self._camera(i)[0]
+            st["view"][i] = cam.viewmatrix; st["proj"][i] = cam.projmatrix
+            st["rgb"][i] = self.frames[i]["rgb"]; st["depth"][i] = self.frames[i]["depth"].reshape(1, h, w)
+        st["n"], st["ids"] = K, ids
+        return st["view"][:K], st["proj"][:K], st["rgb"][:K], st["depth"][:K]
 
     # ---- cached per-frame camera (the intrinsics -> fov step needs host scalars once per frame)
     def _camera(self, idx: int):
@@ -98,6 +129,7 @@ class FusedMapTrainer(GaussianMapTrainer):
     # zoomed-out camera: most surfels in a few tiles) that is far above the instance total, which is all the scan-based
     # binning needs - same images.  Past these thresholds the trainer goes on with AGS_BIN_TILE_SORT.
     SKEW_FACTOR, DIRECT_BUDGET_BYTES = 8, 1 << 30
+    COUNT_CHUNK = 16           # views per batched launch of the prune pass's count render (_render_counts)
     MULTI_VIEW_ROWS = True     # the batched iteration's per-Gaussian backward + Adam as ONE launch (ags_backward_rows)
     _no_grads = api.GaussianGrads(None, None, None, None, None)
 
@@ -284,21 +316,42 @@ class FusedMapTrainer(GaussianMapTrainer):
         self._cap = max(self._cap, 1 << 16, 2 * n)
         g = self._gaussians()
         if len(frame_ids) > 1 and self._uniform_frames():
-            # the prune pass over all keyframes: one batched set of launches, one status read
+            # the prune pass over all keyframes: batched launches over COUNT_CHUNK views at a time, one status read per
+            # chunk, in ONE set of buffers kept across calls (a batch of all K keyframes is K workspaces: 30 GB of
+            # fresh allocations per pass at 300 keyframes)
             cam0, _, _ = self._camera(int(frame_ids[0]))
+            V, CH = len(frame_ids), self.COUNT_CHUNK
             vm = torch.stack([self._camera(int(f))[0].viewmatrix for f in frame_ids])
             pm = torch.stack([self._camera(int(f))[0].projmatrix for f in frame_ids])
-            masks = (depth_gt > 0.0).float().reshape(len(frame_ids), h, w)
-            while True:
-                batch = api.ViewBatch(g, len(frame_ids), h, w, cam0.tanfovx, cam0.tanfovy, self.background, self._cap,
-                                      want_stats=True, front_only=True, render_masks=masks,
-                                      binning_mode=self.binning_mode)
-                batch.render(vm, pm)
-                stw = batch.statuses()
+            masks = (depth_gt > 0.0).float().reshape(V, h, w)
+            out = torch.empty(V, n, device=self.device, dtype=torch.int32)
+            v0 = 0
+            while v0 < V:
+                cnt = min(CH, V - v0)
+                batch = self._count_batch
+                key = (h, w, round(cam0.tanfovx, 7), round(cam0.tanfovy, 7), self.binning_mode)
+                if (batch is None or batch._count_key != key or batch.capacity_n < n or batch.max_instances < self._cap):
+                    self._count_batch = None            # release before the larger one is made
+                    batch = api.ViewBatch(g, CH, h, w, cam0.tanfovx, cam0.tanfovy, self.background, self._cap,
+                                          want_stats=True, front_only=True, render_masks=torch.zeros(CH, h, w, device=self.device),
+                                          binning_mode=self.binning_mode, capacity_n=max(2 * n, 1 << 16))
+                    batch._count_key = key
+                    self._count_batch = batch
+                elif batch.g is not g:
+                    batch.bind(g)
+                batch.masks[:cnt] = masks[v0:v0 + cnt]
+                batch.viewmats[:cnt] = vm[v0:v0 + cnt]
+                batch.projmats[:cnt] = pm[v0:v0 + cnt]
+                batch.forward(cnt)
+                stw = batch.statuses(cnt)
                 need = int(stw[:, 7].max())
-                if need <= self._cap:
-                    return batch.count.clone()
-                self._grow_cap(need, int(stw[:, 0].max()))
+                if need > self._cap:
+                    self._grow_cap(need, int(stw[:, 0].max()))
+                    self._count_batch = None            # rebuilt with the larger capacity (or the other binning mode)
+                    continue
+                out[v0:v0 + cnt] = batch.count[:cnt]
+                v0 += cnt
+            return out
         out = []
         for k, fid in enumerate(frame_ids):
             cam0, _, _ = self._camera(int(fid))
@@ -388,10 +441,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         K = len(self.frames)
         h, w = self.frames[0]["rgb"].shape[-2:]
         cam0, fx, fy = self._camera(0)
-        all_view = torch.stack([self._camera(i)[0].viewmatrix for i in range(K)])
-        all_proj = torch.stack([self._camera(i)[0].projmatrix for i in range(K)])
-        all_rgb = torch.stack([f["rgb"] for f in self.frames]).contiguous()
-        all_depth = torch.stack([f["depth"] for f in self.frames]).contiguous()
+        all_view, all_proj, all_rgb, all_depth = self._frame_store()
         Bmax = self.cfg["batch_size"] + self.cfg["active_size"]
         self._cap = max(self._cap, 1 << 16, 2 * n)
         g = self._gaussians()
@@ -559,10 +609,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         K = len(self.frames)
         h, w = self.frames[0]["rgb"].shape[-2:]
         cam0, fx, fy = self._camera(0)
-        all_view = torch.stack([self._camera(i)[0].viewmatrix for i in range(K)])
-        all_proj = torch.stack([self._camera(i)[0].projmatrix for i in range(K)])
-        all_rgb = torch.stack([f["rgb"] for f in self.frames]).contiguous()
-        all_depth = torch.stack([f["depth"] for f in self.frames]).contiguous()
+        all_view, all_proj, all_rgb, all_depth = self._frame_store()
         B = sampler.num_random + len(sampler.active_ids)
         st_view = torch.empty(B, 4, 4, device=dev); st_proj = torch.empty(B, 4, 4, device=dev)
         st_rgb = torch.empty(B, 3, h, w, device=dev); st_depth = torch.empty(B, 1, h, w, device=dev)

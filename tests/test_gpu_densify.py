@@ -198,3 +198,42 @@ def test_mapper_loop_matches_reference_capture(agslib):
     if tr.means.shape[0] == g["final"]["means"].shape[0]:
         assert float((tr.means.cpu() - g["final"]["means"]).abs().mean()) < 2e-4     # 16 sign-like Adam steps of 5e-4
         assert float((tr.harmonics.cpu() - g["final"]["harmonics"]).abs().mean()) < 2e-4
+
+
+def test_frame_store_and_chunked_count_render(agslib):
+    """A long mapping session: the keyframes live in ONE growing set of arrays (FusedMapTrainer._frame_store: appended
+    to as frames arrive, rebuilt when the list is edited) instead of being stacked at every train() call, and the
+    prune pass renders its count images COUNT_CHUNK views at a time in buffers it keeps (gaussian_map.py:141-192
+    renders ALL keyframes every prune_interval-th frame).  Same arrays as the stack, same counts as one batch of all
+    views, and the loop runs through more keyframes than one chunk holds."""
+    from active_gs_amd.fused_map_trainer import FusedMapTrainer
+    g = _gold()
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    raw = dict(means=z(0, 3), scales=z(0, 3), rotations=z(0, 4), opacities=z(0), harmonics=z(0, 1, 3))
+    np.random.seed(5)
+    torch.manual_seed(5)
+    tr = FusedMapTrainer(raw, [], dict(optimization_steps=2, prune_interval=3, batch_size=3, active_size=2, sampler="device"),
+                         use_graph=False, num_streams=1)
+    tr.COUNT_CHUNK = 4
+    for k in range(10):
+        tr.update(dict(g["frames"][k % 2]))
+        view, proj, rgb, depth = tr._frame_store()
+        K = len(tr.frames)
+        assert view.shape[0] == proj.shape[0] == rgb.shape[0] == depth.shape[0] == K == k + 1
+        assert torch.equal(rgb, torch.stack([f["rgb"] for f in tr.frames]))
+        assert torch.equal(depth, torch.stack([f["depth"] for f in tr.frames]).reshape(depth.shape))
+        assert torch.equal(view, torch.stack([tr._camera(i)[0].viewmatrix for i in range(K)]))
+    assert tr._store["cap"] >= 10 and all(np.isfinite(tr.last_losses))
+    # the count render of all ten keyframes: chunks of 4 (4 + 4 + 2) == chunks of 16 (one launch set)
+    ids = list(range(len(tr.frames)))
+    st = lambda key: torch.stack([tr.frames[i][key] for i in ids])
+    h, w = tr.frames[0]["rgb"].shape[-2:]
+    params = [tr.means, tr.scales, tr.rotations, tr.opacities, tr.harmonics]
+    small = tr._render_counts(ids, st("extrinsic"), st("intrinsic"), st("depth"), params, (h, w))
+    tr.COUNT_CHUNK, tr._count_batch = 16, None
+    whole = tr._render_counts(ids, st("extrinsic"), st("intrinsic"), st("depth"), params, (h, w))
+    assert small.shape == whole.shape == (10, tr.means.shape[0]) and torch.equal(small, whole) and int(whole.sum()) > 0
+    # an edited frame list (a frame replaced) is noticed: the arrays are rebuilt from the list
+    tr.frames[3] = dict(tr.frames[3], rgb=tr.frames[3]["rgb"] * 0.5)
+    _, _, rgb, _ = tr._frame_store()
+    assert torch.equal(rgb[3], tr.frames[3]["rgb"])
