@@ -244,6 +244,11 @@ void ags_launch_voxel_select(int n, const float* points, int32_t* select, float 
 size_t ags_compact_bytes(int n);
 void ags_launch_compact_plan(int n, const int32_t* keep, int32_t* dst_index, int32_t* total, void* scratch, hipStream_t s);
 void ags_launch_compact_rows(int n, int width, const int32_t* dst_index, const float* src, float* dst, hipStream_t s);
+void ags_launch_view_stats(int n, const float* means, const float* raw_rotations, const float* campos, float far,
+                           const int32_t* newest_count, int use_vd, float* view_supports, float* view_means,
+                           float* view_scores, hipStream_t s);
+void ags_launch_confidences(int n, const float* view_supports, const float* view_means, const float* view_scores, int use_vd,
+                            float* out, hipStream_t s);
 void ags_launch_prune_keep(int n, const float* prune_mask, const float* raw_opacities, float min_opacity, int32_t* keep,
                            hipStream_t s);
 

@@ -559,6 +559,27 @@ int ags_prune_keep(int32_t n, const float* prune_mask, const float* raw_opacitie
     return ags_check_launch();
 }
 
+int ags_view_stats_update(int32_t n, const float* means, const float* raw_rotations, const float* campos, float far,
+                          const int32_t* newest_count, int32_t use_view_distribution, float* view_supports,
+                          float* view_means, float* view_scores, ags_stream_t stream) {
+    if (n < 0 || !(far > 0.f)) return AGS_E_INVALID;
+    if (n == 0) return AGS_OK;
+    if (!newest_count || !view_supports) return AGS_E_INVALID;
+    if (use_view_distribution && (!means || !raw_rotations || !campos || !view_means || !view_scores)) return AGS_E_INVALID;
+    ags_launch_view_stats(n, means, raw_rotations, campos, far, newest_count, use_view_distribution ? 1 : 0, view_supports,
+                          view_means, view_scores, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_confidences(int32_t n, const float* view_supports, const float* view_means, const float* view_scores,
+                    int32_t use_view_distribution, float* out, ags_stream_t stream) {
+    if (n < 0) return AGS_E_INVALID;
+    if (n == 0) return AGS_OK;
+    if (!out || (use_view_distribution ? (!view_means || !view_scores) : !view_supports)) return AGS_E_INVALID;
+    ags_launch_confidences(n, view_supports, view_means, view_scores, use_view_distribution ? 1 : 0, out, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
 size_t ags_compact_plan_bytes(int32_t n) { return ags_compact_bytes(n < 0 ? 0 : n); }
 int ags_compact_plan(int32_t n, const int32_t* keep, int32_t* dst_index, int32_t* total, void* scratch,
                      size_t scratch_bytes, ags_stream_t stream) {

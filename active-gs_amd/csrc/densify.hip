@@ -218,6 +218,57 @@ __global__ __launch_bounds__(256) void ags_k_prune_keep(int n, const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// post_processing's per-surfel bookkeeping (/root/reference/mapping/gaussian_map.py:193-232): which surfels the newest
+// keyframe sees (count >= 1), their support count, the running mean of the unit directions they were seen from and
+// the view score (1 - dist / far) * max(cos(normal, direction), 0) - and get_confidences (:552-565) from them.  One
+// launch instead of ~25 torch ops per keyframe.  Plain f32 expressions in the reference's order.
+__global__ __launch_bounds__(256) void ags_k_view_stats(int n, const float* __restrict__ means,
+                                                        const float* __restrict__ raw_rotations,
+                                                        const float* __restrict__ campos, float far,
+                                                        const int32_t* __restrict__ newest_count, int use_vd,
+                                                        float* __restrict__ view_supports, float* __restrict__ view_means,
+                                                        float* __restrict__ view_scores) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool seen = newest_count[i] >= 1;
+    const float sup = view_supports[i] + (seen ? 1.f : 0.f);
+    view_supports[i] = sup;
+    if (!use_vd || !seen) return;
+    const float4 q4 = reinterpret_cast<const float4*>(raw_rotations)[i];
+    const float ql = fmaxf(sqrtf(q4.x * q4.x + q4.y * q4.y + q4.z * q4.z + q4.w * q4.w), 1e-12f);
+    const float r = q4.x / ql, x = q4.y / ql, y = q4.z / ql, z = q4.w / ql;
+    float nx = 2.f * (x * z + r * y), ny = 2.f * (y * z - r * x), nz = 1.f - 2.f * (x * x + y * y);
+    const float nl = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-12f);
+    nx /= nl; ny /= nl; nz /= nl;
+    float tx = campos[0] - means[3 * (size_t)i], ty = campos[1] - means[3 * (size_t)i + 1], tz = campos[2] - means[3 * (size_t)i + 2];
+    const float dist = sqrtf(tx * tx + ty * ty + tz * tz);
+    tx /= dist; ty /= dist; tz /= dist;
+    const float den = fmaxf(sup, 1.f);
+    float* vm = view_means + 3 * (size_t)i;
+    vm[0] = vm[0] + (tx - vm[0]) / den; vm[1] = vm[1] + (ty - vm[1]) / den; vm[2] = vm[2] + (tz - vm[2]) / den;
+    const float c = fminf(fmaxf(nx * tx + ny * ty + nz * tz, 0.f), 1.f);
+    view_scores[i] = view_scores[i] + (1.f - fminf(fmaxf(dist / far, 0.f), 1.f)) * c;
+}
+
+__global__ __launch_bounds__(256) void ags_k_confidences(int n, const float* __restrict__ view_supports,
+                                                         const float* __restrict__ view_means,
+                                                         const float* __restrict__ view_scores, int use_vd,
+                                                         float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float c;
+    if (use_vd) {
+        const float* vm = view_means + 3 * (size_t)i;
+        float var = sqrtf(vm[0] * vm[0] + vm[1] * vm[1] + vm[2] * vm[2]);
+        if (var != var) var = 1.f;                              // NaN -> 1 (gaussian_map.py:556)
+        c = expf(1.f - var) * view_scores[i];
+    } else {
+        c = 1.f - 1.f / expf(view_supports[i]);
+    }
+    out[i] = fminf(fmaxf(c, 0.f), 1.f);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stable compaction plan: dst_index[i] = number of kept rows before i (or -1).  Level 1: per
 // 1024-row chunk counts; level 2: one workgroup scans the chunk counts; level 3: each chunk
 // rescans its flags from its base.  Order-preserving like boolean indexing in torch.
@@ -346,6 +397,17 @@ void ags_launch_compact_rows(int n, int width, const int32_t* dst_index, const f
                        src, dst);
 }
 
+void ags_launch_view_stats(int n, const float* means, const float* raw_rotations, const float* campos, float far,
+                           const int32_t* newest_count, int use_vd, float* view_supports, float* view_means,
+                           float* view_scores, hipStream_t s) {
+    hipLaunchKernelGGL(ags_k_view_stats, dim3((n + 255) / 256), dim3(256), 0, s, n, means, raw_rotations, campos, far,
+                       newest_count, use_vd, view_supports, view_means, view_scores);
+}
+void ags_launch_confidences(int n, const float* view_supports, const float* view_means, const float* view_scores, int use_vd,
+                            float* out, hipStream_t s) {
+    hipLaunchKernelGGL(ags_k_confidences, dim3((n + 255) / 256), dim3(256), 0, s, n, view_supports, view_means, view_scores,
+                       use_vd, out);
+}
 void ags_launch_prune_keep(int n, const float* prune_mask, const float* raw_opacities, float min_opacity, int32_t* keep,
                            hipStream_t s) {
     hipLaunchKernelGGL(ags_k_prune_keep, dim3((n + 255) / 256), dim3(256), 0, s, n, prune_mask, raw_opacities, min_opacity, keep);

@@ -308,6 +308,54 @@ class FusedMapTrainer(GaussianMapTrainer):
         self.last_losses = [float(x) for x in self.last_losses]
         return True
 
+    # ---- post_processing (gaussian_map.py:141-232) and get_confidences (:552-565) without their ~30 torch ops
+    def confidences(self):
+        n = self.means.shape[0]
+        if n == 0 or not self.means.is_cuda:
+            return super().confidences()
+        import ctypes as C
+        from . import _lib
+        from ._lib import ptr
+        for k in ("view_supports", "view_means", "view_scores"):
+            setattr(self, k, getattr(self, k).float().contiguous())
+        out = torch.empty(n, device=self.device, dtype=torch.float32)
+        _lib.check(_lib.load().ags_confidences(n, ptr(self.view_supports), ptr(self.view_means), ptr(self.view_scores),
+                                               int(bool(self.cfg["use_view_distribution"])), ptr(out),
+                                               torch.cuda.current_stream().cuda_stream), "ags_confidences")
+        return out
+
+    def post_processing(self):
+        """The reference's rule (count render of the newest keyframe, or of ALL keyframes every prune_interval-th frame;
+        supports / view means / view scores of the surfels the newest frame sees; prune what no keyframe sees) with the
+        per-surfel bookkeeping as one launch (``ags_view_stats_update``) and the ground-truth depths taken from the
+        frame store instead of a stack of all keyframes."""
+        if self.world > 1 or not self.means.is_cuda or self.means.shape[0] == 0 or not self._uniform_frames():
+            return super().post_processing()
+        from . import _lib
+        from ._lib import ptr
+        k = len(self.frames)
+        prune_now = k % self.cfg["prune_interval"] == 0
+        use = list(range(k)) if prune_now else [k - 1]
+        depth_all = self._frame_store()[3]
+        depth_gt = depth_all if prune_now else depth_all[k - 1:k]
+        h, w = depth_gt.shape[-2:]
+        n = self.means.shape[0]
+        params = [self.means, self.scales, self.rotations, self.opacities, self.harmonics]
+        counts = self._render_counts(use, None, None, depth_gt, params, (h, w))
+        newest = counts[-1].contiguous()
+        last = self.frames[-1]
+        far = last["depth_range"][1]
+        far = float(far.item()) if torch.is_tensor(far) else float(far)
+        campos = last["extrinsic"][:3, 3].float().contiguous()
+        for key in ("view_supports", "view_means", "view_scores", "means", "rotations"):
+            setattr(self, key, getattr(self, key).float().contiguous())
+        _lib.check(_lib.load().ags_view_stats_update(n, ptr(self.means), ptr(self.rotations), ptr(campos), far, ptr(newest),
+                                                     int(bool(self.cfg["use_view_distribution"])), ptr(self.view_supports),
+                                                     ptr(self.view_means), ptr(self.view_scores),
+                                                     torch.cuda.current_stream().cuda_stream), "ags_view_stats_update")
+        if prune_now:
+            self.prune(~(counts.sum(0) >= 1))
+
     def _render_counts(self, frame_ids, extr, intr, depth_gt, params, hw):
         """Count render of post_processing straight through the C ABI (forward only, importance /
         count enabled, front_only, render mask = valid ground-truth depth): no module, no autograd."""

@@ -507,6 +507,19 @@ int ags_voxel_select(int32_t n, const float* points, int32_t* select, float voxe
 int ags_prune_keep(int32_t n, const float* prune_mask, const float* raw_opacities, float min_opacity, int32_t* keep,
                    ags_stream_t stream);
 
+/* post_processing's per-surfel bookkeeping (gaussian_map.py:193-232) in one launch: seen = newest_count >= 1 (the
+ * count image row of the newest keyframe); view_supports += seen; with use_view_distribution also, for seen surfels,
+ * view_means += (direction to the camera - view_means) / max(view_supports, 1) and
+ * view_scores += (1 - clamp(dist / far, 0, 1)) * clamp(normal . direction, 0, 1), normal = third column of the
+ * normalised raw rotation.  campos: 3 floats on the device (the newest keyframe's camera-to-world translation). */
+int ags_view_stats_update(int32_t n, const float* means, const float* raw_rotations, const float* campos, float far,
+                          const int32_t* newest_count, int32_t use_view_distribution, float* view_supports,
+                          float* view_means /* (n,3) */, float* view_scores, ags_stream_t stream);
+/* get_confidences (gaussian_map.py:552-565): clamp(exp(1 - |view_means|) * view_scores, 0, 1) with NaN norms taken
+ * as 1 (use_view_distribution), or clamp(1 - exp(-view_supports), 0, 1). */
+int ags_confidences(int32_t n, const float* view_supports, const float* view_means, const float* view_scores,
+                    int32_t use_view_distribution, float* out, ags_stream_t stream);
+
 /* Stable stream compaction (torch boolean indexing / torch.cat of the selected rows):
  * plan:  dst_index[i] = number of kept rows before i, or -1; *total (device) = kept rows.
  * rows:  dst[dst_index[i]*width + c] = src[i*width + c] for one (n,width) float array. */

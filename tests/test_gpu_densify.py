@@ -237,3 +237,53 @@ def test_frame_store_and_chunked_count_render(agslib):
     tr.frames[3] = dict(tr.frames[3], rgb=tr.frames[3]["rgb"] * 0.5)
     _, _, rgb, _ = tr._frame_store()
     assert torch.equal(rgb[3], tr.frames[3]["rgb"])
+
+
+@pytest.mark.parametrize("use_vd", [True, False])
+def test_view_statistics_kernel_matches_the_torch_statements(agslib, use_vd):
+    """post_processing's per-surfel bookkeeping (gaussian_map.py:193-223) and get_confidences (:552-565) as one launch
+    each (ags_view_stats_update, ags_confidences) against the torch statements of map_trainer.GaussianMapTrainer, over
+    three successive keyframes (the running mean and the scores accumulate), NaN view means included."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from active_gs_amd import _lib
+    from active_gs_amd._lib import ptr
+    from active_gs_amd.map_trainer import _quat_third_column
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(11)
+    n = 5000
+    means = (torch.rand(n, 3, generator=gen) * 4 - 2).to(DEV)
+    rot = torch.randn(n, 4, generator=gen).to(DEV)
+    sup = torch.zeros(n, device=DEV); vm = torch.zeros(n, 3, device=DEV); vs = torch.zeros(n, device=DEV)
+    vm[:7] = float("nan")
+    sup_t, vm_t, vs_t = sup.clone(), vm.clone(), vs.clone()
+    far = 6.0
+    for step in range(3):
+        campos = (torch.rand(3, generator=gen) * 6 - 3).to(DEV)
+        count = (torch.rand(n, generator=gen) > 0.4).to(torch.int32).to(DEV) * torch.randint(1, 50, (n,), generator=gen).to(torch.int32).to(DEV)
+        _lib.check(lib.ags_view_stats_update(n, ptr(means), ptr(rot), ptr(campos), far, ptr(count), int(use_vd), ptr(sup), ptr(vm),
+                                             ptr(vs), torch.cuda.current_stream().cuda_stream), "ags_view_stats_update")
+        seen = count >= 1
+        sup_t += seen.float()
+        if use_vd:
+            normals = F.normalize(_quat_third_column(F.normalize(rot)))
+            to_cam = campos[None] - means
+            dist = torch.linalg.norm(to_cam, dim=1)
+            to_cam = to_cam / dist.unsqueeze(-1)
+            vm_t = torch.where(seen.unsqueeze(-1), vm_t + (to_cam - vm_t) / sup_t.clamp(min=1.0).unsqueeze(-1), vm_t)
+            cos = torch.clamp(torch.sum(normals * to_cam, 1), min=0, max=1)
+            vs_t = vs_t + torch.where(seen, (1 - torch.clamp(dist / far, min=0, max=1)) * cos, torch.zeros_like(cos))
+        assert torch.equal(sup, sup_t)
+        ok = ~torch.isnan(vm_t).any(1)
+        assert torch.equal(torch.isnan(vm).any(1), ~ok)
+        assert float((vm[ok] - vm_t[ok]).abs().max()) < 2e-6 and float((vs - vs_t).abs().max()) < 5e-6
+        conf = torch.empty(n, device=DEV)
+        _lib.check(lib.ags_confidences(n, ptr(sup), ptr(vm), ptr(vs), int(use_vd), ptr(conf), torch.cuda.current_stream().cuda_stream),
+                   "ags_confidences")
+        if use_vd:
+            var = vm_t.norm(dim=-1)
+            var = torch.where(torch.isnan(var), torch.ones_like(var), var)
+            ref = torch.clamp(torch.exp(1 - var) * vs_t, min=0, max=1)
+        else:
+            ref = torch.clamp(1 - 1 / torch.exp(sup_t), min=0, max=1)
+        assert float((conf - ref).abs().max()) < 5e-6 and not bool(torch.isnan(conf).any())
