@@ -6,7 +6,7 @@ from active_gs_amd import raster_api as api
 from active_gs_amd.camera import camera_matrices
 from active_gs_amd.synthetic import make_camera, make_room_scene
 from active_gs_amd.trainer import SurfelTrainer
-dev = torch.device("cuda:0"); n, h, w = int(sys.argv[1]), 2048, 2048
+dev = torch.device("cuda:0"); n = int(sys.argv[1]); h, w = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2048, 2048)
 t0 = time.time()
 raw = {k: v.to(dev) for k, v in make_room_scene(n, "office0", seed=0).items()}
 print("scene made in %.1f s" % (time.time() - t0), flush=True)
