@@ -6,12 +6,16 @@
 #include "../../include/ags_raster.h"
 #include "surfel_math.h"
 
-// AGS_BIN_DIRECT: words between two tiles' key-slot counters.  Device atomics are served per cache LINE: with the
-// counters dense, 32 tiles share a 128-byte line and the ~30 slot requests per tile of a 1200x680 view queue up
-// behind each other (~900 per line).
-#ifndef AGS_TC_STRIDE
-#define AGS_TC_STRIDE 1
-#endif
+// AGS_BIN_DIRECT: words between two tiles' key-slot counters (AgsLayout.tc_stride).  Device atomics are served per cache
+// LINE: with the counters dense, 32 tiles share a 128-byte line and their slot requests queue up behind each other.
+// How far apart pays depends on how many counters there are (round 3, compile-time sweep of 1 / 2 / 4 / 8 / 16 words):
+// a mapper batch of 512x512 views (1 024 tiles per view, ~200 requests per tile) spends two thirds of its per-Gaussian
+// launch waiting for slots with dense counters - 184 -> 95 us at 8 words, mapper loop 0.486 -> 0.446 s at 4; 1200x680
+// (3 225 tiles): per-Gaussian launch 18.5 -> 16.1 us at 2-4 words, neutral at 8; 2048x2048 (16 384 tiles): +0.5 % at 2,
+// +1.6 % at 4, +24 % at 8 (more lines than the L2 keeps).  So: 4 words up to AGS_TC_SPREAD_TILES tiles, dense above.
+#define AGS_TC_STRIDE_MAX 4
+#define AGS_TC_SPREAD_TILES 4096
+static inline int ags_tc_stride(int num_tiles) { return num_tiles <= AGS_TC_SPREAD_TILES ? AGS_TC_STRIDE_MAX : 1; }
 #define AGS_SORT_THREADS 256
 #define AGS_SORT_ITEMS 16
 #define AGS_SORT_TILE (AGS_SORT_THREADS * AGS_SORT_ITEMS) // keys per block per pass
@@ -45,6 +49,7 @@ struct AgsLayout {
     int nb_cap;         // sort blocks at capacity
     int n_blocks;       // preprocess blocks
     int num_tiles;
+    int tc_stride;      // words between two tiles' counters in tile_count (ags_tc_stride)
 };
 
 static inline size_t ags_align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -61,7 +66,8 @@ static inline AgsLayout ags_make_layout(int n, int h, int w, int64_t cap) {
     L.status = o; o += 256;
     L.totals = o; o += (size_t)AGS_SORT_MAX_PASSES * 256 * 4;
     L.ranges = o; o += ags_align256((size_t)L.num_tiles * 8);
-    L.tile_count = o; o += ags_align256((size_t)L.num_tiles * 4 * AGS_TC_STRIDE);
+    L.tc_stride = ags_tc_stride(L.num_tiles);
+    L.tile_count = o; o += ags_align256((size_t)L.num_tiles * 4 * L.tc_stride);
     L.tile_fill = o; o += ags_align256((size_t)L.num_tiles * 4);
     L.clear_bytes = o;
     L.geom = o; o += ags_align256((size_t)n * sizeof(AgsGeom));

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort(const uint2* __restrict__
 __global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict__ ranges, uint64_t* keys_in,
                                                               uint64_t* keys_out, const uint32_t* __restrict__ tile_count,
                                                               uint32_t tile_cap, uint32_t* __restrict__ partial, int num_tiles,
-                                                              AgsViewStride vs) {
+                                                              AgsViewStride vs, uint32_t tc_stride) {
     { // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(keys_in, wo); AGS_WS_SHIFT(keys_out, wo); AGS_WS_SHIFT(tile_count, wo);
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict_
     __shared__ uint32_t rank_part[4];
     if (threadIdx.x < 64) AGS_TL(5, blockIdx.x, 0);
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
-    const uint32_t cnt = tile_count[(size_t)tile * AGS_TC_STRIDE];
+    const uint32_t cnt = tile_count[(size_t)tile * tc_stride];
     const uint32_t K = cnt < tile_cap ? cnt : tile_cap;
     // the tile's slot: band start + number of band tiles with a longer list (ties: lower index first) - exact,
     // deterministic, no counters to reset; <= T/8 counts read per workgroup
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict_
     const int band0 = ags_xcd_band(blockIdx.x & 7, num_tiles, band_size);
     uint32_t ahead = 0;
     for (int j = threadIdx.x; j < band_size; j += 256) {
-        const uint32_t c = tile_count[(size_t)(band0 + j) * AGS_TC_STRIDE];
+        const uint32_t c = tile_count[(size_t)(band0 + j) * tc_stride];
         ahead += (c > cnt || (c == cnt && band0 + j < tile)) ? 1u : 0u;
     }
     ahead = ags_wave_sum_u32(ahead);
@@ -533,7 +533,8 @@ template <int R>
 __global__ __launch_bounds__(256) void ags_k_tile_sort_direct_wave(uint2* __restrict__ ranges, const uint64_t* __restrict__ keys_in,
                                                                    uint64_t* __restrict__ keys_out,
                                                                    const uint32_t* __restrict__ tile_count, uint32_t tile_cap,
-                                                                   uint32_t* __restrict__ partial, int num_tiles, AgsViewStride vs) {
+                                                                   uint32_t* __restrict__ partial, int num_tiles, AgsViewStride vs,
+                                                                   uint32_t tc_stride) {
     { // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(keys_in, wo); AGS_WS_SHIFT(keys_out, wo); AGS_WS_SHIFT(tile_count, wo);
@@ -560,10 +561,10 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct_wave(uint2* __rest
     for (int r = 0; r < R; ++r) mine[r] = ((uint32_t)(64 * r + lane) < tile_cap) ? src[64 * r + lane] : ~0ull;
     uint32_t tc[4];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) tc[w] = (j0 + w < band_size) ? tile_count[(size_t)(band0 + j0 + w) * AGS_TC_STRIDE] : 0u;
+    for (int w = 0; w < 4; ++w) tc[w] = (j0 + w < band_size) ? tile_count[(size_t)(band0 + j0 + w) * tc_stride] : 0u;
     uint32_t ahead[4] = {0u, 0u, 0u, 0u};
     for (int j = threadIdx.x; j < band_size; j += 256) {
-        const uint32_t c = tile_count[(size_t)(band0 + j) * AGS_TC_STRIDE];
+        const uint32_t c = tile_count[(size_t)(band0 + j) * tc_stride];
 #pragma unroll
         for (int w = 0; w < 4; ++w) ahead[w] += (c > tc[w] || (c == tc[w] && j < j0 + w)) ? 1u : 0u;
     }
@@ -617,14 +618,14 @@ void ags_launch_direct_sort(char* ws, const AgsLayout& L, const AgsViewStride& v
 #define AGS_LAUNCH_TSORT_WAVE(R)                                                                                          \
     hipLaunchKernelGGL(ags_k_tile_sort_direct_wave<R>, dim3(8 * ((((L.num_tiles + 7) / 8) + 3) / 4), vs.views), dim3(256), 0, s, (uint2*)(ws + L.ranges), \
                        (const uint64_t*)(ws + L.keys0), (uint64_t*)(ws + L.keys1), (const uint32_t*)(ws + L.tile_count),    \
-                       tile_cap, (uint32_t*)(ws + L.totals), L.num_tiles, vs)
+                       tile_cap, (uint32_t*)(ws + L.totals), L.num_tiles, vs, (uint32_t)L.tc_stride)
         if (tile_cap <= 64u) AGS_LAUNCH_TSORT_WAVE(1); else AGS_LAUNCH_TSORT_WAVE(2);
 #undef AGS_LAUNCH_TSORT_WAVE
         return;
     }
     hipLaunchKernelGGL(ags_k_tile_sort_direct, dim3(L.num_tiles, vs.views), dim3(256), 0, s, (uint2*)(ws + L.ranges),
                        (uint64_t*)(ws + L.keys0), (uint64_t*)(ws + L.keys1), (const uint32_t*)(ws + L.tile_count),
-                       ags_direct_tile_cap(L), (uint32_t*)(ws + L.totals), L.num_tiles, vs);
+                       ags_direct_tile_cap(L), (uint32_t*)(ws + L.totals), L.num_tiles, vs, (uint32_t)L.tc_stride);
 }
 
 void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L,

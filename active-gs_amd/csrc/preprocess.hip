@@ -87,7 +87,7 @@ __device__ __forceinline__ void ags_load_rows3x3(const float* __restrict__ b0, c
     for (int k = 0; k < 3; ++k) { o0[k] = l0[3 * t + k]; o1[k] = l1[3 * t + k]; o2[k] = l2[3 * t + k]; }
 }
 
-struct AgsDirectEmit { uint64_t* keys; uint32_t tile_cap; uint32_t* partial; };
+struct AgsDirectEmit { uint64_t* keys; uint32_t tile_cap; uint32_t* partial; uint32_t tc_stride; };
 
 // EMIT: 0 = nothing, 1 = count the tiles a surfel reaches (tile-sort binning), 2 = AGS_BIN_DIRECT: take a slot in
 // the tile's own key range with ONE returning atomic and write the (depth | id) key at once
@@ -170,7 +170,7 @@ __device__ __forceinline__ void ags_preprocess_block(
         const uint32_t wave_first = (uint32_t)(first + (threadIdx.x & ~63));
         ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, rx0, ry0, rwd, __float_as_uint(g.dc), g, F.tiles_x,
                                 [&](bool hit, uint32_t t, uint32_t depth_bits, int owner_lane) {
-                                    const uint32_t got = ags_wave_agg_inc<AGG, true>(tile_count, t * AGS_TC_STRIDE, hit);
+                                    const uint32_t got = ags_wave_agg_inc<AGG, true>(tile_count, t * direct.tc_stride, hit);
                                     if (hit && got < direct.tile_cap)
                                         direct.keys[(size_t)t * direct.tile_cap + got] =
                                             ((uint64_t)depth_bits << 32) | (wave_first + (uint32_t)owner_lane);
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_cull(
             }
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr)
-                if (hit[rr]) got[rr] = atomicAdd(&tile_count[(size_t)tile[rr] * AGS_TC_STRIDE], 1u);
+                if (hit[rr]) got[rr] = atomicAdd(&tile_count[(size_t)tile[rr] * direct.tc_stride], 1u);
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr)
                 if (hit[rr] && got[rr] < direct.tile_cap)
@@ -615,7 +615,7 @@ __device__ __forceinline__ void ags_emit_keys_rounds(AgsEmitRec* wave_lds, uint3
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r)
-            if (hit[r]) got[r] = atomicAdd(&tile_count[(size_t)tile[r] * AGS_TC_STRIDE], 1u);
+            if (hit[r]) got[r] = atomicAdd(&tile_count[(size_t)tile[r] * direct.tc_stride], 1u);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (base + 64u * r >= total) break;   // wave-uniform
@@ -860,7 +860,7 @@ __device__ __forceinline__ void ags_rows_body(
             if constexpr (AGG)   // images of few tiles: same-tile lanes share an atomic (ags_wave_agg_inc), round by round
                 ags_emit_tiles_balanced(emit_wave, cnt, rx0, ry0, rwd, __float_as_uint(g2.dc), g2, nx->F.tiles_x,
                                         [&](bool hit, uint32_t t, uint32_t depth_bits, int owner_lane) {
-                                            const uint32_t got = ags_wave_agg_inc<AGG, true>(nx->tile_count, t * AGS_TC_STRIDE, hit);
+                                            const uint32_t got = ags_wave_agg_inc<AGG, true>(nx->tile_count, t * nx->direct.tc_stride, hit);
                                             const uint32_t owner_row = (uint32_t)__shfl(my_row, owner_lane);
                                             if (hit && got < nx->direct.tile_cap)
                                                 nx->direct.keys[(size_t)t * nx->direct.tile_cap + got] = ((uint64_t)depth_bits << 32) | owner_row;
@@ -1143,7 +1143,7 @@ void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGau
     const AgsRowSet& touched = pg.touched;
     float* zero_importance = cam.config ? pg.importance : nullptr;
     int* zero_count = cam.config ? pg.count : nullptr;
-    const AgsDirectEmit direct = {(uint64_t*)(ws + L.keys0), ags_direct_tile_cap(L), (uint32_t*)(ws + L.totals)};
+    const AgsDirectEmit direct = {(uint64_t*)(ws + L.keys0), ags_direct_tile_cap(L), (uint32_t*)(ws + L.totals), (uint32_t)L.tc_stride};
 #define AGS_LAUNCH_PRE(EMIT, AGG)                                                                                        \
     hipLaunchKernelGGL((ags_k_preprocess<EMIT, AGG>), dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, F,          \
                        cam.viewmatrix, cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),             \
@@ -1173,7 +1173,7 @@ void ags_launch_rows_adam_preprocess(const AgsFrame& F, const AgsCamera& cam, co
     nx.F = F2; nx.V = cam2.viewmatrix; nx.P = cam2.projmatrix;
     nx.geom = (AgsGeom*)(ws2 + L2.geom); nx.dgeom = (float4*)(ws2 + L2.dgeom); nx.radii = radii2;
     nx.tile_count = (uint32_t*)(ws2 + L2.tile_count);
-    nx.direct = AgsDirectEmit{(uint64_t*)(ws2 + L2.keys0), ags_direct_tile_cap(L2), (uint32_t*)(ws2 + L2.totals)};
+    nx.direct = AgsDirectEmit{(uint64_t*)(ws2 + L2.keys0), ags_direct_tile_cap(L2), (uint32_t*)(ws2 + L2.totals), (uint32_t)L2.tc_stride};
     nx.count_snap = (const uint32_t*)(ws + L.status) + AGS_STATUS_COUNT_SNAP;
     // the member count lives on the device: the member workgroups stride over the list, so any number of them is
     // correct; `rows_hint` (what the caller last saw, 0 = no idea) sizes them for one pass

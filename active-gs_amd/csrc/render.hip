@@ -161,7 +161,7 @@ __device__ __forceinline__ void ags_wave_lds_sync() {
 // AGS_BIN_DIRECT: nobody has added up the view's instance count yet (there is no scan): the first wave of the
 // forward blend kernel turns the spread partial sums / maxima (ags_k_tile_sort_direct, ags_k_preprocess<2>) into the
 // status block and leaves them zeroed for the next pass.  status == nullptr: the other binning modes.
-struct AgsFinalize { uint32_t* status; uint32_t* partial; uint32_t tile_cap; };
+struct AgsFinalize { uint32_t* status; uint32_t* partial; uint32_t tile_cap; uint32_t tc_stride; };
 
 __device__ __forceinline__ void ags_finalize_status(const AgsFinalize& fin, int num_tiles, int lane) {
     uint32_t s = fin.partial[AGS_PART(lane, AGS_PART_SUM)], m = fin.partial[AGS_PART(lane, AGS_PART_MAX)],
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
     const float bx0 = (float)(tx * AGS_TILE), by0 = (float)(ty * AGS_TILE);
     const uint32_t my_strips = ((1u << SLOTS) - 1u) << strip0;
     // last consumer of this tile's binning counters: leave them zero for the next forward pass
-    if (wave == 0 && lane == 0) { tile_count[(size_t)tile * (tile_cap ? AGS_TC_STRIDE : 1)] = 0u; tile_fill[tile] = 0u; }
+    if (wave == 0 && lane == 0) { tile_count[(size_t)tile * (tile_cap ? fin.tc_stride : 1u)] = 0u; tile_fill[tile] = 0u; }
     // the lane's pixel relative to the centre of its quadrant - the same in every quadrant the wave owns
     const float qx = (float)(lane & 7) - 3.5f, qy = (float)(lane >> 3) - 3.5f;
     AgsPix pix[SLOTS];
@@ -807,8 +807,8 @@ static int ags_bwd_mfma() {
 template <int SLOTS>
 static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L, AgsIdList ids,
                        const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs, bool direct, hipStream_t s) {
-    AgsFinalize fin = {nullptr, nullptr, 0u};
-    if (direct) fin = AgsFinalize{(uint32_t*)(ws + L.status), (uint32_t*)(ws + L.totals), ags_direct_tile_cap(L)};
+    AgsFinalize fin = {nullptr, nullptr, 0u, 1u};
+    if (direct) fin = AgsFinalize{(uint32_t*)(ws + L.status), (uint32_t*)(ws + L.totals), ags_direct_tile_cap(L), (uint32_t)L.tc_stride};
     const uint32_t tile_cap = direct ? ags_direct_tile_cap(L) : 0u;
     const uint2* ranges = (const uint2*)(ws + L.ranges);
     const AgsGeom* geom = (const AgsGeom*)(ws + L.geom);
