@@ -438,12 +438,16 @@ class FusedMapTrainer(GaussianMapTrainer):
             self._cap = max(self._cap, 1 << 16, 2 * n)
             g = self._gaussians()
             while True:
+                # the render's capacity check rides on the read-back densify needs anyway (its row count): one wait for
+                # the GPU per keyframe here instead of two; an outgrown workspace (rare) repeats both
                 st = self._state("densify", n, h, w)
                 api.forward(cam, g, st)
+                pred = dict(rgb=st.rgb, depth=st.depth[0], opacity=st.opacity[0])
+                state, added = densify.add_gaussians(self._map_state(), frame, pred, self.cfg["error_thres"])
                 if self._check_capacity(["densify"]):
                     break
-            pred = dict(rgb=st.rgb, depth=st.depth[0], opacity=st.opacity[0])
-        state, added = densify.add_gaussians(self._map_state(), frame, pred, self.cfg["error_thres"])
+        else:
+            state, added = densify.add_gaussians(self._map_state(), frame, pred, self.cfg["error_thres"])
         self._set_map_state(state)
         self.frames.append(frame)
         self.training_performance = torch.cat((self.training_performance, torch.tensor([10.0], device=self.device)), 0)
