@@ -234,6 +234,7 @@ void ags_launch_facade_post(int h, int w, float tanx, float tany, const float* n
 void ags_launch_facade_post_bwd(int h, int w, float tanx, float tany, const float* normal_raw, const float* depth,
                                 const float* opacity, const float* g_normal, const float* g_d2n, float* d_normal_raw,
                                 float* d_depth, hipStream_t s);
+void ags_launch_weighted_topk(const float* u, const float* w, int n, int k, long long* out, hipStream_t s);
 void ags_launch_stage_frames(int views, int hw, const long long* frame_index, const float* all_view, const float* all_proj,
                              const float* all_rgb, const float* all_depth, float* dst_view, float* dst_proj,
                              float* dst_rgb, float* dst_depth, int* msum, hipStream_t s);

@@ -463,6 +463,12 @@ int ags_facade_post_backward(int32_t h, int32_t w, float tanfov_x, float tanfov_
     return ags_check_launch();
 }
 
+int ags_weighted_topk(const float* uniforms, const float* weights, int32_t n, int32_t k, int64_t* out, ags_stream_t stream) {
+    if (!uniforms || !weights || !out || n < 1 || n > 8192 || k < 1 || k > n) return AGS_E_INVALID;
+    ags_launch_weighted_topk(uniforms, weights, n, k, (long long*)out, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
 int ags_stage_frames(int32_t views, int32_t h, int32_t w, const int64_t* frame_index, const float* all_view,
                      const float* all_proj, const float* all_rgb, const float* all_depth, float* dst_view, float* dst_proj,
                      float* dst_rgb, float* dst_depth, int32_t* msum, ags_stream_t stream) {

@@ -351,6 +351,53 @@ void ags_launch_facade_post_bwd(int h, int w, float tanx, float tany, const floa
                        g_normal, g_d2n, d_normal_raw, d_depth);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The weighted frame draw of the batch sampler (mapping/utils.py:190-228: np.random.choice(older, k, replace=False,
+// p = error / sum)) as ONE launch behind torch.rand: successive sampling without replacement == the k largest
+// log(u_i) / w_i (Efraimidis & Spirakis); keys in LDS, k rounds of a workgroup arg-max, indices written in descending key
+// order (what torch.topk returned when this was log + clamp + div + topk + a slice assignment: five launches and
+// 0.26 ms of host time per iteration).
+#define AGS_WTOPK_MAX 8192
+__global__ __launch_bounds__(256) void ags_k_weighted_topk(const float* __restrict__ u, const float* __restrict__ w, int n,
+                                                           int k, long long* __restrict__ out) {
+    __shared__ float key[AGS_WTOPK_MAX];
+    __shared__ float best_v[4];
+    __shared__ int best_i[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < n; i += 256) key[i] = logf(u[i]) / fmaxf(w[i], 1e-30f);
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = t; i < n; i += 256) {
+            const float v = key[i];
+            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { best_v[wave] = bv; best_i[wave] = bi; }
+        __syncthreads();
+        if (t == 0) {
+            float v = best_v[0];
+            int i = best_i[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (best_v[q] > v || (best_v[q] == v && best_i[q] < i)) { v = best_v[q]; i = best_i[q]; }
+            if (i == 0x7fffffff) i = 0;          // (fewer than k finite keys: NaN weights - as arbitrary as topk's answer)
+            out[j] = (long long)i;
+            if (i < n) key[i] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+void ags_launch_weighted_topk(const float* u, const float* w, int n, int k, long long* out, hipStream_t s) {
+    hipLaunchKernelGGL(ags_k_weighted_topk, dim3(1), dim3(256), 0, s, u, w, n, k, out);
+}
+
 static AgsLossDev make_dev(const AgsLossConfig& cfg) {
     AgsLossDev c;
     c.H = cfg.image_height; c.W = cfg.image_width; c.B = cfg.batch_total;

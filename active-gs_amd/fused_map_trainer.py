@@ -30,6 +30,19 @@ def weighted_choice_without_replacement(weights: torch.Tensor, k: int) -> torch.
     return torch.topk(keys, k).indices
 
 
+def weighted_choice_into(weights: torch.Tensor, k: int, out: torch.Tensor) -> None:
+    """The same draw written into ``out`` (k int64 on the device) with two launches - torch.rand_like and
+    ``ags_weighted_topk`` - instead of six; the same uniforms give the same indices as the function above."""
+    n = weights.shape[0]
+    if not weights.is_cuda or n > 8192 or weights.dtype != torch.float32 or not weights.is_contiguous() or not out.is_contiguous():
+        out.copy_(weighted_choice_without_replacement(weights, k))
+        return
+    from . import _lib
+    u = torch.rand_like(weights)
+    _lib.check(_lib.load().ags_weighted_topk(_lib.ptr(u), _lib.ptr(weights), n, int(k), _lib.ptr(out),
+                                             torch.cuda.current_stream().cuda_stream), "ags_weighted_topk")
+
+
 class FusedMapTrainer(GaussianMapTrainer):
     def __init__(self, raw: dict, frames: List[dict], cfg: Optional[dict] = None, process_group=None,
                  binning_mode: int = api.BIN_DIRECT, use_graph: bool = True, num_streams: int = 4,
@@ -179,16 +192,24 @@ class FusedMapTrainer(GaussianMapTrainer):
         import numpy as np
         snap = {k: getattr(self, k).clone() for k in ("means", "scales", "rotations", "opacities", "harmonics",
                                                      "training_performance")}
-        snap["np_rng"] = np.random.get_state()           # the reference's sampler draws from numpy's global stream
-        snap["torch_rng"] = torch.get_rng_state()        # sampler_type "uniform": torch.randperm on the CPU generator
-        snap["cuda_rng"] = torch.cuda.get_rng_state(self.device)   # cfg["sampler"] = "device"
+        # the random streams a repeated call has to draw from again: numpy's global one (the reference's weighted sampler)
+        # only when the host sampler is in use - reading it costs 0.8 ms inside this loop, as much as the rest of the
+        # call's set-up - torch's CPU generator (sampler_type "uniform": randperm), the device generator (cfg["sampler"]
+        # = "device")
+        snap["np_rng"] = None if self._device_sampler() else np.random.get_state()
+        snap["torch_rng"] = torch.get_rng_state()
+        snap["cuda_rng"] = torch.cuda.get_rng_state(self.device)
         return snap
+
+    def _device_sampler(self) -> bool:
+        return self.cfg.get("sampler", "host") == "device" and self.cfg.get("sampler_type", "weighted") == "weighted"
 
     def _restore(self, snap: dict) -> None:
         import numpy as np
         for k in ("means", "scales", "rotations", "opacities", "harmonics", "training_performance"):
             getattr(self, k).copy_(snap[k])
-        np.random.set_state(snap["np_rng"])
+        if snap["np_rng"] is not None:
+            np.random.set_state(snap["np_rng"])
         torch.set_rng_state(snap["torch_rng"])
         torch.cuda.set_rng_state(snap["cuda_rng"], self.device)
 
@@ -571,7 +592,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         graph = None
         self._loss.accum.zero_()           # from here on ags_loss_finish leaves it zeroed
         # (the device draw is the weighted one; the uniform sampler keeps torch.randperm's host stream)
-        device_sampler = self.cfg.get("sampler", "host") == "device" and self.cfg.get("sampler_type", "weighted") == "weighted"
+        device_sampler = self._device_sampler()
         n_active, n_random = len(sampler.active_ids), sampler.num_random
         for it in range(total):
             if device_sampler:
@@ -584,7 +605,7 @@ class FusedMapTrainer(GaussianMapTrainer):
                     state["idx"][:n_active] = torch.as_tensor(sampler.active_ids, dtype=torch.long)
                 if n_random > 0:
                     n_old = len(sampler.older_ids)
-                    state["idx"][n_active:] = weighted_choice_without_replacement(self.training_performance[:n_old], n_random)
+                    weighted_choice_into(self.training_performance[:n_old], n_random, state["idx"][n_active:])
             else:
                 _, _, _, _, ids = sampler.next_frames(self.training_performance)   # host read of the errors
                 B = len(ids)

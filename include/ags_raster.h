@@ -538,6 +538,10 @@ int ags_compact_rows(int32_t n, int32_t width, const int32_t* dst_index, const f
  * frame_error[frame_index[v]] = mean rgb L1 + mean depth L1 of view v (track_performance,
  * gaussian_map.py:132-139; frame_index NULL: frame_error[v]) and *total_loss, and zeroes the
  * accumulators for the next iteration.  frame_error / total_loss may be NULL. */
+/* The weighted draw of the batch sampler (mapping/utils.py:190-228: np.random.choice(older, k, replace=False, p = w / sum w))
+ * on the device: out[0..k) = the indices of the k largest log(uniforms[i]) / max(weights[i], 1e-30), largest first
+ * (successive sampling without replacement; uniforms ~ U(0,1), n <= 8192 of them, drawn by the caller). */
+int ags_weighted_topk(const float* uniforms, const float* weights, int32_t n, int32_t k, int64_t* out, ags_stream_t stream);
 int ags_stage_frames(int32_t views, int32_t h, int32_t w, const int64_t* frame_index, const float* all_view,
                      const float* all_proj, const float* all_rgb, const float* all_depth, float* dst_view, float* dst_proj,
                      float* dst_rgb, float* dst_depth, int32_t* msum, ags_stream_t stream);

@@ -287,3 +287,29 @@ def test_view_statistics_kernel_matches_the_torch_statements(agslib, use_vd):
         else:
             ref = torch.clamp(1 - 1 / torch.exp(sup_t), min=0, max=1)
         assert float((conf - ref).abs().max()) < 5e-6 and not bool(torch.isnan(conf).any())
+
+
+def test_weighted_frame_draw_kernel_equals_the_torch_statement(agslib):
+    """The batch sampler's weighted draw without replacement (mapping/utils.py:190-228) as rand + ONE kernel
+    (ags_weighted_topk: the k largest log(u) / w by k rounds of arg-max) gives the indices, in the order, that
+    log / clamp / div / topk gave from the same uniforms - and every older frame is drawn with the frequency its error
+    weight asks for."""
+    from active_gs_amd.fused_map_trainer import weighted_choice_into, weighted_choice_without_replacement
+    for n, k in ((1, 1), (5, 5), (40, 8), (300, 8), (5000, 64)):
+        w = (torch.rand(n, device=DEV) * 3 + 0.01)
+        w[::7] = 0.0                                                    # frames with zero error: drawn last
+        for rep in range(5):
+            torch.cuda.manual_seed(100 * n + rep)
+            a = weighted_choice_without_replacement(w, k)
+            torch.cuda.manual_seed(100 * n + rep)
+            b = torch.empty(k, device=DEV, dtype=torch.long)
+            weighted_choice_into(w, k, b)
+            assert torch.equal(a, b), (n, k, rep)
+    # frequencies: first draw ~ w / sum(w)
+    w = torch.tensor([1.0, 2.0, 4.0, 8.0, 1.0], device=DEV)
+    draws = torch.empty(3000, device=DEV, dtype=torch.long)
+    torch.cuda.manual_seed(0)
+    for j in range(3000):
+        weighted_choice_into(w, 1, draws[j:j + 1])
+    hits = torch.bincount(draws.cpu(), minlength=5).float()
+    assert float(((hits / 3000) - (w.cpu() / 16)).abs().max()) < 0.03
