@@ -100,7 +100,7 @@ class AgsCandidates(C.Structure):
     _fields_ = [("means", c_f32p), ("rotations", c_f32p), ("harmonics", c_f32p), ("select", C.c_void_p)]
 
 
-EXPORTS = ["ags_workspace_bytes", "ags_workspace_region", "ags_workspace_init", "ags_workspace_discard_pass", "ags_forward", "ags_forward_batch",
+EXPORTS = ["ags_workspace_bytes", "ags_workspace_region", "ags_workspace_init", "ags_workspace_init_batch", "ags_workspace_discard_pass", "ags_forward", "ags_forward_batch",
            "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_backward_rows", "ags_backward_fused_next", "ags_forward_resume", "ags_read_status", "ags_read_status_async", "ags_adam_step",
            "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_rows_index", "ags_adam_step_gathered", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_weighted_topk", "ags_facade_post", "ags_facade_post_backward", "ags_smooth_depth", "ags_densify_candidates",
            "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_view_stats_update", "ags_confidences", "ags_compact_plan_bytes", "ags_compact_plan",
@@ -133,6 +133,8 @@ def load() -> C.CDLL:
                                          C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.ags_workspace_init.restype = C.c_int
     lib.ags_workspace_init.argtypes = [C.POINTER(AgsWorkspace), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.ags_workspace_init_batch.restype = C.c_int
+    lib.ags_workspace_init_batch.argtypes = [C.POINTER(AgsWorkspace), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.ags_workspace_discard_pass.restype = C.c_int
     lib.ags_workspace_discard_pass.argtypes = [C.POINTER(AgsWorkspace), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.ags_forward.restype = C.c_int

@@ -36,6 +36,16 @@ int ags_workspace_init(const AgsWorkspace* ws, int32_t n, int32_t h, int32_t w, 
     return AGS_OK;
 }
 
+int ags_workspace_init_batch(const AgsWorkspace* ws, int32_t views, int32_t n, int32_t h, int32_t w, ags_stream_t stream) {
+    if (!ws || !ws->ptr || views < 1 || n < 0 || h <= 0 || w <= 0 || ws->max_instances < 1) return AGS_E_INVALID;
+    const AgsLayout L = ags_make_layout(n, h, w, ws->max_instances);
+    if (ws->bytes / (size_t)views < L.total) return AGS_E_WORKSPACE;
+    for (int32_t v = 0; v < views; ++v)
+        if (hipMemsetAsync((char*)ws->ptr + (size_t)v * L.total + L.status, 0, L.clear_bytes, (hipStream_t)stream) != hipSuccess)
+            return AGS_E_LAUNCH;
+    return AGS_OK;
+}
+
 int ags_workspace_region(int32_t n, int32_t h, int32_t w, int64_t max_instances, int32_t binning_mode, int32_t region,
                          size_t* offset, size_t* bytes) {
     if (n < 0 || h <= 0 || w <= 0 || max_instances < 1 || !offset || !bytes) return AGS_E_INVALID;

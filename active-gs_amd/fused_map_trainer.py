@@ -68,6 +68,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         self._streams = None
         self._cams = {}          # frame index -> (api.Camera, fov_x, fov_y)
         self._store = None       # _frame_store()
+        self._uniform = None     # _uniform_frames()
         self._count_batch = None # _render_counts(): the chunk of views the prune pass renders at a time
         self._states = {}        # view slot -> ForwardState
         self._loss = None
@@ -487,11 +488,22 @@ class FusedMapTrainer(GaussianMapTrainer):
 
     # ------------------------------------------------------------------ batched iteration
     def _uniform_frames(self) -> bool:
+        """One image size and one field of view for all keyframes (one AgsFrame for the whole batch)?  Looked at frame by
+        frame as the list grows (the answer for the first K frames is kept; a list that was edited is looked at again)."""
         if self.world > 1 or len(self.frames) == 0 or self.means.shape[0] == 0:
             return False
-        shapes = {tuple(f["rgb"].shape) for f in self.frames}
-        tans = {(round(self._camera(i)[0].tanfovx, 7), round(self._camera(i)[0].tanfovy, 7)) for i in range(len(self.frames))}
-        return len(shapes) == 1 and len(tans) == 1   # one AgsFrame for the whole batch
+        K = len(self.frames)
+        c = self._uniform
+        if c is None or c["n"] > K or c["first"] is not self.frames[0] or (c["n"] and c["last"] is not self.frames[c["n"] - 1]):
+            c = self._uniform = dict(n=0, key=None, ok=True, first=self.frames[0], last=None)
+        for i in range(c["n"], K):
+            cam = self._camera(i)[0]
+            key = (tuple(self.frames[i]["rgb"].shape), round(cam.tanfovx, 7), round(cam.tanfovy, 7))
+            if c["key"] is None:
+                c["key"] = key
+            c["ok"] = c["ok"] and key == c["key"]
+        c["n"], c["last"] = K, self.frames[K - 1]
+        return c["ok"]
 
     def train_batched(self, steps: Optional[int] = None):
         self._all_or_nothing(self._train_batched, steps)

@@ -480,10 +480,8 @@ class ViewBatch:
                                     self.importance[v], self.count[v], self.radii[v],
                                     self.workspace[v * per:(v + 1) * per], self.max_instances, self.binning_mode)
                        for v in range(V)]
-        lib = _lib.load()
-        for st in self.states:
-            ws = st.ws_struct()
-            _lib.check(lib.ags_workspace_init(C.byref(ws), n, h, w, _stream()), "ags_workspace_init")
+        ws = _lib.AgsWorkspace(ptr(self.workspace), V * per, self.max_instances, self.binning_mode)
+        _lib.check(_lib.load().ags_workspace_init_batch(C.byref(ws), V, n, h, w, _stream()), "ags_workspace_init_batch")
 
     def _structs(self, touched=None):
         im = _lib.AgsImages(ptr(self.rgb), ptr(self.normal), ptr(self.depth), ptr(self.opacity), ptr(self.confidence))

@@ -235,6 +235,10 @@ int ags_workspace_region(int32_t n, int32_t h, int32_t w, int64_t max_instances,
  * memset in the default binning mode. */
 int ags_workspace_init(const AgsWorkspace* ws, int32_t n, int32_t h, int32_t w, ags_stream_t stream);
 
+/* The same for the `views` consecutive per-view workspaces of a batch (ags_forward_batch's layout: view v at
+ * ptr + v * ags_workspace_bytes(n, h, w, max_instances); ws->bytes covers all of them) in one call. */
+int ags_workspace_init_batch(const AgsWorkspace* ws, int32_t views, int32_t n, int32_t h, int32_t w, ags_stream_t stream);
+
 /* Forgets a per-Gaussian stage that has run into this workspace without the rest of its pass (the prepared pass of
  * ags_backward_fused_next when the caller leaves the pipeline: it has taken key slots and added to the partial sums):
  * clears the binning counters like ags_workspace_init but KEEPS the status block, whose sticky words

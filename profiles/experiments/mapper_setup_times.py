@@ -16,8 +16,11 @@ def wrap(obj, name, label):
     setattr(obj, name, w)
 wrap(optimizer.FusedAdam, "__init__", "FusedAdam()"); wrap(trainer.GradSlab, "__init__", "GradSlab()"); wrap(api.RowSet, "__init__", "RowSet()")
 wrap(fmt, "make_frame_sampler", "make_frame_sampler"); wrap(fmt.FusedMapTrainer, "_frame_store", "_frame_store"); wrap(fmt.FusedMapTrainer, "_gaussians", "_gaussians")
-wrap(api.ViewBatch, "bind", "ViewBatch.bind"); wrap(fmt.FusedMapTrainer, "_uniform_frames", "_uniform_frames"); wrap(fmt.FusedMapTrainer, "_snapshot", "_snapshot")
-wrap(fmt, "weighted_choice_without_replacement", "sampler draw (per iteration)"); wrap(fmt.FusedMapTrainer, "_train_batched", "_train_batched (whole, incl. waits)")
+wrap(api.ViewBatch, "bind", "ViewBatch.bind"); wrap(api.ViewBatch, "forward", "batch.forward (per iteration)"); wrap(api.ViewBatch, "backward", "batch.backward (per iteration)"); wrap(api, "backward_rows", "backward_rows (per iteration)")
+from active_gs_amd import fused_loss
+for nm in ("stage_frames", "stage1_batch", "stage2_batch", "finish", "set_batch_total"):
+    wrap(fused_loss.FusedLoss, nm, "loss." + nm + " (per iteration)"); wrap(fmt.FusedMapTrainer, "_uniform_frames", "_uniform_frames"); wrap(fmt.FusedMapTrainer, "_snapshot", "_snapshot")
+wrap(fmt, "weighted_choice_into", "sampler draw (per iteration)"); wrap(fmt.FusedMapTrainer, "_train_batched", "_train_batched (whole, incl. waits)")
 wrap(fmt.FusedMapTrainer, "post_processing", "post_processing (incl. waits)"); wrap(fmt.FusedMapTrainer, "add_gaussians", "add_gaussians (incl. waits)")
 wrap(fmt.FusedMapTrainer, "_make_camera", "_make_camera"); wrap(api.ViewBatch, "statuses", "ViewBatch.statuses (wait)")
 ml.main()
