@@ -86,8 +86,8 @@ class FusedMapTrainer(GaussianMapTrainer):
         K = len(self.frames)
         st = self._store
         h, w = self.frames[0]["rgb"].shape[-2:]
-        ids = [id(f) for f in self.frames]
-        if st is not None and (st["hw"] != (h, w) or st["n"] > K or st["ids"] != ids[:st["n"]]):
+        ids = list(self.frames)                          # (the frame objects themselves: identity, not id() - ids are reused)
+        if st is not None and (st["hw"] != (h, w) or st["n"] > K or any(a is not b for a, b in zip(st["ids"], ids))):
             st = None                                   # another image size, or the list was edited: rebuild
         if st is None or st["cap"] < K:
             cap = max(16, 2 * K)
