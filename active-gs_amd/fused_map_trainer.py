@@ -121,8 +121,15 @@ class FusedMapTrainer(GaussianMapTrainer):
         # camera.camera_matrices for one frame in numpy (float64, rounded to float32 at the end): the same algebra as ~40
         # small torch ops took 0.34 ms of every keyframe
         import numpy as np
-        c2w = f["extrinsic"].detach().to("cpu", torch.float64).numpy()
-        Kinv = np.linalg.inv(f["intrinsic"].detach().to("cpu", torch.float64).numpy())
+        # (pose, intrinsics and the far bound in ONE read-back when the frame lives on the device)
+        dr = f.get("depth_range")
+        parts = [f["extrinsic"].detach().reshape(-1).double(), f["intrinsic"].detach().reshape(-1).double()]
+        if torch.is_tensor(dr):
+            parts.append(dr.detach().reshape(-1).double().to(parts[0].device))
+        host = torch.cat(parts).cpu().numpy()
+        c2w, Kinv = host[:16].reshape(4, 4), np.linalg.inv(host[16:25].reshape(3, 3))
+        if torch.is_tensor(dr):
+            f["_far_host"] = float(host[25 + 1])
         ray = lambda u, v: (lambda d: d / np.linalg.norm(d))(Kinv @ np.array([u, v, 1.0]))
         fov_x = float(np.arccos(np.clip(ray(0.0, 0.5) @ ray(1.0, 0.5), -1.0, 1.0)))
         fov_y = float(np.arccos(np.clip(ray(0.5, 0.0) @ ray(0.5, 1.0), -1.0, 1.0)))
@@ -379,8 +386,10 @@ class FusedMapTrainer(GaussianMapTrainer):
         counts = self._render_counts(use, None, None, depth_gt, params, (h, w))
         newest = counts[-1].contiguous()
         last = self.frames[-1]
-        far = last["depth_range"][1]
-        far = float(far.item()) if torch.is_tensor(far) else float(far)
+        far = last.get("_far_host")           # (read back with the frame's pose: _make_camera)
+        if far is None:
+            far = last["depth_range"][1]
+            far = float(far.item()) if torch.is_tensor(far) else float(far)
         campos = last["extrinsic"][:3, 3].float().contiguous()
         for key in ("view_supports", "view_means", "view_scores", "means", "rotations"):
             setattr(self, key, getattr(self, key).float().contiguous())
