@@ -355,7 +355,6 @@ class FusedMapTrainer(GaussianMapTrainer):
         n = self.means.shape[0]
         if n == 0 or not self.means.is_cuda:
             return super().confidences()
-        import ctypes as C
         from . import _lib
         from ._lib import ptr
         for k in ("view_supports", "view_means", "view_scores"):
