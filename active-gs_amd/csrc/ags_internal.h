@@ -7,15 +7,21 @@
 #include "surfel_math.h"
 
 // AGS_BIN_DIRECT: words between two tiles' key-slot counters (AgsLayout.tc_stride).  Device atomics are served per cache
-// LINE: with the counters dense, 32 tiles share a 128-byte line and their slot requests queue up behind each other.
-// How far apart pays depends on how many counters there are (round 3, compile-time sweep of 1 / 2 / 4 / 8 / 16 words):
-// a mapper batch of 512x512 views (1 024 tiles per view, ~200 requests per tile) spends two thirds of its per-Gaussian
-// launch waiting for slots with dense counters - 184 -> 95 us at 8 words, mapper loop 0.486 -> 0.446 s at 4; 1200x680
-// (3 225 tiles): per-Gaussian launch 18.5 -> 16.1 us at 2-4 words, neutral at 8; 2048x2048 (16 384 tiles): +0.5 % at 2,
-// +1.6 % at 4, +24 % at 8 (more lines than the L2 keeps).  So: 4 words up to AGS_TC_SPREAD_TILES tiles, dense above.
-#define AGS_TC_STRIDE_MAX 4
-#define AGS_TC_SPREAD_TILES 4096
-static inline int ags_tc_stride(int num_tiles) { return num_tiles <= AGS_TC_SPREAD_TILES ? AGS_TC_STRIDE_MAX : 1; }
+// LINE: with the counters dense, 32 tiles share a 128-byte line and their slot requests queue up behind each other -
+// but every line the counters occupy is one more line the atomic units keep, and what pays depends on how many counters
+// there are (round 3, compile-time sweeps of 1 .. 32 words, per-Gaussian launch unless noted):
+//   64 tiles    (planner views, 128x128, 100 views batched):  whole batch 2.06 ms dense-ish (4) -> 1.80 (8) -> 1.77 (16) -> 1.52 (32)
+//   1 024 tiles (a mapper batch of 512x512 views, ~200 requests per tile): 184 us dense -> 124 (2) -> 115 (4) -> 93 (8) -> 114 (16) -> 103 (32)
+//   3 225 tiles (1200x680): 15.8 us dense -> 14.5-14.8 (2) -> 14.3-14.9 (4) -> 15.1-15.6 (8)
+//   16 384 tiles (2048x2048): +0.5 % of the step at 2, +1.6 % at 4, +24 % of the launch at 8
+// i.e. the counters want to cover a few tens of KB, never more than a line each: the largest power of two that keeps them
+// within AGS_TC_SPREAD_BYTES, at most 32 words.
+#define AGS_TC_SPREAD_BYTES (48 * 1024)
+static inline int ags_tc_stride(int num_tiles) {
+    int s = 32;
+    while (s > 1 && (size_t)num_tiles * 4 * s > AGS_TC_SPREAD_BYTES) s >>= 1;
+    return s;
+}
 #define AGS_SORT_THREADS 256
 #define AGS_SORT_ITEMS 16
 #define AGS_SORT_TILE (AGS_SORT_THREADS * AGS_SORT_ITEMS) // keys per block per pass
