@@ -373,7 +373,9 @@ struct AgsEmitRec { uint32_t excl, xy, wd, pa; float mx, my, ca, cb, cc, o; }; /
 // instruction: a single round trip), and members take base + rank.  RETURN = false drops the result
 // (counting pass: fire and forget).  Must be called by all lanes of the wave.
 #define AGS_AGG_ROUNDS 6
+#ifndef AGS_AGG_MAX_TILES
 #define AGS_AGG_MAX_TILES 256
+#endif
 template <bool AGG, bool RETURN>
 __device__ __forceinline__ uint32_t ags_wave_agg_inc(uint32_t* __restrict__ counter, uint32_t t, bool active) {
     if (!AGG) {
