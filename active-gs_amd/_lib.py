@@ -55,9 +55,77 @@ class AgsGaussianGrads(C.Structure):
 
 
 
+class AgsTuning(C.Structure):
+    _fields_ = [("bwd_reduce", C.c_int32), ("render_slots", C.c_int32), ("cull_first_min_n", C.c_int32),
+                ("tile_sort_no_wave", C.c_int32), ("bucket_no_scan", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+BWD_F32, BWD_BF16_SPLIT, BWD_VALU = 0, 1, 2
+_BWD_NAMES = {"f32": BWD_F32, "bf16": BWD_BF16_SPLIT, "bf16_split": BWD_BF16_SPLIT, "valu": BWD_VALU}
+
+
+def tuning_from_env(env=None) -> AgsTuning:
+    """The library reads no environment variable (AgsTuning travels with the workspace); THIS binding fills the struct
+    from the AGS_* variables INTEGRATION.md lists, once per process, for experiments and the tests that select kernels:
+      AGS_BWD_REDUCE=f32|bf16|valu  (AGS_BWD_BF16=1 = bf16, AGS_BWD_MFMA=0 = valu)   blend backward's per-surfel sums
+      AGS_RENDER_SLOTS=1|2|4, AGS_PRE_CULL_MIN_N=<rows> (0: always), AGS_TSORT_NO_WAVE, AGS_BUCKET_NO_SCAN"""
+    env = os.environ if env is None else env
+    t = AgsTuning()
+    mode = env.get("AGS_BWD_REDUCE")
+    if mode is not None:
+        if mode not in _BWD_NAMES:
+            raise ValueError(f"AGS_BWD_REDUCE={mode!r}: expected one of {sorted(_BWD_NAMES)}")
+        t.bwd_reduce = _BWD_NAMES[mode]
+    elif env.get("AGS_BWD_BF16", "0") not in ("", "0"):
+        t.bwd_reduce = BWD_BF16_SPLIT
+    elif env.get("AGS_BWD_MFMA") == "0":
+        t.bwd_reduce = BWD_VALU
+    if env.get("AGS_RENDER_SLOTS") in ("1", "2", "4"):
+        t.render_slots = int(env["AGS_RENDER_SLOTS"])
+    if env.get("AGS_PRE_CULL_MIN_N") is not None:
+        v = int(env["AGS_PRE_CULL_MIN_N"])
+        t.cull_first_min_n = 1 if v <= 0 else min(v, 0x7FFFFFFF)
+    t.tile_sort_no_wave = int(env.get("AGS_TSORT_NO_WAVE") is not None)
+    t.bucket_no_scan = int(env.get("AGS_BUCKET_NO_SCAN") is not None)
+    return t
+
+
+_default_tuning = None
+
+
+def default_tuning() -> AgsTuning:
+    """The process's default selection (from the environment, see tuning_from_env); kept alive for the structs that
+    point at it."""
+    global _default_tuning
+    if _default_tuning is None:
+        _default_tuning = tuning_from_env()
+    return _default_tuning
+
+
+def make_tuning(bwd_reduce=None, render_slots=None, cull_first_min_n=None) -> AgsTuning:
+    """A copy of the default selection with some fields replaced (bwd_reduce: "f32" | "bf16" | "valu" or AGS_BWD_*)."""
+    d = default_tuning()
+    t = AgsTuning(d.bwd_reduce, d.render_slots, d.cull_first_min_n, d.tile_sort_no_wave, d.bucket_no_scan)
+    if bwd_reduce is not None:
+        t.bwd_reduce = _BWD_NAMES[bwd_reduce] if isinstance(bwd_reduce, str) else int(bwd_reduce)
+    if render_slots is not None:
+        t.render_slots = int(render_slots)
+    if cull_first_min_n is not None:
+        t.cull_first_min_n = int(cull_first_min_n)
+    return t
+
+
 class AgsWorkspace(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_size_t), ("max_instances", C.c_int64),
-                ("binning_mode", C.c_int32)]
+                ("binning_mode", C.c_int32), ("tuning", C.POINTER(AgsTuning))]
+
+
+def workspace(ptr_, nbytes, max_instances, binning_mode, tuning: "AgsTuning | None" = None) -> AgsWorkspace:
+    """AgsWorkspace with the caller's (or the process's default) kernel selection attached."""
+    t = tuning if tuning is not None else default_tuning()
+    ws = AgsWorkspace(ptr_, nbytes, int(max_instances), int(binning_mode), C.pointer(t))
+    ws._tuning_ref = t           # (the pointer above does not own the struct)
+    return ws
 
 
 class AgsViewRef(C.Structure):

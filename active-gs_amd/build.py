@@ -71,12 +71,10 @@ def is_stale() -> bool:
         return f.read().strip() != source_digest()
 
 
-# A second build of the same library whose blend backward forms its per-surfel sums with EXACT f32 matrix instructions
-# (render.hip -DAGS_BWD_F32_MFMA: 16 v_mfma_f32_16x16x4_f32 per flush instead of 6 bf16 ones on hi/lo splits).  Not used
-# by the product; bench.py times it beside the default (`ms_per_step_f32_exact`, a child process with AGS_LIB_PATH) so
-# that what the bf16 split buys is on the record next to the headline.
-LIB_F32 = os.path.join(LIBDIR, "libags_raster_f32exact.so")
-VARIANT_FLAGS = {"f32exact": {"render.hip": ["-DAGS_BWD_F32_MFMA"]}}
+# (Until round 3 a second library, libags_raster_f32exact.so, carried the blend backward with exact f32 matrix
+# instructions.  Both forms now live in the ONE library as two instantiations of ags_k_render_bwd_mfma, selected per
+# workspace with AgsTuning.bwd_reduce - exact f32 is the default.)
+VARIANT_FLAGS = {}   # tag -> {source: extra flags}: experiment builds only (profiles/experiments)
 
 
 def _link(hipcc, objs, out):
@@ -89,9 +87,8 @@ def _link(hipcc, objs, out):
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 and link libags_raster.so (and the f32-exact variant, see LIB_F32).
-    Returns the product library's path."""
-    if not force and not is_stale() and os.path.exists(LIB_F32):
+    """Compile every HIP source for gfx950 and link libags_raster.so.  Returns the library's path."""
+    if not force and not is_stale():
         return LIB
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
@@ -114,8 +111,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs = list(ex.map(compile_one, jobs))
     main_objs = objs[:len(SOURCES)]
     _link(hipcc, main_objs, LIB)
-    f32_objs = [objs[len(SOURCES)] if s == "render.hip" else o for s, o in zip(SOURCES, main_objs)]
-    _link(hipcc, f32_objs, LIB_F32)
+    stale = os.path.join(LIBDIR, "libags_raster_f32exact.so")   # the round-3 variant library: gone
+    if os.path.exists(stale):
+        os.remove(stale)
     with open(STAMP, "w") as f:
         f.write(source_digest() + "\n")
     return LIB

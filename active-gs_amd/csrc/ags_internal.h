@@ -56,6 +56,7 @@ struct AgsLayout {
     int n_blocks;       // preprocess blocks
     int num_tiles;
     int tc_stride;      // words between two tiles' counters in tile_count (ags_tc_stride)
+    AgsTuning tune;     // the caller's kernel selection (AgsWorkspace.tuning; zeros = defaults): ags_layout_for()
 };
 
 static inline size_t ags_align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -90,6 +91,13 @@ static inline AgsLayout ags_make_layout(int n, int h, int w, int64_t cap) {
     L.n_contrib = o; o += ags_align256(P * 4);
     L.dgeom = o; o += ags_align256((size_t)n * sizeof(AgsGeomGrad));
     L.total = o;
+    L.tune = AgsTuning{};
+    return L;
+}
+// the layout of a caller's workspace together with the caller's tuning (what the launchers look at)
+static inline AgsLayout ags_layout_for(int n, int h, int w, const AgsWorkspace* ws) {
+    AgsLayout L = ags_make_layout(n, h, w, ws->max_instances);
+    if (ws->tuning) L.tune = *ws->tuning;
     return L;
 }
 
@@ -475,7 +483,7 @@ __device__ __forceinline__ void ags_bitonic(Ptr a, uint32_t K, int tid) {
 // the stages 2, 4, 8 run entirely in its registers (one pass over the LDS instead of six) and so do the last three
 // sub-steps (distances 4, 2, 1) of every later stage - 28 passes instead of 45 for 512 keys, 45 instead of 66 for 2048.
 // Same network, same result (keys are unique).  A thread's 8 keys are four 16-byte granules 64 bytes apart from its
-// neighbour's: the granule index inside a block is XOR-swizzled with bits 5-6 of the key index so that the 16 lanes the
+// neighbour's (the array must be 16-byte aligned: ds_read/write_b128): the granule index inside a block is XOR-swizzled with bits 5-6 of the key index so that the 16 lanes the
 // hardware serves together (MI355X_MICROARCH.md, LDS) hit 64 different banks.  EVERY access to the array goes through
 // ags_sk() - the caller's loads and stores too.
 __device__ __forceinline__ uint32_t ags_sk(uint32_t idx) { return idx ^ (((idx >> 5) & 3u) << 1); }

@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort(const uint2* __restrict__
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws;
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(keys, wo);
     }
-    __shared__ uint64_t sk[AGS_TSORT_LDS_KEYS];
+    __shared__ __attribute__((aligned(16))) uint64_t sk[AGS_TSORT_LDS_KEYS];   // ags_bitonic8_load/store move 16-byte granules
     if (threadIdx.x < 64) AGS_TL(5, blockIdx.x, 0);
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
     const uint2 rg = ranges[tile];
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct(uint2* __restrict_
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(keys_in, wo); AGS_WS_SHIFT(keys_out, wo); AGS_WS_SHIFT(tile_count, wo);
         AGS_WS_SHIFT(partial, wo);
     }
-    __shared__ uint64_t sk[AGS_TSORT_LDS_KEYS];
+    __shared__ __attribute__((aligned(16))) uint64_t sk[AGS_TSORT_LDS_KEYS];   // ags_bitonic8_load/store move 16-byte granules
     __shared__ uint32_t rank_part[4];
     if (threadIdx.x < 64) AGS_TL(5, blockIdx.x, 0);
     const int tile = ags_xcd_remap(blockIdx.x, num_tiles);
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct_wave(uint2* __rest
 }
 
 void ags_launch_direct_sort(char* ws, const AgsLayout& L, const AgsViewStride& vs, hipStream_t s) {
-    static const bool no_wave = getenv("AGS_TSORT_NO_WAVE") != nullptr;   // experiment knob: always the 256-thread form
+    const bool no_wave = L.tune.tile_sort_no_wave != 0;   // AgsTuning: always the 256-thread form
     const uint32_t tile_cap = ags_direct_tile_cap(L);
     if (tile_cap <= 128u && !no_wave) {
 #define AGS_LAUNCH_TSORT_WAVE(R)                                                                                          \
@@ -635,7 +635,7 @@ void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws
     uint64_t* keys = (uint64_t*)(ws + L.keys0);
     const uint32_t* tile_count = (const uint32_t*)(ws + L.tile_count);
     const uint32_t* block_vis = (const uint32_t*)(ws + L.block_vis);
-    static const bool no_fuse = getenv("AGS_BUCKET_NO_SCAN") != nullptr; // experiment knob
+    const bool no_fuse = L.tune.bucket_no_scan != 0;   // AgsTuning: always the separate tile-scan launch
     if (L.num_tiles <= AGS_BUCKET_SCAN_TILES && !no_fuse) {
 #define AGS_LAUNCH_BUCKET(SCAN, AGG)                                                                                     \
     hipLaunchKernelGGL((ags_k_bucket<SCAN, AGG>), dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, in.n, F.tiles_x, \

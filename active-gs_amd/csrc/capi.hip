@@ -1,7 +1,7 @@
 // extern "C" entry points of libags_raster.so (include/ags_raster.h).
 #include "ags_internal.h"
 
-#define AGS_VERSION 100
+#define AGS_VERSION 101
 
 static int ags_check_launch() { return hipGetLastError() == hipSuccess ? AGS_OK : AGS_E_LAUNCH; }
 
@@ -77,6 +77,13 @@ int ags_workspace_discard_pass(const AgsWorkspace* ws, int32_t n, int32_t h, int
 
 static const AgsViewStride kOneView = {0, 0, 0, 1};
 
+static bool ags_tuning_ok(const AgsWorkspace* ws) {
+    const AgsTuning* t = ws->tuning;
+    if (!t) return true;
+    if (t->bwd_reduce < AGS_BWD_F32 || t->bwd_reduce > AGS_BWD_VALU) return false;
+    return t->render_slots == 0 || t->render_slots == 1 || t->render_slots == 2 || t->render_slots == 4;
+}
+
 int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* out,
                 const AgsPerGaussian* pg, const AgsWorkspace* ws, ags_stream_t stream) {
     if (!cam || !in || !out || !pg || !ws || !ws->ptr) return AGS_E_INVALID;
@@ -87,10 +94,10 @@ int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* o
     if (in->n > 0 && (cam->want_stats || cam->config) && (!pg->importance || !pg->count)) return AGS_E_INVALID;
     if (in->n > 0 && (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences))
         return AGS_E_INVALID;
-    if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll) return AGS_E_INVALID;
+    if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll || !ags_tuning_ok(ws)) return AGS_E_INVALID;
     if (ws->binning_mode != AGS_BIN_TILE_SORT && ws->binning_mode != AGS_BIN_RADIX && ws->binning_mode != AGS_BIN_DIRECT)
         return AGS_E_INVALID;
-    const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
+    const AgsLayout L = ags_layout_for(in->n, cam->image_height, cam->image_width, ws);
     if (ws->bytes < L.total) return AGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char* base = (char*)ws->ptr;
@@ -131,9 +138,9 @@ int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* i
     if (!out->rgb || !out->normal || !out->depth || !out->opacity || !out->confidence) return AGS_E_INVALID;
     if ((cam->want_stats || cam->config) && (!pg->importance || !pg->count)) return AGS_E_INVALID;
     if (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences) return AGS_E_INVALID;
-    if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll) return AGS_E_INVALID;
+    if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll || !ags_tuning_ok(ws)) return AGS_E_INVALID;
     if (ws->binning_mode != AGS_BIN_TILE_SORT && ws->binning_mode != AGS_BIN_DIRECT) return AGS_E_INVALID;
-    const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
+    const AgsLayout L = ags_layout_for(in->n, cam->image_height, cam->image_width, ws);
     if (ws->bytes < (size_t)views * L.total) return AGS_E_WORKSPACE;
     const bool direct = ws->binning_mode == AGS_BIN_DIRECT;
     if (direct && ags_direct_tile_cap(L) < 1) return AGS_E_WORKSPACE;
@@ -171,7 +178,7 @@ static int ags_backward_impl(const AgsCamera* cam, const AgsGaussians* in, const
                              const AgsPerGaussian* pg, const AgsImageGrads* dout, const AgsGaussianGrads* din,
                              const AgsWorkspace* ws, const AgsCamera* next_cam, const AgsPerGaussian* next_pg,
                              const AgsWorkspace* next_ws, int32_t rows_hint, ags_stream_t stream) {
-    if (!cam || !in || !fwd || !pg || !dout || !din || !ws || !ws->ptr) return AGS_E_INVALID;
+    if (!cam || !in || !fwd || !pg || !dout || !din || !ws || !ws->ptr || !ags_tuning_ok(ws)) return AGS_E_INVALID;
     if (in->n == 0) return next_cam ? AGS_E_INVALID : AGS_OK;
     if (!pg->radii || !fwd->depth || !fwd->opacity) return AGS_E_INVALID;
     if (!din->defer_rows) {   // all five gradient arrays, or - fused optimiser step, overwrite mode - none at all
@@ -181,7 +188,7 @@ static int ags_backward_impl(const AgsCamera* cam, const AgsGaussians* in, const
     } else if (next_cam || din->fused_adam || din->pack_segment) {
         return AGS_E_INVALID;   // a deferred view runs its blend backward only; the optimiser / exchange tail belongs to ags_backward_rows
     }
-    const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
+    const AgsLayout L = ags_layout_for(in->n, cam->image_height, cam->image_width, ws);
     if (ws->bytes < L.total) return AGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char* base = (char*)ws->ptr;
@@ -213,6 +220,7 @@ static int ags_backward_impl(const AgsCamera* cam, const AgsGaussians* in, const
         // (all of this is checked BEFORE the blend backward is enqueued: a refused call must leave dgeom and the Adam
         // clock exactly as they were)
         if (!next_pg || !next_ws || !next_ws->ptr || !next_pg->radii || !din->fused_adam || !in->raw_params) return AGS_E_INVALID;
+        if (next_cam->config) return AGS_E_INVALID;   // (see ags_forward_resume: the prepared pass does not clear the statistics)
         if (!din->fused_adam->state_rows) return AGS_E_INVALID;   // the pipelined kernel reads the interleaved moments
         if (!next_cam->viewmatrix || !next_cam->projmatrix || next_cam->image_height <= 0 || next_cam->image_width <= 0) return AGS_E_INVALID;
         if (ws->binning_mode != AGS_BIN_DIRECT || next_ws->binning_mode != AGS_BIN_DIRECT) return AGS_E_INVALID;
@@ -221,7 +229,7 @@ static int ags_backward_impl(const AgsCamera* cam, const AgsGaussians* in, const
         // the next pass's row set is the optimiser's (new members are appended while this step's rows are walked)
         if (next_pg->touched.member != din->touched.member || next_pg->touched.rows != din->touched.rows ||
             next_pg->touched.count != din->touched.count) return AGS_E_INVALID;
-        const AgsLayout L2 = ags_make_layout(in->n, next_cam->image_height, next_cam->image_width, next_ws->max_instances);
+        const AgsLayout L2 = ags_layout_for(in->n, next_cam->image_height, next_cam->image_width, next_ws);
         if (next_ws->bytes < L2.total) return AGS_E_WORKSPACE;
         if (ags_direct_tile_cap(L2) < 1) return AGS_E_WORKSPACE;
     }
@@ -229,7 +237,7 @@ static int ags_backward_impl(const AgsCamera* cam, const AgsGaussians* in, const
       ags_launch_render_bwd(F, *cam, base, L, vals_sorted, *fwd, *dout, tick, kOneView, ws->binning_mode == AGS_BIN_DIRECT, s); }
     if (din->defer_rows) return ags_check_launch();
     if (next_cam) {
-        const AgsLayout L2 = ags_make_layout(in->n, next_cam->image_height, next_cam->image_width, next_ws->max_instances);
+        const AgsLayout L2 = ags_layout_for(in->n, next_cam->image_height, next_cam->image_width, next_ws);
         const AgsFrame F2 = ags_make_frame(next_cam);
         StageScope t(AGS_STAGE_PREPROCESS_BWD, s);
         ags_launch_rows_adam_preprocess(F, *cam, *in, base, L, pg->radii, *din, F2, *next_cam, (char*)next_ws->ptr, L2,
@@ -262,9 +270,13 @@ int ags_forward_resume(const AgsCamera* cam, const AgsGaussians* in, const AgsIm
     if (in->n <= 0 || cam->image_height <= 0 || cam->image_width <= 0) return AGS_E_INVALID;
     if (!cam->viewmatrix || !cam->projmatrix || !cam->bg || !pg->radii) return AGS_E_INVALID;
     if (!out->rgb || !out->normal || !out->depth || !out->opacity || !out->confidence) return AGS_E_INVALID;
-    if ((cam->want_stats || cam->config) && (!pg->importance || !pg->count)) return AGS_E_INVALID;
-    if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll || ws->binning_mode != AGS_BIN_DIRECT) return AGS_E_INVALID;
-    const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
+    // device-side configuration is not available in the pipelined form: the prepared per-Gaussian stage ran inside
+    // ags_k_rows_adam_preprocess, which does not clear importance / count (with config they would accumulate onto stale
+    // contents); the optimisation loops that pipeline pass host flags
+    if (cam->config) return AGS_E_INVALID;
+    if (cam->want_stats && (!pg->importance || !pg->count)) return AGS_E_INVALID;
+    if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll || ws->binning_mode != AGS_BIN_DIRECT || !ags_tuning_ok(ws)) return AGS_E_INVALID;
+    const AgsLayout L = ags_layout_for(in->n, cam->image_height, cam->image_width, ws);
     if (ws->bytes < L.total) return AGS_E_WORKSPACE;
     if (ags_direct_tile_cap(L) < 1) return AGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -286,8 +298,8 @@ int ags_backward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* 
         if (din->accumulate != 2) return AGS_E_INVALID;     // views sum with atomics into a pre-zeroed slab
     }
     if (din->fused_adam || din->pack_segment) return AGS_E_INVALID;
-    if (ws->binning_mode != AGS_BIN_TILE_SORT && ws->binning_mode != AGS_BIN_DIRECT) return AGS_E_INVALID;
-    const AgsLayout L = ags_make_layout(in->n, cam->image_height, cam->image_width, ws->max_instances);
+    if ((ws->binning_mode != AGS_BIN_TILE_SORT && ws->binning_mode != AGS_BIN_DIRECT) || !ags_tuning_ok(ws)) return AGS_E_INVALID;
+    const AgsLayout L = ags_layout_for(in->n, cam->image_height, cam->image_width, ws);
     if (ws->bytes < (size_t)views * L.total) return AGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char* base = (char*)ws->ptr;

@@ -364,13 +364,19 @@ __global__ __launch_bounds__(256) void ags_k_weighted_topk(const float* __restri
     __shared__ float best_v[4];
     __shared__ int best_i[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int i = t; i < n; i += 256) key[i] = logf(u[i]) / fmaxf(w[i], 1e-30f);
+    // every key stays FINITE (u = 0 from torch.rand would give log(0) = -inf, a NaN weight a NaN key: both become the lowest
+    // finite key), so that a drawn slot can be marked with NaN and never be selected again: the k indices are distinct
+    // whatever the inputs, like np.random.choice(replace=False) and torch.topk
+    for (int i = t; i < n; i += 256) {
+        const float kv = logf(fmaxf(u[i], 1.17549435e-38f)) / fmaxf(w[i], 1e-30f);
+        key[i] = (kv == kv && kv > -3.4e38f) ? kv : -3.4e38f;
+    }
     __syncthreads();
     for (int j = 0; j < k; ++j) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
         for (int i = t; i < n; i += 256) {
-            const float v = key[i];
+            const float v = key[i];                      // NaN = already drawn: no comparison with it is true
             if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
         }
 #pragma unroll
@@ -387,9 +393,9 @@ __global__ __launch_bounds__(256) void ags_k_weighted_topk(const float* __restri
 #pragma unroll
             for (int q = 1; q < 4; ++q)
                 if (best_v[q] > v || (best_v[q] == v && best_i[q] < i)) { v = best_v[q]; i = best_i[q]; }
-            if (i == 0x7fffffff) i = 0;          // (fewer than k finite keys: NaN weights - as arbitrary as topk's answer)
+            if (i == 0x7fffffff) i = 0;          // (cannot happen for k <= n: every undrawn key is finite)
             out[j] = (long long)i;
-            if (i < n) key[i] = -INFINITY;
+            if (i < n) key[i] = __builtin_nanf("");
         }
         __syncthreads();
     }

@@ -2,7 +2,6 @@
 // (conic/mean2D/depth/normal gradients -> means3D, scales, rotations, opacity, colour).
 // One lane per Gaussian; the camera matrices are wave-uniform (scalar loads).
 // Counterpart of the preprocess / preprocess-backward stages listed in SURVEY.md §2.3.
-#include <stdlib.h>
 
 #include "ags_internal.h"
 
@@ -1152,8 +1151,9 @@ void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGau
                        zero_count, vs)
     const bool agg = L.num_tiles <= AGS_AGG_MAX_TILES;
     // large maps, raw parameters, one-pass binning: cull with the means first, project the survivors on full waves
-    static const int cull_min_n = [] { const char* e = getenv("AGS_PRE_CULL_MIN_N"); return e ? atoi(e) : AGS_CULL_MIN_N; }();
-    if (emit == 2 && !agg && in.raw_params && in.n >= cull_min_n && in.max_scale > 0.f) {
+    // (AgsTuning.cull_first_min_n: 0 = AGS_CULL_MIN_N rows, < 0 = never)
+    const int cull_min_n = L.tune.cull_first_min_n ? L.tune.cull_first_min_n : AGS_CULL_MIN_N;
+    if (emit == 2 && !agg && in.raw_params && cull_min_n > 0 && in.n >= cull_min_n && in.max_scale > 0.f) {
         hipLaunchKernelGGL(ags_k_preprocess_cull, dim3((in.n + AGS_CULL_ROWS - 1) / AGS_CULL_ROWS, vs.views), dim3(AGS_PRE_THREADS), 0, s, F,
                            cam.viewmatrix, cam.projmatrix, in, (AgsGeom*)(ws + L.geom), radii, (uint32_t*)(ws + L.tile_count),
                            (float4*)(ws + L.dgeom), touched, direct, zero_importance, zero_count, vs);

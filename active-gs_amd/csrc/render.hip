@@ -23,8 +23,6 @@
 // Blocks are mapped to tiles XCD-aware (ags_xcd_remap) so one XCD's L2 serves a contiguous
 // band of tiles.  Counterpart of renderCUDA fwd/bwd in SURVEY.md §2.3; arithmetic in
 // surfel_math.h.
-#include <stdlib.h>
-
 #include "ags_internal.h"
 
 AGS_TL_DEFINE(render)
@@ -467,7 +465,8 @@ typedef float ags_f32x4 __attribute__((ext_vector_type(4)));
 #ifndef AGS_MFMA_STAGE
 #define AGS_MFMA_STAGE 32   // records staged per round: 32 keeps a wave at 6.4 KB of LDS = 6 waves per SIMD
 #endif
-// The per-surfel reduction of the blend backward on the bf16 matrix pipe (default) or in exact f32 (-DAGS_BWD_F32_MFMA).
+// The per-surfel reduction of the blend backward in exact f32 (default, BF16 = false) or on the bf16 matrix pipe
+// (AgsTuning.bwd_reduce = AGS_BWD_BF16_SPLIT, BF16 = true).
 // An f32 matrix instruction (v_mfma_f32_16x16x4_f32, 1024 multiply-adds in ~37 cycles) runs at the vector ALUs' rate and
 // does not overlap with other waves' vector instructions on its SIMD (profiles/experiments/mfma_valu_overlap.cpp: a
 // VALU stream and an f32-MFMA stream on one SIMD take the SUM of their times): the sixteen of a flush cost as much as
@@ -477,25 +476,20 @@ typedef float ags_f32x4 __attribute__((ext_vector_type(4)));
 // 2^-16 relative; every term's truncation error is below 2^-16 of the term): six matrix instructions per flush instead
 // of sixteen, four more vector instructions per pixel and surfel for the split.  Gradients move by ~1e-5 relative
 // (tolerance 1e-3); the accumulator leaves the matrix pipe in the same layout, so the rest of the flush is unchanged.
-#ifndef AGS_BWD_F32_MFMA
-#define AGS_BWD_BF16 1
-#endif
+// The reference's arithmetic is fp32, so the exact form is what a caller gets unless it asks for the split.
 struct AgsWaveBatch {       // one per wave, in LDS: 2048 + 4352 = 6400 B = five 1280-byte granules -> 25 waves per CU
     AgsStagedRec<1> sg[AGS_MFMA_STAGE];
-#ifdef AGS_BWD_BF16
-    unsigned short gh[16][68];   // bf16 hi parts: row 2 i = gp of slot i, row 2 i + 1 = its w; [row][pixel], 136-byte rows
-    unsigned short gl[16][68];   // bf16 lo parts
-#else
-    float gw[16][68];       // row 2 i: gp of slot i, row 2 i + 1: its w; 68 floats: 16-byte row reads of 16 lanes hit 64 banks
-#endif
+    union {
+        struct {
+            unsigned short gh[16][68];   // bf16 hi parts: row 2 i = gp of slot i, row 2 i + 1 = its w; [row][pixel], 136-byte rows
+            unsigned short gl[16][68];   // bf16 lo parts
+        };
+        float gw[16][68];   // f32 form: row 2 i: gp of slot i, row 2 i + 1: its w; 68 floats: 16-byte row reads of 16 lanes hit 64 banks
+    };
 };
 // the 8 bytes behind the 64 pixels of batch row `row` (hi rows of the bf16 form / the f32 rows): where a slot's
 // (mean - quadrant centre) [even row] and surfel id [odd row] ride along
-#ifdef AGS_BWD_BF16
-#define AGS_BWD_PAD(row) wb.gh[(row)][64]
-#else
-#define AGS_BWD_PAD(row) wb.gw[(row)][64]
-#endif
+#define AGS_BWD_PAD(row) (BF16 ? (void*)&wb.gh[(row)][64] : (void*)&wb.gw[(row)][64])
 typedef __bf16 ags_bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned int ags_u4 __attribute__((ext_vector_type(4)));
 // two floats -> one register of two truncated bf16 (lo half = a, hi half = b)
@@ -507,6 +501,7 @@ __device__ __forceinline__ float ags_bf16_residual(float x) { return x - __uint_
 #ifndef AGS_MFMA_WAVES
 #define AGS_MFMA_WAVES 6      // register budget: 512 / 6 -> 80 VGPRs
 #endif
+template <bool BF16>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAVES, AGS_MFMA_WAVES))) void ags_k_render_bwd_mfma(
     AgsFrame F, int normalize_depth, const float* __restrict__ bgp, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
@@ -595,11 +590,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
     // ---- B operands: field (lane & 15) of the 16 pixels t + 16 (lane >> 4) --------------------------
     const int fld = lane & 15, kgrp = lane >> 4;
     const float qx = (float)(lane & 7) - 3.5f, qy = (float)(lane >> 3) - 3.5f;   // the lane's pixel about the quadrant centre
-#ifdef AGS_BWD_BF16
     // B operands of v_mfma_f32_16x16x32_bf16: lane = (feature fld, k-group kgrp) holds the feature of pixels
     // 32 b + 8 kgrp .. + 7 for the two K blocks b, as bf16 hi and lo parts: 2 x 4 + 2 x 4 registers
-    ags_u4 BH[2], BL[2];
-    {
+    // (f32 form: FE = the feature of pixels t + 16 kgrp, 16 registers; only one of the two sets is live)
+    ags_u4 BH[2] = {}, BL[2] = {};
+    float FE[16] = {};
+    if constexpr (BF16) {
         float* ex = reinterpret_cast<float*>(&wb.gh[0][0]);       // [feature][pixel] f32, rows of 68 floats: 4080 B of the 4352
         const float feat[16] = {qx, qy, qx * qx, qx * qy, qy * qy, 1.f, pg.dDn, pg.dDn * qx, pg.dDn * qy,
                                 pg.dC0, pg.dC1, pg.dC2, pg.dN0, pg.dN1, pg.dN2, 0.f};
@@ -620,10 +616,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
                            ags_pack_bf16_trunc(ags_bf16_residual(v.z), ags_bf16_residual(v.w))};
         }
         ags_wave_lds_sync();
-    }
-#else
-    float FE[16];
-    {
+    } else {
         // every pixel lane publishes its 16 feature values ([field][pixel], rows of 68 floats: the
         // 16-byte row reads below are conflict-free); the batch buffer is still unused
         float* ex = &wb.gw[0][0];
@@ -642,7 +635,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
         }
         ags_wave_lds_sync();
     }
-#endif
     // per-lane constants of the shift to the surfel's mean (see flush): which of ox, oy and their products
     // this lane's field takes
     const float gx1 = fld == 0 ? 1.f : 0.f, gy1 = fld == 1 ? 1.f : 0.f;                     // gp rows: m1x, m1y
@@ -664,11 +656,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
         uint32_t slot_sid[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            slot_oxy[h] = *reinterpret_cast<const float2*>(&AGS_BWD_PAD(4 * kgrp + 2 * h));
-            slot_sid[h] = *reinterpret_cast<const uint32_t*>(&AGS_BWD_PAD(4 * kgrp + 2 * h + 1));
+            slot_oxy[h] = *reinterpret_cast<const float2*>(AGS_BWD_PAD(4 * kgrp + 2 * h));
+            slot_sid[h] = *reinterpret_cast<const uint32_t*>(AGS_BWD_PAD(4 * kgrp + 2 * h + 1));
         }
         ags_f32x4 d = {0.f, 0.f, 0.f, 0.f}, d_odd = {0.f, 0.f, 0.f, 0.f}; // two chains: a dependent MFMA waits 40 cycles, an independent one 32
-#ifdef AGS_BWD_BF16
+        if constexpr (BF16) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             // A operand: row fld, pixels 32 b + 8 kgrp .. + 7 as eight bf16 = two 8-byte reads (136-byte rows are 8-byte aligned)
@@ -682,7 +674,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             d_odd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d_odd, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
         }
-#else
+        } else {
         const float4* col = reinterpret_cast<const float4*>(&wb.gw[fld][16 * kgrp]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -692,7 +684,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, FE[4 * q + 2], d, 0, 0, 0);
             d_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, FE[4 * q + 3], d_odd, 0, 0, 0);
         }
-#endif
+        }
         d += d_odd;
         // lane: field fld of rows 4 kgrp + r = (gp, w) of slots 2 kgrp and 2 kgrp + 1
 #pragma unroll
@@ -760,19 +752,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             const float dalpha = pg.T * gsum - pg.S * iom;
             pg.S += w * gsum;
             const float gp = (alpha < AGS_ALPHA_MAX) ? alpha * dalpha : 0.f;
-#ifdef AGS_BWD_BF16
-            // park the two factors as bf16 hi + lo (truncations: the stores take the registers' upper halves)
-            wb.gh[2 * nb][lane] = (unsigned short)(__float_as_uint(gp) >> 16);
-            wb.gh[2 * nb + 1][lane] = (unsigned short)(__float_as_uint(w) >> 16);
-            wb.gl[2 * nb][lane] = (unsigned short)(__float_as_uint(ags_bf16_residual(gp)) >> 16);
-            wb.gl[2 * nb + 1][lane] = (unsigned short)(__float_as_uint(ags_bf16_residual(w)) >> 16);
-#else
-            wb.gw[2 * nb][lane] = gp;
-            wb.gw[2 * nb + 1][lane] = w;
-#endif
+            if constexpr (BF16) {
+                // park the two factors as bf16 hi + lo (truncations: the stores take the registers' upper halves)
+                wb.gh[2 * nb][lane] = (unsigned short)(__float_as_uint(gp) >> 16);
+                wb.gh[2 * nb + 1][lane] = (unsigned short)(__float_as_uint(w) >> 16);
+                wb.gl[2 * nb][lane] = (unsigned short)(__float_as_uint(ags_bf16_residual(gp)) >> 16);
+                wb.gl[2 * nb + 1][lane] = (unsigned short)(__float_as_uint(ags_bf16_residual(w)) >> 16);
+            } else {
+                wb.gw[2 * nb][lane] = gp;
+                wb.gw[2 * nb + 1][lane] = w;
+            }
             if (lane == k) {   // the surfel's staging lane (k is wave-uniform: one exec-masked pair of LDS writes)
-                *reinterpret_cast<float2*>(&AGS_BWD_PAD(2 * nb)) = my_oxy;
-                *reinterpret_cast<uint32_t*>(&AGS_BWD_PAD(2 * nb + 1)) = my_gid;
+                *reinterpret_cast<float2*>(AGS_BWD_PAD(2 * nb)) = my_oxy;
+                *reinterpret_cast<uint32_t*>(AGS_BWD_PAD(2 * nb + 1)) = my_gid;
             }
             if (++nb == 8) { flush(); ++tl_flush; }
         }
@@ -786,22 +778,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
 
 // How many strips per wave: one wave per tile when the image has enough tiles to fill the
 // 1024 SIMDs several times over, otherwise split tiles over more waves.
-static int ags_pick_slots(int num_tiles) {
-    // tuning knob, read ONCE per process (like AGS_BWD_MFMA below): 1 / 2 / 4 force the slots per wave
-    static const int forced = [] { const char* e = getenv("AGS_RENDER_SLOTS"); return (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) ? e[0] - '0' : 0; }();
-    if (forced) return forced;
+static int ags_pick_slots(int num_tiles, const AgsTuning& tune) {
+    if (tune.render_slots) return tune.render_slots;   // the caller's choice (AgsTuning.render_slots: 1 / 2 / 4)
     // measured (re-measured after the r01-k..o slimming of the per-wave overhead): one slot per
     // wave (four waves per tile) wins up to ~11 k tiles in flight (1200x680 = 3225, a training batch of 11 views
     // at 512x512 = 11 264); two slots per wave from 2048x2048 (16 384 tiles, ~500 surfels per tile) up
     if (num_tiles >= 12288) return 2;
     return 1;
-}
-
-// matrix-core reduction in the blend backward: AGS_BWD_MFMA = 0 never (the VALU kernels below), 1 where one
-// quadrant per wave would be picked anyway, 2 always (default: measured faster on every configuration)
-static int ags_bwd_mfma() {
-    static const int mode = [] { const char* e = getenv("AGS_BWD_MFMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
-    return mode;
 }
 
 template <int SLOTS>
@@ -841,7 +824,7 @@ void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
                            AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs,
                            bool direct, hipStream_t s) {
     // strips per wave by the number of tiles in flight: a batch of views fills the GPU like one big image
-    switch (ags_pick_slots(L.num_tiles * vs.views)) {
+    switch (ags_pick_slots(L.num_tiles * vs.views, L.tune)) {
         case 1: launch_fwd<1>(F, cam, ws, L, ids, out, pg, vs, direct, s); break;
         case 2: launch_fwd<2>(F, cam, ws, L, ids, out, pg, vs, direct, s); break;
         default: launch_fwd<4>(F, cam, ws, L, ids, out, pg, vs, direct, s); break;
@@ -852,14 +835,18 @@ void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
                            AgsIdList ids, const AgsImages& fwd, const AgsImageGrads& dout, const AgsTick& tick,
                            const AgsViewStride& vs, bool direct, hipStream_t s) {
     const uint32_t tile_cap = direct ? ags_direct_tile_cap(L) : 0u;
-    const int slots = ags_pick_slots(L.num_tiles * vs.views), mfma = ags_bwd_mfma();
-    if (mfma == 2 || (mfma == 1 && slots == 1)) {
-        hipLaunchKernelGGL(ags_k_render_bwd_mfma, dim3(8 * ags_wave_blocks_per_xcd(L.num_tiles, 4), vs.views), dim3(64), 0, s, F, cam.normalize_depth,
-                           cam.bg, (const uint2*)(ws + L.ranges), ids.ids, ids.stride, (const AgsGeom*)(ws + L.geom),
-                           fwd.depth, fwd.opacity, (const float*)(ws + L.final_T),
-                           (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick, tile_cap, vs);
+    // AgsTuning.bwd_reduce: exact f32 matrix instructions (default), the bf16 hi/lo split, or no matrix instructions
+    if (L.tune.bwd_reduce != AGS_BWD_VALU) {
+#define AGS_LAUNCH_BWD_MFMA(BF16)                                                                                         \
+    hipLaunchKernelGGL(ags_k_render_bwd_mfma<BF16>, dim3(8 * ags_wave_blocks_per_xcd(L.num_tiles, 4), vs.views), dim3(64), 0, s, F, \
+                       cam.normalize_depth, cam.bg, (const uint2*)(ws + L.ranges), ids.ids, ids.stride,                    \
+                       (const AgsGeom*)(ws + L.geom), fwd.depth, fwd.opacity, (const float*)(ws + L.final_T),             \
+                       (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick, tile_cap, vs)
+        if (L.tune.bwd_reduce == AGS_BWD_BF16_SPLIT) AGS_LAUNCH_BWD_MFMA(true); else AGS_LAUNCH_BWD_MFMA(false);
+#undef AGS_LAUNCH_BWD_MFMA
         return;
     }
+    const int slots = ags_pick_slots(L.num_tiles * vs.views, L.tune);
     switch (slots) {
         case 1: launch_bwd<1>(F, cam, ws, L, ids, fwd, dout, tick, tile_cap, vs, s); break;
         case 2: launch_bwd<2>(F, cam, ws, L, ids, fwd, dout, tick, tile_cap, vs, s); break;

@@ -15,11 +15,15 @@
 //   * outputs are fresh tensors; the view's workspace (projected records, keys, per-pixel blend state, gradient
 //     records) comes from a pool keyed by (device, image size, binning mode) - a slab laid out for another map size is
 //     re-initialised if it is large enough - and goes back when the autograd node is destroyed (the graph is dropped);
-//   * the workspace check: a call that has to MAKE a workspace reads the status block back and repairs an overflow on
-//     the spot (what the CUDA extension's num_rendered read-back does on every call); a call that finds a pooled one
-//     copies the status block to page-locked memory without waiting and a LATER call (or check_overflow()) looks at
-//     it - no stream synchronisation per view.  A pooled workspace holds 2x the largest need seen so far; a view that
-//     outgrew it anyway is reported by an exception from the next call, with the size raised so that a repeat succeeds.
+//   * the workspace check.  DEFAULT (round 4): every call reads the status block back before it returns and repairs an
+//     overflow on the spot - what the CUDA extension's num_rendered read-back does on every call; an unmodified caller
+//     (mapping/mapper.py:98-104 has no retry anywhere above the rasterizer) can never see truncated tile lists or an
+//     exception for a legitimately larger view.  OPT-IN (`deferred`: the per-call flag of rasterize(), which
+//     facade.SurfelRenderer sets around its own loops and settles per batch, or AGS_DROPIN_STATUS=deferred for callers that
+//     call check_overflow() every iteration): a call that finds a pooled workspace (2x the largest need seen so far)
+//     copies the status block to page-locked memory without waiting and a LATER call / settle() / check_overflow() looks
+//     at it - no stream synchronisation per view.  Passes without grad are always checked at once unless the per-call flag
+//     says otherwise (their callers read the result on the host anyway).
 //   * one-pass binning needs tiles x the LONGEST tile list of key slots; a view size whose lists are badly skewed is
 //     moved to the scan-based binning (same images), which needs the instance total.
 #include <torch/custom_class.h>
@@ -63,7 +67,8 @@ struct Options {
     int binning_mode = AGS_BIN_DIRECT;
     double skew_factor = 8.0;            // direct binning is left when it needs this many times the instance total ...
     double direct_budget_bytes = double(1ull << 30);   // ... AND more than this much workspace for its key slots (24 B each)
-    bool always_check = false;           // status read-back after every forward pass (the CUDA extension's behaviour)
+    bool always_check = true;            // status read-back after every forward pass (the CUDA extension's behaviour): safe for
+                                         // callers that never look at check_overflow(); false = deferred checks (opt-in)
     double headroom = 2.0;               // a new workspace holds this many times the largest need seen so far
     double min_headroom = 1.25;          // a pooled workspace is reused while it holds at least this many times that need
     int max_pending = 64;
@@ -78,6 +83,8 @@ using PoolKey = std::tuple<int, int, int, int>;      // device, h, w, mode
 // re-initialises a slab that is large enough instead of leaving one set of workspaces per map size behind
 struct Pooled { at::Tensor ws; int64_t cap; int n; };
 std::mutex mu;
+AgsTuning tuning{};                  // kernel selection handed to the library with every workspace (set_tuning: the Python side
+                                     // fills it from AGS_* environment variables; the library itself reads none)
 std::map<NeedKey, int64_t> need_seen;
 std::map<SizeKey, int> mode_for;
 std::map<PoolKey, std::vector<Pooled>> pool;
@@ -118,37 +125,41 @@ std::string note_need(const SizeKey& key, int mode, int n, const AgsStatus& st) 
     return os.str();
 }
 
-// look at the status copies that have landed (all of them if `block`); throws if one of them reports an overflow
-void poll_pending(bool block) {
-    std::string msg;
-    {
-        std::lock_guard<std::mutex> g(mu);
-        while (!pending.empty()) {
-            Pending& p = pending.front();
-            hipError_t q = hipEventQuery(p.slot.ev);
-            if (q == hipErrorNotReady) {
-                if (!block && (int)pending.size() <= opt.max_pending) break;
-                HIP_OK(hipEventSynchronize(p.slot.ev));
-            } else {
-                TORCH_CHECK(q == hipSuccess, "hipEventQuery failed");
-            }
-            cnt.deferred_checks++;
-            const std::string what = note_need(p.key, p.mode, p.n, *p.slot.host);
-            if (!what.empty()) {
-                cnt.overflows++;
-                overflow_reports.push_back(what + " but its workspace held " + std::to_string(p.cap));
-            }
-            free_slots.push_back(p.slot);
-            pending.pop_front();
+// look at the status copies that have landed (all of them if `block`); returns the overflow reports gathered so far
+// (and forgets them): empty = every deferred check so far was fine
+std::vector<std::string> collect_pending(bool block, bool take = true) {
+    std::vector<std::string> out;
+    std::lock_guard<std::mutex> g(mu);
+    while (!pending.empty()) {
+        Pending& p = pending.front();
+        hipError_t q = hipEventQuery(p.slot.ev);
+        if (q == hipErrorNotReady) {
+            if (!block && (int)pending.size() <= opt.max_pending) break;
+            HIP_OK(hipEventSynchronize(p.slot.ev));
+        } else {
+            TORCH_CHECK(q == hipSuccess, "hipEventQuery failed");
         }
-        if (!overflow_reports.empty()) {
-            for (size_t i = 0; i < overflow_reports.size(); ++i) msg += (i ? "; " : "") + overflow_reports[i];
-            overflow_reports.clear();
+        cnt.deferred_checks++;
+        const std::string what = note_need(p.key, p.mode, p.n, *p.slot.host);
+        if (!what.empty()) {
+            cnt.overflows++;
+            overflow_reports.push_back(what + " but its workspace held " + std::to_string(p.cap));
         }
+        free_slots.push_back(p.slot);
+        pending.pop_front();
     }
+    if (take) out.swap(overflow_reports);
+    return out;
+}
+// ... and throws if one of them reports an overflow
+void poll_pending(bool block) {
+    const std::vector<std::string> reports = collect_pending(block);
+    std::string msg;
+    for (size_t i = 0; i < reports.size(); ++i) msg += (i ? "; " : "") + reports[i];
     TORCH_CHECK(msg.empty(), "diff_gaussian_rasterization_2d: ", msg,
-                ": the tile lists of that call were truncated, its images and gradients are invalid.  The workspace size "
-                "has been raised - repeat the iteration (AGS_DROPIN_STATUS=always checks every call before it returns).");
+                ": the tile lists of that DEFERRED-check call were truncated, its images and gradients are invalid.  The "
+                "workspace size has been raised - repeat the iteration (deferred checks are opt-in: the default checks "
+                "and repairs every call before it returns).");
 }
 
 // a pooled workspace laid out for n surfels with at least min_cap key slots; else a pooled slab that is large enough,
@@ -176,7 +187,7 @@ std::tuple<at::Tensor, int64_t, bool> take_workspace(const PoolKey& pk, int n, i
         }
     }
     at::Tensor ws = reuse.defined() ? reuse : at::empty({(int64_t)bytes}, bytes_opt);
-    AgsWorkspace wss{ws.data_ptr(), (size_t)ws.numel(), cap, mode};
+    AgsWorkspace wss{ws.data_ptr(), (size_t)ws.numel(), cap, mode, &tuning};
     check_rc(abi.workspace_init(&wss, n, h, w, stream), "ags_workspace_init");
     return {ws, cap, true};
 }
@@ -215,13 +226,16 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                                                   const at::Tensor& view_in, const at::Tensor& proj_in,
                                                   const at::Tensor& mask_in, const at::Tensor& config_in, int64_t h, int64_t w,
                                                   double tanx, double tany, double scale_mod, double weight_thres,
-                                                  int64_t grad_flags /* bit 0: a backward may follow; bit 1: means2D wants its gradient */) {
+                                                  int64_t grad_flags /* bit 0: a backward may follow; bit 1: means2D wants its gradient;
+                                                                        bit 2: the caller settles deferred checks itself (settle()) */) {
         TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization_2d (MI355X build): tensors must be on the GPU; "
                                        "there is no CPU fallback");
         TORCH_CHECK(abi.forward, "the rasterizer library is not loaded (torch_binding.init)");
         const c10::Device dev = means3D.device();
         const c10::DeviceGuard guard(dev);
-        poll_pending(false);                       // non-blocking look at earlier calls' status copies
+        // non-blocking look at earlier calls' status copies (sizes learnt); an overflow among them is raised here unless
+        // this caller settles its passes itself (bit 2: the reports wait for settle())
+        if (grad_flags & 4) collect_pending(false, false); else poll_pending(false);
         hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
         const at::Tensor V = f32c(view_in, dev, "viewmatrix"), P = f32c(proj_in, dev, "projmatrix"), bg = f32c(bg_in, dev, "bg");
         at::Tensor mask, cfg;
@@ -266,7 +280,10 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                           n ? radii.data_ptr<int32_t>() : nullptr, AgsRowSet{nullptr, nullptr, nullptr}};
         const SizeKey key{dev.index(), (int)h, (int)w};
         bool must_sync;
-        { std::lock_guard<std::mutex> g(mu); cnt.forward_calls++; must_sync = opt.always_check; }
+        // checked before it returns: by default every call; with deferred checks switched on (option / per-call flag)
+        // still every pass without grad unless the caller itself asked to defer (it settles the batch)
+        { std::lock_guard<std::mutex> g(mu); cnt.forward_calls++;
+          must_sync = (grad_flags & 4) ? false : (opt.always_check || !(grad_flags & 1)); }
         at::Tensor ws;
         int64_t ws_cap = 0;
         int mode = 0;
@@ -286,7 +303,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
             pk = PoolKey{dev.index(), (int)h, (int)w, mode};
             bool fresh;
             std::tie(ws, ws_cap, fresh) = take_workspace(pk, (int)n, (int)h, (int)w, min_cap, new_cap, fo.dtype(at::kByte), mode, stream);
-            AgsWorkspace wss{ws.data_ptr(), (size_t)ws.numel(), ws_cap, mode};
+            AgsWorkspace wss{ws.data_ptr(), (size_t)ws.numel(), ws_cap, mode, &tuning};
             check_rc(abi.forward(&cs, &gs, &im, &pg, &wss, stream), "ags_forward");
             if (fresh || must_sync) {
                 // a workspace had to be made (first views of this map size / image size, or the need has outgrown the
@@ -374,7 +391,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         // (the blend backward reads the forward's depth and opacity images, its per-pixel state in the workspace and radii)
         AgsImages im{nullptr, nullptr, depth.data_ptr<float>(), opacity.data_ptr<float>(), nullptr};
         AgsPerGaussian pg{nullptr, nullptr, n ? radii.data_ptr<int32_t>() : nullptr, AgsRowSet{nullptr, nullptr, nullptr}};
-        AgsWorkspace wss{lease->ws.data_ptr(), (size_t)lease->ws.numel(), (int64_t)s[10], (int32_t)s[11]};
+        AgsWorkspace wss{lease->ws.data_ptr(), (size_t)lease->ws.numel(), (int64_t)s[10], (int32_t)s[11], &tuning};
         check_rc(abi.backward(&cs, &gs, &im, &pg, &dout, &din, &wss, stream), "ags_backward");
         at::Tensor none;
         return {g_m, need_m2d ? g_m2 : none, g_o.reshape(opac_shape), none, g_c, g_s, g_r,
@@ -386,7 +403,7 @@ std::vector<at::Tensor> rasterize(const at::Tensor& means3D, const at::Tensor& m
                                   const at::Tensor& confidences, const at::Tensor& colors, const at::Tensor& scales,
                                   const at::Tensor& rotations, const at::Tensor& bg, const at::Tensor& viewmatrix,
                                   const at::Tensor& projmatrix, const at::Tensor& render_mask, const at::Tensor& config, int64_t h,
-                                  int64_t w, double tanx, double tany, double scale_mod, double weight_thres) {
+                                  int64_t w, double tanx, double tany, double scale_mod, double weight_thres, bool deferred) {
     // (inside apply() grad mode is off and the node may not exist: what the forward needs to know is decided here)
     int64_t grad_flags = 0;
     if (at::GradMode::is_enabled()) {
@@ -394,6 +411,7 @@ std::vector<at::Tensor> rasterize(const at::Tensor& means3D, const at::Tensor& m
                          colors.requires_grad() || scales.requires_grad() || rotations.requires_grad();
         grad_flags = (any ? 1 : 0) | ((means2D.defined() && means2D.numel() && means2D.requires_grad()) ? 2 : 0);
     }
+    if (deferred) grad_flags |= 4;
     return RasterizeFn::apply(means3D, means2D, opacities, confidences, colors, scales, rotations, bg, viewmatrix, projmatrix,
                               render_mask, config, h, w, tanx, tany, scale_mod, weight_thres, grad_flags);
 }
@@ -421,6 +439,12 @@ void set_option(const std::string& name, double v) {
     else if (name == "min_headroom") opt.min_headroom = v;
     else if (name == "max_pending") opt.max_pending = (int)v;
     else TORCH_CHECK(false, "unknown option ", name);
+}
+
+void set_tuning(int64_t bwd_reduce, int64_t render_slots, int64_t cull_first_min_n, int64_t tile_sort_no_wave, int64_t bucket_no_scan) {
+    std::lock_guard<std::mutex> g(mu);
+    tuning = AgsTuning{(int32_t)bwd_reduce, (int32_t)render_slots, (int32_t)cull_first_min_n, (int32_t)tile_sort_no_wave,
+                       (int32_t)bucket_no_scan, {0, 0, 0}};
 }
 
 double get_option(const std::string& name) {
@@ -472,7 +496,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("rasterize", &rasterize);
     m.def("check_overflow", []() { poll_pending(true); },
           "wait for the status copies of all forward passes issued so far; raises if one of them outgrew its workspace");
+    m.def("settle", []() { return collect_pending(true); },
+          "wait for the status copies of all deferred-check passes issued so far; returns the overflow reports (empty: none) "
+          "and forgets them - the sizes have been raised, the caller repeats the passes");
     m.def("set_option", &set_option);
+    m.def("set_tuning", &set_tuning, "AgsTuning fields handed to the library with every workspace");
     m.def("get_option", &get_option);
     m.def("counters", &counters);
     m.def("state", &state);

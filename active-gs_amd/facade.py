@@ -131,9 +131,52 @@ def render_core(module, cam_pos, fov, view_matrix, projection_matrix, render_mas
     return rgb, depth, normal, opacity, d2n, confidence, importance, count, radii
 
 
+# ---- the forward-only views of a renderer as ONE set of launches.  The planners build one renderer for ~100 candidate
+# poses and call render_view(i) per candidate under no_grad (/root/reference/planning/confidence.py:24-46,
+# exploration.py:24-44); evaluation, mesh extraction and the prune pass loop over views the same way.  One 128x128 view
+# is 64 tiles - it cannot fill 256 CUs, and a launch set per view is host-bound besides (100 views one by one: 22 ms;
+# as one batch: 1.5 ms).  The workspaces of a batch are the big allocation; they are kept (module level, a few entries)
+# and re-bound to the next renderer's map, the OUTPUT images belong to the renderer that asked for them.
+_BATCH_POOL = {}
+_BATCH_POOL_MAX = 3
+BATCH_BYTES_BUDGET = 12 << 30        # views per batched launch set are limited so that their workspaces stay below this
+
+
+def _pooled_view_batch(g, key, V, h, w, tanx, tany, bg, cap, want_stats, front_only, has_mask, mode):
+    from . import raster_api as api
+    vb = _BATCH_POOL.get(key)
+    if vb is not None and (vb.capacity_n < g.n or vb.max_instances < cap or vb.binning_mode != mode):
+        _BATCH_POOL.pop(key)
+        vb = None                       # release before the larger one is made
+    if vb is None:
+        while len(_BATCH_POOL) >= _BATCH_POOL_MAX:
+            _BATCH_POOL.pop(next(iter(_BATCH_POOL)))
+        masks = torch.zeros(V, h, w, device=g.means3D.device) if has_mask else None
+        vb = api.ViewBatch(g, V, h, w, tanx, tany, bg, cap, want_stats=want_stats, front_only=front_only,
+                           render_masks=masks, binning_mode=mode, capacity_n=max(int(1.5 * g.n) + 4096, 1 << 16))
+        _BATCH_POOL[key] = vb
+    else:
+        _BATCH_POOL[key] = _BATCH_POOL.pop(key)       # most recently used last
+        vb.bind(g)
+        vb.cam.bg = bg
+    return vb
+
+
 class SurfelRenderer:
+    """``GaussianRenderer`` (/root/reference/utils/operations.py:723-904): same constructor, same ``render_view`` /
+    ``render_view_all`` / ``update_attr``, same 9-tuples.  Two things differ underneath, neither visible in the results:
+
+    * passes WITHOUT grad (planners, evaluation, mesh, GUI, the count render of post-processing) of a renderer whose views
+      share one field of view are rendered as one batch the first time one of them is asked for (``ViewBatch``:
+      blockIdx.y = view) and served from it afterwards; ``update_attr`` forgets the batch;
+    * passes WITH grad go view by view through the drop-in module with its workspace checks deferred to ONE wait per
+      batch of views (``rasterizer.deferred_status``); a view that outgrew its workspace makes the loop run again with
+      the size just learnt - the caller never sees truncated tile lists or an exception.
+    A module injected by the caller (``rasterizer_module``: the CPU tests' adapter over the oracle) takes neither path."""
+
     def __init__(self, extrinsics, intrinsics, gaussians_attr, background_color, near_far, resolution, device,
                  render_masks=None, rasterizer_module=None):
+        self._own_module = rasterizer_module is None
         self.module = rasterizer_module if rasterizer_module is not None else _default_module()
         self.device = device
         (self.gaussian_means, self.gaussian_harmonics, self.gaussian_opacities, self.gaussian_confidences,
@@ -148,6 +191,8 @@ class SurfelRenderer:
         self.fovs = 2.0 * torch.atan(cm["tanfov"])
         self._tan_host = [(float(a), float(b)) for a, b in (0.5 * self.fovs).tan().cpu().tolist()]   # one read-back per batch
         self._configs = {}
+        self._batched = {}           # (require_importance, front_only) -> batched outputs of all views
+        self._has_masks = render_masks is not None
         if render_masks is None:
             self.render_masks = [torch.tensor([], device=device) for _ in range(self.batch_size)]
         else:
@@ -156,6 +201,7 @@ class SurfelRenderer:
     def update_attr(self, gaussians_attr):
         (self.gaussian_means, self.gaussian_harmonics, self.gaussian_opacities, self.gaussian_confidences,
          self.gaussian_scales, self.gaussian_rotations) = gaussians_attr
+        self._batched = {}
 
     def _core(self, i, front_only, require_importance):
         key = (bool(require_importance), bool(front_only))
@@ -169,13 +215,103 @@ class SurfelRenderer:
                            self.gaussian_rotations, front_only=front_only, require_importance=require_importance,
                            tan_fov_host=self._tan_host[i], config=self._configs[key])
 
+    # ---- forward-only views as one batch
+    def _batchable(self) -> bool:
+        if not self._own_module or self.batch_size < 2 or not self.gaussian_means.is_cuda or len(self.gaussian_means) == 0:
+            return False
+        t0 = self._tan_host[0]
+        return all(abs(t[0] - t0[0]) <= 1e-7 * abs(t0[0]) and abs(t[1] - t0[1]) <= 1e-7 * abs(t0[1]) for t in self._tan_host)
+
+    def _render_batch(self, require_importance, front_only):
+        """All views of this renderer, forward only, in chunks of as many views as BATCH_BYTES_BUDGET allows; returns
+        the batched outputs (rgb, normal_raw, depth, opacity, confidence, importance, count, radii) of ALL views, owned by
+        this renderer.  One wait per chunk (the views' status blocks): a chunk whose views outgrew their workspaces is
+        rendered again with the capacity just learnt."""
+        from . import raster_api as api
+        dev = self.gaussian_means.device
+        n, V, h, w = len(self.gaussian_means), self.batch_size, self.h, self.w
+        f32 = lambda t: t.detach().float().contiguous()
+        g = api.Gaussians(f32(self.gaussian_means), f32(self.gaussian_scales), f32(self.gaussian_rotations),
+                          f32(self.gaussian_opacities).reshape(-1), f32(self.gaussian_harmonics[:, 0, :]),
+                          f32(self.gaussian_confidences).reshape(-1))
+        tanx, tany = self._tan_host[0]
+        bg = f32(self.background_color.to(dev))
+        masks = None
+        if self._has_masks:
+            masks = f32(torch.stack([m.to(dev).reshape(h, w) for m in self.render_masks]) if not torch.is_tensor(self.render_masks)
+                        else self.render_masks.to(dev).reshape(V, h, w))
+        st = getattr(SurfelRenderer, "_batch_caps", None)
+        if st is None:
+            st = SurfelRenderer._batch_caps = {}
+        ckey = (dev.index, h, w)
+        cap, mode = st.get(ckey, (max(1 << 16, 2 * n), api.BIN_DIRECT))
+        cap = max(cap, 1 << 16, 2 * n)
+        o = dict(device=dev, dtype=torch.float32)
+        out = dict(rgb=torch.empty(V, 3, h, w, **o), normal=torch.empty(V, 3, h, w, **o), depth=torch.empty(V, 1, h, w, **o),
+                   opacity=torch.empty(V, 1, h, w, **o), confidence=torch.empty(V, 1, h, w, **o),
+                   importance=torch.zeros(V, n, **o), count=torch.zeros(V, n, device=dev, dtype=torch.int32),
+                   radii=torch.empty(V, n, device=dev, dtype=torch.int32))
+        v0 = 0
+        while v0 < V:
+            per = api.workspace_bytes(max(int(1.5 * n) + 4096, 1 << 16), h, w, cap)
+            CH = int(max(1, min(V - v0, BATCH_BYTES_BUDGET // max(per, 1))))
+            CH = min(CH, 65535)
+            key = (dev.index, CH, h, w, round(tanx, 7), round(tany, 7), bool(require_importance), bool(front_only),
+                   masks is not None)
+            vb = _pooled_view_batch(g, key, CH, h, w, tanx, tany, bg, cap, bool(require_importance), bool(front_only),
+                                    masks is not None, mode)
+            cnt = min(CH, V - v0)
+            vb.viewmats[:cnt] = self.view_matrices[v0:v0 + cnt]
+            vb.projmats[:cnt] = self.projection_matrices[v0:v0 + cnt]
+            if masks is not None:
+                vb.masks[:cnt] = masks[v0:v0 + cnt]
+            vb.forward(cnt)
+            stw = vb.statuses(cnt)                         # the one wait of the chunk
+            need, inst = int(stw[:, 7].max()), int(stw[:, 0].max())
+            if need > vb.max_instances:
+                # one-pass binning needs tiles x the LONGEST tile list; badly skewed lists go on with the scan-based
+                # binning, which needs the instance total (same images) - the rule of FusedMapTrainer._grow_cap
+                if mode == api.BIN_DIRECT and need > 8 * max(inst, 1 << 16) and need * 24 > (1 << 30):
+                    mode, need = api.BIN_TILE_SORT, inst
+                cap = min(max(int(need * 1.5) + 4096, cap + 1), 0xFFFFFFFF)
+                st[ckey] = (cap, mode)
+                _BATCH_POOL.pop(key, None)
+                continue
+            st[ckey] = (max(cap, vb.max_instances), mode)
+            for name in ("rgb", "normal", "depth", "opacity", "confidence"):
+                out[name][v0:v0 + cnt] = getattr(vb, name)[:cnt]
+            out["radii"][v0:v0 + cnt] = vb.radii[:cnt]
+            if require_importance:
+                out["importance"][v0:v0 + cnt] = vb.importance[:cnt]
+                out["count"][v0:v0 + cnt] = vb.count[:cnt]
+            v0 += cnt
+        return out
+
+    def _batched_view(self, i, require_importance, front_only):
+        key = (bool(require_importance), bool(front_only))
+        b = self._batched.get(key)
+        if b is None:
+            b = self._batched[key] = dict(raw=self._render_batch(*key), views={})
+        v = b["views"].get(i)
+        if v is None:
+            r = b["raw"]
+            normal, d2n = _FacadePost.apply(r["normal"][i], r["depth"][i], r["opacity"][i], *self._tan_host[i])
+            v = b["views"][i] = (r["rgb"][i], r["depth"][i], normal, r["opacity"][i], d2n, r["confidence"][i],
+                                 r["importance"][i], r["count"][i], r["radii"][i])
+        return v
+
     def render_view(self, i=0, require_grad=False, require_importance=False, front_only=False):
+        if not require_grad and self._batchable():
+            with torch.no_grad():
+                rgb, depth, normal, opacity, d2n, confidence, importance, count, radii = self._batched_view(
+                    i, require_importance, front_only)
+            return rgb, depth, normal, opacity, d2n, confidence, importance, count, radii > 0
         with torch.set_grad_enabled(require_grad):
             rgb, depth, normal, opacity, d2n, confidence, importance, count, radii = self._core(
                 i, front_only, require_importance)
         return rgb, depth, normal, opacity, d2n, confidence, importance, count, radii > 0
 
-    def render_view_all(self, require_grad=False, require_importance=False, front_only=False):
+    def _loop_views(self, require_grad, require_importance, front_only):
         per_view = []
         radii_sum = torch.zeros(len(self.gaussian_means), device=self.device, dtype=torch.int32)
         with torch.set_grad_enabled(require_grad):
@@ -183,6 +319,28 @@ class SurfelRenderer:
                 out = self._core(i, front_only, require_importance)
                 per_view.append(out[:8])
                 radii_sum = radii_sum + out[8].to(radii_sum.device)
+        return per_view, radii_sum
+
+    def render_view_all(self, require_grad=False, require_importance=False, front_only=False):
+        if not require_grad and self._batchable():
+            with torch.no_grad():
+                per_view = [self._batched_view(i, require_importance, front_only) for i in range(self.batch_size)]
+                radii_sum = self._batched[(bool(require_importance), bool(front_only))]["raw"]["radii"].sum(0, dtype=torch.int32)
+        elif self._own_module and self.gaussian_means.is_cuda:
+            # the module's workspace checks wait ONCE for the whole batch of views; a truncated view repeats the loop
+            from .rasterizer import deferred_status
+            for attempt in range(6):
+                with deferred_status() as d:
+                    per_view, radii_sum = self._loop_views(require_grad, require_importance, front_only)
+                    ok = d.settle()
+                if ok:
+                    break
+                del per_view, radii_sum
+            else:
+                raise RuntimeError("render_view_all: the rasterizer workspace kept overflowing after six enlargements: " +
+                                   "; ".join(d.reports))
+        else:
+            per_view, radii_sum = self._loop_views(require_grad, require_importance, front_only)
         stack = lambda k: torch.stack([v[k] for v in per_view], 0)
         return (stack(0), stack(1), stack(2), stack(3), stack(4), stack(5), stack(6), stack(7), radii_sum > 0)
 

@@ -56,6 +56,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         if self.device.type != "cuda":
             raise RuntimeError("FusedMapTrainer needs GPU tensors: there is no CPU fallback")
         self.binning_mode = binning_mode
+        self.tuning = None       # _lib.AgsTuning handed over with every workspace this trainer makes (None: process default)
         # hipGraph replay of the iteration (single rank): the launch sequence of an iteration is
         # fixed for a given batch shape; what changes (which frames) is staged into static
         # per-slot camera / ground-truth buffers by four index_select launches before the replay.
@@ -149,7 +150,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         st = self._states.get(slot)
         if (st is None or st.max_instances < self._cap or st.radii.shape[0] != n or st.rgb.shape[-2:] != (h, w)
                 or st.binning_mode != self.binning_mode):
-            st = api.alloc_state(n, h, w, self._cap, self.device, self.binning_mode)
+            st = api.alloc_state(n, h, w, self._cap, self.device, self.binning_mode, tuning=self.tuning)
             self._states[slot] = st
         return st
 
@@ -425,7 +426,7 @@ class FusedMapTrainer(GaussianMapTrainer):
                     self._count_batch = None            # release before the larger one is made
                     batch = api.ViewBatch(g, CH, h, w, cam0.tanfovx, cam0.tanfovy, self.background, self._cap,
                                           want_stats=True, front_only=True, render_masks=torch.zeros(CH, h, w, device=self.device),
-                                          binning_mode=self.binning_mode, capacity_n=max(2 * n, 1 << 16))
+                                          binning_mode=self.binning_mode, capacity_n=max(2 * n, 1 << 16), tuning=self.tuning)
                     batch._count_key = key
                     self._count_batch = batch
                 elif batch.g is not g:
@@ -662,7 +663,7 @@ class FusedMapTrainer(GaussianMapTrainer):
                     self._cap = max(self._cap, 4 * ncap)
                     state["batch"] = keep["batch"] = api.ViewBatch(
                         g, Bmax, h, w, cam0.tanfovx, cam0.tanfovy, self.background, self._cap,
-                        binning_mode=self.binning_mode, capacity_n=ncap)
+                        binning_mode=self.binning_mode, capacity_n=ncap, tuning=self.tuning)
                 iteration(losses[it:it + 1])
                 if self.use_graph and total >= self.graph_min_steps and it + 1 < total:
                     # for a given batch size the iteration is a fixed launch sequence: record it once

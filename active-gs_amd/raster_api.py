@@ -107,6 +107,7 @@ class ForwardState:
     workspace: torch.Tensor
     max_instances: int
     binning_mode: int = 2  # AGS_BIN_DIRECT (default) | 0 = AGS_BIN_TILE_SORT | 1 = AGS_BIN_RADIX
+    tuning: Optional["_lib.AgsTuning"] = None   # kernel selection handed over with the workspace (None: the process default)
 
     def images_struct(self) -> _lib.AgsImages:
         return _lib.AgsImages(ptr(self.rgb), ptr(self.normal), ptr(self.depth), ptr(self.opacity), ptr(self.confidence))
@@ -115,8 +116,8 @@ class ForwardState:
         return _lib.AgsPerGaussian(ptr(self.importance), ptr(self.count), ptr(self.radii), _rowset_struct(touched))
 
     def ws_struct(self) -> _lib.AgsWorkspace:
-        return _lib.AgsWorkspace(ptr(self.workspace), self.workspace.numel(), self.max_instances,
-                                 int(self.binning_mode))
+        return _lib.workspace(ptr(self.workspace), self.workspace.numel(), self.max_instances,
+                              int(self.binning_mode), self.tuning)
 
 
 def _require_cuda(t: torch.Tensor, name: str) -> None:
@@ -173,7 +174,8 @@ def last_contributor(state: "ForwardState", n: int, h: int, w: int) -> torch.Ten
     return torch.where(last > 0, ids[pos.clamp_max(ids.numel() - 1)], torch.full_like(last, -1))
 
 
-def alloc_state(n: int, h: int, w: int, max_instances: int, device, binning_mode: int = BIN_DIRECT) -> ForwardState:
+def alloc_state(n: int, h: int, w: int, max_instances: int, device, binning_mode: int = BIN_DIRECT,
+                tuning: Optional["_lib.AgsTuning"] = None) -> ForwardState:
     """Buffers + workspace for views of one size.  ``max_instances``: key slots of the workspace; what a view needs is
     ``read_status(state)["needed"]`` (mode-aware: total tile instances for the scan-based modes, tiles x longest
     tile list for ``BIN_DIRECT``, whose tiles own ``max_instances // tiles`` slots each)."""
@@ -184,7 +186,7 @@ def alloc_state(n: int, h: int, w: int, max_instances: int, device, binning_mode
         importance=torch.zeros(n, **f), count=torch.zeros(n, device=device, dtype=torch.int32),
         radii=torch.empty(n, device=device, dtype=torch.int32),
         workspace=torch.empty(workspace_bytes(n, h, w, max_instances), device=device, dtype=torch.uint8),
-        max_instances=int(max_instances), binning_mode=int(binning_mode))
+        max_instances=int(max_instances), binning_mode=int(binning_mode), tuning=tuning)
     ws = st.ws_struct()
     _lib.check(_lib.load().ags_workspace_init(C.byref(ws), n, h, w, _stream()), "ags_workspace_init")
     return st
@@ -204,7 +206,7 @@ def discard_pass(state: ForwardState, n: int, h: int, w: int) -> None:
 
 
 def alloc_outputs(n: int, h: int, w: int, device, workspace: torch.Tensor, max_instances: int,
-                  binning_mode: int = BIN_DIRECT, stats: bool = True) -> ForwardState:
+                  binning_mode: int = BIN_DIRECT, stats: bool = True, tuning: Optional["_lib.AgsTuning"] = None) -> ForwardState:
     """Fresh output tensors around an existing (initialised) workspace - what the drop-in module hands to its caller
     per call while the workspace itself is pooled."""
     f = dict(device=device, dtype=torch.float32)
@@ -213,7 +215,7 @@ def alloc_outputs(n: int, h: int, w: int, device, workspace: torch.Tensor, max_i
         opacity=torch.empty(1, h, w, **f), confidence=torch.empty(1, h, w, **f),
         importance=torch.zeros(n, **f), count=torch.zeros(n, device=device, dtype=torch.int32),
         radii=torch.empty(n, device=device, dtype=torch.int32), workspace=workspace,
-        max_instances=int(max_instances), binning_mode=int(binning_mode))
+        max_instances=int(max_instances), binning_mode=int(binning_mode), tuning=tuning)
 
 
 def forward(cam: Camera, g: Gaussians, state: ForwardState, stream: Optional[int] = None, checked: bool = False,
@@ -432,7 +434,9 @@ class ViewBatch:
     def __init__(self, g: Gaussians, num_views: int, height: int, width: int, tanfovx: float, tanfovy: float,
                  bg: torch.Tensor, max_instances: int, num_streams: int = 8, want_stats: bool = False,
                  front_only: bool = False, render_masks: Optional[torch.Tensor] = None,
-                 binning_mode: int = BIN_DIRECT, mode: str = "batched", capacity_n: Optional[int] = None):
+                 binning_mode: int = BIN_DIRECT, mode: str = "batched", capacity_n: Optional[int] = None,
+                 tuning: Optional["_lib.AgsTuning"] = None):
+        self.tuning = tuning
         if mode not in ("batched", "streams"):
             raise ValueError("mode is 'batched' or 'streams'")
         dev = g.means3D.device
@@ -478,15 +482,15 @@ class ViewBatch:
         self.radii = self._radii[:V * n].view(V, n)
         self.states = [ForwardState(self.rgb[v], self.normal[v], self.depth[v], self.opacity[v], self.confidence[v],
                                     self.importance[v], self.count[v], self.radii[v],
-                                    self.workspace[v * per:(v + 1) * per], self.max_instances, self.binning_mode)
+                                    self.workspace[v * per:(v + 1) * per], self.max_instances, self.binning_mode, self.tuning)
                        for v in range(V)]
-        ws = _lib.AgsWorkspace(ptr(self.workspace), V * per, self.max_instances, self.binning_mode)
+        ws = _lib.workspace(ptr(self.workspace), V * per, self.max_instances, self.binning_mode, self.tuning)
         _lib.check(_lib.load().ags_workspace_init_batch(C.byref(ws), V, n, h, w, _stream()), "ags_workspace_init_batch")
 
     def _structs(self, touched=None):
         im = _lib.AgsImages(ptr(self.rgb), ptr(self.normal), ptr(self.depth), ptr(self.opacity), ptr(self.confidence))
         pg = _lib.AgsPerGaussian(ptr(self.importance), ptr(self.count), ptr(self.radii), _rowset_struct(touched))
-        ws = _lib.AgsWorkspace(ptr(self.workspace), self.workspace.numel(), self.max_instances, self.binning_mode)
+        ws = _lib.workspace(ptr(self.workspace), self.workspace.numel(), self.max_instances, self.binning_mode, self.tuning)
         return im, pg, ws
 
     def _enqueue_batched(self, views: Optional[int] = None, touched: Optional[RowSet] = None) -> None:

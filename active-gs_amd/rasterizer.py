@@ -92,10 +92,17 @@ def _load_binding():
     spec.loader.exec_module(mod)
     _lib.load()                                  # the ctypes handle of the same file: fails loudly if the library is absent
     mod.init(_lib.library_path())
-    # AGS_DROPIN_STATUS=always: read the status block back after every forward pass (one stream synchronisation per
-    # view, what the CUDA extension's num_rendered read-back costs); default: deferred (see torch_binding.cpp)
-    if os.environ.get("AGS_DROPIN_STATUS", "deferred") == "always":
-        mod.set_option("always_check", 1.0)
+    # Default: every call reads its status block back before it returns and repairs an outgrown workspace on the spot
+    # (one stream synchronisation per view - what the CUDA extension's num_rendered read-back costs): an unmodified
+    # caller never sees truncated tile lists.  AGS_DROPIN_STATUS=deferred: checks one call late, for loops that call
+    # check_overflow() every iteration (see torch_binding.cpp); deferred_status() does the same for one block of code.
+    mode = os.environ.get("AGS_DROPIN_STATUS", "always")
+    if mode not in ("always", "deferred"):
+        raise ValueError(f"AGS_DROPIN_STATUS={mode!r}: 'always' (default) or 'deferred'")
+    mod.set_option("always_check", 0.0 if mode == "deferred" else 1.0)
+    # the library reads no environment variable: this binding hands it the process's kernel selection (AgsTuning)
+    t = _lib.default_tuning()
+    mod.set_tuning(t.bwd_reduce, t.render_slots, t.cull_first_min_n, t.tile_sort_no_wave, t.bucket_no_scan)
     _binding = mod
     return mod
 
@@ -127,10 +134,49 @@ def reset_state() -> None:
 
 
 def check_overflow() -> None:
-    """Wait for the status copies of all forward passes issued so far and raise if one of them outgrew its workspace.
-    A training loop calls this where it synchronises anyway (e.g. once per iteration); without it the NEXT module call
-    raises."""
+    """Deferred checks only (AGS_DROPIN_STATUS=deferred / set_option("always_check", 0)): wait for the status copies of
+    all forward passes issued so far and raise if one of them outgrew its workspace.  A training loop calls this where
+    it synchronises anyway (e.g. once per iteration); without it the NEXT module call raises.  With the default
+    (every call checked and repaired before it returns) there is never anything to report."""
     _load_binding().check_overflow()
+
+
+def set_tuning(tuning: "_lib.AgsTuning") -> None:
+    """The kernel selection the module hands to the library with every workspace (default: _lib.default_tuning())."""
+    _load_binding().set_tuning(tuning.bwd_reduce, tuning.render_slots, tuning.cull_first_min_n, tuning.tile_sort_no_wave,
+                               tuning.bucket_no_scan)
+
+
+import threading as _threading
+
+_tls = _threading.local()
+
+
+class deferred_status:
+    """``with deferred_status() as d: ... module calls ...; ok = d.settle()`` - inside the block (this thread) the
+    module's calls do not wait for their status blocks; ``d.settle()`` waits once for all of them and returns True when
+    every pass fitted its workspace.  False: at least one pass of the block was truncated - the sizes have been raised,
+    REPEAT the block's passes (facade.SurfelRenderer does exactly that around its view loops: one wait per batch of views
+    instead of one per view, and no exception reaches its caller).  A block that ends without having settled is settled
+    then, and raises if a pass was truncated."""
+
+    def __enter__(self):
+        self._outer = getattr(_tls, "deferred", False)
+        _tls.deferred = True
+        self.reports, self._settled = [], False
+        return self
+
+    def settle(self) -> bool:
+        self.reports = list(_load_binding().settle())
+        self._settled = True
+        return not self.reports
+
+    def __exit__(self, exc_type, exc, tb):
+        _tls.deferred = self._outer
+        if exc_type is None and not self._settled and not self.settle():
+            raise RuntimeError("diff_gaussian_rasterization_2d: " + "; ".join(self.reports) + ": the tile lists of that pass "
+                               "were truncated - repeat the block's passes (the workspace size has been raised)")
+        return False
 
 
 _EMPTY = {}
@@ -151,6 +197,9 @@ class GaussianRasterizer(nn.Module):
     def forward(self, means3D, means2D, opacities, confidences, shs=None, colors_precomp=None, scales=None,
                 rotations=None, cov3D_precomp=None):
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            # (this and the next message are the upstream package's own strings, typo included - typed from memory of
+            #  the public diff-gaussian-rasterization Python shim, which is not on this filesystem - so that a caller
+            #  matching on them behaves the same)
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
         if ((scales is None or rotations is None) and cov3D_precomp is None) or (
                 (scales is not None or rotations is not None) and cov3D_precomp is not None):
@@ -177,7 +226,8 @@ class GaussianRasterizer(nn.Module):
             means2D = none
         return tuple(b.rasterize(means3D, means2D, opacities, confidences, colors_precomp, scales, rotations, s.bg,
                                  s.viewmatrix, s.projmatrix, mask, cfg, int(s.image_height), int(s.image_width),
-                                 float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), float(s.weight_thres)))
+                                 float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), float(s.weight_thres),
+                                 getattr(_tls, "deferred", False)))
 
     # (nn.Module.__call__ goes through the hook machinery: ~3 us per call that this module has no use for)
     __call__ = forward

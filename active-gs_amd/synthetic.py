@@ -119,3 +119,91 @@ def make_camera(view: int, height: int, width: int, focal_px: float | None = Non
         focal_px = 0.5 * width  # 90 deg horizontal, as 600 px at 1200x680
     K = torch.tensor([[focal_px / width, 0, 0.5], [0, focal_px / height, 0.5], [0, 0, 1.0]], dtype=torch.float32)
     return c2w, K
+
+
+def make_keyframes(count: int, height: int, width: int, device, gt_surfels: int = 400_000, room: str = "office0"):
+    """``count`` RGB-D keyframes of the room stand-in as the simulator would hand them to ``GaussianMap.update``
+    (/root/reference/mapping/mapper.py:95-101: dict of ``rgb (3,H,W)``, ``depth (1,H,W)``, ``extrinsic (4,4)`` camera-to-world,
+    ``intrinsic (3,3)`` normalised, ``depth_range (2,)``), rendered from a dense, opaque ground-truth surfel room with this
+    library's own rasterizer (Replica / habitat are not available offline).  GPU only."""
+    from . import raster_api as api
+    from .camera import camera_matrices
+    dev = torch.device(device)
+    gt = {k: v.to(dev) for k, v in make_room_scene(gt_surfels, room=room, seed=0).items()}
+    gt["scales"][:, :2] += 0.6                       # dense coverage: the ground truth is a closed room
+    gt["opacities"] += 4.0
+    a = activate(gt)
+    g = api.Gaussians(a["means"], a["scales"], a["rotations"], a["opacities"], gt["harmonics"].view(-1, 3).contiguous(),
+                      a["confidences"])
+    st = api.alloc_state(gt_surfels, height, width, 1 << 24, dev)
+    frames = []
+    for v in range(count):
+        c2w, K = make_camera(v, height, width, room=room)
+        cm = camera_matrices(c2w[None].to(dev), K[None].to(dev), 0.001, 10.0)
+        tan = cm["tanfov"][0].cpu()
+        cam = api.Camera(height, width, float(tan[0]), float(tan[1]), cm["viewmatrix"][0].contiguous(),
+                         cm["projmatrix"][0].contiguous(), torch.zeros(4, device=dev))
+        api.forward(cam, g, st)
+        if api.read_status(st)["overflow"]:
+            raise RuntimeError("make_keyframes: the ground-truth render outgrew its workspace")
+        depth = torch.where(st.opacity > 0.5, st.depth, torch.zeros_like(st.depth))
+        frames.append(dict(rgb=st.rgb.clone().clamp(0, 1), depth=depth.clone(), extrinsic=c2w.to(dev),
+                           intrinsic=K.to(dev), depth_range=torch.tensor([0.001, 10.0], device=dev)))
+    return frames
+
+
+def mapper_cfg(optimization_steps: int = 10, draw: str = "device"):
+    """config/mapper/incremental.yaml:12-32 (``cfg.gaussian_map`` of the reference's mapper) as an attribute-style object."""
+    from types import SimpleNamespace as NS
+    return NS(bound=[0.001, 10.0], background=[0.0, 0.0, 0.0, 0.0], sparse_ratio=0.1, error_thres=0.25, scale_factor=0.01,
+              optimization_steps=optimization_steps, prune_interval=5, use_view_distribution=True,
+              sampler=NS(sampler_type="weighted", batch_size=8, active_size=3, draw=draw),
+              optimizer=NS(mean_lr=0.0005, rotation_lr=0.0005, opacity_lr=0.01, scale_lr=0.01, harmonic_lr=0.0001))
+
+
+def run_mapper_loop(frames, steps: int = 10, draw: str = "device", warmup_frames: int = 2, split: bool = False):
+    """BASELINE.json configuration 3: what /root/reference/mapping/mapper.py:98-104 does per keyframe -
+    ``gaussian_map.update(dataframe)`` - from an EMPTY map over ``frames``, through the drop-in ``GaussianMap`` class.
+    ``warmup_frames`` keyframes first go through a scratch map so that every kernel module is loaded before the timed
+    loop.  ``split``: synchronise around growth and training to report them separately (two more waits per keyframe).
+    -> dict(seconds, iterations, ms_per_iteration, final_surfels, ...)."""
+    import time
+    from .gaussian_map import GaussianMap
+    dev = frames[0]["rgb"].device
+    if warmup_frames:
+        warm = GaussianMap(mapper_cfg(steps, draw), dev)
+        for f in frames[:warmup_frames]:
+            warm.update(f)
+        del warm
+    torch.cuda.synchronize(dev)
+    gm = GaussianMap(mapper_cfg(steps, draw), dev)
+    ms0 = torch.cuda.memory_stats(dev)
+    t_grow = t_train = 0.0
+    sizes = []
+    t0 = time.perf_counter()
+    for f in frames:
+        if split:
+            torch.cuda.synchronize(dev); a = time.perf_counter()
+            gm.add_gaussians(f)
+            torch.cuda.synchronize(dev); b = time.perf_counter()
+            gm.train()
+            torch.cuda.synchronize(dev); c = time.perf_counter()
+            t_grow += b - a; t_train += c - b
+        else:
+            gm.update(f)
+        sizes.append(gm.get_means.shape[0])
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    iters = len(frames) * steps
+    h, w = frames[0]["rgb"].shape[-2:]
+    tr = gm._trainer
+    out = dict(workload=f"mapper loop through GaussianMap.update(): {len(frames)} keyframes x {steps} iterations @{h}x{w}, batch 8 with "
+                        f"3 active frames, prune every 5th keyframe, from an empty map",
+               frame_sampler=draw, iterations=iters, seconds=round(dt, 4), ms_per_iteration=round(1e3 * dt / iters, 4),
+               final_surfels=sizes[-1], surfels_after_10=sizes[min(9, len(sizes) - 1)],
+               mean_frame_error=round(float(gm.training_performance.mean()), 5), last_loss=round(tr.last_losses[-1], 5),
+               device_mallocs=int(torch.cuda.memory_stats(dev)["num_device_alloc"] - ms0["num_device_alloc"]),
+               overflow_retries=int(getattr(tr, "overflow_retries", 0)))
+    if split:
+        out.update(grow_ms_per_keyframe=round(1e3 * t_grow / len(frames), 3), train_ms_per_keyframe=round(1e3 * t_train / len(frames), 3))
+    return out

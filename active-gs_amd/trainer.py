@@ -154,8 +154,11 @@ class SurfelTrainer:
 
     def __init__(self, raw: dict, lrs: Optional[dict] = None, scale_factor: float = 0.01, max_scale: float = 0.05,
                  eps: float = 1e-15, process_group=None, binning_mode: int = api.BIN_DIRECT,
-                 fused_activations: bool = True, sparse_rows: bool = True):
+                 fused_activations: bool = True, sparse_rows: bool = True, tuning=None, view_streams: Optional[int] = None):
         from .optimizer import FusedAdam
+        if view_streams is not None:
+            self.VIEW_STREAMS = max(1, int(view_streams))
+        self.tuning = tuning     # _lib.AgsTuning handed over with every workspace this trainer makes (None: process default)
         lrs = {**DEFAULT_LRS, **(lrs or {})}
         self.raw = {k: v.contiguous() for k, v in raw.items()}
         dev = self.raw["means"].device
@@ -203,9 +206,12 @@ class SurfelTrainer:
         self._rows_hint = 0      # members of the row set when last looked at (+ slack): sizes the pipelined launch
 
     CHECK_EVERY = 16     # optimisation steps between two reads of the overflow notes (one 64-byte D2H each)
-    # views of a multi-view step run on this many streams (their launches overlap each other's ramps and tails: config 4's
-    # four 1200x680 views 1.82 -> 1.53 ms per step; 2: 1.57, 3: 1.54); AGS_VIEW_STREAMS overrides
-    VIEW_STREAMS = int(os.environ.get("AGS_VIEW_STREAMS", "4"))
+    # Views of a multi-view step can run on several streams (their launches overlap each other's ramps and tails: config 4's
+    # four 1200x680 views 1.82 -> 1.53 ms per step on 4 streams; 2: 1.57, 3: 1.54).  OPT-IN (``view_streams=`` / this
+    # attribute / AGS_VIEW_STREAMS): the caller's ``image_grads(v, st)`` then runs under the view's stream, so it must not
+    # share scratch buffers between views and must consume what it allocates on that stream - a callback written for the
+    # one-stream step (the default) need not know any of this.
+    VIEW_STREAMS = int(os.environ.get("AGS_VIEW_STREAMS", "1"))
     MULTI_VIEW_ROWS = True   # several views per step: one per-Gaussian backward launch for all of them (ags_backward_rows)
 
     def reset_optimizer(self) -> None:
@@ -246,7 +252,7 @@ class SurfelTrainer:
         key = (h, w, slot)
         st = self._state.get(key)
         if st is None or st.max_instances < max_instances or st.radii.shape[0] != self.n:
-            st = api.alloc_state(self.n, h, w, max_instances, self.device, self.binning_mode)
+            st = api.alloc_state(self.n, h, w, max_instances, self.device, self.binning_mode, tuning=self.tuning)
             self._state[key] = st
         return st
 
@@ -363,9 +369,9 @@ class SurfelTrainer:
         """``cams``: this rank's views. ``image_grads(view_index, state)`` returns the five
         image gradients (d_rgb, d_normal, d_depth, d_opacity, d_confidence; None = zero)
         for that view, already divided by the GLOBAL number of views where the loss is a
-        batch mean.  With several views per step it is called under the stream that view runs on
-        (``VIEW_STREAMS``): what it enqueues for different views may overlap, so it must not share
-        scratch buffers between views.  Asynchronous except for the collective and, every ``CHECK_EVERY`` steps, one small
+        batch mean.  With ``view_streams`` > 1 (opt-in) and several views per step it is called under the stream that
+        view runs on: what it enqueues for different views may overlap, so it must not share scratch buffers between
+        views.  Asynchronous except for the collective and, every ``CHECK_EVERY`` steps, one small
         read-back (``check_overflow``).  ``device_clock`` (default): the Adam step counter lives on the GPU,
         the same clock ``capture()`` replays on; False = the host-side counter of ``ags_adam_step``.
         ``next_cam`` (single rank): the first view of the NEXT step, its matrices already in place - this step's
@@ -557,6 +563,11 @@ class SurfelTrainer:
         self.optim.use_clock(True)
         dist_on = self._distributed()
         # (the pipelined kernel continues from the fused Adam update on raw parameters: _local_pass's own conditions)
+        if pipeline and len(cams) > 1 and self.rows is not None and self.MULTI_VIEW_ROWS:
+            import warnings
+            warnings.warn("SurfelTrainer.capture(pipeline=True) with several cameras: a multi-view step joins its views in one "
+                          "per-Gaussian launch (ags_backward_rows) and does not software-pipeline; recording the un-pipelined step")
+            pipeline = False
         pipeline = (pipeline and not dist_on and self.binning_mode == api.BIN_DIRECT and len(cams) > 0
                     and self.rows is not None and self.fused_activations)
         if pipeline:

@@ -10,7 +10,7 @@ Workload at every N: BASELINE.json configs[1] per GPU (office0 stand-in, 200k su
 Timing: after W warm-up steps the K steps are timed R times (R >= 21, >= 0.25 s in total), every sample bracketed
 by barrier + torch.cuda.synchronize() on both sides and the MAX taken over the ranks; `ms_per_step` / `value` are the
 MEDIAN sample, min / max are printed beside it.  Everything else in the line (stage times, the un-pipelined and the
-exact-f32 forms of the same step, the drop-in module's call path, the larger configurations, the CPU oracle) is
+bf16-split forms of the same step, the drop-in module's call path, the larger configurations, the CPU oracle) is
 measured AFTER that region and labelled.
 
 ``python bench.py --gpus N`` with N > 1 and no RANK in the environment launches the N ranks itself
@@ -36,9 +36,8 @@ H, W = 680, 1200
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PMC_HBM_FILE = "pmc_hbm_bytes.json"   # per-stage HBM bytes per launch of this command (rocprofv3 --pmc, committed)
 PMC_SQ_FILE = "sq_counters.json"      # per-stage SQ instruction counters per launch of this command
-DTYPE = ("f32 (the blend backward forms its 15 per-surfel sums on the bf16 matrix pipe from hi/lo splits of both "
-         "operands - hi.hi + lo.hi + hi.lo, f32 accumulate, every dropped term < 2^-16 of its product; "
-         "ms_per_step_f32_exact is the same step with exact f32 matrix instructions)")
+DTYPE = "f32"   # every stage computes in fp32, like the reference's extension (the blend backward's per-surfel sums run on
+                # exact f32 matrix instructions; the bf16 hi/lo-split form is an opt-in, timed as ms_per_step_bf16_split)
 
 
 def stage_bytes(N, V, I, P, T, rows=None, direct=True, fused_single_view=True, bwd_extra_images=0):
@@ -113,10 +112,13 @@ def read_stage_times(lib):
     return med, mean
 
 
-def measure_dropin(dev, n, h, w, views, iters=30, focal=None):
+def measure_dropin(dev, n, h, w, views, iters=30, focal=None, deferred=False):
     """The path an UNMODIFIED caller takes (operations.py:682-713, :854): ``GaussianRasterizer(settings)(...)`` per view
     under autograd + one backward through all of them - the module alone (no facade post-processing, no loss head,
-    no optimiser).  -> (ms per view, host synchronisations the module itself issued per view)."""
+    no optimiser).  ``deferred`` False: the module's default - every call reads its status block back and repairs an
+    outgrown workspace before it returns (what the CUDA extension's num_rendered read-back does; safe for a caller that
+    has no retry).  True: the opt-in for loops that settle once per iteration (``check_overflow()`` after the backward,
+    inside the timed loop).  -> (ms per view, host synchronisations the module itself issued per view)."""
     from active_gs_amd.camera import camera_matrices
     from active_gs_amd.synthetic import activate, make_camera, make_room_scene
     import active_gs_amd.rasterizer as R
@@ -145,20 +147,28 @@ def measure_dropin(dev, n, h, w, views, iters=30, focal=None):
         for t in leaves:
             t.grad = None
 
-    for _ in range(3):
-        iteration()
-    torch.cuda.synchronize()
-    check_overflow()
-    syncs0 = R.counters()["status_syncs"]
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        iteration()
-    host_s = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    check_overflow()
+    was = R.get_option("always_check")
+    R.set_option("always_check", 0.0 if deferred else 1.0)
+    try:
+        for _ in range(3):
+            iteration()
+        torch.cuda.synchronize()
+        check_overflow()
+        syncs0 = R.counters()["status_syncs"]
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            iteration()
+            if deferred:
+                check_overflow()          # one wait per iteration for the views' status copies (they have long landed)
+        host_s = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        check_overflow()
+    finally:
+        R.set_option("always_check", was)
     return dict(ms_per_view=dt / (iters * views) * 1e3, host_enqueue_ms_per_view=host_s / (iters * views) * 1e3,
-                module_syncs_per_view=(R.counters()["status_syncs"] - syncs0) / (iters * views))
+                module_syncs_per_view=(R.counters()["status_syncs"] - syncs0) / (iters * views),
+                workspace_checks="deferred, settled once per iteration (opt-in)" if deferred else "every call, before it returns (default)")
 
 
 def measure_config(tag, n, h, w, views, room, steps, dev, lrs=None, binning_mode=None):
@@ -170,7 +180,9 @@ def measure_config(tag, n, h, w, views, room, steps, dev, lrs=None, binning_mode
     from active_gs_amd.trainer import SurfelTrainer
     lib = _lib.load()
     raw = {k: v.to(dev) for k, v in make_room_scene(n, room=room, seed=0).items()}
-    trainer = SurfelTrainer(raw, lrs=lrs, binning_mode=api.BIN_DIRECT if binning_mode is None else binning_mode)
+    # (the views of a step on four streams: this bench's image_grads hands out fixed tensors - nothing shared, nothing allocated)
+    trainer = SurfelTrainer(raw, lrs=lrs, binning_mode=api.BIN_DIRECT if binning_mode is None else binning_mode,
+                            view_streams=int(os.environ.get("AGS_VIEW_STREAMS", "4")))
     cams = []
     for v in range(views):
         c2w, K = make_camera(v, h, w)
@@ -238,6 +250,36 @@ def measure_config(tag, n, h, w, views, room, steps, dev, lrs=None, binning_mode
     return out
 
 
+def measure_c3(dev):
+    """BASELINE.json configs[2]: "full mapper loop (densify/prune + Adam), 1 MI355X, 500 iters" - 50 keyframes x 10
+    iterations from an empty map through ``active_gs_amd.gaussian_map.GaussianMap.update`` (the class an untouched
+    mapping.Mapper constructs and calls), frames rendered from the room stand-in.  The fraction of the loop during which
+    kernels run comes from a committed rocprofv3 kernel trace of examples/mapper_loop.py (it cannot be collected from
+    inside this process) and is labelled as such."""
+    from active_gs_amd.synthetic import make_keyframes, run_mapper_loop
+    res = {}
+    for tag, (h, w) in (("512x512", (512, 512)), ("1200x680", (680, 1200))):
+        frames = make_keyframes(50, h, w, dev)
+        r = run_mapper_loop(frames, steps=10, draw="device", warmup_frames=2)
+        res[tag] = dict(seconds=r["seconds"], ms_per_iteration=r["ms_per_iteration"], final_surfels=r["final_surfels"],
+                        iterations=r["iterations"], mean_frame_error=r["mean_frame_error"], overflow_retries=r["overflow_retries"],
+                        device_mallocs=r["device_mallocs"])
+        del frames
+        torch.cuda.empty_cache()
+    busy = None
+    try:
+        kb = json.load(open(os.path.join(ROOT, "profiles", "c3_kernels_busy.json")))
+        busy = dict(kernels_busy_frac=kb.get("kernels_busy_frac"), source=f"profiles/c3_kernels_busy.json (rocprofv3 --kernel-trace of "
+                    f"examples/mapper_loop.py, session {kb.get('_session', '?')}; not collected in this run)")
+    except Exception:
+        pass
+    return dict(seconds=res["512x512"]["seconds"], ms_per_iteration=res["512x512"]["ms_per_iteration"],
+                final_surfels=res["512x512"]["final_surfels"], kernels_busy=busy, **res,
+                what="GaussianMap(cfg, device).update(dataframe) x 50 keyframes (10 iterations each, batch 8 with 3 active frames, "
+                     "prune every 5th keyframe) from an empty map, after two warm-up keyframes on a scratch map; the error-weighted "
+                     "frame draw on the device (the same distribution as the reference's np.random.choice)")
+
+
 def cpu_baseline(raw_cpu, cam_cpu, d_img_cpu, gpu_check, budget_s=15.0, max_threads=16):
     """The oracle (oracle/surfel_oracle.py, PyTorch CPU, fp32) timed on this host: the full
     per-Gaussian stage + binning of the same view, then fwd+bwd of strided batches of tiles
@@ -287,7 +329,7 @@ def cpu_baseline(raw_cpu, cam_cpu, d_img_cpu, gpu_check, budget_s=15.0, max_thre
     est = t_pre + t_tiles * len(nonempty) / max(done, 1)
     base = {"value": N_GAUSS / est, "unit": "Gaussians/s", "cores": cores, "kind": "port",
             "sample": f"oracle (PyTorch CPU fp32, {cores} threads): full preprocess+binning of the 200k-surfel "
-                      f"1200x680 view ({t_pre:.1f}s) + fwd+bwd of {done} of {len(nonempty)} non-empty tiles "
+                      f"1200x680 view ({t_pre:.2f}s) + fwd+bwd of {done} of {len(nonempty)} non-empty tiles "
                       f"({t_tiles:.1f}s), extrapolated to all tiles"}
     # ---- parity of the HIP path against what the oracle just computed (checker role only)
     gpu_images, gpu_grads, gpu_radii = gpu_check(covered)
@@ -366,8 +408,8 @@ def main():
     ap.add_argument("--samples", type=int, default=0, help="timed samples of --steps steps each (0 = automatic: >= 21, >= 0.25 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip what is measured after the timed region besides the stage times: un-pipelined / exact-f32 forms, "
-                         "the drop-in module's call path, configurations 4 and 5")
+                    help="skip what is measured after the timed region besides the stage times: pipelined / bf16-split forms, "
+                         "the drop-in module's call path, configurations 3, 4 and 5")
     ap.add_argument("--binning", choices=["direct", "tile_sort", "radix"], default="direct")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--pipeline", action="store_true",
@@ -728,37 +770,57 @@ def main():
         if valu is not None:
             out["roofline_valu"] = valu
         if not dist_on and not args.no_extras and not args.eager:
-            # -- the same step with the blend backward's per-surfel sums in exact f32 (a second build of the library,
-            #    loaded by a CHILD process through AGS_LIB_PATH; this process keeps the GPU, the child runs beside it)
+            # -- the same step with the blend backward's per-surfel sums on the bf16 matrix pipe (hi/lo splits, f32
+            #    accumulation: AgsTuning.bwd_reduce = AGS_BWD_BF16_SPLIT, an opt-in per workspace) - same process, same
+            #    library, a second trainer on a fresh copy of the scene, sampled like the headline
             try:
-                import subprocess
-                from active_gs_amd import build as B
-                env = dict(os.environ, AGS_LIB_PATH=B.LIB_F32)
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
-                                    "--no-cpu-baseline", "--no-extras"] + (["--pipeline"] if pipe else []),
-                                   env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                out["ms_per_step_f32_exact"] = json.loads(line[-1])["ms_per_step"] if (r.returncode == 0 and line) else None
-                if out["ms_per_step_f32_exact"] is None:
-                    out["f32_exact_note"] = (r.stderr or "")[-300:]
+                t2 = SurfelTrainer({k: v.to(dev) for k, v in raw_cpu.items()}, binning_mode=bin_mode,
+                                   tuning=_lib.make_tuning(bwd_reduce="bf16"))
+                for _ in range(3):
+                    t2.step([cam], grads_fn, cap)
+                torch.cuda.synchronize()
+                rep = max(d for d in range(1, max(1, args.graph_steps) + 1) if args.steps % d == 0)
+                many2 = t2.capture([cam], grads_fn, cap, repeat=rep, pipeline=pipe)
+                run2 = lambda: [many2() for _ in range(args.steps // many2.steps)]
+                for _ in range(max(1, args.warmup // max(args.steps, 1))):
+                    run2()
+                out["ms_per_step_bf16_split"] = summarise(time_samples(run2, max(5, n_samples // 3), False, dev), args.steps)["median"]
+                out["bf16_split_note"] = ("opt-in (AgsTuning.bwd_reduce = AGS_BWD_BF16_SPLIT): the blend backward's per-surfel sums "
+                                          "from bf16 hi/lo splits of both operands, f32 accumulation; gradients move by ~1e-5 "
+                                          "relative; `value` / `ms_per_step` are the exact-f32 default")
+                t2.check_overflow()
+                del t2, many2
             except Exception as e:
-                out["ms_per_step_f32_exact"] = None
-                out["f32_exact_note"] = f"{type(e).__name__}: {e}"
+                out["ms_per_step_bf16_split"] = None
+                out["bf16_split_note"] = f"{type(e).__name__}: {e}"
+                torch.cuda.synchronize()
             # -- the path an UNMODIFIED caller takes: the drop-in module under autograd, per view
             try:
                 d1 = measure_dropin(dev, N_GAUSS, H, W, 1, iters=100)
                 d2 = measure_dropin(dev, N_GAUSS, 512, 512, 8, iters=25, focal=0.5 * 512 / 0.57735)
+                d1d = measure_dropin(dev, N_GAUSS, H, W, 1, iters=100, deferred=True)
+                d2d = measure_dropin(dev, N_GAUSS, 512, 512, 8, iters=25, focal=0.5 * 512 / 0.57735, deferred=True)
                 out["config"]["dropin_ms_per_view"] = round(d1["ms_per_view"], 4)
                 out["config"]["dropin"] = {"c2_1200x680_1_view": d1, "reference_shape_512x512_8_views": d2,
+                                           "c2_1200x680_1_view_deferred": d1d, "reference_shape_512x512_8_views_deferred": d2d,
                                            "what": "diff_gaussian_rasterization_2d.GaussianRasterizer under autograd, forward + "
                                                    "backward per view (no facade, no loss head, no optimiser), measured after "
                                                    "the timed region"}
             except Exception as e:
                 out["config"]["dropin_ms_per_view"] = None
                 out["config"]["dropin"] = f"{type(e).__name__}: {e}"
-            # -- one GPU's share of BASELINE.json's configurations 4 and 5
+            # -- BASELINE.json's configuration 3: the full mapper loop (grow from every new keyframe, train 10 iterations,
+            #    post-process / prune) for 500 iterations from an empty map, through the drop-in GaussianMap class - the
+            #    calls /root/reference/mapping/mapper.py:44,101 makes - at the reference's 512x512 and at 1200x680
             try:
                 del trainer, one_step, many_steps
+                torch.cuda.empty_cache()
+                out["config"]["c3"] = measure_c3(dev)
+            except Exception as e:
+                out["config"]["c3"] = f"{type(e).__name__}: {e}"
+                torch.cuda.synchronize()
+            # -- one GPU's share of BASELINE.json's configurations 4 and 5
+            try:
                 torch.cuda.empty_cache()
                 sec = {"c4_share": measure_config("c4: one GPU's 4 of 32 views, 1.5 M surfels @1200x680", 1_500_000, 680, 1200, 4,
                                                   "room0", 20, dev),

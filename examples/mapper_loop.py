@@ -1,19 +1,17 @@
 #!/usr/bin/env python3
-"""Configuration 3 of BASELINE.json in one script: the full mapper loop (grow from each new
-RGB-D keyframe, train, post-process / prune) for 500 optimisation iterations on one MI355X.
+"""Configuration 3 of BASELINE.json in one script: the full mapper loop (grow from each new RGB-D keyframe, train,
+post-process / prune) for 500 optimisation iterations on one MI355X.
 
-Mirrors how /root/reference/main.py drives ``GaussianMap.update`` (mapping/gaussian_map.py:62-64)
-with the values of config/mapper/incremental.yaml (10 iterations per keyframe, batch 8 + 3 active
-frames, prune every 5th keyframe) and the simulator's 512x512 frames (config/simulator/habitat.yaml).
-Replica is not available offline, so the keyframes are rendered from a dense ground-truth surfel
-room (the office0 stand-in of active_gs_amd.synthetic) with this library's own rasterizer.
-Prints one JSON line with the time split between growth, training and post-processing.
+Drives the drop-in class the way /root/reference/mapping/mapper.py:44,98-104 drives the reference's:
+``GaussianMap(cfg.gaussian_map, device)`` once, ``gaussian_map.update(dataframe)`` per keyframe, with the values of
+config/mapper/incremental.yaml (10 iterations per keyframe, batch 8 with 3 active frames, prune every 5th keyframe) and
+the simulator's 512x512 frames (config/simulator/habitat.yaml).  Replica is not available offline, so the keyframes are
+rendered from a dense ground-truth surfel room (``active_gs_amd.synthetic.make_keyframes``).  Prints one JSON line.
 """
 import argparse
 import json
 import os
 import sys
-import time
 
 import numpy as np
 import torch
@@ -27,95 +25,22 @@ def main():
     ap.add_argument("--steps", type=int, default=10, help="optimisation iterations per keyframe")
     ap.add_argument("--size", type=int, nargs=2, default=[512, 512], metavar=("H", "W"))
     ap.add_argument("--gt-surfels", type=int, default=400_000)
-    ap.add_argument("--streams", type=int, default=4)
-    ap.add_argument("--no-graph", action="store_true", help="launch every iteration eagerly instead of replaying it")
-    ap.add_argument("--per-view", action="store_true", help="per-view launches on HIP streams instead of one batch")
     ap.add_argument("--no-warmup", action="store_true",
                     help="time the loop cold: the first process on a box then also pays torch's lazy kernel-module loads "
                          "(~0.25 s: topk, sort, index kernels) inside the timed region")
     ap.add_argument("--host-sampler", action="store_true",
                     help="draw the error-weighted frames with the reference's np.random.choice on the host (one read-back "
                          "of the per-frame errors per iteration) instead of the same distribution on the GPU")
+    ap.add_argument("--split", action="store_true", help="synchronise around growth and training to time them separately")
     args = ap.parse_args()
 
-    from active_gs_amd import raster_api as api
-    from active_gs_amd.camera import camera_matrices
-    from active_gs_amd.fused_map_trainer import FusedMapTrainer
-    from active_gs_amd.synthetic import activate, make_camera, make_room_scene
-
+    from active_gs_amd.synthetic import make_keyframes, run_mapper_loop
     dev = torch.device("cuda:0")
     h, w = args.size
-    gt = {k: v.to(dev) for k, v in make_room_scene(args.gt_surfels, seed=0).items()}
-    gt["scales"][:, :2] += 0.6                       # dense coverage: the ground truth is a closed room
-    gt["opacities"] += 4.0
-    a = activate(gt)
-    g = api.Gaussians(a["means"], a["scales"], a["rotations"], a["opacities"], gt["harmonics"].view(-1, 3).contiguous(),
-                      a["confidences"])
-    st = api.alloc_state(args.gt_surfels, h, w, 1 << 24, dev)
-    frames = []
-    for v in range(args.keyframes):
-        c2w, K = make_camera(v, h, w)
-        cm = camera_matrices(c2w[None].to(dev), K[None].to(dev), 0.001, 10.0)
-        tan = cm["tanfov"][0].cpu()
-        cam = api.Camera(h, w, float(tan[0]), float(tan[1]), cm["viewmatrix"][0].contiguous(),
-                         cm["projmatrix"][0].contiguous(), torch.zeros(4, device=dev))
-        api.forward(cam, g, st)
-        assert not api.read_status(st)["overflow"]
-        depth = torch.where(st.opacity > 0.5, st.depth, torch.zeros_like(st.depth))
-        frames.append(dict(rgb=st.rgb.clone().clamp(0, 1), depth=depth.clone(), extrinsic=c2w.to(dev),
-                           intrinsic=K.to(dev), depth_range=torch.tensor([0.001, 10.0], device=dev)))
-    z = lambda *s: torch.zeros(*s, device=dev)
-    raw = dict(means=z(0, 3), scales=z(0, 3), rotations=z(0, 4), opacities=z(0), harmonics=z(0, 1, 3))
-    cfg = dict(optimization_steps=args.steps, sampler="host" if args.host_sampler else "device")
-    if not args.no_warmup:
-        # two keyframes on a scratch map: every kernel module the loop uses is loaded, nothing of the timed map exists yet
-        warm = FusedMapTrainer({k: v.clone() for k, v in raw.items()}, [], dict(cfg), use_graph=not args.no_graph,
-                               num_streams=args.streams, batched=not args.per_view)
-        for f in frames[:2]:
-            warm.add_gaussians(f); warm.train(); warm.is_init = True
-        del warm
-        torch.cuda.synchronize()
+    frames = make_keyframes(args.keyframes, h, w, dev, gt_surfels=args.gt_surfels)
     np.random.seed(0)
-    tr = FusedMapTrainer(raw, [], cfg, use_graph=not args.no_graph,
-                         num_streams=args.streams, batched=not args.per_view)
-
-    def timed(fn):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        r = fn()
-        torch.cuda.synchronize()
-        return r, time.perf_counter() - t0
-
-    t_grow = t_train = 0.0
-    sizes, added = [], []
-    ms0 = torch.cuda.memory_stats(dev)
-    t_all0 = time.perf_counter()
-    for k, f in enumerate(frames):
-        n_add, dt = timed(lambda: tr.add_gaussians(f))
-        t_grow += dt
-        added.append(n_add)
-        _, dt = timed(lambda: tr.train())             # includes post_processing (confidence update, prune)
-        t_train += dt
-        tr.is_init = True
-        sizes.append(tr.means.shape[0])
-    torch.cuda.synchronize()
-    t_all = time.perf_counter() - t_all0
-    iters = args.keyframes * args.steps
-    print(json.dumps(dict(
-        workload=f"mapper loop: {args.keyframes} keyframes x {args.steps} iterations @{h}x{w}, batch 8 + 3 active, "
-                 f"prune every 5th keyframe, from an empty map"
-                 + ("" if args.no_warmup else " (after two warm-up keyframes on a scratch map: kernel modules loaded)"),
-        frame_sampler="host (np.random.choice, as the reference)" if args.host_sampler else "device (same distribution)",
-        iterations=iters, seconds=round(t_all, 3), ms_per_iteration_incl_growth=round(1e3 * t_all / iters, 3),
-        grow_ms_per_keyframe=round(1e3 * t_grow / args.keyframes, 3),
-        train_ms_per_keyframe=round(1e3 * t_train / args.keyframes, 3),
-        final_surfels=sizes[-1], surfels_after_10=sizes[min(9, len(sizes) - 1)],
-        added_first=added[0], added_last=added[-1],
-        mean_frame_error=round(float(tr.training_performance.mean()), 5), last_loss=round(tr.last_losses[-1], 5),
-        # hipMalloc / hipFree calls of torch's caching allocator inside the timed loop (each is a host stall of ~0.1-1 ms)
-        device_mallocs=int(torch.cuda.memory_stats(dev)["num_device_alloc"] - ms0["num_device_alloc"]),
-        device_frees=int(torch.cuda.memory_stats(dev)["num_device_free"] - ms0["num_device_free"]),
-        overflow_retries=int(getattr(tr, "overflow_retries", 0)))))
+    print(json.dumps(run_mapper_loop(frames, steps=args.steps, draw="host" if args.host_sampler else "device",
+                                     warmup_frames=0 if args.no_warmup else 2, split=args.split)))
 
 
 if __name__ == "__main__":

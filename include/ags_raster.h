@@ -182,11 +182,33 @@ typedef struct AgsGaussianGrads {
                              * no scan, no second emission pass); per-tile sort as in AGS_BIN_TILE_SORT.  Overflows when ONE
                              * tile's list exceeds its slots (AgsStatus.needed_instances says what would do).  Same per-tile
                              * (depth, id) order and bit-identical images as the other two modes. */
+/* Kernel-selection knobs, handed over WITH the workspace (AgsWorkspace.tuning; NULL or an all-zero struct = the
+ * defaults).  The library itself reads no environment variable and keeps no process-wide setting: two callers in one
+ * process can run different selections side by side.  Every selection gives the same images; the gradients differ only
+ * where stated.  (The Python / torch bindings of this repository fill the struct from AGS_* environment variables for
+ * experiments - that is the bindings' business, see INTEGRATION.md.) */
+#define AGS_BWD_F32 0        /* blend backward: per-surfel sums on the matrix cores in EXACT f32 (v_mfma_f32_16x16x4_f32),
+                              * the arithmetic of the reference's fp32 atomics up to summation order.  Default. */
+#define AGS_BWD_BF16_SPLIT 1 /* the same sums on the bf16 matrix pipe from hi/lo splits of both operands (hi.hi + lo.hi +
+                              * hi.lo, f32 accumulation; every dropped term < 2^-16 of its product): ~4 % faster step,
+                              * gradients move by ~1e-5 relative.  Opt-in. */
+#define AGS_BWD_VALU 2       /* no matrix instructions: per-lane sums + transposed wave reduction (exact f32) */
+typedef struct AgsTuning {
+    int32_t bwd_reduce;        /* AGS_BWD_* */
+    int32_t render_slots;      /* 0 = by the number of tiles in flight; 1 / 2 / 4 = 8x8 quadrants per wave in the blend kernels */
+    int32_t cull_first_min_n;  /* 0 = default (2^20 rows): from this map size up the per-Gaussian stage of raw-parameter maps
+                                * culls on the means first; < 0 = never; 1 = always */
+    int32_t tile_sort_no_wave; /* != 0: AGS_BIN_DIRECT always sorts with the 256-thread kernel (never one wave per tile) */
+    int32_t bucket_no_scan;    /* != 0: AGS_BIN_TILE_SORT always runs the separate tile-scan launch */
+    int32_t reserved[3];       /* 0 */
+} AgsTuning;
+
 typedef struct AgsWorkspace {
     void* ptr;    /* device, 256-byte aligned */
     size_t bytes; /* >= ags_workspace_bytes(n,h,w,max_instances) */
     int64_t max_instances; /* capacity in (Gaussian,tile) instances */
     int32_t binning_mode;  /* AGS_BIN_*; all give the same per-tile (depth, id) order */
+    const AgsTuning* tuning; /* optional (NULL = defaults), HOST memory, read during the call only */
 } AgsWorkspace;
 
 /* Device-side status block = the first 64 bytes of the workspace. */
@@ -308,7 +330,9 @@ int ags_backward_rows(const AgsViewRef* views, int32_t num_views, const AgsGauss
  *                              the view that was handed to ags_backward_fused_next, with the same camera contents.
  * The next view's matrices must be in place when ags_backward_fused_next runs.  To leave the pipeline (the prepared
  * pass is not wanted after all) call ags_workspace_discard_pass on `next_ws` before its next ags_forward - the
- * prepared pass has already taken key slots in it.  `rows_hint`: about how many rows the row set holds (it lives on the
+ * prepared pass has already taken key slots in it.  The next view's camera takes HOST flags (AgsCamera.config must be NULL
+ * in both calls: the prepared per-Gaussian stage does not clear importance / count; want_stats with zero-filled arrays
+ * works as in ags_forward).  `rows_hint`: about how many rows the row set holds (it lives on the
  * device; 0 = unknown) - sizes the part of the launch that walks the list, any value is correct.  Results are identical
  * to ags_backward + ags_forward. */
 int ags_backward_fused_next(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* fwd,

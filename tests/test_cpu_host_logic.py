@@ -176,7 +176,8 @@ def test_public_header_is_plain_c(tmp_path):
     src = tmp_path / "probe.c"
     fields = {"AgsCamera": _lib.AgsCamera, "AgsGaussians": _lib.AgsGaussians, "AgsImages": _lib.AgsImages,
               "AgsPerGaussian": _lib.AgsPerGaussian, "AgsImageGrads": _lib.AgsImageGrads,
-              "AgsGaussianGrads": _lib.AgsGaussianGrads, "AgsWorkspace": _lib.AgsWorkspace, "AgsStatus": _lib.AgsStatus,
+              "AgsGaussianGrads": _lib.AgsGaussianGrads, "AgsWorkspace": _lib.AgsWorkspace, "AgsTuning": _lib.AgsTuning,
+              "AgsStatus": _lib.AgsStatus,
               "AgsAdamTensors": _lib.AgsAdamTensors, "AgsActivation": _lib.AgsActivation,
               "AgsLossConfig": _lib.AgsLossConfig, "AgsRowSet": _lib.AgsRowSet, "AgsKeyframe": _lib.AgsKeyframe,
               "AgsDensifyPred": _lib.AgsDensifyPred, "AgsCandidates": _lib.AgsCandidates}
@@ -347,3 +348,77 @@ def test_spherical_harmonics_follow_the_reference_viewer_shader():
         assert np.abs(got - want).max() < 1e-12, deg
     with pytest.raises(ValueError):
         eval_sh(2, torch.zeros(4, 4, 3), torch.zeros(4, 3))
+
+
+def test_kernel_selection_travels_with_the_workspace_not_with_the_environment(agslib):
+    """include/ags_raster.h: AgsTuning is handed over with the workspace; the LIBRARY reads no environment variable (its
+    code object has no getenv import), the Python binding maps the documented AGS_* variables onto the struct, and an
+    out-of-range selection is refused by the entry points."""
+    import subprocess
+    from active_gs_amd import _lib, build
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", build.LIB], text=True)
+    assert "getenv" not in syms
+    t = _lib.tuning_from_env({})
+    assert (t.bwd_reduce, t.render_slots, t.cull_first_min_n, t.tile_sort_no_wave, t.bucket_no_scan) == (0, 0, 0, 0, 0)
+    assert _lib.tuning_from_env({"AGS_BWD_REDUCE": "bf16"}).bwd_reduce == _lib.BWD_BF16_SPLIT
+    assert _lib.tuning_from_env({"AGS_BWD_BF16": "1"}).bwd_reduce == _lib.BWD_BF16_SPLIT
+    assert _lib.tuning_from_env({"AGS_BWD_MFMA": "0"}).bwd_reduce == _lib.BWD_VALU
+    assert _lib.tuning_from_env({"AGS_RENDER_SLOTS": "2", "AGS_PRE_CULL_MIN_N": "0"}).render_slots == 2
+    assert _lib.tuning_from_env({"AGS_PRE_CULL_MIN_N": "0"}).cull_first_min_n == 1          # "always"
+    with pytest.raises(ValueError):
+        _lib.tuning_from_env({"AGS_BWD_REDUCE": "fp8"})
+    # the entry points validate the struct before they touch anything (null device pointers here: AGS_E_INVALID either way,
+    # so compare with a call that passes its checks up to the workspace size)
+    bad = _lib.AgsTuning(7, 0, 0, 0, 0)
+    ws = _lib.workspace(1 << 20, 0, 10, 0, bad)         # a non-null "pointer", 0 bytes
+    cam = _lib.AgsCamera(16, 16, 1.0, 1.0, 1.0, 0.03, 1, 1, 0, 0, 1 << 20, 1 << 20, 1 << 20, None, None)
+    g = _lib.AgsGaussians(0, None, None, None, None, None, None, 0, 0.01, 0.05)
+    im = _lib.AgsImages(*([1 << 20] * 5))
+    pg = _lib.AgsPerGaussian(None, None, None, _lib.AgsRowSet(None, None, None))
+    assert agslib.ags_forward(C.byref(cam), C.byref(g), C.byref(im), C.byref(pg), C.byref(ws), None) == -1      # AGS_E_INVALID
+    ok = _lib.workspace(1 << 20, 0, 10, 0, _lib.AgsTuning(1, 2, 0, 0, 0))
+    assert agslib.ags_forward(C.byref(cam), C.byref(g), C.byref(im), C.byref(pg), C.byref(ok), None) == -2      # AGS_E_WORKSPACE
+
+
+def test_gaussian_map_class_reads_cfg_like_the_reference_and_serves_a_cpu_map(tmp_path):
+    """active_gs_amd.gaussian_map.GaussianMap: the reference's constructor contract (gaussian_map.py:18-60: attribute
+    access on cfg.bound / cfg.background / cfg.optimizer.* / cfg.sampler.*; cfg = None for maps that are only loaded),
+    its getters on a CPU map, the checkpoint in the reference's schema - and no CPU fallback for anything that computes."""
+    from types import SimpleNamespace as NS
+    from active_gs_amd.gaussian_map import GaussianMap
+    cfg = NS(bound=[0.002, 8.0], background=[0.1, 0.2, 0.3, 0.0], sparse_ratio=0.1, error_thres=0.3, scale_factor=0.02,
+             optimization_steps=7, prune_interval=4, use_view_distribution=True,
+             sampler=NS(sampler_type="weighted", batch_size=6, active_size=2),
+             optimizer=NS(mean_lr=1e-3, rotation_lr=2e-3, opacity_lr=3e-3, scale_lr=4e-3, harmonic_lr=5e-3))
+    gm = GaussianMap(cfg, "cpu")
+    assert (gm.scene_near, gm.scene_far, gm.scale_factor, gm.error_thres, gm.prune_interval, gm.optimization_steps) == \
+           (0.002, 8.0, 0.02, 0.3, 4, 7)
+    assert torch.equal(gm.background_color, torch.tensor([0.1, 0.2, 0.3, 0.0])) and not gm.is_init and gm.training_data == []
+    tc = gm._trainer_cfg()
+    assert tc["batch_size"] == 6 and tc["active_size"] == 2 and tc["lrs"] == dict(mean=1e-3, scale=4e-3, rotation=2e-3,
+                                                                                 opacity=3e-3, harmonic=5e-3)
+    assert tc["bound"] == (0.002, 8.0) and tc["optimization_steps"] == 7
+    gm.optimization_steps = 3                              # attributes stay live, like the reference's
+    assert gm._trainer_cfg()["optimization_steps"] == 3
+    # a reference-written checkpoint through load(): the getters are the reference's expressions
+    ref = torch.load(os.path.join(GOLD, "map_ref.th"))
+    g2 = GaussianMap(None, "cpu")
+    g2.load(os.path.join(GOLD, "map_ref.th"))
+    assert g2.is_init and g2.scene_far == ref["far"] and g2.scale_factor == ref["scale_factor"]
+    means, harmonics, opac, conf, scales, rot = g2.get_attr()
+    n = ref["means"].shape[0]
+    assert means.shape == (n, 3) and harmonics.shape == (n, 1, 3) and opac.shape == conf.shape == (n,)
+    assert torch.equal(opac, torch.sigmoid(ref["opacities"])) and torch.equal(rot, torch.nn.functional.normalize(ref["rotations"]))
+    assert torch.equal(scales, torch.clamp(ref["scale_factor"] * torch.exp(ref["scales"]), min=0, max=0.05))
+    var = ref["view_means"].norm(dim=-1)
+    assert torch.allclose(conf, torch.clamp(torch.exp(1 - var) * ref["view_scores"], min=0, max=1))
+    nrm = g2.get_normals                                    # voxel_map.py:72; third column of the rotation matrix
+    r, x, y, z = rot.unbind(-1)
+    assert torch.allclose(nrm, torch.nn.functional.normalize(torch.stack([2 * (x * z + r * y), 2 * (y * z - r * x),
+                                                                          1 - 2 * (x * x + y * y)], -1)))
+    g2.save(str(tmp_path), index="007")                     # utils/common.py:249
+    back = torch.load(os.path.join(str(tmp_path), "map_007.th"))
+    assert sorted(back) == sorted(ref) and all(torch.equal(back[k], ref[k]) for k in ("means", "scales", "view_means"))
+    for call in (lambda: g2.train(), lambda: g2.post_processing(), lambda: g2.update({}), lambda: g2.prune(torch.zeros(n))):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()

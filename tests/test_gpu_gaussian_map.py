@@ -1,0 +1,210 @@
+"""The reference's REAL entry points over the fused path: ``active_gs_amd.gaussian_map.GaussianMap(cfg, device)`` with the
+surface an untouched ``mapping.Mapper`` / planner / voxel map / recorder uses (/root/reference/mapping/mapper.py:44,101,
+mapping/gaussian_map.py:62-64,491-581, mapping/voxel_map.py:71-74, utils/common.py:249) and ``facade.SurfelRenderer`` serving
+``render_view(i)`` under no_grad from ONE batched render (/root/reference/planning/confidence.py:24-46)."""
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = torch.device("cuda:0")
+
+
+def _ns(d):
+    """a nested dict as attribute-style config (what hydra hands to mapping.Mapper: cfg.gaussian_map)"""
+    return NS(**{k: (_ns(v) if isinstance(v, dict) else v) for k, v in d.items()})
+
+
+def _to_dev(frame):
+    return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in frame.items()}      # mapper.py:95
+
+
+def test_class_api_replays_the_reference_mapper_loop_capture(agslib):
+    """tests/golden/mapper_loop.pt = the reference's own ``GaussianMap.update()`` x 4 keyframes from an empty map (over the
+    CPU oracle).  The same calls on the drop-in class - ``GaussianMap(cfg, device)``, ``.update(dataframe)`` - give the same
+    growth after every keyframe, the same per-frame errors, supports and scores, the same prune decisions."""
+    from active_gs_amd.gaussian_map import GaussianMap
+    g = torch.load(os.path.join(GOLD, "mapper_loop.pt"))
+    gm = GaussianMap(_ns(g["cfg"]), DEV)
+    gm.frame_sampler = "host"                      # the capture drew its batches from a seeded numpy stream
+    np.random.seed(g["seed"])
+    assert not gm.is_init and gm.get_means.shape[0] == 0
+    for k, ref in enumerate(g["history"]):
+        assert gm.get_means.shape[0] == pytest.approx(ref["n_before"], rel=0.01, abs=3)
+        gm.update(_to_dev(g["frames"][k % 2]))
+        assert gm.is_init and len(gm.training_data) == k + 1
+        n = gm.get_means.shape[0]
+        assert n == pytest.approx(ref["n_after"], rel=0.01, abs=3)
+        perf = gm.training_performance.cpu()
+        assert torch.allclose(perf, ref["training_performance"], rtol=0.03, atol=1e-4), (k, perf, ref["training_performance"])
+        assert float(gm.get_opacities.mean()) == pytest.approx(ref["opacity_mean"], abs=2e-3)
+        assert float(gm.view_supports.mean()) == pytest.approx(float(ref["supports"].mean()), rel=0.02)
+        assert float(gm.view_scores.mean()) == pytest.approx(ref["scores_mean"], rel=0.02)
+        # the surface the reference's other components read after every keyframe
+        means, harmonics, opac, conf, scales, rot = gm.get_attr()                   # planners, eval, mesh
+        assert means.shape == (n, 3) and harmonics.shape == (n, 1, 3) and opac.shape == conf.shape == (n,)
+        assert scales.shape == (n, 3) and rot.shape == (n, 4)
+    if gm.get_means.shape[0] == g["final"]["means"].shape[0]:
+        assert float((gm._means.cpu() - g["final"]["means"]).abs().mean()) < 2e-4
+        assert float((gm._harmonics.cpu() - g["final"]["harmonics"]).abs().mean()) < 2e-4
+
+
+def test_voxel_map_properties_recorder_save_and_planner_inputs(agslib, tmp_path):
+    """What mapping/voxel_map.py:71-74 reads (``get_means / get_normals / get_confidences / get_opacities``), what the
+    recorder calls (``save(path, index=)``, utils/common.py:249) and what the planners hand to ``GaussianRenderer``
+    (``get_attr()``, ``background_color``, ``scene_near / scene_far``: planning/confidence.py:24-32), on a map grown by the
+    class itself; ``load`` in a fresh map gives the same getters back (eval.py / mesh_generation.py / visualize.py)."""
+    from active_gs_amd.gaussian_map import GaussianMap
+    g = torch.load(os.path.join(GOLD, "mapper_loop.pt"))
+    cfg = _ns(g["cfg"])
+    gm = GaussianMap(cfg, DEV)
+    for k in range(2):
+        gm.update(_to_dev(g["frames"][k]))
+    n = gm.get_means.shape[0]
+    mean, normal = gm.get_means.detach(), gm.get_normals.detach()
+    conf, opac = gm.get_confidences.detach(), gm.get_opacities.detach()
+    assert mean.shape == normal.shape == (n, 3) and conf.shape == opac.shape == (n,)
+    assert torch.allclose(normal.norm(dim=-1), torch.ones(n, device=DEV), atol=1e-5)
+    # the same four through the reference's own expressions (gaussian_map.py:529-571)
+    q = torch.nn.functional.normalize(gm._rotations)
+    r, x, y, z = q.unbind(-1)
+    assert torch.allclose(normal, torch.nn.functional.normalize(torch.stack([2 * (x * z + r * y), 2 * (y * z - r * x),
+                                                                            1 - 2 * (x * x + y * y)], -1)), atol=1e-6)
+    var = gm.view_means.norm(dim=-1)
+    var = torch.where(torch.isnan(var), torch.ones_like(var), var)
+    assert torch.allclose(conf, torch.clamp(torch.exp(1 - var) * gm.view_scores, min=0, max=1), atol=1e-6)
+    assert torch.equal(opac, torch.sigmoid(gm._opacities)) and float(conf.min()) >= 0.0 and float(conf.max()) <= 1.0
+    assert gm.background_color.shape == (4,) and (gm.scene_near, gm.scene_far) == (0.001, 10.0)
+    gm.save(str(tmp_path), index="003")
+    path = os.path.join(str(tmp_path), "map_003.th")
+    st = torch.load(path)
+    assert sorted(st) == sorted(["means", "scales", "harmonics", "opacities", "rotations", "view_scores", "view_supports",
+                                 "view_means", "near", "far", "use_view_direction", "background_color", "scale_factor"])
+    g2 = GaussianMap(None, DEV)
+    g2.load(path)
+    for a, b in zip(gm.get_attr(), g2.get_attr()):
+        assert torch.equal(a, b)
+    assert torch.equal(g2.get_normals, gm.get_normals) and g2.is_init
+    # a loaded map renders (mesh_generation.py:74-82) and trains on (cfg = None: the yaml's defaults)
+    from active_gs_amd.facade import SurfelRenderer
+    f = _to_dev(g["frames"][0])
+    h, w = f["rgb"].shape[-2:]
+    with torch.no_grad():
+        rgb, depth, *_ = SurfelRenderer(f["extrinsic"][None], f["intrinsic"][None], g2.get_attr(), g2.background_color,
+                                        (g2.scene_near, g2.scene_far), (h, w), DEV).render_view_all()
+    assert float((rgb[0] - f["rgb"]).abs().mean()) < 0.1 and float((depth[0] - f["depth"]).abs().mean()) < 0.1
+
+
+def test_prune_add_and_train_as_separate_calls(agslib):
+    """The reference's methods one by one (gaussian_map.py:66,141,234,294): add_gaussians registers the frame and grows the
+    map, train(steps) runs that many iterations + post_processing, prune(mask) deletes the masked surfels and those whose
+    opacity fell under 0.1, attribute changes between calls are honoured."""
+    from active_gs_amd.gaussian_map import GaussianMap
+    g = torch.load(os.path.join(GOLD, "mapper_loop.pt"))
+    gm = GaussianMap(_ns(g["cfg"]), DEV)
+    added = gm.add_gaussians(_to_dev(g["frames"][0]))
+    n0 = gm.get_means.shape[0]
+    assert added == n0 > 1000 and len(gm.training_data) == 1 and gm.training_performance.tolist() == [10.0] and not gm.is_init
+    assert float(gm.view_supports.sum()) == 0.0
+    gm.optimization_steps = 3
+    gm.train()
+    assert gm.is_init and len(gm._trainer.last_losses) == 3 and float(gm.training_performance[0]) < 10.0
+    assert float(gm.view_supports.sum()) > 0.5 * n0          # post_processing counted the newest view
+    gm.train(steps=2)
+    assert len(gm._trainer.last_losses) == 2
+    n1 = gm.get_means.shape[0]
+    mask = torch.zeros(n1, device=DEV)
+    mask[::3] = 1.0
+    low = int((gm.get_opacities < 0.1).sum())
+    expect = int((((mask > 0) | (gm.get_opacities < 0.1))).sum())
+    gm.prune(mask)
+    assert gm.get_means.shape[0] == n1 - expect and expect >= (n1 + 2) // 3 and low >= 0
+    for t, wdt in ((gm._scales, 3), (gm._rotations, 4), (gm._harmonics, 3), (gm.view_means, 3)):
+        assert t.numel() == gm.get_means.shape[0] * wdt
+    gm.update(_to_dev(g["frames"][1]))                       # and the loop goes on
+    assert len(gm.training_data) == 2 and gm.get_means.shape[0] > n1 - expect
+
+
+def test_batched_render_view_serves_the_reference_renderer_capture(agslib):
+    """tests/golden/facade.pt = the reference's own ``GaussianRenderer.render_view_all`` (over the CPU oracle).  On the
+    GPU ``SurfelRenderer.render_view(i)`` under no_grad renders ALL the renderer's views as one batch at the first
+    request and serves view i from it: same 9-tuples as the capture and - bitwise - as the view-by-view path."""
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.facade import SurfelRenderer
+    d = torch.load(os.path.join(GOLD, "facade.pt"))
+    t = lambda x: x.to(DEV)
+    attr = (t(d["attr"]["means"]), t(d["attr"]["harmonics"]), t(d["attr"]["opacities"]), t(d["confidences"]),
+            t(d["attr"]["scales"]), t(d["attr"]["rotations"]))
+    calls = dict(n=0)
+    orig = api.ViewBatch.forward
+
+    def counting(self, *a, **k):
+        calls["n"] += 1
+        return orig(self, *a, **k)
+    api.ViewBatch.forward = counting
+    try:
+        r = SurfelRenderer(t(d["c2w"]), t(d["K"]), attr, t(d["bg"]), (d["near"], d["far"]), (d["h"], d["w"]), DEV)
+        views = [r.render_view(i) for i in range(d["c2w"].shape[0])]
+        assert calls["n"] == 1                                   # one batched render served both requests
+        allv = r.render_view_all()
+        assert calls["n"] == 1
+    finally:
+        api.ViewBatch.forward = orig
+    for i, v in enumerate(views):
+        assert len(v) == 9
+        for k in range(8):
+            ref = d["outputs"][k][i]
+            assert v[k].shape == ref.shape and v[k].dtype == ref.dtype, (i, k)
+            if ref.dtype.is_floating_point:
+                assert torch.allclose(v[k].cpu(), ref, rtol=2e-3, atol=2e-4), (i, k, float((v[k].cpu() - ref).abs().max()))
+            else:
+                assert torch.equal(v[k].cpu(), ref), (i, k)
+            assert torch.equal(allv[k][i], v[k])
+        assert v[8].dtype == torch.bool
+    assert torch.equal(allv[8].cpu(), d["outputs"][8])
+    # the view-by-view path (what render_view(i, require_grad=True) takes) renders the same bits
+    one = [SurfelRenderer(t(d["c2w"])[i:i + 1], t(d["K"])[i:i + 1], attr, t(d["bg"]), (d["near"], d["far"]), (d["h"], d["w"]),
+                          DEV).render_view(0, require_grad=True) for i in range(len(views))]
+    for i, v in enumerate(views):
+        for k in range(9):
+            assert torch.equal(one[i][k].detach(), v[k]), (i, k)
+    # update_attr forgets the batch
+    moved = (attr[0] + 0.01,) + attr[1:]
+    r.update_attr(moved)
+    assert not torch.equal(r.render_view(0)[0], views[0][0])
+
+
+def test_planner_shaped_batch_of_candidate_views(agslib):
+    """planning/confidence.py:24-46: one renderer for ~100 candidate poses at 128x128, ``render_view(i)`` per candidate under
+    no_grad, ``confidence[0]`` and ``depth[0]`` consumed.  Importance / front_only / render-mask requests (post-processing,
+    gaussian_map.py:183-192) batch the same way; every view equals the one-view-at-a-time render bitwise."""
+    from active_gs_amd.facade import SurfelRenderer
+    from active_gs_amd.synthetic import activate, make_camera, make_room_scene
+    n, V, h, w = 40000, 24, 128, 128
+    a = {k: v.to(DEV) for k, v in activate(make_room_scene(n, seed=2)).items()}
+    attr = (a["means"], a["colors"][:, None, :].contiguous(), a["opacities"], a["confidences"], a["scales"] * 2.5, a["rotations"])
+    cams = [make_camera(100 + v, h, w, focal_px=0.5 * w / np.tan(np.pi / 6)) for v in range(V)]
+    c2w, K = torch.stack([c[0] for c in cams]).to(DEV), torch.stack([c[1] for c in cams]).to(DEV)
+    bg = torch.zeros(4, device=DEV)
+    gen = torch.Generator().manual_seed(0)
+    masks = (torch.rand(V, 1, h, w, generator=gen) > 0.2).float().to(DEV)
+    for kw, m in ((dict(), None), (dict(require_importance=True, front_only=True), masks)):
+        r = SurfelRenderer(c2w, K, attr, bg, (0.001, 10.0), (h, w), DEV, render_masks=m)
+        with torch.no_grad():
+            got = [r.render_view(i, **kw) for i in range(V)]
+        for i in (0, 7, V - 1):
+            one = SurfelRenderer(c2w[i:i + 1], K[i:i + 1], attr, bg, (0.001, 10.0), (h, w), DEV,
+                                 render_masks=None if m is None else m[i:i + 1]).render_view(0, **kw)
+            for k in range(9):
+                if k == 6:       # importance: float atomics over the waves that blended a surfel
+                    assert float((one[k] - got[i][k]).abs().sum()) <= 1e-5 * float(one[k].abs().sum()) + 1e-12
+                else:
+                    assert torch.equal(one[k], got[i][k]), (i, k)
+            conf, depth = got[i][5][0], got[i][1][0]
+            assert float(conf.min()) >= 0.0 and float(conf.max()) <= 1.0 and depth.shape == (h, w)
+        if kw:
+            assert int(got[0][7].sum()) > 0 and got[0][7].dtype == torch.int32

@@ -212,11 +212,51 @@ def test_c5_size_scene_16384_tiles(agslib):
     assert torch.isfinite(g2.scales).all() and float(st.opacity.max()) <= 1.0 and float(st.opacity.min()) >= 0.0
 
 
+def test_bf16_split_backward_passes_the_same_fixtures(agslib):
+    """AgsTuning.bwd_reduce: the blend backward's per-surfel sums run on the matrix cores in exact f32 by default
+    (the reference's arithmetic); AGS_BWD_BF16_SPLIT forms them on the bf16 pipe from hi/lo splits (opt-in, ~4 % faster
+    step).  Every other test runs the default; this one holds the OTHER form to the same oracle comparisons and
+    reference fixtures (the Python binding maps AGS_BWD_REDUCE onto the struct once per process, hence the subprocess),
+    and checks in-process that the two forms are told apart per workspace: same images, gradients within the split's
+    2^-16 per product."""
+    import subprocess
+    import sys
+    from active_gs_amd import _lib, raster_api as api
+    from _scenes import oracle_inputs, room_case
+    dev = torch.device("cuda:0")
+    a, S = room_case(5000, 170, 300, view=1, seed=1, scale_mult=2.0)
+    ins = [t.to(dev) for t in oracle_inputs(a, requires_grad=False)]
+    g = api.Gaussians(ins[0], ins[5].contiguous(), ins[6], ins[2].reshape(-1).contiguous(), ins[4], ins[3])
+    cam = api.Camera(170, 300, S.tanfovx, S.tanfovy, S.viewmatrix.to(dev), S.projmatrix.to(dev), S.bg.to(dev))
+    gen = torch.Generator().manual_seed(0)
+    d = [torch.randn(c, 170, 300, generator=gen).to(dev) for c in (3, 3, 1)]
+    res = {}
+    for mode in ("f32", "bf16", "valu"):
+        st = api.alloc_state(5000, 170, 300, 1 << 20, dev, tuning=_lib.make_tuning(bwd_reduce=mode))
+        api.forward(cam, g, st)
+        res[mode] = (st.rgb.clone(), api.backward(cam, g, st, *d))
+    for mode in ("bf16", "valu"):
+        assert torch.equal(res[mode][0], res["f32"][0])
+        for name in ("means3D", "scales", "rotations", "opacities", "colors"):
+            x, y = getattr(res[mode][1], name), getattr(res["f32"][1], name)
+            rel = float((x - y).abs().sum() / y.abs().sum())
+            assert rel < (2e-4 if mode == "bf16" else 2e-5), (mode, name, rel)
+    assert not torch.equal(res["bf16"][1].means3D, res["f32"][1].means3D)        # (they ARE different kernels)
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, AGS_BWD_REDUCE="bf16")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_golden.py"),
+                        os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "not valu_backward and not two_quadrants and not bf16_split and (oracle or train or properties or c4_size or c5_size "
+                        "or row_set or batched_backward or overfull or alpha_clamp)"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
+
+
 def test_valu_backward_passes_the_same_fixtures(agslib):
-    """The blend backward has two forms: the default reduces each surfel's gradients on the matrix
-    cores (render.hip: ags_k_render_bwd_mfma), AGS_BWD_MFMA=0 selects the VALU kernels
-    (ags_k_render_bwd<SLOTS>).  Every other test runs the default; this one re-runs the reference
-    fixtures and the oracle comparisons with the VALU form.  The switch is read once per process,
+    """The blend backward has a third form without matrix instructions (ags_k_render_bwd<SLOTS>: per-lane sums and a
+    transposed wave reduction; AgsTuning.bwd_reduce = AGS_BWD_VALU, AGS_BWD_MFMA=0 in the Python binding).  This
+    re-runs the reference fixtures and the oracle comparisons with it.  The binding reads the switch once per process,
     hence the subprocess."""
     import subprocess
     import sys
@@ -224,7 +264,7 @@ def test_valu_backward_passes_the_same_fixtures(agslib):
     env = dict(os.environ, AGS_BWD_MFMA="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_golden.py"),
                         os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
-                        "not valu_backward and not two_quadrants and (oracle or train or properties or c4_size or c5_size or row_set or batched_backward "
+                        "not valu_backward and not two_quadrants and not bf16_split and (oracle or train or properties or c4_size or c5_size or row_set or batched_backward "
                         "or overfull or alpha_clamp)"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
@@ -244,7 +284,7 @@ def test_two_quadrants_per_wave_kernels_pass_the_same_fixtures(agslib):
     env = dict(os.environ, AGS_RENDER_SLOTS="2")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_golden.py"),
                         os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
-                        "not valu_backward and not two_quadrants and (oracle or train or properties or c4_size or c5_size or row_set "
+                        "not valu_backward and not two_quadrants and not bf16_split and (oracle or train or properties or c4_size or c5_size or row_set "
                         "or batched_backward or overfull or alpha_clamp or argument_variants)"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
