@@ -71,10 +71,20 @@ def test_bench_single_rank_contract_fields(agslib):
     # the line is one program, sampled: median of >= 21 samples of exactly K steps, min / max beside it; the other forms of
     # the same step and the other workloads are separate, labelled fields measured after the timed region
     assert d["samples"] >= 21 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
-    assert 0.7 * d["ms_per_step"] < d["ms_per_step_pipelined"] < 1.05 * d["ms_per_step"] and d["ms_per_step_f32_exact"] > 0.9 * d["ms_per_step"]
+    # the headline computes in the reference's arithmetic (fp32 throughout); the bf16 hi/lo-split form of the blend backward
+    # is an opt-in, timed as a labelled secondary field
+    assert 0.7 * d["ms_per_step"] < d["ms_per_step_pipelined"] < 1.05 * d["ms_per_step"]
+    assert 0.8 * d["ms_per_step"] < d["ms_per_step_bf16_split"] < 1.02 * d["ms_per_step"]
     assert "5 launches per step" in d["config"]["launch"]
-    assert d["dtype"].startswith("f32 (") and "bf16" in d["dtype"]
-    assert 0 < d["config"]["dropin_ms_per_view"] < 1.0 and d["config"]["dropin"]["c2_1200x680_1_view"]["module_syncs_per_view"] == 0
+    assert d["dtype"] == "f32"
+    # the drop-in module: safe by default (every call checked before it returns), no synchronisation in the opt-in form
+    dr = d["config"]["dropin"]
+    assert 0 < d["config"]["dropin_ms_per_view"] < 1.0 and dr["c2_1200x680_1_view"]["module_syncs_per_view"] == 1
+    assert dr["c2_1200x680_1_view_deferred"]["module_syncs_per_view"] == 0
+    # configuration 3 (the mapper loop through the GaussianMap class) is in the driver's line
+    c3 = d["config"]["c3"]
+    assert c3["512x512"]["iterations"] == 500 and 0 < c3["seconds"] < 5 and c3["final_surfels"] > 50_000
+    assert c3["1200x680"]["seconds"] > 0 and c3["512x512"]["overflow_retries"] == 0
     sec = d["config"]["secondary"]
     assert sec["c4_share_ms"] > 0 and sec["c5_ms"] > 0 and set(sec["c5"]["stage_hbm_frac"]) >= {"preprocess", "render_bwd"}
     assert d["roofline"]["traffic_read"] is not None and d["roofline"]["traffic_write"] is not None

@@ -86,8 +86,9 @@ def test_voxel_map_properties_recorder_save_and_planner_inputs(agslib, tmp_path)
                                  "view_means", "near", "far", "use_view_direction", "background_color", "scale_factor"])
     g2 = GaussianMap(None, DEV)
     g2.load(path)
-    for a, b in zip(gm.get_attr(), g2.get_attr()):
-        assert torch.equal(a, b)
+    for k, (a, b) in enumerate(zip(gm.get_attr(), g2.get_attr())):
+        # (confidences: one launch on a map that has a trainer, the reference's torch expression on a freshly loaded one)
+        assert torch.allclose(a, b, atol=1e-6) if k == 3 else torch.equal(a, b), k
     assert torch.equal(g2.get_normals, gm.get_normals) and g2.is_init
     # a loaded map renders (mesh_generation.py:74-82) and trains on (cfg = None: the yaml's defaults)
     from active_gs_amd.facade import SurfelRenderer
