@@ -44,6 +44,19 @@ def weighted_choice_into(weights: torch.Tensor, k: int, out: torch.Tensor) -> No
 
 
 class FusedMapTrainer(GaussianMapTrainer):
+    # the losses of the last train() call: kept on the device by the batched loop and read when somebody asks
+    @property
+    def last_losses(self):
+        if self._losses_dev is not None:
+            self._losses_host, self._losses_dev = [float(x) for x in self._losses_dev.cpu()], None
+        return self._losses_host
+
+    @last_losses.setter
+    def last_losses(self, value):
+        self._losses_host, self._losses_dev = value, None
+
+    _losses_host, _losses_dev = [], None
+
     def __init__(self, raw: dict, frames: List[dict], cfg: Optional[dict] = None, process_group=None,
                  binning_mode: int = api.BIN_DIRECT, use_graph: bool = True, num_streams: int = 4,
                  batched: bool = True):
@@ -107,6 +120,21 @@ class FusedMapTrainer(GaussianMapTrainer):
         st["n"], st["ids"] = K, ids
         return st["view"][:K], st["proj"][:K], st["rgb"][:K], st["depth"][:K]
 
+    # ---- small host -> device uploads (a keyframe's matrices) through page-locked memory: a copy from pageable memory
+    # makes the host wait for everything the stream still has to do
+    def _upload(self, array) -> torch.Tensor:
+        import numpy as np
+        a = np.ascontiguousarray(array, dtype=np.float32).reshape(-1)
+        ring = getattr(self, "_ring", None)
+        if ring is None:
+            ring = self._ring = dict(buf=torch.empty(128, 64, dtype=torch.float32).pin_memory(), k=0)
+        if a.size > 64:
+            return torch.from_numpy(a).to(self.device)
+        slot = ring["buf"][ring["k"] % 128]
+        ring["k"] += 1
+        slot[:a.size] = torch.from_numpy(a)
+        return slot[:a.size].to(self.device, non_blocking=True)
+
     # ---- cached per-frame camera (the intrinsics -> fov step needs host scalars once per frame)
     def _camera(self, idx: int):
         c = self._cams.get(idx)
@@ -131,6 +159,8 @@ class FusedMapTrainer(GaussianMapTrainer):
         c2w, Kinv = host[:16].reshape(4, 4), np.linalg.inv(host[16:25].reshape(3, 3))
         if torch.is_tensor(dr):
             f["_far_host"] = float(host[25 + 1])
+        if "intrinsic_inv" not in f:       # what densify.candidates needs of the intrinsics: no second read-back for it
+            f["intrinsic_inv"] = self._upload(np.linalg.inv(host[16:25].astype(np.float32).reshape(3, 3))).reshape(3, 3)
         ray = lambda u, v: (lambda d: d / np.linalg.norm(d))(Kinv @ np.array([u, v, 1.0]))
         fov_x = float(np.arccos(np.clip(ray(0.0, 0.5) @ ray(1.0, 0.5), -1.0, 1.0)))
         fov_y = float(np.arccos(np.clip(ray(0.5, 0.0) @ ray(0.5, 1.0), -1.0, 1.0)))
@@ -141,9 +171,9 @@ class FusedMapTrainer(GaussianMapTrainer):
         P[2, 2], P[2, 3] = far / (far - near), -(far * near) / (far - near)
         view = np.linalg.inv(c2w).T
         proj = view @ P.T
-        mats = torch.from_numpy(np.stack([view, proj]).astype(np.float32)).to(self.device)
+        mats = self._upload(np.stack([view, proj])).reshape(2, 4, 4)
         tanx, tany = float(np.float32(tx)), float(np.float32(ty))
-        cam = api.Camera(h, w, tanx, tany, mats[0].contiguous(), mats[1].contiguous(), self.background)
+        cam = api.Camera(h, w, tanx, tany, mats[0], mats[1], self.background)
         return (cam, 2.0 * float(np.arctan(tanx)), 2.0 * float(np.arctan(tany)))
 
     def _state(self, slot: int, n: int, h: int, w: int) -> api.ForwardState:
@@ -373,18 +403,50 @@ class FusedMapTrainer(GaussianMapTrainer):
         frame store instead of a stack of all keyframes."""
         if self.world > 1 or not self.means.is_cuda or self.means.shape[0] == 0 or not self._uniform_frames():
             return super().post_processing()
+        self._post_processing_end(self._post_processing_begin())
+
+    def _post_processing_begin(self):
+        """Enqueue the count render of the newest keyframe WITHOUT waiting for its status (``_post_processing_end`` looks at
+        it); the prune pass over all keyframes (every prune_interval-th frame) is left to ``_post_processing_end`` whole."""
+        if self.world > 1 or not self.means.is_cuda or self.means.shape[0] == 0 or not self._uniform_frames():
+            return None
+        k = len(self.frames)
+        if k % self.cfg["prune_interval"] == 0:
+            return None
+        depth_gt = self._frame_store()[3][k - 1]
+        h, w = depth_gt.shape[-2:]
+        n = self.means.shape[0]
+        self._cap = max(self._cap, 1 << 16, 2 * n)
+        g = self._gaussians()
+        cam0, _, _ = self._camera(k - 1)
+        cam = api.Camera(h, w, cam0.tanfovx, cam0.tanfovy, cam0.viewmatrix, cam0.projmatrix, self.background,
+                         want_stats=True, front_only=True, render_mask=(depth_gt > 0.0).float().contiguous())
+        st = self._state("count", n, h, w)
+        api.forward(cam, g, st)
+        return dict(cam=cam, g=g, n=n, hw=(h, w))
+
+    def _post_processing_end(self, pending):
+        if self.world > 1 or not self.means.is_cuda or self.means.shape[0] == 0 or not self._uniform_frames():
+            return super().post_processing()
         from . import _lib
         from ._lib import ptr
         k = len(self.frames)
         prune_now = k % self.cfg["prune_interval"] == 0
-        use = list(range(k)) if prune_now else [k - 1]
-        depth_all = self._frame_store()[3]
-        depth_gt = depth_all if prune_now else depth_all[k - 1:k]
-        h, w = depth_gt.shape[-2:]
         n = self.means.shape[0]
-        params = [self.means, self.scales, self.rotations, self.opacities, self.harmonics]
-        counts = self._render_counts(use, None, None, depth_gt, params, (h, w))
-        newest = counts[-1].contiguous()
+        if pending is not None and not prune_now and pending["n"] == n:
+            while not self._check_capacity(["count"]):       # (the GPU has drained by now: this read does not wait)
+                st = self._state("count", n, *pending["hw"])
+                api.forward(pending["cam"], pending["g"], st)
+            newest = self._states["count"].count
+            counts = None
+        else:
+            use = list(range(k)) if prune_now else [k - 1]
+            depth_all = self._frame_store()[3]
+            depth_gt = depth_all if prune_now else depth_all[k - 1:k]
+            h, w = depth_gt.shape[-2:]
+            params = [self.means, self.scales, self.rotations, self.opacities, self.harmonics]
+            counts = self._render_counts(use, None, None, depth_gt, params, (h, w))
+            newest = counts[-1].contiguous()
         last = self.frames[-1]
         far = last.get("_far_host")           # (read back with the frame's pose: _make_camera)
         if far is None:
@@ -528,9 +590,21 @@ class FusedMapTrainer(GaussianMapTrainer):
         return c["ok"]
 
     def train_batched(self, steps: Optional[int] = None):
-        self._all_or_nothing(self._train_batched, steps)
+        """All-or-nothing like every train() here, with ONE wait at its end: the loop's iterations and the count render of
+        post_processing are enqueued back to back, then the sticky status words of the loop's views and the count
+        render's status are read together (round 3 waited for the loop, then again for the count render)."""
+        snap = self._snapshot()
+        for _ in range(6):
+            settle = self._train_batched(steps, defer=True)
+            pending = self._post_processing_begin()
+            if settle():
+                self._post_processing_end(pending)
+                return
+            self.overflow_retries = getattr(self, "overflow_retries", 0) + 1
+            self._restore(snap)
+        raise RuntimeError("train(): the rasterizer workspace kept overflowing after six enlargements")
 
-    def _train_batched(self, steps: Optional[int] = None) -> bool:
+    def _train_batched(self, steps: Optional[int] = None, defer: bool = False):
         """``train`` with the B views of an iteration in ONE set of launches: 4 forward kernels, 2 loss
         kernels, 2 backward kernels and the row-set Adam per ITERATION instead of per view (a 512x512
         view is 1024 tiles - a quarter of what the GPU holds).  The sampled frames' poses and
@@ -679,16 +753,20 @@ class FusedMapTrainer(GaussianMapTrainer):
                 continue
             losses[it].copy_(loss_now)
         batch = state["batch"]
-        if batch is not None:
-            status = batch.statuses()                     # every slot, sticky words: any pass of any iteration
-            self._last_need, self._last_need_n = int(status[:, 4].max()), n
-            if bool(status[:, 5].any()):
-                self._grow_cap(self._last_need, int(status[:, 0].max()))
-                self._last_need = None
-                keep["batch"] = None                      # too small: the repeat allocates a larger one
-                return False
-        self.last_losses = [float(x) for x in losses[:total].cpu()]
-        return True
+        self._losses_host, self._losses_dev = [], losses[:total]      # (read when somebody asks: last_losses)
+
+        def settle() -> bool:
+            """the wait of the call: did any pass of any iteration outgrow its workspace?"""
+            if batch is not None:
+                status = batch.statuses()                     # every slot, sticky words: any pass of any iteration
+                self._last_need, self._last_need_n = int(status[:, 4].max()), n
+                if bool(status[:, 5].any()):
+                    self._grow_cap(self._last_need, int(status[:, 0].max()))
+                    self._last_need = None
+                    keep["batch"] = None                      # too small: the repeat allocates a larger one
+                    return False
+            return True
+        return settle if defer else settle()
 
     # ------------------------------------------------------------------ hipGraph iteration
     def _graph_ok(self) -> bool:

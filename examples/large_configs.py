@@ -26,7 +26,7 @@ def run(tag, n, h, w, views, room, steps, warmup):
     # gradients are, so per-kernel times of different builds can be compared
     import os
     lrs = dict(mean=0.0, scale=0.0, rotation=0.0, opacity=0.0, harmonic=0.0) if os.environ.get("AGS_FREEZE") == "1" else None
-    trainer = SurfelTrainer(raw, lrs=lrs)
+    trainer = SurfelTrainer(raw, lrs=lrs, view_streams=int(os.environ.get("AGS_VIEW_STREAMS", "4")))
     cams = []
     for v in range(views):
         c2w, K = make_camera(v, h, w)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where the GPU idles: from a rocprofv3 rocpd database (--kernel-trace), the idle time between consecutive kernel
 dispatches (all queues merged), attributed to the pair (kernel that ended, kernel that started).
-Usage: rocpd_gaps.py results.db [min_gap_us=5] [top=25] [first_kernel_substring: analyse from its first launch on]"""
+Usage: rocpd_gaps.py results.db [min_gap_us=5] [top=25] [first_kernel_substring[@k]: analyse from its first launch on
+(@k: from its k-th launch; negative k counts from the end, e.g. ags_k_bilateral@-50 = the last 50 keyframes of a mapper loop)]"""
 import collections
 import sqlite3
 import sys
@@ -19,8 +20,9 @@ name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
 rows = list(db.execute(f"select {name_col}, start, end from {view} order by start"))
 short = lambda n: n.split("(")[0].replace("void ", "")[:60]
 if len(sys.argv) > 4:
-    first = next(i for i, r in enumerate(rows) if sys.argv[4] in r[0])
-    rows = rows[first:]
+    pat, _, kth = sys.argv[4].partition("@")
+    hits = [i for i, r in enumerate(rows) if pat in r[0]]
+    rows = rows[hits[int(kth) if kth else 0]:]
 busy = sum(e - s for _, s, e in rows) / 1e6
 busy_end = rows[0][2]
 t0, t1 = rows[0][1], max(r[2] for r in rows)
