@@ -384,19 +384,40 @@ struct AgsEmitRec { uint32_t excl, xy, wd, pa; float mx, my, ca, cb, cc, o; }; /
 #ifndef AGS_AGG_MAX_TILES
 #define AGS_AGG_MAX_TILES 256
 #endif
-template <bool AGG, bool RETURN>
+// AGG = 2 (round 4): the ADAPTIVE form for images of many tiles.  Whether a wave's emissions share tiles depends on the
+// map, not on the image: a map grown by the mapper is spatially coherent (a keyframe's surfels are appended pixel by
+// pixel, so the 64 rows of a wave sit next to each other and their pairs fall on the same handful of tiles - a 512x512
+// training batch asks every tile counter ~200 times per view), a synthetic room in random order shares nothing.  Same
+// leader rounds, but the search stops at the first group of fewer than AGS_AGG_MIN_GROUP lanes (a round costs about as
+// much issue time as four serialised same-address atomics cost the L2 channel): coherent waves issue a few atomics
+// instead of 64, incoherent ones pay one or two short rounds and go lane by lane.
+#define AGS_AGG_ADAPT_ROUNDS 8
+#define AGS_AGG_MIN_GROUP 4
+template <int AGG, bool RETURN>
 __device__ __forceinline__ uint32_t ags_wave_agg_inc(uint32_t* __restrict__ counter, uint32_t t, bool active) {
-    if (!AGG) {
+    if (AGG == 0) {
         uint32_t slot = 0;
         if (active) { if (RETURN) slot = atomicAdd(&counter[t], 1u); else atomicAdd(&counter[t], 1u); }
         return slot;
     }
     const int lane = threadIdx.x & 63;
     unsigned long long rem = __ballot(active);
+    if (AGG == 2) {
+        // probe: does the first active lane's counter have company?  If not, the wave goes lane by lane (nothing below
+        // - no ranks, no broadcast of the leaders' results - stands between the lanes and their atomics)
+        if (!rem) return 0;
+        const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)t, __ffsll((long long)rem) - 1);
+        if (__builtin_popcountll(__ballot(active && t == tp)) < AGS_AGG_MIN_GROUP) {
+            uint32_t slot = 0;
+            if (active) { if (RETURN) slot = atomicAdd(&counter[t], 1u); else atomicAdd(&counter[t], 1u); }
+            return slot;
+        }
+    }
     int leader_of = lane;
     uint32_t rank = 0, size = active ? 1u : 0u;
+    constexpr int ROUNDS = AGG == 2 ? AGS_AGG_ADAPT_ROUNDS : AGS_AGG_ROUNDS;
 #pragma unroll 1
-    for (int round = 0; round < AGS_AGG_ROUNDS && rem; ++round) {
+    for (int round = 0; round < ROUNDS && rem; ++round) {
         const int leader = __ffsll((long long)rem) - 1;
         const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);
         const unsigned long long m = __ballot(active && t == t0) & rem;
@@ -406,6 +427,7 @@ __device__ __forceinline__ uint32_t ags_wave_agg_inc(uint32_t* __restrict__ coun
             size = lane == leader ? (uint32_t)__builtin_popcountll(m) : 0u;
         }
         rem &= ~m;
+        if (AGG == 2 && __builtin_popcountll(m) < AGS_AGG_MIN_GROUP) break;   // wave-uniform: no sharing worth another round
     }
     uint32_t base = 0;
     if (size) { if (RETURN) base = atomicAdd(&counter[t], size); else atomicAdd(&counter[t], size); }

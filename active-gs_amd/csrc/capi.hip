@@ -40,10 +40,11 @@ int ags_workspace_init_batch(const AgsWorkspace* ws, int32_t views, int32_t n, i
     if (!ws || !ws->ptr || views < 1 || n < 0 || h <= 0 || w <= 0 || ws->max_instances < 1) return AGS_E_INVALID;
     const AgsLayout L = ags_make_layout(n, h, w, ws->max_instances);
     if (ws->bytes / (size_t)views < L.total) return AGS_E_WORKSPACE;
-    // the views' counter regions are `L.total` bytes apart: one strided fill instead of a memset per view (a training
-    // batch re-binds its 11 workspaces at every keyframe)
-    if (hipMemset2DAsync((char*)ws->ptr + L.status, L.total, 0, L.clear_bytes, (size_t)views, (hipStream_t)stream) != hipSuccess)
-        return AGS_E_LAUNCH;
+    // (one hipMemset2DAsync over the views' counter regions was tried: ~170 us of host time per call on ROCm 7.2 against
+    //  ~7 us per plain memset - round 4)
+    for (int32_t v = 0; v < views; ++v)
+        if (hipMemsetAsync((char*)ws->ptr + (size_t)v * L.total + L.status, 0, L.clear_bytes, (hipStream_t)stream) != hipSuccess)
+            return AGS_E_LAUNCH;
     return AGS_OK;
 }
 

@@ -87,6 +87,12 @@ __device__ __forceinline__ void ags_load_rows3x3(const float* __restrict__ b0, c
 }
 
 struct AgsDirectEmit { uint64_t* keys; uint32_t tile_cap; uint32_t* partial; uint32_t tc_stride; };
+#ifndef AGS_DIRECT_AGG_LARGE
+#define AGS_DIRECT_AGG_LARGE 2   // slot atomics of images with more than AGS_AGG_MAX_TILES tiles: 2 = adaptive grouping, 0 = per lane (probe builds)
+#endif
+#ifndef AGS_DIRECT_AGG_MIN_PAIRS
+#define AGS_DIRECT_AGG_MIN_PAIRS 64    // (surfel, candidate tile) pairs of a wave from which the grouping is tried at all
+#endif
 
 // EMIT: 0 = nothing, 1 = count the tiles a surfel reaches (tile-sort binning), 2 = AGS_BIN_DIRECT: take a slot in
 // the tile's own key range with ONE returning atomic and write the (depth | id) key at once
@@ -165,18 +171,26 @@ __device__ __forceinline__ void ags_preprocess_block(
                                 [&](bool hit, uint32_t t, uint32_t, int) {
                                     ags_wave_agg_inc<AGG, false>(tile_count, t, hit);
                                 });
+    const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
     if (EMIT == 2) { // one-pass binning: the tile's counter hands out the slot, the key is written at once
         const uint32_t wave_first = (uint32_t)(first + (threadIdx.x & ~63));
+        // images of many tiles: lanes that ask the same counter share an atomic only in waves that are DENSE with
+        // candidate tiles (a mapper-grown map: the wave's 64 rows are neighbours in space and most are visible - hundreds of
+        // pairs on a handful of tiles); a sparse wave (a random-order map: a few visible rows, ~30 pairs, all on different
+        // tiles) takes the plain per-lane path without looking
+        const bool dense = AGS_DIRECT_AGG_LARGE != 0 && ws >= AGS_DIRECT_AGG_MIN_PAIRS;     // wave-uniform
         ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, rx0, ry0, rwd, __float_as_uint(g.dc), g, F.tiles_x,
                                 [&](bool hit, uint32_t t, uint32_t depth_bits, int owner_lane) {
-                                    const uint32_t got = ags_wave_agg_inc<AGG, true>(tile_count, t * direct.tc_stride, hit);
+                                    uint32_t got;
+                                    if (AGG) got = ags_wave_agg_inc<1, true>(tile_count, t * direct.tc_stride, hit);
+                                    else if (dense) got = ags_wave_agg_inc<2, true>(tile_count, t * direct.tc_stride, hit);
+                                    else got = ags_wave_agg_inc<0, true>(tile_count, t * direct.tc_stride, hit);
                                     if (hit && got < direct.tile_cap)
                                         direct.keys[(size_t)t * direct.tile_cap + got] =
                                             ((uint64_t)depth_bits << 32) | (wave_first + (uint32_t)owner_lane);
                                 });
     }
     AGS_TL(0, tl_w, 4);
-    const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
     if (EMIT == 2) { // no block-level reduction (and no barrier): one spread atomic per wave that shows anything
         if ((threadIdx.x & 63) == 0 && wv) atomicAdd(&direct.partial[AGS_PART(bx, AGS_PART_VIS)], wv);
     } else {
