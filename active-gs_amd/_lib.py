@@ -51,7 +51,8 @@ class AgsGaussianGrads(C.Structure):
                 ("d_colors", c_f32p), ("d_means2D", c_f32p), ("accumulate", C.c_int32), ("adam_clock", C.c_void_p),
                 ("adam_lr", C.c_float * 5), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float),
                 ("touched", AgsRowSet), ("fused_adam", C.c_void_p), ("adam_eps", C.c_float),
-                ("pack_segment", c_f32p), ("pack_capacity", C.c_int32), ("defer_rows", C.c_int32)]
+                ("pack_segment", c_f32p), ("pack_capacity", C.c_int32), ("defer_rows", C.c_int32),
+                ("row_begin", C.c_int32), ("row_end", C.c_int32)]
 
 
 

@@ -324,7 +324,14 @@ int ags_backward_rows(const AgsViewRef* views, int32_t num_views, const AgsGauss
                       ags_stream_t stream) {
     if (!views || !in || !din || num_views < 1 || num_views > AGS_MAX_ROW_VIEWS) return AGS_E_INVALID;
     if (in->n == 0) return AGS_OK;
-    if (!din->touched.member || !din->touched.rows || !din->touched.count || din->accumulate == 2) return AGS_E_INVALID;
+    const bool ranged = !din->touched.member && !din->touched.rows && !din->touched.count;   // rows [row_begin, row_end) of the map
+    if (ranged) {
+        if (din->row_begin < 0 || din->row_end <= din->row_begin || din->row_end > in->n) return AGS_E_INVALID;
+        if (din->fused_adam || din->pack_segment || din->accumulate != 0) return AGS_E_INVALID;
+        if (!din->d_means3D || !din->d_scales || !din->d_rotations || !din->d_opacities || !din->d_colors) return AGS_E_INVALID;
+    } else if (!din->touched.member || !din->touched.rows || !din->touched.count || din->accumulate == 2) {
+        return AGS_E_INVALID;
+    }
     if (!in->means3D || !in->scales || !in->rotations || !in->opacities) return AGS_E_INVALID;
     {
         const int have = (din->d_means3D != nullptr) + (din->d_scales != nullptr) + (din->d_rotations != nullptr) +

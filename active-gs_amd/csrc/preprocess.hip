@@ -899,25 +899,27 @@ __device__ __forceinline__ void ags_rows_body(
 template <int MODE>
 __global__ __launch_bounds__(AGS_ROWS_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void ags_k_rows_multi(AgsRowViews rv, AgsGaussians in, AgsGaussianGrads out,
                                                                     AgsAdamArgs adam) {
-    constexpr bool FUSED_ADAM = MODE == 1, PACK = MODE == 2;
+    // MODE 3 (data-parallel ranks that exchange the dense gradient slab in row chunks): no row set - the rows
+    // [out.row_begin, out.row_end) of the MAP, gradient arrays overwritten (zeros where no view shows the row)
+    constexpr bool FUSED_ADAM = MODE == 1, PACK = MODE == 2, RANGE = MODE == 3;
     const int lane = threadIdx.x & 63;
     const int wave_index = (int)blockIdx.x, num_waves = (int)gridDim.x;
     const int slot0 = min(wave_index * 64 + lane, in.n - 1);
-    int i_next = out.touched.rows[slot0];
-    const int count = *out.touched.count;
+    int i_next = RANGE ? 0 : out.touched.rows[slot0];
+    const int count = RANGE ? 0 : *out.touched.count;
     if (PACK && wave_index == 0 && lane < 16) // segment header: rows shipped, rows the set holds
         out.pack_segment[lane] = __int_as_float(lane == 0 ? min(count, out.pack_capacity) : lane == 1 ? count : 0);
     // When most of the map is listed (a room seen from inside: config 4's four views list 73 % of the rows) walking the
     // MAP in row order with a membership test beats walking the list: every access of a wave is then a stream instead
     // of 64 scattered 12-16-byte pieces per array (six sectors per row for 52 useful bytes).  Not for the exchange
     // segment, whose record positions are list positions.
-    const bool dense = !PACK && 2 * (long long)count > (long long)in.n;
-    const int total = dense ? in.n : count;
-    for (int base = wave_index * 64; base < total; base += num_waves * 64) { // wave-uniform
+    const bool dense = RANGE || (!PACK && 2 * (long long)count > (long long)in.n);
+    const int total = RANGE ? out.row_end : (dense ? in.n : count);
+    for (int base = (RANGE ? out.row_begin : 0) + wave_index * 64; base < total; base += num_waves * 64) { // wave-uniform
         bool valid = base + lane < total;
         int i = dense ? min(base + lane, in.n - 1) : (valid ? i_next : 0);
         if (dense) {
-            valid = valid && out.touched.member[i] != 0;
+            if (!RANGE) valid = valid && out.touched.member[i] != 0;
             if (!__any(valid)) continue;            // wave-uniform
             if (!valid) i = 0;
         } else {
@@ -1082,6 +1084,12 @@ __global__ __launch_bounds__(AGS_ROWS_THREADS) __attribute__((amdgpu_waves_per_e
 }
 
 void ags_launch_rows_multi(const AgsRowViews& rv, const AgsGaussians& in, const AgsGaussianGrads& din, hipStream_t s) {
+    if (!din.touched.rows) {   // a row range of the map, no row set (capi.hip checked the range)
+        int blocks = (din.row_end - din.row_begin + AGS_ROWS_THREADS - 1) / AGS_ROWS_THREADS;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(ags_k_rows_multi<3>, dim3(blocks), dim3(AGS_ROWS_THREADS), 0, s, rv, in, din, AgsAdamArgs());
+        return;
+    }
     int blocks = (in.n + AGS_ROWS_THREADS - 1) / AGS_ROWS_THREADS;
     if (blocks > 16384) blocks = 16384; // fixed grid (the member count lives on the device): idle blocks exit at once
     if (din.fused_adam)

@@ -75,9 +75,26 @@ class FusedAdam:
         """What ``raster_api.backward(adam_tick=...)`` needs to advance this optimizer's device clock."""
         return (self.device_clock, self.lrs, self.betas[0], self.betas[1])
 
-    def tensors_struct(self, grads: Sequence[torch.Tensor]) -> "_lib.AgsAdamTensors":
-        """The C-ABI view of this optimiser (also what ``raster_api.backward(fused_adam=...)`` takes)."""
+    def tensors_struct(self, grads: Sequence[torch.Tensor], rows: "tuple | None" = None) -> "_lib.AgsAdamTensors":
+        """The C-ABI view of this optimiser (also what ``raster_api.backward(fused_adam=...)`` takes).  ``rows`` =
+        (begin, end): the view of the rows [begin, end) of the five map tensors only (pointers moved, element counts cut:
+        the kernels see a smaller map) - the row chunks of a data-parallel rank's overlapped exchange."""
         t = _lib.AgsAdamTensors()
+        if rows is not None:
+            if self.state_rows is None or self.touched is not None:
+                raise ValueError("a row range needs the five map tensors and no row set")
+            a, b = int(rows[0]), int(rows[1])
+            for k, width in enumerate((3, 3, 4, 1, 3)):
+                gk = grads[k]
+                if not gk.is_contiguous() or gk.numel() != self.params[k].numel():
+                    raise ValueError("gradient arrays must be contiguous and shaped like the parameters")
+                t.param[k] = ptr(self.params[k]) + 4 * a * width
+                t.grad[k] = ptr(gk) + 4 * a * width
+                t.numel[k] = (b - a) * width
+                t.lr[k] = self.lrs[k]
+            t.state_rows = ptr(self.state_rows) + 4 * 28 * a
+            self._keep = grads
+            return t
         for k in range(5):
             g = grads[k]
             if g.shape != self.params[k].shape and g.numel() == self.params[k].numel():
@@ -114,6 +131,23 @@ class FusedAdam:
         else:
             _lib.check(lib.ags_adam_step(C.byref(t), self.betas[0], self.betas[1], self.eps, self.step_count,
                                          stream), "ags_adam_step")
+
+    def step_range(self, grads: Sequence[torch.Tensor], begin: int, end: int, device_clock: bool = True,
+                   pre_ticked: bool = False, first: bool = True) -> None:
+        """The Adam update of the rows [begin, end) only (same arithmetic per element as ``step``).  The chunks of one
+        optimisation step share ONE tick of the clock: pass ``first=True`` for the chunk that comes first."""
+        lib = _lib.load()
+        self.use_clock(device_clock)
+        if not device_clock and first:
+            self.step_count += 1
+        t = self.tensors_struct(grads, rows=(begin, end))
+        stream = torch.cuda.current_stream().cuda_stream
+        if device_clock:
+            _lib.check(lib.ags_adam_step_device(C.byref(t), self.betas[0], self.betas[1], self.eps, ptr(self.device_clock),
+                                                int(pre_ticked or not first), stream), "ags_adam_step_device")
+        else:
+            _lib.check(lib.ags_adam_step(C.byref(t), self.betas[0], self.betas[1], self.eps, self.step_count, stream),
+                       "ags_adam_step")
 
     def step_gathered(self, grads: Sequence[torch.Tensor], segments: torch.Tensor, world: int, capacity: int,
                       slot_table: torch.Tensor, pre_ticked: bool = False) -> None:

@@ -333,13 +333,16 @@ def backward(cam: Camera, g: Gaussians, state: ForwardState, d_rgb=None, d_norma
     return grads
 
 
-def backward_rows(views: Sequence, g: Gaussians, grads: GaussianGrads, touched: RowSet, accumulate: bool = False,
-                  adam_clock=None, fused_adam=None, pack=None, stream: Optional[int] = None) -> GaussianGrads:
+def backward_rows(views: Sequence, g: Gaussians, grads: GaussianGrads, touched: Optional[RowSet], accumulate: bool = False,
+                  adam_clock=None, fused_adam=None, pack=None, stream: Optional[int] = None,
+                  row_range: Optional[tuple] = None) -> GaussianGrads:
     """``ags_backward_rows``: the per-Gaussian backward of ALL the views of a step (``views`` = [(Camera, ForwardState)],
     each rendered and taken through ``backward(..., defer_rows=True)``) in one launch over the member rows of ``touched``:
     the views' gradients are summed in registers, then written to ``grads`` / packed as the rank's exchange segment
     (``pack``) / consumed by the fused Adam step (``fused_adam`` = (AgsAdamTensors, eps), ``adam_clock`` = the optimiser's
-    ``tick_args()`` whose clock one of the views' ``backward`` calls has already advanced)."""
+    ``tick_args()`` whose clock one of the views' ``backward`` calls has already advanced).
+    ``touched=None`` with ``row_range=(begin, end)``: no row set - the rows [begin, end) of the map, ``grads`` overwritten
+    (the dense form of data-parallel ranks, cut into row chunks whose all-reduces overlap the next chunk's launch)."""
     lib = _lib.load()
     n = len(views)
     refs = (_lib.AgsViewRef * n)()
@@ -352,6 +355,8 @@ def backward_rows(views: Sequence, g: Gaussians, grads: GaussianGrads, touched: 
     din = _lib.AgsGaussianGrads(ptr(grads.means3D), ptr(grads.scales), ptr(grads.rotations), ptr(grads.opacities),
                                 ptr(grads.colors), ptr(grads.means2D), int(accumulate))
     din.touched = _rowset_struct(touched)
+    if row_range is not None:
+        din.row_begin, din.row_end = int(row_range[0]), int(row_range[1])
     if adam_clock is not None:
         clock, lrs, b1, b2 = adam_clock
         din.adam_clock = ptr(clock)

@@ -213,6 +213,13 @@ class SurfelTrainer:
     # one-stream step (the default) need not know any of this.
     VIEW_STREAMS = int(os.environ.get("AGS_VIEW_STREAMS", "1"))
     MULTI_VIEW_ROWS = True   # several views per step: one per-Gaussian backward launch for all of them (ags_backward_rows)
+    # Data-parallel ranks that exchange the DENSE gradient slab (row sets covering most of the map: configuration 4): the
+    # per-Gaussian backward, the all-reduce and the Adam update are cut into this many row chunks; chunk k's all-reduce
+    # runs on a communication stream under chunk k + 1's chain rule and the Adam update of the chunks that have arrived.
+    # Every element is summed over the ranks exactly as in one all-reduce, so the replicas stay bit-identical; 1 = one
+    # all-reduce of the whole slab behind the whole backward.  AGS_DENSE_CHUNKS overrides.
+    DENSE_CHUNKS = int(os.environ.get("AGS_DENSE_CHUNKS", "4"))
+    DENSE_CHUNK_MIN_ROWS = 1 << 14
 
     def reset_optimizer(self) -> None:
         """What the reference does at the start of every ``train()`` call (``init_training``,
@@ -383,8 +390,80 @@ class SurfelTrainer:
         if len(self._pending) >= self.CHECK_EVERY:
             self.check_overflow()
 
+    def _dense_chunked(self, cams) -> bool:
+        return (self._distributed() and self.rows is None and self.fused_activations and self.MULTI_VIEW_ROWS
+                and len(cams) <= 16 and self.DENSE_CHUNKS >= 1)
+
+    def _dense_step(self, cams, image_grads, max_instances, device_clock: bool) -> None:
+        """The data-parallel step with the dense slab: blend passes of this rank's views, then per ROW CHUNK the
+        per-Gaussian backward of all views (``ags_backward_rows`` without a row set), the chunk's all-reduce on the
+        communication stream, and its Adam update once the sum has arrived."""
+        done, ticked = self._dense_blend(cams, image_grads, max_instances, device_clock)
+        self._dense_tail(done, ticked, device_clock)
+
+    def _dense_blend(self, cams, image_grads, max_instances, device_clock: bool):
+        """forward + blend backward of this rank's views; every view keeps its gradient records in its own workspace"""
+        g = self.gaussians()
+        self._drop_prepared()
+        self.adam_fused, self._packed = False, False
+        done, ticked = [], False
+        main = torch.cuda.current_stream()
+        lanes = self._view_streams(len(cams))
+        for s_ in lanes:
+            s_.wait_stream(main)
+        for v, cam in enumerate(cams):
+            st = self.state_for(cam.image_height, cam.image_width, max_instances, slot=v)
+            with torch.cuda.stream(lanes[v % len(lanes)]) if lanes else contextlib.nullcontext():
+                api.forward(cam, g, st)
+                d = image_grads(v, st)
+                last = device_clock and v == len(cams) - 1
+                api.backward(cam, g, st, *d, adam_tick=self.optim.tick_args() if last else None, defer_rows=True)
+            done.append((cam, st))
+            ticked |= last
+        for s_ in lanes:
+            main.wait_stream(s_)
+        return done, ticked
+
+    def _dense_tail(self, done, ticked: bool, device_clock: bool) -> None:
+        """per row chunk: chain rule of all views -> all-reduce (communication stream) -> Adam"""
+        g = self.gaussians()
+        main = torch.cuda.current_stream()
+        n = self.n
+        K = max(1, min(int(self.DENSE_CHUNKS), n // self.DENSE_CHUNK_MIN_ROWS))
+        bounds = [(n * c // K) & ~63 if 0 < c < K else (0 if c == 0 else n) for c in range(K + 1)]
+        segs = [t.view(-1) for t in self.slab.as_list()]
+        if getattr(self, "_comm", None) is None:
+            self._comm = torch.cuda.Stream()
+        arrived = []
+        for c in range(K):
+            a, b = bounds[c], bounds[c + 1]
+            if done:
+                api.backward_rows(done, g, self.slab.grads, None, row_range=(a, b))
+            elif c == 0:
+                self.slab.flat.zero_()            # a rank without views this step contributes zeros
+            if K == 1:
+                all_reduce_(self.slab.flat, group=self.pg)
+                continue
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(self._comm):
+                self._comm.wait_event(ready)
+                for seg, width in zip(segs, (3, 3, 4, 1, 3)):
+                    all_reduce_(seg[a * width:b * width], group=self.pg)
+                ev = torch.cuda.Event()
+                ev.record(self._comm)
+            arrived.append(ev)
+        for c in range(K):
+            if K > 1:
+                main.wait_event(arrived[c])
+            self.optim.step_range(self.slab.as_list(), bounds[c], bounds[c + 1], device_clock=device_clock,
+                                  pre_ticked=ticked, first=(c == 0))
+
     def _step_once(self, cams, image_grads, max_instances, device_clock, next_cam=None) -> None:
         dist_on = self._distributed()
+        if dist_on and self._dense_chunked(cams):
+            self._dense_step(cams, image_grads, max_instances, device_clock)
+            return
         ticked = self._local_pass(cams, image_grads, max_instances, tick=device_clock, fuse_adam=not dist_on,
                                   next_cam=None if dist_on else next_cam)
         if dist_on:
@@ -576,6 +655,12 @@ class SurfelTrainer:
         rows_x = dist_on and self._row_exchange_on()
         in_graph = dist_on and self._collectives_capturable()
         repeat = max(1, int(repeat)) if (not dist_on or in_graph) else 1
+        if dist_on and not in_graph and self._dense_chunked(cams):
+            # host-driven collectives (gloo) between the row chunks: nothing to record, the step is replayed eagerly
+            def replay_eager():
+                self._dense_step(cams, image_grads, max_instances, True)
+            replay_eager.collective_in_graph, replay_eager.pipelined, replay_eager.steps = False, False, 1
+            return replay_eager
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         g_local, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -585,6 +670,9 @@ class SurfelTrainer:
                 try:
                     with torch.cuda.graph(g_local, stream=side, capture_error_mode="thread_local"):
                         for _ in range(repeat):
+                            if self._dense_chunked(cams):       # chunked chain rule | all-reduce | Adam, all in the graph
+                                self._dense_step(cams, image_grads, max_instances, True)
+                                continue
                             ticked = self._local_pass(cams, image_grads, max_instances, tick=True)
                             self._exchange_gradients()
                             self._optimizer_step(True, ticked)

@@ -173,6 +173,11 @@ typedef struct AgsGaussianGrads {
      * its workspace - and ags_backward_rows later turns the records of ALL the step's views into parameter gradients in
      * one launch.  The five d_* pointers are not used by such a call (they may be NULL); adam_clock still works. */
     int32_t defer_rows;
+    /* ags_backward_rows WITHOUT a row set (touched all NULL): the rows [row_begin, row_end) of the map - what a data-parallel
+     * rank that exchanges the dense gradient slab uses to cut its per-Gaussian backward into row chunks, so that chunk k's
+     * all-reduce (on another stream) runs under chunk k + 1's chain rule.  The five gradient arrays are required and
+     * OVERWRITTEN for those rows (zeros where no view shows the row); no fused_adam, no pack_segment.  Ignored elsewhere. */
+    int32_t row_begin, row_end;
 } AgsGaussianGrads;
 
 #define AGS_BIN_TILE_SORT 0 /* tile counting + bucket scatter + per-tile LDS bitonic sort */

@@ -125,6 +125,67 @@ def test_two_ranks_equal_single_process_two_views(agslib, use_graph, sparse_rows
         assert moved >= 4                                          # the optimiser did move the map (scales may sit on their clamp)
 
 
+def _dense_worker(rank, world, port, chunks, use_graph, ret):
+    _watchdog()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from active_gs_amd.trainer import SurfelTrainer
+        SurfelTrainer.DENSE_CHUNKS, SurfelTrainer.DENSE_CHUNK_MIN_ROWS = chunks, 1024      # 8000 rows: 4 chunks of ~2000
+        raw, cams, grads = _setup([rank, rank + world])                                    # two views per rank
+        tr = SurfelTrainer(raw, sparse_rows=False)
+        fn = lambda v, st: (grads[v][0], grads[v][1], grads[v][2], None, None)
+        tr.step(cams, fn, CAP, device_clock=True)
+        assert tr.rows is None and tr.exchange is None and tr._dense_chunked(cams)
+        if use_graph:
+            replay = tr.capture(cams, fn, CAP)
+            for _ in range(STEPS - 1):
+                replay()
+        else:
+            for _ in range(STEPS - 1):
+                tr.step(cams, fn, CAP, device_clock=True)
+        tr.check_overflow()
+        torch.cuda.synchronize()
+        ret[rank] = dict(params=[p.cpu() for p in tr.params], m=[t.cpu() for t in tr.optim.exp_avg],
+                         v=[t.cpu() for t in tr.optim.exp_avg_sq], step=int(tr.optim.device_clock[0].item()),
+                         slab=tr.slab.flat.cpu())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_chunked_dense_exchange_keeps_the_replicas_identical(agslib, use_graph):
+    """Data-parallel ranks that exchange the dense slab (configuration 4's shape: the row sets cover most of the map) cut
+    the per-Gaussian backward, the all-reduce and the Adam update into row chunks, chunk k's all-reduce on a communication
+    stream under chunk k + 1's chain rule (SurfelTrainer.DENSE_CHUNKS).  Two ranks, two views each, four chunks: the
+    replicas' parameters, both moments and the reduced slab are bit-identical, and they are the single-process result
+    over the four views.  (That the chunked tail gives the SAME BITS as one all-reduce of the whole slab is checked from
+    identical gradient records in tests/tools/rccl_one_rank.py - two separate runs of the blend backward differ in the
+    order of its float atomics.)"""
+    four = _spawn_two(_dense_worker, (4, use_graph))
+    assert four[0]["step"] == four[1]["step"] == STEPS
+    for key in ("params", "m", "v"):
+        for c, d in zip(four[0][key], four[1][key]):
+            assert torch.equal(c, d), key                              # replicas
+    assert torch.equal(four[0]["slab"], four[1]["slab"]) and float(four[0]["slab"].abs().max()) > 0
+    from active_gs_amd.trainer import SurfelTrainer
+    raw, cams, grads = _setup([0, 2, 1, 3])
+    init = [raw[k].clone().cpu() for k in ("means", "scales", "rotations", "opacities", "harmonics")]
+    tr = SurfelTrainer(raw)
+    fn = lambda v, st: (grads[v][0], grads[v][1], grads[v][2], None, None)
+    for _ in range(STEPS):
+        tr.step(cams, fn, CAP, device_clock=True)
+    torch.cuda.synchronize()
+    moved = 0
+    for a, r, i0 in zip(four[0]["params"], [p.cpu() for p in tr.params], init):
+        travel = (r - i0).abs().mean()
+        moved += int(travel > 1e-6)
+        assert (a - r).abs().mean() < 5e-3 * travel + 1e-9
+    assert moved >= 4
+
+
 MOVE_STEPS = 7
 
 

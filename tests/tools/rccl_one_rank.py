@@ -44,5 +44,45 @@ for sparse in (True, False):
     for a, b, i0 in zip(tr.params, tr2.params, init):
         travel = (b - i0).abs().mean()
         assert (a - b).abs().mean() < 5e-3 * travel + 1e-9, (float((a - b).abs().mean()), float(travel))
+# the dense slab in ROW CHUNKS (SurfelTrainer.DENSE_CHUNKS): chain rule | all-reduce on the communication stream | Adam per
+# chunk.  (1) from IDENTICAL gradient records the chunked tail gives the same bits as one all-reduce of the whole slab
+# (two runs of the blend backward differ in the order of its float atomics, so the records are snapshotted);
+# (2) the forks and joins of the chunks are recorded inside the captured step graph.
+SurfelTrainer.DENSE_CHUNK_MIN_ROWS = 1024
+raw, cams, grads = T._setup([0, 1])
+fn = lambda v, st: (grads[v][0], grads[v][1], grads[v][2], None, None)
+tr = SurfelTrainer(raw, sparse_rows=False)
+SurfelTrainer.DENSE_CHUNKS = 1
+tr.step(cams, fn, T.CAP, device_clock=True)
+assert tr.rows is None and tr._dense_chunked(cams)
+done, ticked = tr._dense_blend(cams, fn, T.CAP, True)
+torch.cuda.synchronize()
+snap = dict(ws=[st.workspace.clone() for _, st in done], params=[p.clone() for p in tr.params], state=tr.optim.state_rows.clone(),
+            clock=tr.optim.device_clock.clone(), slab=tr.slab.flat.clone())
+out = []
+for chunks in (1, 4, 3):
+    SurfelTrainer.DENSE_CHUNKS = chunks
+    for (_, st), w in zip(done, snap["ws"]):
+        st.workspace.copy_(w)
+    for p, q in zip(tr.params, snap["params"]):
+        p.copy_(q)
+    tr.optim.state_rows.copy_(snap["state"]); tr.optim.device_clock.copy_(snap["clock"]); tr.slab.flat.copy_(snap["slab"])
+    tr._dense_tail(done, ticked, True)
+    torch.cuda.synchronize()
+    out.append([p.clone() for p in tr.params] + [tr.optim.state_rows.clone(), tr.slab.flat.clone(), tr.optim.device_clock.clone()])
+for other in out[1:]:
+    for a, b in zip(out[0], other):
+        assert torch.equal(a, b)
+assert float(out[0][-2].abs().max()) > 0
+SurfelTrainer.DENSE_CHUNKS = 4
+replay = tr.capture(cams, fn, T.CAP, repeat=2)
+assert replay.collective_in_graph and replay.steps == 2
+step0 = int(tr.optim.device_clock.view(torch.int32)[0])
+for _ in range(3):
+    replay()
+torch.cuda.synchronize()
+tr.check_overflow()
+assert int(tr.optim.device_clock.view(torch.int32)[0]) == step0 + 6
+assert all(bool(torch.isfinite(p).all()) for p in tr.params)
 dist.destroy_process_group()
 print("OK")
