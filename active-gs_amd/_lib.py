@@ -118,7 +118,8 @@ def make_tuning(bwd_reduce=None, render_slots=None, cull_first_min_n=None) -> Ag
 
 class AgsWorkspace(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_size_t), ("max_instances", C.c_int64),
-                ("binning_mode", C.c_int32), ("tuning", C.POINTER(AgsTuning))]
+                ("binning_mode", C.c_int32), ("tuning", C.POINTER(AgsTuning)), ("early_status_host", C.c_void_p),
+                ("early_status_event", C.c_void_p)]
 
 
 def workspace(ptr_, nbytes, max_instances, binning_mode, tuning: "AgsTuning | None" = None) -> AgsWorkspace:
@@ -136,7 +137,8 @@ class AgsViewRef(C.Structure):
 class AgsStatus(C.Structure):
     _fields_ = [("num_instances", C.c_uint32), ("num_sorted", C.c_uint32), ("overflow", C.c_uint32),
                 ("num_visible", C.c_uint32), ("peak_instances", C.c_uint32), ("overflow_passes", C.c_uint32),
-                ("max_tile_instances", C.c_uint32), ("needed_instances", C.c_uint32), ("reserved", C.c_uint32 * 8)]
+                ("max_tile_instances", C.c_uint32), ("needed_instances", C.c_uint32), ("reserved0", C.c_uint32),
+                ("early_tile_need", C.c_uint32), ("reserved", C.c_uint32 * 6)]
 
 
 class AgsAdamTensors(C.Structure):

@@ -136,6 +136,7 @@ struct AgsAdamArgs {
 // own workgroups append to the list while others walk it)
 struct AgsTick { AgsAdamClock* clock; float lr[5]; float beta1, beta2; const int* rows_count; uint32_t* count_snap; };
 #define AGS_STATUS_COUNT_SNAP 8   // word index of AgsStatus.reserved[0]
+#define AGS_STATUS_EARLY 9        // word index of AgsStatus.early_tile_need
 inline AgsAdamArgs ags_adam_args(const AgsAdamTensors& t) {
     AgsAdamArgs a;
     long long run = 0;

@@ -74,6 +74,8 @@ int ags_workspace_discard_pass(const AgsWorkspace* ws, int32_t n, int32_t h, int
     if (ws->bytes < L.total) return AGS_E_WORKSPACE;
     // everything behind the status block: partial sums / digit totals, tile ranges, tile counters, tile fills
     if (hipMemsetAsync((char*)ws->ptr + L.totals, 0, L.clear_bytes - L.totals, (hipStream_t)stream) != hipSuccess) return AGS_E_LAUNCH;
+    // ... and the discarded pass's early overflow note (the blend kernel that would have cleared it never ran)
+    if (hipMemsetAsync((char*)ws->ptr + L.status + 4 * AGS_STATUS_EARLY, 0, 4, (hipStream_t)stream) != hipSuccess) return AGS_E_LAUNCH;
     return AGS_OK;
 }
 
@@ -116,6 +118,11 @@ int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* o
     if (in->n > 0) {
         { StageScope t(AGS_STAGE_PREPROCESS, s);
           ags_launch_preprocess(F, *cam, *in, base, L, *pg, radix ? 0 : direct ? 2 : 1, kOneView, s); }
+        if (direct && ws->early_status_host && ws->early_status_event) {
+            // the key slots are taken: whether a tile's list outgrew its range is known NOW (AgsStatus.early_tile_need)
+            if (hipMemcpyAsync(ws->early_status_host, base + L.status, sizeof(AgsStatus), hipMemcpyDeviceToHost, s) != hipSuccess) return AGS_E_LAUNCH;
+            if (hipEventRecord((hipEvent_t)ws->early_status_event, s) != hipSuccess) return AGS_E_LAUNCH;
+        }
         { StageScope t(AGS_STAGE_BINNING, s);
           if (radix) ags_launch_binning(F, *in, base, L, s);
           else if (direct) ags_launch_direct_sort(base, L, kOneView, s);

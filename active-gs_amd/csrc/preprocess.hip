@@ -86,7 +86,9 @@ __device__ __forceinline__ void ags_load_rows3x3(const float* __restrict__ b0, c
     for (int k = 0; k < 3; ++k) { o0[k] = l0[3 * t + k]; o1[k] = l1[3 * t + k]; o2[k] = l2[3 * t + k]; }
 }
 
-struct AgsDirectEmit { uint64_t* keys; uint32_t tile_cap; uint32_t* partial; uint32_t tc_stride; };
+// `early`: AgsStatus.early_tile_need - a lane whose slot lies beyond its tile's range notes slot + 1 there (atomicMax;
+// only overflowing passes ever touch it), so that the pass's overflow is known behind THIS kernel, not behind the blend
+struct AgsDirectEmit { uint64_t* keys; uint32_t tile_cap; uint32_t* partial; uint32_t tc_stride; uint32_t* early; };
 #ifndef AGS_DIRECT_AGG_LARGE
 #define AGS_DIRECT_AGG_LARGE 2   // slot atomics of images with more than AGS_AGG_MAX_TILES tiles: 2 = adaptive grouping, 0 = per lane (probe builds)
 #endif
@@ -188,6 +190,7 @@ __device__ __forceinline__ void ags_preprocess_block(
                                     if (hit && got < direct.tile_cap)
                                         direct.keys[(size_t)t * direct.tile_cap + got] =
                                             ((uint64_t)depth_bits << 32) | (wave_first + (uint32_t)owner_lane);
+                                    else if (hit) atomicMax(direct.early, got + 1u);
                                 });
     }
     AGS_TL(0, tl_w, 4);
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
         }
         AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(tiles, wo); AGS_WS_SHIFT(rect, wo); AGS_WS_SHIFT(block_sums, wo);
         AGS_WS_SHIFT(block_vis, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(dgeom, wo);
-        if (EMIT == 2) { AGS_WS_SHIFT(direct.keys, wo); AGS_WS_SHIFT(direct.partial, wo); }
+        if (EMIT == 2) { AGS_WS_SHIFT(direct.keys, wo); AGS_WS_SHIFT(direct.partial, wo); AGS_WS_SHIFT(direct.early, wo); }
     }
     ags_preprocess_block<EMIT, AGG, false>(F, Vp, Pp, in, geom, tiles, rect, radii, block_sums, block_vis, tile_count, dgeom,
                                            touched, direct, (int)blockIdx.x);
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_cull(
         radii += (size_t)blockIdx.y * (size_t)vs.n;
         if (zero_importance) { zero_importance += (size_t)blockIdx.y * (size_t)vs.n; zero_count += (size_t)blockIdx.y * (size_t)vs.n; }
         AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(dgeom, wo);
-        AGS_WS_SHIFT(direct.keys, wo); AGS_WS_SHIFT(direct.partial, wo);
+        AGS_WS_SHIFT(direct.keys, wo); AGS_WS_SHIFT(direct.partial, wo); AGS_WS_SHIFT(direct.early, wo);
     }
     constexpr int R = AGS_CULL_ROWS, NT = AGS_PRE_THREADS;
     __shared__ __attribute__((aligned(16))) float lmeans[3 * R];
@@ -425,6 +428,7 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_cull(
             for (int rr = 0; rr < NR; ++rr)
                 if (hit[rr] && got[rr] < direct.tile_cap)
                     direct.keys[(size_t)tile[rr] * direct.tile_cap + got[rr]] = ((uint64_t)owner_depth[rr] << 32) | owner_row[rr];
+                else if (hit[rr]) atomicMax(direct.early, got[rr] + 1u);
         }
     }
     if (lane == 0 && vis_total) atomicAdd(&direct.partial[AGS_PART(blockIdx.x * (NT / 64) + wave, AGS_PART_VIS)], vis_total);
@@ -635,6 +639,7 @@ __device__ __forceinline__ void ags_emit_keys_rounds(AgsEmitRec* wave_lds, uint3
             const uint32_t owner_row = (uint32_t)__shfl(row_of_lane, lo[r]);
             if (hit[r] && got[r] < direct.tile_cap)
                 direct.keys[(size_t)tile[r] * direct.tile_cap + got[r]] = ((uint64_t)owner_depth[r] << 32) | owner_row;
+            else if (hit[r]) atomicMax(direct.early, got[r] + 1u);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -877,6 +882,7 @@ __device__ __forceinline__ void ags_rows_body(
                                             const uint32_t owner_row = (uint32_t)__shfl(my_row, owner_lane);
                                             if (hit && got < nx->direct.tile_cap)
                                                 nx->direct.keys[(size_t)t * nx->direct.tile_cap + got] = ((uint64_t)depth_bits << 32) | owner_row;
+                                            else if (hit) atomicMax(nx->direct.early, got + 1u);
                                         });
             else
                 ags_emit_keys_rounds(emit_wave, cnt, rx0, ry0, rwd, __float_as_uint(g2.dc), g2, nx->F.tiles_x, my_row,
@@ -1164,7 +1170,8 @@ void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGau
     const AgsRowSet& touched = pg.touched;
     float* zero_importance = cam.config ? pg.importance : nullptr;
     int* zero_count = cam.config ? pg.count : nullptr;
-    const AgsDirectEmit direct = {(uint64_t*)(ws + L.keys0), ags_direct_tile_cap(L), (uint32_t*)(ws + L.totals), (uint32_t)L.tc_stride};
+    const AgsDirectEmit direct = {(uint64_t*)(ws + L.keys0), ags_direct_tile_cap(L), (uint32_t*)(ws + L.totals), (uint32_t)L.tc_stride,
+                                  (uint32_t*)(ws + L.status) + AGS_STATUS_EARLY};
 #define AGS_LAUNCH_PRE(EMIT, AGG)                                                                                        \
     hipLaunchKernelGGL((ags_k_preprocess<EMIT, AGG>), dim3(L.n_blocks, vs.views), dim3(AGS_PRE_THREADS), 0, s, F,          \
                        cam.viewmatrix, cam.projmatrix, in, (AgsGeom*)(ws + L.geom), (uint32_t*)(ws + L.tiles),             \
@@ -1195,7 +1202,8 @@ void ags_launch_rows_adam_preprocess(const AgsFrame& F, const AgsCamera& cam, co
     nx.F = F2; nx.V = cam2.viewmatrix; nx.P = cam2.projmatrix;
     nx.geom = (AgsGeom*)(ws2 + L2.geom); nx.dgeom = (float4*)(ws2 + L2.dgeom); nx.radii = radii2;
     nx.tile_count = (uint32_t*)(ws2 + L2.tile_count);
-    nx.direct = AgsDirectEmit{(uint64_t*)(ws2 + L2.keys0), ags_direct_tile_cap(L2), (uint32_t*)(ws2 + L2.totals), (uint32_t)L2.tc_stride};
+    nx.direct = AgsDirectEmit{(uint64_t*)(ws2 + L2.keys0), ags_direct_tile_cap(L2), (uint32_t*)(ws2 + L2.totals), (uint32_t)L2.tc_stride,
+                              (uint32_t*)(ws2 + L2.status) + AGS_STATUS_EARLY};
     nx.count_snap = (const uint32_t*)(ws + L.status) + AGS_STATUS_COUNT_SNAP;
     // the member count lives on the device: the member workgroups stride over the list, so any number of them is
     // correct; `rows_hint` (what the caller last saw, 0 = no idea) sizes them for one pass

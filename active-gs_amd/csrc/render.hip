@@ -175,6 +175,7 @@ __device__ __forceinline__ void ags_finalize_status(const AgsFinalize& fin, int 
         if (need > fin.status[4]) fin.status[4] = need;
         if (over) fin.status[5] += 1u;
         fin.status[6] = m; fin.status[7] = need;
+        fin.status[AGS_STATUS_EARLY] = 0u;   // the per-Gaussian kernel's early overflow note: consumed (AgsWorkspace.early_status_host)
     }
 }
 

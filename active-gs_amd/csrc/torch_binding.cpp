@@ -74,7 +74,8 @@ struct Options {
     int max_pending = 64;
     int pool_max_per_key = 16;
 } opt;
-struct Counters { int64_t forward_calls = 0, status_syncs = 0, deferred_checks = 0, overflows = 0, mode_switches = 0; } cnt;
+struct Counters { int64_t forward_calls = 0, status_syncs = 0, deferred_checks = 0, overflows = 0, mode_switches = 0, early_waits = 0,
+                  repaired = 0; } cnt;
 
 using SizeKey = std::tuple<int, int, int>;           // device, h, w
 using NeedKey = std::tuple<int, int, int, int>;      // device, h, w, mode
@@ -303,11 +304,51 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
             pk = PoolKey{dev.index(), (int)h, (int)w, mode};
             bool fresh;
             std::tie(ws, ws_cap, fresh) = take_workspace(pk, (int)n, (int)h, (int)w, min_cap, new_cap, fo.dtype(at::kByte), mode, stream);
-            AgsWorkspace wss{ws.data_ptr(), (size_t)ws.numel(), ws_cap, mode, &tuning};
+            AgsWorkspace wss{ws.data_ptr(), (size_t)ws.numel(), ws_cap, mode, &tuning, nullptr, nullptr};
+            // A call that must be checked before it returns does not wait for the whole pass where it need not: with
+            // one-pass binning the per-Gaussian kernel takes the key slots, so whether a tile's list outgrew its range is
+            // known behind THAT kernel.  ags_forward copies the status block to page-locked memory and records an event
+            // right there (AgsWorkspace.early_status_*); the tile sort and the blend are already queued when this thread
+            // waits for the event - it waits for one kernel, not for three, and the stream never drains.
+            const bool early = must_sync && mode == AGS_BIN_DIRECT && n > 0;
+            Slot eslot;
+            if (early) {
+                { std::lock_guard<std::mutex> g(mu); eslot = take_slot(); }
+                wss.early_status_host = eslot.host; wss.early_status_event = eslot.ev;
+            }
             check_rc(abi.forward(&cs, &gs, &im, &pg, &wss, stream), "ags_forward");
-            if (fresh || must_sync) {
-                // a workspace had to be made (first views of this map size / image size, or the need has outgrown the
-                // pooled ones) or every call is to be checked: read the need back, like upstream's num_rendered read-back
+            if (early) {
+                HIP_OK(hipEventSynchronize(eslot.ev));
+                const uint32_t longest = eslot.host->early_tile_need;
+                const int64_t tiles = ((h + 15) / 16) * ((w + 15) / 16);
+                std::string over;
+                bool mode_left = false;
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    cnt.early_waits++;
+                    free_slots.push_back(eslot);
+                    if (longest) {       // a tile's list outgrew its slots: tiles x the longest list would have held the pass
+                        AgsStatus st{};
+                        st.overflow = 1;
+                        st.needed_instances = (uint32_t)std::min<int64_t>((int64_t)longest * tiles, kU32);
+                        st.max_tile_instances = longest;
+                        over = note_need(key, mode, (int)n, st);
+                        cnt.repaired++;
+                        auto mf = mode_for.find(key);
+                        mode_left = (mf == mode_for.end() ? opt.binning_mode : mf->second) != mode;
+                    }
+                }
+                if (longest) {
+                    // repaired here: the pass that is still running is abandoned (its outputs are overwritten by the
+                    // repeat, which the stream orders behind it) and re-run in a workspace of the size just learnt
+                    TORCH_CHECK(attempts < 4 && (ws_cap < kU32 || mode_left), "diff_gaussian_rasterization_2d: ", over,
+                                " - more than a workspace can hold");
+                    continue;
+                }
+                // fits.  What the pass needed in full (for sizing the next workspaces) arrives with the deferred copy below.
+            } else if (fresh || must_sync) {
+                // (scan-based binning modes, or a workspace that had to be made while checks are deferred): read the need
+                // back behind the whole pass, like upstream's num_rendered read-back
                 AgsStatus st;
                 check_rc(abi.read_status(&wss, &st, stream), "ags_read_status");
                 std::string over;
@@ -462,7 +503,8 @@ double get_option(const std::string& name) {
 std::map<std::string, int64_t> counters() {
     std::lock_guard<std::mutex> g(mu);
     return {{"forward_calls", cnt.forward_calls}, {"status_syncs", cnt.status_syncs}, {"deferred_checks", cnt.deferred_checks},
-            {"overflows", cnt.overflows}, {"mode_switches", cnt.mode_switches}, {"pending", (int64_t)pending.size()}};
+            {"overflows", cnt.overflows}, {"mode_switches", cnt.mode_switches}, {"pending", (int64_t)pending.size()},
+            {"early_waits", cnt.early_waits}, {"repaired", cnt.repaired}};
 }
 
 // what the module has learnt: [(device, h, w, mode, largest need seen)], [(device, h, w, mode in use)], pooled workspaces

@@ -154,7 +154,7 @@ def measure_dropin(dev, n, h, w, views, iters=30, focal=None, deferred=False):
             iteration()
         torch.cuda.synchronize()
         check_overflow()
-        syncs0 = R.counters()["status_syncs"]
+        syncs0, early0 = R.counters()["status_syncs"], R.counters().get("early_waits", 0)
         t0 = time.perf_counter()
         for _ in range(iters):
             iteration()
@@ -168,7 +168,10 @@ def measure_dropin(dev, n, h, w, views, iters=30, focal=None, deferred=False):
         R.set_option("always_check", was)
     return dict(ms_per_view=dt / (iters * views) * 1e3, host_enqueue_ms_per_view=host_s / (iters * views) * 1e3,
                 module_syncs_per_view=(R.counters()["status_syncs"] - syncs0) / (iters * views),
-                workspace_checks="deferred, settled once per iteration (opt-in)" if deferred else "every call, before it returns (default)")
+                module_event_waits_per_view=(R.counters().get("early_waits", 0) - early0) / (iters * views),
+                workspace_checks="deferred, settled once per iteration (opt-in)" if deferred else
+                                 "every call, before it returns (default): the call waits for the event behind its per-Gaussian "
+                                 "kernel (the pass's overflow is known there), not for the stream")
 
 
 def measure_config(tag, n, h, w, views, room, steps, dev, lrs=None, binning_mode=None):

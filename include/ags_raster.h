@@ -214,6 +214,16 @@ typedef struct AgsWorkspace {
     int64_t max_instances; /* capacity in (Gaussian,tile) instances */
     int32_t binning_mode;  /* AGS_BIN_*; all give the same per-tile (depth, id) order */
     const AgsTuning* tuning; /* optional (NULL = defaults), HOST memory, read during the call only */
+    /* Optional (both NULL = off; AGS_BIN_DIRECT, ags_forward only): a caller that must know whether a pass fits its
+     * workspace BEFORE it hands the images on - the drop-in module, whose callers have no retry - but does not want to wait
+     * for the whole pass: right behind the per-Gaussian kernel (which takes the key slots, so it is the kernel that knows)
+     * ags_forward enqueues a copy of the status block to `early_status_host` (page-locked host memory, sizeof(AgsStatus))
+     * and records `early_status_event` (a hipEvent_t) behind the copy; the tile sort and the blend are queued behind that.
+     * The caller waits for the EVENT - by then the rest of the pass is already in the stream - and reads
+     * host->early_tile_need: 0 = every tile's list fitted (the pass is good), else the longest list's length: the pass
+     * overflowed and tiles x that many key slots would have held it. */
+    void* early_status_host;
+    void* early_status_event;
 } AgsWorkspace;
 
 /* Device-side status block = the first 64 bytes of the workspace. */
@@ -231,7 +241,11 @@ typedef struct AgsStatus {
     uint32_t max_tile_instances; /* longest tile list of the view (0 in AGS_BIN_RADIX mode) */
     uint32_t needed_instances;   /* the max_instances that would have held this view in this binning mode:
                                   * num_instances, or tiles * max_tile_instances for AGS_BIN_DIRECT */
-    uint32_t reserved[8];
+    uint32_t reserved0;          /* (internal: the software-pipelined step's member count) */
+    uint32_t early_tile_need;    /* AGS_BIN_DIRECT, valid BEHIND THE PER-GAUSSIAN KERNEL of a pass (AgsWorkspace.early_status_host)
+                                  * and cleared again by the pass's blend kernel: 0, or the longest tile list when a list
+                                  * outgrew its tile's max_instances / tiles key slots */
+    uint32_t reserved[6];
 } AgsStatus;
 
 /* Bytes of workspace for n Gaussians, an h x w image and room for max_instances instances.

@@ -79,8 +79,9 @@ def test_bench_single_rank_contract_fields(agslib):
     assert d["dtype"] == "f32"
     # the drop-in module: safe by default (every call checked before it returns), no synchronisation in the opt-in form
     dr = d["config"]["dropin"]
-    assert 0 < d["config"]["dropin_ms_per_view"] < 1.0 and dr["c2_1200x680_1_view"]["module_syncs_per_view"] == 1
-    assert dr["c2_1200x680_1_view_deferred"]["module_syncs_per_view"] == 0
+    assert 0 < d["config"]["dropin_ms_per_view"] < 1.0 and dr["c2_1200x680_1_view"]["module_event_waits_per_view"] == 1
+    assert dr["c2_1200x680_1_view"]["module_syncs_per_view"] == 0 and dr["c2_1200x680_1_view_deferred"]["module_syncs_per_view"] == 0
+    assert dr["c2_1200x680_1_view_deferred"]["module_event_waits_per_view"] == 0
     # configuration 3 (the mapper loop through the GaussianMap class) is in the driver's line
     c3 = d["config"]["c3"]
     assert c3["512x512"]["iterations"] == 500 and 0 < c3["seconds"] < 5 and c3["final_surfels"] > 50_000
