@@ -272,8 +272,11 @@ def measure_c3(dev):
     busy = None
     try:
         kb = json.load(open(os.path.join(ROOT, "profiles", "c3_kernels_busy.json")))
-        busy = dict(kernels_busy_frac=kb.get("kernels_busy_frac"), source=f"profiles/c3_kernels_busy.json (rocprofv3 --kernel-trace of "
-                    f"examples/mapper_loop.py, session {kb.get('_session', '?')}; not collected in this run)")
+        busy = dict(kernels_busy_frac=round(min(1.0, kb["busy_ms"] / (res["512x512"]["seconds"] * 1e3)), 3),
+                    kernels_busy_frac_under_profiler=kb.get("kernels_busy_frac"), kernel_ms_profiled=kb.get("busy_ms"),
+                    source=f"kernel time of the same loop from profiles/c3_kernels_busy.json (rocprofv3 --kernel-trace of "
+                           f"examples/mapper_loop.py, session {kb.get('_session', '?')}: union of the kernel intervals; not collected in "
+                           "this run) / this run's wall time; under the profiler itself the host side is slower")
     except Exception:
         pass
     return dict(seconds=res["512x512"]["seconds"], ms_per_iteration=res["512x512"]["ms_per_iteration"],
