@@ -247,9 +247,12 @@ class SurfelRenderer:
         cap, mode = st.get(ckey, (max(1 << 16, 2 * n), api.BIN_DIRECT))
         cap = max(cap, 1 << 16, 2 * n)
         o = dict(device=dev, dtype=torch.float32)
+        # (without statistics every view's importance / count are zeros, like the extension's: ONE row, shown V times)
+        stat_rows = V if require_importance else 1
         out = dict(rgb=torch.empty(V, 3, h, w, **o), normal=torch.empty(V, 3, h, w, **o), depth=torch.empty(V, 1, h, w, **o),
                    opacity=torch.empty(V, 1, h, w, **o), confidence=torch.empty(V, 1, h, w, **o),
-                   importance=torch.zeros(V, n, **o), count=torch.zeros(V, n, device=dev, dtype=torch.int32),
+                   importance=torch.zeros(stat_rows, n, **o).expand(V, n),
+                   count=torch.zeros(stat_rows, n, device=dev, dtype=torch.int32).expand(V, n),
                    radii=torch.empty(V, n, device=dev, dtype=torch.int32))
         v0 = 0
         while v0 < V:
