@@ -173,7 +173,7 @@ class AgsCandidates(C.Structure):
 
 EXPORTS = ["ags_workspace_bytes", "ags_workspace_region", "ags_workspace_init", "ags_workspace_init_batch", "ags_workspace_discard_pass", "ags_forward", "ags_forward_batch",
            "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_backward_rows", "ags_backward_fused_next", "ags_forward_resume", "ags_read_status", "ags_read_status_async", "ags_adam_step",
-           "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_rows_index", "ags_adam_step_gathered", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_weighted_topk", "ags_facade_post", "ags_facade_post_backward", "ags_smooth_depth", "ags_densify_candidates",
+           "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_rows_index", "ags_adam_step_gathered", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_weighted_topk", "ags_facade_post", "ags_facade_post_batch", "ags_facade_post_backward", "ags_smooth_depth", "ags_densify_candidates",
            "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_view_stats_update", "ags_confidences", "ags_compact_plan_bytes", "ags_compact_plan",
            "ags_compact_rows", "ags_profile_enable", "ags_profile_read",
            "ags_error_string", "ags_version"]
@@ -266,6 +266,8 @@ def load() -> C.CDLL:
     lib.ags_loss_stage2.argtypes = [C.POINTER(AgsLossConfig), C.POINTER(AgsImages)] + [C.c_void_p] * 6 + [C.c_void_p]
     lib.ags_facade_post.restype = C.c_int
     lib.ags_facade_post.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 5 + [C.c_void_p]
+    lib.ags_facade_post_batch.restype = C.c_int
+    lib.ags_facade_post_batch.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 5 + [C.c_void_p]
     lib.ags_facade_post_backward.restype = C.c_int
     lib.ags_facade_post_backward.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 7 + [C.c_void_p]
     lib.ags_weighted_topk.restype = C.c_int

@@ -244,7 +244,7 @@ void ags_launch_loss_stage1(const AgsLossConfig& cfg, const AgsImages& img, cons
                             int first_view, hipStream_t s);
 void ags_launch_loss_stage2(const AgsLossConfig& cfg, const AgsImages& img, const float* n_img, const float* gt_depth,
                             const int* msum, float* d_normal, float* d_depth, float* accum, hipStream_t s);
-void ags_launch_facade_post(int h, int w, float tanx, float tany, const float* normal_raw, const float* depth,
+void ags_launch_facade_post(int views, int h, int w, float tanx, float tany, const float* normal_raw, const float* depth,
                             const float* opacity, float* normal_out, float* d2n_out, hipStream_t s);
 void ags_launch_facade_post_bwd(int h, int w, float tanx, float tany, const float* normal_raw, const float* depth,
                                 const float* opacity, const float* g_normal, const float* g_d2n, float* d_normal_raw,

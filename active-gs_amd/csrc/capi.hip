@@ -486,7 +486,16 @@ int ags_facade_post(int32_t h, int32_t w, float tanfov_x, float tanfov_y, const 
                     const float* opacity, float* normal_out, float* d2n_out, ags_stream_t stream) {
     if (h <= 0 || w <= 0 || !(tanfov_x > 0.f) || !(tanfov_y > 0.f) || !depth || !opacity || !d2n_out) return AGS_E_INVALID;
     if ((normal_raw == nullptr) != (normal_out == nullptr)) return AGS_E_INVALID;
-    ags_launch_facade_post(h, w, tanfov_x, tanfov_y, normal_raw, depth, opacity, normal_out, d2n_out, (hipStream_t)stream);
+    ags_launch_facade_post(1, h, w, tanfov_x, tanfov_y, normal_raw, depth, opacity, normal_out, d2n_out, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_facade_post_batch(int32_t views, int32_t h, int32_t w, float tanfov_x, float tanfov_y, const float* normal_raw,
+                          const float* depth, const float* opacity, float* normal_out, float* d2n_out, ags_stream_t stream) {
+    if (views < 1 || views > 65535 || h <= 0 || w <= 0 || !(tanfov_x > 0.f) || !(tanfov_y > 0.f) || !depth || !opacity || !d2n_out)
+        return AGS_E_INVALID;
+    if ((normal_raw == nullptr) != (normal_out == nullptr)) return AGS_E_INVALID;
+    ags_launch_facade_post(views, h, w, tanfov_x, tanfov_y, normal_raw, depth, opacity, normal_out, d2n_out, (hipStream_t)stream);
     return ags_check_launch();
 }
 

@@ -286,6 +286,11 @@ __global__ __launch_bounds__(256) void ags_k_facade_post(AgsPostDev c, const flo
                                                          float* __restrict__ normal_out, float* __restrict__ d2n_out) {
     const int HW = c.H * c.W, p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
+    { // a batch of views (ags_facade_post_batch): blockIdx.y = view, images contiguous (views,C,H,W)
+        const size_t v = blockIdx.y;
+        depth += v * HW; opacity += v * HW; d2n_out += 3 * v * HW;
+        if (normal_raw && normal_out) { normal_raw += 3 * v * HW; normal_out += 3 * v * HW; }
+    }
     const int y = p / c.W, x = p - y * c.W;
     const AgsD2n r = ags_d2n_at(c, depth, opacity, x, y, p);
     if (normal_raw && normal_out) {
@@ -337,10 +342,10 @@ __global__ __launch_bounds__(256) void ags_k_facade_post_bwd(AgsPostDev c, const
     atomicAdd(&d_depth[r.ib], dot3(gpb, r.ray_b) * r.Mb);
 }
 
-void ags_launch_facade_post(int h, int w, float tanx, float tany, const float* normal_raw, const float* depth,
+void ags_launch_facade_post(int views, int h, int w, float tanx, float tany, const float* normal_raw, const float* depth,
                             const float* opacity, float* normal_out, float* d2n_out, hipStream_t s) {
     const AgsPostDev c = {h, w, (float)h / (2.0f * tanx), (float)w / (2.0f * tany)};   // the reference pairs fov_x with H (sic)
-    hipLaunchKernelGGL(ags_k_facade_post, dim3((h * w + 255) / 256), dim3(256), 0, s, c, normal_raw, depth, opacity,
+    hipLaunchKernelGGL(ags_k_facade_post, dim3((h * w + 255) / 256, views), dim3(256), 0, s, c, normal_raw, depth, opacity,
                        normal_out, d2n_out);
 }
 void ags_launch_facade_post_bwd(int h, int w, float tanx, float tany, const float* normal_raw, const float* depth,

@@ -294,21 +294,29 @@ class SurfelRenderer:
         key = (bool(require_importance), bool(front_only))
         b = self._batched.get(key)
         if b is None:
-            b = self._batched[key] = dict(raw=self._render_batch(*key), views={})
+            from . import _lib
+            from ._lib import ptr
+            r = self._render_batch(*key)
+            # the facade's post-processing of ALL the views in one launch (ags_facade_post_batch), the in-frustum masks in one op
+            V, h, w = self.batch_size, self.h, self.w
+            normal, d2n = torch.empty_like(r["normal"]), torch.empty_like(r["normal"])
+            tanx, tany = self._tan_host[0]
+            _lib.check(_lib.load().ags_facade_post_batch(V, h, w, float(tanx), float(tany), ptr(r["normal"]), ptr(r["depth"]),
+                                                         ptr(r["opacity"]), ptr(normal), ptr(d2n),
+                                                         torch.cuda.current_stream().cuda_stream), "ags_facade_post_batch")
+            r["normal_post"], r["d2n"], r["seen"] = normal, d2n, r["radii"] > 0
+            b = self._batched[key] = dict(raw=r, views={})
         v = b["views"].get(i)
         if v is None:
             r = b["raw"]
-            normal, d2n = _FacadePost.apply(r["normal"][i], r["depth"][i], r["opacity"][i], *self._tan_host[i])
-            v = b["views"][i] = (r["rgb"][i], r["depth"][i], normal, r["opacity"][i], d2n, r["confidence"][i],
-                                 r["importance"][i], r["count"][i], r["radii"][i])
+            v = b["views"][i] = (r["rgb"][i], r["depth"][i], r["normal_post"][i], r["opacity"][i], r["d2n"][i], r["confidence"][i],
+                                 r["importance"][i], r["count"][i], r["seen"][i])
         return v
 
     def render_view(self, i=0, require_grad=False, require_importance=False, front_only=False):
         if not require_grad and self._batchable():
             with torch.no_grad():
-                rgb, depth, normal, opacity, d2n, confidence, importance, count, radii = self._batched_view(
-                    i, require_importance, front_only)
-            return rgb, depth, normal, opacity, d2n, confidence, importance, count, radii > 0
+                return self._batched_view(i, require_importance, front_only)
         with torch.set_grad_enabled(require_grad):
             rgb, depth, normal, opacity, d2n, confidence, importance, count, radii = self._core(
                 i, front_only, require_importance)
@@ -328,7 +336,7 @@ class SurfelRenderer:
         if not require_grad and self._batchable():
             with torch.no_grad():
                 per_view = [self._batched_view(i, require_importance, front_only) for i in range(self.batch_size)]
-                radii_sum = self._batched[(bool(require_importance), bool(front_only))]["raw"]["radii"].sum(0, dtype=torch.int32)
+                radii_sum = self._batched[(bool(require_importance), bool(front_only))]["raw"]["seen"].sum(0, dtype=torch.int32)
         elif self._own_module and self.gaussian_means.is_cuda:
             # the module's workspace checks wait ONCE for the whole batch of views; a truncated view repeats the loop
             from .rasterizer import deferred_status

@@ -47,9 +47,28 @@ def main():
     t_batched = round(timed(lambda: batch.render(vm, pm)), 2)
     assert not batch.overflowed()
     diff = max(float((a_.rgb - b_.rgb).abs().max()) for a_, b_ in zip(states, batch.states))
+    # what an UNTOUCHED planner gets (planning/confidence.py:24-46: one renderer for the candidates, render_view(i) per
+    # candidate under no_grad, confidence[0] and depth[0] consumed) once utils/operations.py's GaussianRenderer is
+    # facade.SurfelRenderer: the first request renders all views as one batch, the others are served from it
+    from active_gs_amd.facade import SurfelRenderer
+    attr = (g.means3D, g.colors[:, None, :].contiguous(), g.opacities, g.confidences, g.scales, g.rotations)
+    extr, intr = torch.stack(c2w).to(dev), torch.stack(K).to(dev)
+
+    def planner_loop():
+        r = SurfelRenderer(extr, intr, attr, bg, (0.001, 10.0), (h, w), dev)
+        acc = 0.0
+        with torch.no_grad():
+            for i in range(V):
+                rgb, depth, normal, opacity, d2n, confidence, importance, count, _ = r.render_view(i)
+                acc = acc + confidence[0].sum() + depth[0].sum()
+        return acc
+
+    t_facade = round(timed(planner_loop, reps=3), 2)
     print(json.dumps(dict(workload=f"{V} candidate views @{h}x{w}, {n} surfels, forward only",
                           ms_one_by_one=round(t_seq, 2), ms_streams8=round(t_streams, 2), ms_streams8_graph_replay=t_graph,
-                          ms_one_batched_launch=t_batched,
+                          ms_one_batched_launch=t_batched, ms_facade_render_view_loop=t_facade,
+                          facade_note="GaussianRenderer-shaped: a new renderer per planning step, render_view(i) for every candidate "
+                                      "(incl. the per-view normal / depth2normal post-processing and the consumer's two reductions)",
                           max_abs_rgb_difference_batched_vs_single=diff)))
 
 

@@ -504,6 +504,10 @@ int ags_loss_stage2(const AgsLossConfig* cfg, const AgsImages* fwd, const float*
  * (depth -> normal only). */
 int ags_facade_post(int32_t h, int32_t w, float tanfov_x, float tanfov_y, const float* normal_raw, const float* depth,
                     const float* opacity, float* normal_out, float* d2n_out, ags_stream_t stream);
+/* The same for `views` views of one size and field of view in ONE launch (forward-only consumers: the planners' candidate
+ * views, /root/reference/planning/confidence.py:24-46): every image argument points at a contiguous (views,C,H,W) batch. */
+int ags_facade_post_batch(int32_t views, int32_t h, int32_t w, float tanfov_x, float tanfov_y, const float* normal_raw,
+                          const float* depth, const float* opacity, float* normal_out, float* d2n_out, ags_stream_t stream);
 /* Its backward in one launch: g_normal / g_d2n are the gradients wrt normal_out / d2n_out (either may be NULL = zero);
  * d_normal_raw (3,H,W) is written (may be NULL), d_depth (H,W) is ADDED to with atomics - zero it first. */
 int ags_facade_post_backward(int32_t h, int32_t w, float tanfov_x, float tanfov_y, const float* normal_raw,
