@@ -297,7 +297,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         self.last_losses = []
         self._cap = max(self._cap, 1 << 16, 2 * n)
         for it in range(self.cfg["optimization_steps"] if steps is None else steps):
-            _, _, _, _, ids = sampler.next_frames(self.training_performance)
+            ids = sampler.next_ids(self.training_performance)
             B = len(ids)
             mine = list(range(self.rank, B, self.world))
             h, w = self.frames[int(ids[0])]["rgb"].shape[-2:]
@@ -715,7 +715,7 @@ class FusedMapTrainer(GaussianMapTrainer):
                     n_old = len(sampler.older_ids)
                     weighted_choice_into(self.training_performance[:n_old], n_random, state["idx"][n_active:])
             else:
-                _, _, _, _, ids = sampler.next_frames(self.training_performance)   # host read of the errors
+                ids = sampler.next_ids(self.training_performance)   # host read of the errors
                 B = len(ids)
                 if state["idx"] is None or B != state["B"]:
                     state["idx"], state["B"], graph = torch.empty(B, device=dev, dtype=torch.long), B, None
@@ -829,7 +829,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         self.last_losses = []
         graph = None
         for it in range(total):
-            _, _, _, _, ids = sampler.next_frames(self.training_performance)
+            ids = sampler.next_ids(self.training_performance)
             stage(ids)
             if it == 0:
                 iteration(tick=True)   # eager first iteration: creates every buffer (an overflow shows in the sticky status)

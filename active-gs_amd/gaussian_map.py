@@ -78,8 +78,12 @@ class GaussianMap:
     view_means = _state_property("view_means")
     training_performance = _state_property("training_performance")
 
-    def __init__(self, cfg, device):
+    def __init__(self, cfg, device, process_group=None):
+        """``cfg``, ``device``: the reference's arguments (gaussian_map.py:18).  ``process_group`` (not in the reference, which
+        is single process): a torch.distributed group over which the views of every training iteration are sharded
+        (rank r renders views r::world, gradients exchanged once per iteration, parameters and Adam replicated)."""
         self.device = torch.device(device)
+        self.process_group = process_group
         dev = self.device
         # before the trainer exists (a CPU map, or nothing has needed it yet) the state sits here
         self._cold = dict(means=torch.empty(0, 3, device=dev), scales=torch.empty(0, 3, device=dev),
@@ -172,7 +176,7 @@ class GaussianMap:
         if self._trainer is None:
             from .fused_map_trainer import FusedMapTrainer
             raw = {k: self._cold[k].to(self.device).float() for k in _RAW + _VIEW}
-            tr = FusedMapTrainer(raw, self._frames, cfg)
+            tr = FusedMapTrainer(raw, self._frames, cfg, process_group=self.process_group)
             tr.training_performance = self._cold["training_performance"].to(self.device).float()
             tr.is_init = self._is_init
             self._trainer = tr

@@ -38,13 +38,18 @@ class WeightedFrameSampler:
         self.older_ids = np.array(ids[:-active])
         self.num_random = min(len(self.older_ids), batch_size - active)
 
-    def next_frames(self, weight: torch.Tensor):
+    def next_ids(self, weight: torch.Tensor):
+        """the frame indices of the next batch (what the fused trainers need: they gather the frames on the device)"""
         sel = self.active_ids.copy()
         if self.num_random > 0:
             w = weight[self.older_ids]
             w = w / torch.sum(w)
             picked = np.random.choice(self.older_ids, size=self.num_random, p=w.cpu().numpy(), replace=False)
             sel = np.append(sel, self.older_ids[picked])  # the reference indexes by the drawn values
+        return sel
+
+    def next_frames(self, weight: torch.Tensor):
+        sel = self.next_ids(weight)
         st = lambda k: torch.stack([self.frames[i][k] for i in sel])
         return st("rgb"), st("depth"), st("extrinsic"), st("intrinsic"), sel
 
@@ -66,11 +71,15 @@ class UniformFrameSampler:
         self.num_random = min(len(self.older_ids), batch_size - active_size)
         self.v = len(self.active_ids) + self.num_random
 
-    def next_frames(self, weight: Optional[torch.Tensor] = None):
+    def next_ids(self, weight: Optional[torch.Tensor] = None):
         sel = self.active_ids.copy()
         if self.num_random > 0:
             picked = torch.randperm(len(self.older_ids))[: self.num_random]
             sel = np.append(sel, self.older_ids[picked.numpy()])
+        return sel
+
+    def next_frames(self, weight: Optional[torch.Tensor] = None):
+        sel = self.next_ids(weight)
         st = lambda k: torch.stack([self.frames[i][k] for i in sel])
         return st("rgb"), st("depth"), st("extrinsic"), st("intrinsic"), sel
 

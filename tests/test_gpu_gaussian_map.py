@@ -210,3 +210,48 @@ def test_planner_shaped_batch_of_candidate_views(agslib):
             assert float(conf.min()) >= 0.0 and float(conf.max()) <= 1.0 and depth.shape == (h, w)
         if kw:
             assert int(got[0][7].sum()) > 0 and got[0][7].dtype == torch.int32
+
+
+def test_class_api_on_the_less_travelled_paths(agslib):
+    """The same class where the fused batch does not apply or the configuration differs from the yaml's defaults:
+    keyframes of DIFFERENT sizes (per-view launches, the torch-side post-processing), ``use_view_distribution = False``
+    (confidence from the support count, gaussian_map.py:560-563), ``sampler_type: uniform`` (gaussian_map.py:253-254), the
+    host-side frame draw, ``train(steps=0)`` (post-processing only)."""
+    import torch.nn.functional as F
+    from active_gs_amd.gaussian_map import GaussianMap
+    g = torch.load(os.path.join(GOLD, "mapper_loop.pt"))
+    base = dict(g["cfg"])
+    # (a) a third keyframe at another resolution: the batch path needs frames of one size
+    gm = GaussianMap(_ns(base), DEV)
+    gm.frame_sampler = "host"
+    np.random.seed(1)
+    for k in range(2):
+        gm.update(_to_dev(g["frames"][k]))
+    f = _to_dev(g["frames"][0])
+    small = dict(f, rgb=F.interpolate(f["rgb"][None], size=(48, 80), mode="bilinear")[0].contiguous(),
+                 depth=F.interpolate(f["depth"][None], size=(48, 80), mode="nearest")[0].contiguous())
+    n0 = gm.get_means.shape[0]
+    gm.update(small)
+    assert len(gm.training_data) == 3 and gm.training_performance.numel() == 3 and not gm._trainer._uniform_frames()
+    assert bool(torch.isfinite(gm._means).all()) and float(gm.training_performance[2]) < 10.0 and gm.get_means.shape[0] > 0.5 * n0
+    assert len(gm._trainer.last_losses) == base["optimization_steps"] and all(np.isfinite(gm._trainer.last_losses))
+    # (b) confidence from the support count
+    cfg_b = dict(base, use_view_distribution=False)
+    gb = GaussianMap(_ns(cfg_b), DEV)
+    gb.update(_to_dev(g["frames"][0]))
+    conf = gb.get_confidences
+    assert torch.allclose(conf, torch.clamp(1 - torch.exp(-gb.view_supports), 0, 1), atol=1e-6)
+    assert float(gb.view_scores.abs().sum()) == 0.0 and float(gb.view_supports.sum()) > 0
+    # (c) the uniform sampler and a post-processing-only call
+    cfg_c = dict(base, sampler=dict(base["sampler"], sampler_type="uniform"))
+    gc = GaussianMap(_ns(cfg_c), DEV)
+    torch.manual_seed(0)
+    for k in range(4):
+        gc.update(_to_dev(g["frames"][k % 2]))
+    assert gc._trainer_cfg()["sampler_type"] == "uniform" and len(gc.training_data) == 4
+    assert float(gc.training_performance.max()) < 10.0 and all(np.isfinite(gc._trainer.last_losses))
+    before = [p.clone() for p in gc.get_params()]
+    supports = gc.view_supports.clone()
+    gc.train(steps=0)
+    assert all(torch.equal(a, b) for a, b in zip(before, gc.get_params()))          # no iteration ran ...
+    assert float((gc.view_supports - supports).sum()) > 0                             # ... post_processing did
