@@ -26,7 +26,7 @@ NEW_Z_SCALE = -1e10                  # gaussian_map.py:373: surfels are flat
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream()
 
 
 def _need_gpu(t: torch.Tensor, name: str) -> torch.Tensor:

@@ -40,7 +40,7 @@ class _FacadePost(torch.autograd.Function):
         d2n = torch.empty(3, H, W, device=depth.device, dtype=torch.float32)
         n_out = None if nr_c is None else torch.empty_like(d2n)
         _lib.check(_lib.load().ags_facade_post(H, W, float(tanx), float(tany), ptr(nr_c), ptr(depth_c), ptr(op_c), ptr(n_out),
-                                               ptr(d2n), torch.cuda.current_stream().cuda_stream), "ags_facade_post")
+                                               ptr(d2n), _lib.current_stream()), "ags_facade_post")
         ctx.save_for_backward(*([depth_c, op_c] + ([nr_c] if nr_c is not None else [])))
         ctx.geom = (H, W, float(tanx), float(tany), nr_c is not None)
         if n_out is None:
@@ -62,7 +62,7 @@ class _FacadePost(torch.autograd.Function):
         d_depth = torch.zeros(1, H, W, device=depth_c.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
         _lib.check(_lib.load().ags_facade_post_backward(H, W, tanx, tany, ptr(nr_c), ptr(depth_c), ptr(op_c), ptr(g_n),
                                                         ptr(g_d if d_depth is not None else None), ptr(d_nr), ptr(d_depth),
-                                                        torch.cuda.current_stream().cuda_stream), "ags_facade_post_backward")
+                                                        _lib.current_stream()), "ags_facade_post_backward")
         return d_nr, d_depth, None, None, None
 
 
@@ -303,7 +303,7 @@ class SurfelRenderer:
             tanx, tany = self._tan_host[0]
             _lib.check(_lib.load().ags_facade_post_batch(V, h, w, float(tanx), float(tany), ptr(r["normal"]), ptr(r["depth"]),
                                                          ptr(r["opacity"]), ptr(normal), ptr(d2n),
-                                                         torch.cuda.current_stream().cuda_stream), "ags_facade_post_batch")
+                                                         _lib.current_stream()), "ags_facade_post_batch")
             r["normal_post"], r["d2n"], r["seen"] = normal, d2n, r["radii"] > 0
             b = self._batched[key] = dict(raw=r, views={})
         v = b["views"].get(i)

@@ -52,14 +52,14 @@ class FusedLoss:
         _lib.check(_lib.load().ags_loss_stage1(C.byref(self.cfg), C.byref(img), ptr(gt_rgb), ptr(gt_depth), ptr(buf.n_img),
                                                ptr(buf.d_rgb), ptr(buf.d_depth), ptr(self.msum), ptr(self.accum),
                                                int(view), int(first_view),
-                                               torch.cuda.current_stream().cuda_stream if stream is None else stream),
+                                               _lib.current_stream() if stream is None else stream),
                    "ags_loss_stage1")
 
     def stage2(self, st: ForwardState, gt_depth, buf: LossBuffers, stream=None) -> None:
         img = st.images_struct()
         _lib.check(_lib.load().ags_loss_stage2(C.byref(self.cfg), C.byref(img), ptr(buf.n_img), ptr(gt_depth),
                                                ptr(self.msum), ptr(buf.d_normal), ptr(buf.d_depth), ptr(self.accum),
-                                               torch.cuda.current_stream().cuda_stream if stream is None else stream),
+                                               _lib.current_stream() if stream is None else stream),
                    "ags_loss_stage2")
 
     # ---- all views of the batch in one launch each (blockIdx.y = view)
@@ -74,7 +74,7 @@ class FusedLoss:
         try:
             _lib.check(_lib.load().ags_loss_stage1(C.byref(self.cfg), C.byref(images), ptr(gt_rgb), ptr(gt_depth),
                                                    ptr(buf.n_img), ptr(buf.d_rgb), ptr(buf.d_depth), ptr(self.msum),
-                                                   ptr(self.accum), 0, -1, torch.cuda.current_stream().cuda_stream),
+                                                   ptr(self.accum), 0, -1, _lib.current_stream()),
                        "ags_loss_stage1")
         finally:
             self.cfg.num_views = 0
@@ -84,7 +84,7 @@ class FusedLoss:
         try:
             _lib.check(_lib.load().ags_loss_stage2(C.byref(self.cfg), C.byref(images), ptr(buf.n_img), ptr(gt_depth),
                                                    ptr(self.msum), ptr(buf.d_normal), ptr(buf.d_depth), ptr(self.accum),
-                                                   torch.cuda.current_stream().cuda_stream), "ags_loss_stage2")
+                                                   _lib.current_stream()), "ags_loss_stage2")
         finally:
             self.cfg.num_views = 0
 
@@ -93,7 +93,7 @@ class FusedLoss:
         """Gather the sampled frames into the batch buffers and zero ``msum`` - one launch."""
         _lib.check(_lib.load().ags_stage_frames(int(views), self.h, self.w, ptr(frame_index), ptr(all_view), ptr(all_proj),
                                                 ptr(all_rgb), ptr(all_depth), ptr(dst_view), ptr(dst_proj), ptr(dst_rgb),
-                                                ptr(dst_depth), ptr(self.msum), torch.cuda.current_stream().cuda_stream),
+                                                ptr(dst_depth), ptr(self.msum), _lib.current_stream()),
                    "ags_stage_frames")
 
     def finish(self, views: int, frame_index, frame_error, total_loss) -> None:
@@ -101,7 +101,7 @@ class FusedLoss:
         tensor), accumulators zeroed - one launch instead of per_frame_errors + total_loss + begin_step."""
         _lib.check(_lib.load().ags_loss_finish(C.byref(self.cfg), ptr(self.accum), int(views), ptr(frame_index),
                                                ptr(frame_error), ptr(total_loss),
-                                               torch.cuda.current_stream().cuda_stream), "ags_loss_finish")
+                                               _lib.current_stream()), "ags_loss_finish")
 
     def total_loss(self) -> torch.Tensor:
         c, a, hw = self.cfg, self.accum.sum(0), float(self.h * self.w)

@@ -40,7 +40,7 @@ def weighted_choice_into(weights: torch.Tensor, k: int, out: torch.Tensor) -> No
     from . import _lib
     u = torch.rand_like(weights)
     _lib.check(_lib.load().ags_weighted_topk(_lib.ptr(u), _lib.ptr(weights), n, int(k), _lib.ptr(out),
-                                             torch.cuda.current_stream().cuda_stream), "ags_weighted_topk")
+                                             _lib.current_stream()), "ags_weighted_topk")
 
 
 class FusedMapTrainer(GaussianMapTrainer):
@@ -393,7 +393,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         out = torch.empty(n, device=self.device, dtype=torch.float32)
         _lib.check(_lib.load().ags_confidences(n, ptr(self.view_supports), ptr(self.view_means), ptr(self.view_scores),
                                                int(bool(self.cfg["use_view_distribution"])), ptr(out),
-                                               torch.cuda.current_stream().cuda_stream), "ags_confidences")
+                                               _lib.current_stream()), "ags_confidences")
         return out
 
     def post_processing(self):
@@ -458,7 +458,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         _lib.check(_lib.load().ags_view_stats_update(n, ptr(self.means), ptr(self.rotations), ptr(campos), far, ptr(newest),
                                                      int(bool(self.cfg["use_view_distribution"])), ptr(self.view_supports),
                                                      ptr(self.view_means), ptr(self.view_scores),
-                                                     torch.cuda.current_stream().cuda_stream), "ags_view_stats_update")
+                                                     _lib.current_stream()), "ags_view_stats_update")
         if prune_now:
             self.prune(~(counts.sum(0) >= 1))
 

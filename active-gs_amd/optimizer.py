@@ -124,7 +124,7 @@ class FusedAdam:
         if not device_clock:
             self.step_count += 1
         t = self.tensors_struct(grads)
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _lib.current_stream()
         if device_clock:
             _lib.check(lib.ags_adam_step_device(C.byref(t), self.betas[0], self.betas[1], self.eps,
                                                 ptr(self.device_clock), int(pre_ticked), stream), "ags_adam_step_device")
@@ -141,7 +141,7 @@ class FusedAdam:
         if not device_clock and first:
             self.step_count += 1
         t = self.tensors_struct(grads, rows=(begin, end))
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _lib.current_stream()
         if device_clock:
             _lib.check(lib.ags_adam_step_device(C.byref(t), self.betas[0], self.betas[1], self.eps, ptr(self.device_clock),
                                                 int(pre_ticked or not first), stream), "ags_adam_step_device")
@@ -156,6 +156,6 @@ class FusedAdam:
         t = self.tensors_struct(grads)
         _lib.check(_lib.load().ags_adam_step_gathered(C.byref(t), ptr(segments), int(world), int(capacity), ptr(slot_table),
                                                       self.betas[0], self.betas[1], self.eps, ptr(self.device_clock),
-                                                      int(pre_ticked), torch.cuda.current_stream().cuda_stream),
+                                                      int(pre_ticked), _lib.current_stream()),
                    "ags_adam_step_gathered")
 

@@ -128,7 +128,7 @@ def _require_cuda(t: torch.Tensor, name: str) -> None:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream()
 
 
 def workspace_bytes(n: int, h: int, w: int, max_instances: int) -> int:

@@ -101,7 +101,7 @@ class RowExchange:
     def pack(self, rows: "api.RowSet") -> None:
         r = rows.c_struct()
         _lib.check(_lib.load().ags_rows_pack(C.byref(r), C.byref(self._grads), self.capacity, ptr(self.send),
-                                             torch.cuda.current_stream().cuda_stream), "ags_rows_pack")
+                                             _lib.current_stream()), "ags_rows_pack")
 
     def gather(self) -> None:
         if torch.distributed.get_backend(self.pg) == "nccl":     # RCCL: one all-gather over xGMI
@@ -115,7 +115,7 @@ class RowExchange:
 
     def unpack(self) -> None:
         lib, u = _lib.load(), self.union.c_struct()
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _lib.current_stream()
         for r in range(self.world):                               # rank order: same sums everywhere
             _lib.check(lib.ags_rows_unpack(ptr(self.recv[r]), self.capacity, C.byref(self._grads), C.byref(u), stream),
                        "ags_rows_unpack")
@@ -123,7 +123,7 @@ class RowExchange:
     def index(self) -> None:
         u = self.union.c_struct()
         _lib.check(_lib.load().ags_rows_index(ptr(self.recv), self.world, self.capacity, ptr(self.slot_table), C.byref(u),
-                                              torch.cuda.current_stream().cuda_stream), "ags_rows_index")
+                                              _lib.current_stream()), "ags_rows_index")
 
     def overflowed(self) -> bool:
         """Host-synchronous: has any rank needed more rows than the agreed capacity in the last exchange?
@@ -142,7 +142,7 @@ class RowExchange:
         never left them), so the arrays hold the rank's complete gradient again."""
         lib, u = _lib.load(), self.union.c_struct()
         _lib.check(lib.ags_rows_unpack(ptr(self.send), self.capacity, C.byref(self._grads), C.byref(u),
-                                       torch.cuda.current_stream().cuda_stream), "ags_rows_unpack")
+                                       _lib.current_stream()), "ags_rows_unpack")
 
     def reset(self) -> None:
         self.union.reset()
@@ -245,7 +245,7 @@ class SurfelTrainer:
     def activate(self) -> api.Gaussians:
         a = self._act_struct()
         _lib.check(_lib.load().ags_activate(C.byref(a), ptr(self.act_scales), ptr(self.act_rot), ptr(self.act_opac),
-                                            torch.cuda.current_stream().cuda_stream), "ags_activate")
+                                            _lib.current_stream()), "ags_activate")
         return api.Gaussians(self.raw["means"], self.act_scales, self.act_rot, self.act_opac,
                              self.raw["harmonics"].view(self.n, 3), self.raw["confidences"])
 
@@ -253,7 +253,7 @@ class SurfelTrainer:
         a = self._act_struct()
         g = self.slab.grads
         _lib.check(_lib.load().ags_activate_backward(C.byref(a), ptr(g.scales), ptr(g.rotations), ptr(g.opacities),
-                                                     torch.cuda.current_stream().cuda_stream), "ags_activate_backward")
+                                                     _lib.current_stream()), "ags_activate_backward")
 
     def state_for(self, h: int, w: int, max_instances: int, slot: int = 0) -> api.ForwardState:
         key = (h, w, slot)

@@ -1,10 +1,16 @@
-"""Host-side profile of the mapper loop (cProfile, sorted by own time): python profiles/experiments/mapper_cprofile.py"""
-import sys, os, cProfile, pstats, io
-sys.path.insert(0, os.getcwd())
-sys.argv = [sys.argv[0]]
-import importlib.util
-spec = importlib.util.spec_from_file_location("ml", "examples/mapper_loop.py"); ml = importlib.util.module_from_spec(spec); spec.loader.exec_module(ml)
+"""Host-side cProfile of the mapper loop (config 3 through GaussianMap.update): where the interpreter's time goes.
+usage: python profiles/experiments/mapper_cprofile.py [top=45]"""
+import cProfile, os, pstats, sys
+import numpy as np, torch
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, R)
+from active_gs_amd.synthetic import make_keyframes, run_mapper_loop
+dev = torch.device("cuda:0")
+frames = make_keyframes(50, 512, 512, dev)
+run_mapper_loop(frames, warmup_frames=2)          # everything loaded
+np.random.seed(0)
 pr = cProfile.Profile()
-pr.enable(); ml.main(); pr.disable()
-for key in ("tottime", "cumulative"):
-    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45); print(s.getvalue()[:9000])
+pr.enable()
+out = run_mapper_loop(frames, warmup_frames=0)
+pr.disable()
+print(out["seconds"])
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 45)
