@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""What an UNTOUCHED ActiveGS mission does to the map, phase by phase, once the two one-line changes of INTEGRATION.md
+section 1b are in place (mapping/gaussian_map.py imports active_gs_amd.gaussian_map.GaussianMap, utils/operations.py's
+GaussianRenderer is active_gs_amd.facade.SurfelRenderer).  Per mission step, like /root/reference/mapping/mapper.py:73-129:
+
+  planning   planning/confidence.py:12-109 - ONE renderer for ~100 candidate poses at 128x128 built from gaussian_map.get_attr(),
+             background_color, (scene_near, scene_far); render_view(i) per candidate under no_grad; confidence[0] / depth[0] reduced
+  mapping    mapper.py:98-101 - dataframe moved to the device, gaussian_map.update(dataframe)
+  voxel map  mapping/voxel_map.py:71-74 - get_means / get_normals / get_confidences / get_opacities read (detached)
+  recorder   utils/common.py:249 - gaussian_map.save(path, index) every `--save-every` steps
+
+The simulator, the voxel map's own update and the A* path planner are not part of the hot path and are not run here: the
+keyframes are rendered from the room stand-in beforehand (Replica / habitat are not available offline) and the "next best
+view" is simply the next keyframe.  Prints one JSON line with the time per phase.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=30, help="mission steps (keyframes)")
+    ap.add_argument("--candidates", type=int, default=100)
+    ap.add_argument("--save-every", type=int, default=10)
+    args = ap.parse_args()
+    from active_gs_amd.facade import SurfelRenderer as GaussianRenderer
+    from active_gs_amd.gaussian_map import GaussianMap
+    from active_gs_amd.synthetic import make_camera, make_keyframes, mapper_cfg
+    dev = torch.device("cuda:0")
+    frames = make_keyframes(args.steps, 512, 512, dev)
+    frames_host = [{k: v.cpu() for k, v in f.items()} for f in frames]          # the simulator hands over CPU tensors
+    cand = [make_camera(1000 + v, 128, 128, focal_px=0.5 * 128 / np.tan(np.pi / 6)) for v in range(args.candidates)]
+    cand_extr = torch.stack([c[0] for c in cand])
+    cand_intr = cand[0][1]
+    h = w = 128
+
+    def mission(gm, tmp, timed=True):
+        t = dict(planning=0.0, mapping=0.0, voxel_reads=0.0, save=0.0)
+        clock = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
+        for i, df in enumerate(frames_host):
+            t0 = clock()
+            if gm.is_init:                                           # planning: utility of the candidate views
+                with torch.no_grad():
+                    extrinsics = cand_extr.to(dev)
+                    intrinsics = cand_intr[None].repeat(len(cand), 1, 1).to(dev)
+                    renderer = GaussianRenderer(extrinsics, intrinsics, gm.get_attr(), gm.background_color,
+                                                (gm.scene_near, gm.scene_far), (h, w), dev)
+                    util = torch.zeros(len(cand))
+                    for c in range(len(cand)):
+                        rgb, depth, normal, opacity, d2n, confidence, importance, count, _ = renderer.render_view(c)
+                        confidences, depths = confidence[0], depth[0]
+                        unseen = (depths < 0.001).float().mean()
+                        util[c] = float(unseen + (1.0 - confidences[depths >= 0.001].mean() if bool((depths >= 0.001).any()) else 0.0))
+            t1 = clock()
+            dataframe = {k: v.to(dev) for k, v in df.items()}        # mapper.py:95
+            gm.update(dataframe)                                     # mapper.py:101
+            t2 = clock()
+            mean, normal = gm.get_means.detach(), gm.get_normals.detach()           # voxel_map.py:71-74
+            conf, opac = gm.get_confidences.detach(), gm.get_opacities.detach()
+            _ = float(mean.sum() + normal.sum() + conf.sum() + opac.sum())
+            t3 = clock()
+            if (i + 1) % args.save_every == 0:
+                gm.save(tmp, index=f"{i + 1:03}")                    # common.py:249
+            t4 = clock()
+            t["planning"] += t1 - t0; t["mapping"] += t2 - t1; t["voxel_reads"] += t3 - t2; t["save"] += t4 - t3
+        return t
+
+    with tempfile.TemporaryDirectory() as tmp:
+        warm = GaussianMap(mapper_cfg(), dev)
+        frames_backup, frames_host[:] = list(frames_host), frames_host[:3]
+        mission(warm, tmp)                                           # kernel modules loaded
+        frames_host[:] = frames_backup
+        del warm
+        np.random.seed(0)
+        gm = GaussianMap(mapper_cfg(), dev)
+        t = mission(gm, tmp)
+    steps = len(frames_host)
+    print(json.dumps(dict(
+        workload=f"{steps} mission steps: {args.candidates} candidate views @128x128 through GaussianRenderer.render_view(i) (planner), "
+                 f"GaussianMap.update() of a 512x512 keyframe (10 iterations, batch 8), the voxel map's four property reads, "
+                 f"a checkpoint every {args.save_every} steps",
+        seconds={k: round(v, 4) for k, v in t.items()}, ms_per_step={k: round(1e3 * v / steps, 3) for k, v in t.items()},
+        planning_ms_per_candidate=round(1e3 * t["planning"] / max(steps - 1, 1) / args.candidates, 4),
+        final_surfels=int(gm.get_means.shape[0]), mean_frame_error=round(float(gm.training_performance.mean()), 5),
+        note="every phase is bracketed by torch.cuda.synchronize() (the reference's own timers are not: mapper.py:98,106); the planning "
+             "phase includes the per-candidate host reductions a planner does on the images")))
+
+
+if __name__ == "__main__":
+    main()
