@@ -142,6 +142,12 @@ _BATCH_POOL_MAX = 3
 BATCH_BYTES_BUDGET = 12 << 30        # views per batched launch set are limited so that their workspaces stay below this
 
 
+def release_batches() -> None:
+    """Drop the pooled batch workspaces (at most _BATCH_POOL_MAX sets of up to BATCH_BYTES_BUDGET bytes are kept between
+    renderers); the next forward-only renderer allocates again."""
+    _BATCH_POOL.clear()
+
+
 def _pooled_view_batch(g, key, V, h, w, tanx, tany, bg, cap, want_stats, front_only, has_mask, mode):
     from . import raster_api as api
     vb = _BATCH_POOL.get(key)
