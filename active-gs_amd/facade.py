@@ -190,6 +190,7 @@ class SurfelRenderer:
         self.background_color = background_color
         self.h, self.w = resolution
         self.batch_size = extrinsics.shape[0]
+        self._intrinsic0 = intrinsics[0]
         cm = camera_matrices(extrinsics, intrinsics, near_far[0], near_far[1])
         self.cam_pos = cm["campos"]
         self.view_matrices = cm["viewmatrix"]
@@ -203,6 +204,20 @@ class SurfelRenderer:
             self.render_masks = [torch.tensor([], device=device) for _ in range(self.batch_size)]
         else:
             self.render_masks = render_masks
+
+    @property
+    def raydir_map(self):
+        """(3,H,W) unit ray directions of view 0 in camera space (operations.py:764-772 builds it in the constructor; the
+        reference's only use of it is a dead ``visible_mask``, :716) - made when somebody asks."""
+        if getattr(self, "_raydir", None) is None:
+            h, w = self.h, self.w
+            dev = self.view_matrices.device
+            ys, xs = torch.meshgrid((torch.arange(h, device=dev, dtype=torch.float32) + 0.5) / h,
+                                    (torch.arange(w, device=dev, dtype=torch.float32) + 0.5) / w, indexing="ij")
+            pix = torch.stack([xs, ys, torch.ones_like(xs)], -1).reshape(-1, 3)
+            d = pix @ torch.linalg.inv(self._intrinsic0.float().to(dev)).T
+            self._raydir = F.normalize(d, dim=-1).reshape(h, w, 3).permute(2, 0, 1).contiguous()
+        return self._raydir
 
     def update_attr(self, gaussians_attr):
         (self.gaussian_means, self.gaussian_harmonics, self.gaussian_opacities, self.gaussian_confidences,

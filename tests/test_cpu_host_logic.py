@@ -422,3 +422,43 @@ def test_gaussian_map_class_reads_cfg_like_the_reference_and_serves_a_cpu_map(tm
     for call in (lambda: g2.train(), lambda: g2.post_processing(), lambda: g2.update({}), lambda: g2.prune(torch.zeros(n))):
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             call()
+
+
+def test_drop_in_classes_cover_the_reference_classes_public_surface():
+    """tests/golden/class_surface.json = the method names / parameter lists / properties / constructor-set attributes of the
+    reference's ``mapping.gaussian_map.GaussianMap`` and ``utils.operations.GaussianRenderer`` (captured by importing the
+    reference in the build container, make_surface.py).  The classes that replace them BY NAME must offer every one of them:
+    same methods taking the reference's parameters in the reference's order (more, defaulted, ones may follow), the same
+    properties as properties, and every attribute an outside caller could read."""
+    import inspect
+    import json
+    from types import SimpleNamespace as NS
+    from active_gs_amd.facade import SurfelRenderer
+    from active_gs_amd.gaussian_map import GaussianMap
+    ref = json.load(open(os.path.join(GOLD, "class_surface.json")))
+    cfg = NS(bound=[0.001, 10.0], background=[0.0, 0.0, 0.0, 0.0], sparse_ratio=0.1, error_thres=0.25, scale_factor=0.01,
+             optimization_steps=10, prune_interval=5, use_view_distribution=True,
+             sampler=NS(sampler_type="weighted", batch_size=8, active_size=3),
+             optimizer=NS(mean_lr=5e-4, rotation_lr=5e-4, opacity_lr=1e-2, scale_lr=1e-2, harmonic_lr=1e-4))
+    extr = torch.eye(4)[None]
+    K = torch.tensor([[[0.866, 0, 0.5], [0, 0.866, 0.5], [0, 0, 1.0]]])
+    attr = (torch.zeros(1, 3), torch.zeros(1, 1, 3), torch.zeros(1), torch.zeros(1), torch.zeros(1, 3), torch.tensor([[1.0, 0, 0, 0]]))
+    instances = {"GaussianMap": (GaussianMap, GaussianMap(cfg, "cpu")),
+                 "GaussianRenderer": (SurfelRenderer, SurfelRenderer(extr, K, attr, torch.zeros(4), (0.001, 10.0), (16, 16), "cpu",
+                                                                     rasterizer_module=_oracle_module))}
+    for name, (cls, inst) in instances.items():
+        want = ref[name]
+        for m, params in want["methods"].items():
+            assert callable(getattr(cls, m, None)), (name, m)
+            mine = list(inspect.signature(getattr(cls, m)).parameters.values())
+            assert [p.name for p in mine[:len(params)]] == [p["name"] for p in params], (name, m)
+            for p, q in zip(mine, params):
+                assert (p.default is not inspect.Parameter.empty) == q["has_default"], (name, m, p.name)
+                if q["has_default"]:
+                    assert repr(p.default) == q["default"], (name, m, p.name)
+            assert all(p.default is not inspect.Parameter.empty for p in mine[len(params):]), (name, m)   # extras are optional
+        for prop in want["properties"]:
+            assert isinstance(inspect.getattr_static(cls, prop), property), (name, prop)
+        for a in want["instance_attributes"]:
+            assert hasattr(inst, a), (name, a)
+    assert instances["GaussianRenderer"][1].raydir_map.shape == (3, 16, 16)
