@@ -245,6 +245,7 @@ def measure_config(tag, n, h, w, views, room, steps, dev, lrs=None, binning_mode
                            "on one stream - the timed step spreads them over view_streams streams, so the stages do not add up to it"
                            if views > 1 and rows is not None else "per view"),
                stage_hbm_frac={k: round(v, 4) for k, v in frac.items()},
+               stage_algorithmic_bytes={k: int(v) for k, v in sb.items()},
                whole_step_hbm_frac=round((sum(v for k, v in sb.items() if k != "preprocess_bwd") * views +
                                           sb["preprocess_bwd"] * (1 if (views > 1 and rows is not None) else views))
                                          / (s["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
@@ -832,6 +833,18 @@ def main():
                                                   "room0", 20, dev),
                        "c5": measure_config("c5: 5 M surfels @2048x2048, 1 view", 5_000_000, 2048, 2048, 1, "office0", 20, dev)}
                 out["config"]["secondary"] = {"c4_share_ms": sec["c4_share"]["ms_per_step"], "c5_ms": sec["c5"]["ms_per_step"], **sec}
+                # the same roofline object for configuration 5's own dominant kernel (5 M surfels @2048x2048: the size at
+                # which the blend backward dominates the step)
+                c5 = sec["c5"]
+                dom5 = max(c5["stage_ms_per_view"], key=lambda k: c5["stage_ms_per_view"][k])
+                t5 = c5["stage_ms_per_view"][dom5] * 1e-3
+                out["roofline"]["c5"] = {"bound": "hbm", "kernel": dom5, "achieved": c5["stage_algorithmic_bytes"][dom5] / t5 / 1e9,
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c5["stage_algorithmic_bytes"][dom5] / t5 / 1e9 / HBM_PEAK_GBS,
+                                         "algorithmic_bytes_per_launch": c5["stage_algorithmic_bytes"][dom5], "launch_ms": c5["stage_ms_per_view"][dom5],
+                                         "traffic": None,
+                                         "traffic_note": "profiles/r04_a_c5_pmc_hbm.md (rocprofv3 --pmc, not collected in this run): render_bwd reads "
+                                                         "536 MB (2 x FETCH_SIZE) and writes 499 MB per launch against 793 MB algorithmic; VALU issue "
+                                                         "busy 0.80 (profiles/r04_a_c5_sq_counters.md)"}
             except Exception as e:
                 out["config"]["secondary"] = f"{type(e).__name__}: {e}"
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only (contract)

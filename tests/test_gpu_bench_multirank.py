@@ -89,6 +89,7 @@ def test_bench_single_rank_contract_fields(agslib):
     sec = d["config"]["secondary"]
     assert sec["c4_share_ms"] > 0 and sec["c5_ms"] > 0 and set(sec["c5"]["stage_hbm_frac"]) >= {"preprocess", "render_bwd"}
     assert d["roofline"]["traffic_read"] is not None and d["roofline"]["traffic_write"] is not None
+    assert d["roofline"]["c5"]["kernel"] == "render_bwd" and 0.05 < d["roofline"]["c5"]["frac"] < 0.5
     dr = d["config"]["derived_rates"]
     assert 0 < dr["visible_gaussians_per_s"] < dr["tile_instances_per_s"] < d["value"]
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and not d["config"]["overflow"]
