@@ -150,7 +150,8 @@ class AgsAdamTensors(C.Structure):
 class AgsLossConfig(C.Structure):
     _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("fov_x", C.c_float), ("fov_y", C.c_float),
                 ("batch_total", C.c_int32), ("w_rgb", C.c_float), ("w_depth", C.c_float), ("w_cons", C.c_float),
-                ("w_tv", C.c_float), ("sigma", C.c_float), ("accum_stride", C.c_int32), ("num_views", C.c_int32)]
+                ("w_tv", C.c_float), ("sigma", C.c_float), ("accum_stride", C.c_int32), ("num_views", C.c_int32),
+                ("gt_frame_index", C.c_void_p)]
 
 
 class AgsActivation(C.Structure):

@@ -520,8 +520,9 @@ int ags_stage_frames(int32_t views, int32_t h, int32_t w, const int64_t* frame_i
                      const float* all_proj, const float* all_rgb, const float* all_depth, float* dst_view, float* dst_proj,
                      float* dst_rgb, float* dst_depth, int32_t* msum, ags_stream_t stream) {
     if (views < 1 || views > 65535 || h <= 0 || w <= 0 || ((long long)h * w) % 4 != 0) return AGS_E_INVALID;
-    if (!frame_index || !all_view || !all_proj || !all_rgb || !all_depth || !dst_view || !dst_proj || !dst_rgb || !dst_depth)
-        return AGS_E_INVALID;
+    if (!frame_index || !all_view || !all_proj || !dst_view || !dst_proj) return AGS_E_INVALID;
+    if ((dst_rgb == nullptr) != (dst_depth == nullptr)) return AGS_E_INVALID;
+    if (dst_rgb && (!all_rgb || !all_depth)) return AGS_E_INVALID;
     ags_launch_stage_frames(views, h * w, (const long long*)frame_index, all_view, all_proj, all_rgb, all_depth, dst_view,
                             dst_proj, dst_rgb, dst_depth, msum, (hipStream_t)stream);
     return ags_check_launch();

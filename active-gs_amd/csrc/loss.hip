@@ -23,6 +23,7 @@ struct AgsLossDev {
     int H, W, B;
     float fxq, fyq;          // H/(2 tan(fov_x/2)), W/(2 tan(fov_y/2))  (the reference's pairing)
     float w_rgb, w_depth, w_cons, w_tv, inv_2sig2;
+    const long long* gt_index;   // AgsLossConfig.gt_frame_index: batched calls read view v's ground truth at frame gt_index[v]
 };
 
 __device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(256) void ags_k_loss_stage1(
     const int HW = c.H * c.W;
     if (gridDim.y > 1) { // batched: blockIdx.y = view of the batch, image batches are contiguous
         const size_t po = (size_t)blockIdx.y * (size_t)HW;
-        rgb += 3 * po; normal_raw += 3 * po; depth += po; opacity += po; gt_rgb += 3 * po; gt_depth += po;
+        const size_t go = c.gt_index ? (size_t)c.gt_index[blockIdx.y] * (size_t)HW : po;   // ground truth straight from the keyframe store
+        rgb += 3 * po; normal_raw += 3 * po; depth += po; opacity += po; gt_rgb += 3 * go; gt_depth += go;
         n_img += 3 * po; d_rgb += 3 * po; d_depth += po;
         view += blockIdx.y;
     }
@@ -113,7 +115,8 @@ __global__ __launch_bounds__(256) void ags_k_loss_stage2(
     const int H = c.H, W = c.W, HW = H * W;
     if (gridDim.y > 1) {
         const size_t po = (size_t)blockIdx.y * (size_t)HW;
-        depth += po; opacity += po; normal_raw += 3 * po; n_img += 3 * po; gt_depth += po;
+        const size_t go = c.gt_index ? (size_t)c.gt_index[blockIdx.y] * (size_t)HW : po;
+        depth += po; opacity += po; normal_raw += 3 * po; n_img += 3 * po; gt_depth += go;
         d_normal += 3 * po; d_depth += po;
     }
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -216,10 +219,12 @@ __global__ __launch_bounds__(256) void ags_k_stage_frames(
     const int q = blockIdx.x * 256 + threadIdx.x;          // float4 index within a plane
     const int HW4 = HW >> 2;                                 // HW is a multiple of 4 (checked by the caller)
     if (q < HW4) {
-        const float4* r = reinterpret_cast<const float4*>(all_rgb + f * 3 * (size_t)HW);
-        float4* o = reinterpret_cast<float4*>(dst_rgb + (size_t)v * 3 * (size_t)HW);
-        o[q] = r[q]; o[HW4 + q] = r[HW4 + q]; o[2 * HW4 + q] = r[2 * HW4 + q];
-        reinterpret_cast<float4*>(dst_depth + (size_t)v * HW)[q] = reinterpret_cast<const float4*>(all_depth + f * (size_t)HW)[q];
+        if (dst_rgb) {   // (NULL: the loss stages read the ground truth in place, AgsLossConfig.gt_frame_index)
+            const float4* r = reinterpret_cast<const float4*>(all_rgb + f * 3 * (size_t)HW);
+            float4* o = reinterpret_cast<float4*>(dst_rgb + (size_t)v * 3 * (size_t)HW);
+            o[q] = r[q]; o[HW4 + q] = r[HW4 + q]; o[2 * HW4 + q] = r[2 * HW4 + q];
+            reinterpret_cast<float4*>(dst_depth + (size_t)v * HW)[q] = reinterpret_cast<const float4*>(all_depth + f * (size_t)HW)[q];
+        }
         if (v == 0 && msum) reinterpret_cast<int4*>(msum)[q] = make_int4(0, 0, 0, 0);
     }
     if (blockIdx.x == 0 && threadIdx.x < 32) {
@@ -416,6 +421,7 @@ static AgsLossDev make_dev(const AgsLossConfig& cfg) {
     c.fyq = (float)cfg.image_width / (2.0f * tanf(0.5f * cfg.fov_y));
     c.w_rgb = cfg.w_rgb; c.w_depth = cfg.w_depth; c.w_cons = cfg.w_cons; c.w_tv = cfg.w_tv;
     c.inv_2sig2 = 1.0f / (2.0f * cfg.sigma * cfg.sigma);
+    c.gt_index = cfg.num_views > 1 ? (const long long*)cfg.gt_frame_index : nullptr;
     return c;
 }
 
@@ -440,6 +446,7 @@ void ags_launch_loss_stage2(const AgsLossConfig& cfg, const AgsImages& img, cons
 void ags_launch_stage_frames(int views, int hw, const long long* frame_index, const float* all_view, const float* all_proj,
                              const float* all_rgb, const float* all_depth, float* dst_view, float* dst_proj,
                              float* dst_rgb, float* dst_depth, int* msum, hipStream_t s) {
+    // without image copies only view 0's workgroups have pixels to touch (the visibility count) - one workgroup per other view
     hipLaunchKernelGGL(ags_k_stage_frames, dim3(((hw >> 2) + 255) / 256, views), dim3(256), 0, s, hw, frame_index, all_view,
                        all_proj, all_rgb, all_depth, dst_view, dst_proj, dst_rgb, dst_depth, msum);
 }

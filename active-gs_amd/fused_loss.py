@@ -68,9 +68,11 @@ class FusedLoss:
         return LossBuffers(torch.empty(views, 3, self.h, self.w, **f), torch.empty(views, 3, self.h, self.w, **f),
                            torch.empty(views, 3, self.h, self.w, **f), torch.empty(views, 1, self.h, self.w, **f))
 
-    def stage1_batch(self, images: "_lib.AgsImages", gt_rgb, gt_depth, buf: LossBuffers, views: int) -> None:
-        """``images``: AgsImages of (views,C,H,W) batches; ``msum`` must be zero (atomic counting)."""
+    def stage1_batch(self, images: "_lib.AgsImages", gt_rgb, gt_depth, buf: LossBuffers, views: int, gt_index=None) -> None:
+        """``images``: AgsImages of (views,C,H,W) batches; ``msum`` must be zero (atomic counting).  ``gt_index`` (int64 on
+        the device): view v's ground truth is frame ``gt_index[v]`` of ``gt_rgb`` / ``gt_depth`` = the whole keyframe store."""
         self.cfg.num_views = int(views)
+        self.cfg.gt_frame_index = ptr(gt_index)
         try:
             _lib.check(_lib.load().ags_loss_stage1(C.byref(self.cfg), C.byref(images), ptr(gt_rgb), ptr(gt_depth),
                                                    ptr(buf.n_img), ptr(buf.d_rgb), ptr(buf.d_depth), ptr(self.msum),
@@ -78,15 +80,18 @@ class FusedLoss:
                        "ags_loss_stage1")
         finally:
             self.cfg.num_views = 0
+            self.cfg.gt_frame_index = None
 
-    def stage2_batch(self, images: "_lib.AgsImages", gt_depth, buf: LossBuffers, views: int) -> None:
+    def stage2_batch(self, images: "_lib.AgsImages", gt_depth, buf: LossBuffers, views: int, gt_index=None) -> None:
         self.cfg.num_views = int(views)
+        self.cfg.gt_frame_index = ptr(gt_index)
         try:
             _lib.check(_lib.load().ags_loss_stage2(C.byref(self.cfg), C.byref(images), ptr(buf.n_img), ptr(gt_depth),
                                                    ptr(self.msum), ptr(buf.d_normal), ptr(buf.d_depth), ptr(self.accum),
                                                    _lib.current_stream()), "ags_loss_stage2")
         finally:
             self.cfg.num_views = 0
+            self.cfg.gt_frame_index = None
 
     def stage_frames(self, views: int, frame_index, all_view, all_proj, all_rgb, all_depth, dst_view, dst_proj,
                      dst_rgb, dst_depth) -> None:

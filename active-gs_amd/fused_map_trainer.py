@@ -656,8 +656,9 @@ class FusedMapTrainer(GaussianMapTrainer):
             state['idx'] (device), output: per-frame errors and the loss value"""
             batch, idx, B = state["batch"], state["idx"], state["B"]
             if fast_stage:
-                self._loss.stage_frames(B, idx, all_view, all_proj, all_rgb, all_depth, batch.viewmats, batch.projmats,
-                                        gt_rgb, gt_depth)
+                # the sampled frames' matrices into the batch; their images stay where they are (the loss stages read view
+                # v's ground truth at frame idx[v] of the keyframe store: no 4 MB copy per view and iteration)
+                self._loss.stage_frames(B, idx, all_view, all_proj, None, None, batch.viewmats, batch.projmats, None, None)
             else:
                 torch.index_select(all_view, 0, idx, out=batch.viewmats[:B])
                 torch.index_select(all_proj, 0, idx, out=batch.projmats[:B])
@@ -666,8 +667,12 @@ class FusedMapTrainer(GaussianMapTrainer):
                 self._loss.msum.zero_()
             batch.forward(B, touched=rows)
             images = batch._structs()[0]
-            self._loss.stage1_batch(images, gt_rgb, gt_depth, bufs, B)
-            self._loss.stage2_batch(images, gt_depth, bufs, B)
+            if fast_stage:
+                self._loss.stage1_batch(images, all_rgb, all_depth, bufs, B, gt_index=idx)
+                self._loss.stage2_batch(images, all_depth, bufs, B, gt_index=idx)
+            else:
+                self._loss.stage1_batch(images, gt_rgb, gt_depth, bufs, B)
+                self._loss.stage2_batch(images, gt_depth, bufs, B)
             if self.MULTI_VIEW_ROWS and B <= 16:
                 # the blend backward of all views, then ONE per-Gaussian launch over the member rows: the views' chain rules
                 # meet in registers and the Adam update follows in the same lane (no gradient slab, no atomics into it, no

@@ -484,6 +484,11 @@ typedef struct AgsLossConfig {
     int32_t num_views;     /* 0 / 1: one view per call.  > 1: the call handles that many views at once
                             * (blockIdx.y): every image argument points at a contiguous (views,C,H,W) batch,
                             * `view` is the index of the first one, and stage 1 needs first_view = -1. */
+    /* Optional (NULL = off; with num_views > 1): `num_views` int64 on the DEVICE - view v's ground truth is frame
+     * gt_frame_index[v] of gt_rgb / gt_depth, which then point at the WHOLE keyframe store (K,3,H,W) / (K,1,H,W): the sampled
+     * frames' images are read in place instead of being gathered into batch buffers first (ags_stage_frames with
+     * dst_rgb = dst_depth = NULL then stages the matrices and clears msum only). */
+    const int64_t* gt_frame_index;
 } AgsLossConfig;
 int ags_loss_stage1(const AgsLossConfig* cfg, const AgsImages* fwd, const float* gt_rgb, const float* gt_depth,
                     float* n_img /* (3,H,W) */, float* d_rgb, float* d_depth, int32_t* msum /* (H,W) */,
@@ -583,8 +588,8 @@ int ags_compact_rows(int32_t n, int32_t width, const int32_t* dst_index, const f
 /* Two helpers that keep a batched training iteration to a handful of launches:
  * ags_stage_frames gathers the sampled frames (frame_index: `views` int64 indices, device) of the
  * stacked keyframe arrays all_view / all_proj (K,16), all_rgb (K,3,H,W), all_depth (K,1,H,W) into the
- * batch buffers dst_* (what four index_select calls would do) and, if msum != NULL, zeroes that (H,W)
- * visibility count; H*W must be a multiple of 4.
+ * batch buffers dst_* (what four index_select calls would do; dst_rgb = dst_depth = NULL: the matrices only) and, if
+ * msum != NULL, zeroes that (H,W) visibility count; H*W must be a multiple of 4.
  * ags_loss_finish sums the accumulator rows of the loss stages, writes
  * frame_error[frame_index[v]] = mean rgb L1 + mean depth L1 of view v (track_performance,
  * gaussian_map.py:132-139; frame_index NULL: frame_error[v]) and *total_loss, and zeroes the
