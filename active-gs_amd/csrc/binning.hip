@@ -611,6 +611,18 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct_wave(uint2* __rest
     AGS_TL_VAL(5, tl_w, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32));
 }
 
+// ags_workspace_init_batch: the counter regions of `views` consecutive workspaces cleared by ONE launch (a memset per view
+// is ~7 us of host time each; a training batch re-binds eleven workspaces at every keyframe)
+__global__ __launch_bounds__(256) void ags_k_clear_regions(char* __restrict__ base, size_t stride, size_t offset, size_t bytes) {
+    uint4* p = reinterpret_cast<uint4*>(base + (size_t)blockIdx.y * stride + offset);
+    const size_t n16 = bytes >> 4;                                    // (the region is a multiple of 256 bytes)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+void ags_launch_clear_regions(char* base, size_t stride, size_t offset, size_t bytes, int views, hipStream_t s) {
+    const int blocks = (int)((((bytes >> 4) + 255) / 256) < 64 ? (((bytes >> 4) + 255) / 256) : 64);
+    hipLaunchKernelGGL(ags_k_clear_regions, dim3(blocks < 1 ? 1 : blocks, views), dim3(256), 0, s, base, stride, offset, bytes);
+}
+
 void ags_launch_direct_sort(char* ws, const AgsLayout& L, const AgsViewStride& vs, hipStream_t s) {
     const bool no_wave = L.tune.tile_sort_no_wave != 0;   // AgsTuning: always the 256-thread form
     const uint32_t tile_cap = ags_direct_tile_cap(L);
