@@ -26,6 +26,7 @@
 #include "ags_internal.h"
 
 AGS_TL_DEFINE(render)
+AGS_PROBE_DEFINE()
 
 // Issue priority by phase.  The SIMD arbitrates VALU issue between its resident waves by priority, then AGE: a wave
 // that has just started competes with older waves that sit in their blend loops and keep the vector pipe busy, and
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
     }
     AGS_TL(2, tl_w, 1);
     [[maybe_unused]] uint32_t tl_iters = 0;
+    AGS_PROBE_VARS();
     for (uint32_t base = rg.x; base < rg.y; base += 64) {
         if (__all(alldone)) break;
         ags_wave_lds_sync();
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
                     any |= take;
                 }
             }
+            AGS_PROBE_PAIR(any);
             if (!__any(any)) continue;
             const uint32_t pos1 = base - rg.x + k + 1;
             const float4 gb = ags_lds_read16(&g.b), gc = ags_lds_read16(&g.c);   // gy, r, g, b | nx, ny, nz, conf
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
         for (int s = 0; s < SLOTS; ++s) alldone &= pix[s].done;
     }
     AGS_TL(2, tl_w, 3);
+    AGS_PROBE_FLUSH(0);
     AGS_PRIO_HIGH();
     AGS_TL_VAL(2, tl_w, 5, rg.y - rg.x);
     AGS_TL_VAL(2, tl_w, 6, tl_iters);
@@ -649,6 +653,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
     // and selects took ten), and the flush reads them back with the lane's row address
     AGS_TL(3, tl_w, 2);
     [[maybe_unused]] uint32_t tl_iters = 0, tl_flush = 0;
+    AGS_PROBE_VARS();
 
     auto flush = [&]() {
         ags_wave_lds_sync();
@@ -740,6 +745,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             const AgsQuadCoef qc = {gs.x, gs.y, gs.z, gs.w};
             const float a = ags_alpha_quad(sh, qc, qx, qy);
             const bool take = a >= AGS_ALPHA_MIN && pos1 <= pg.last;   // (alpha >= 1/255 > 0 when taken: the mask is the test)
+            AGS_PROBE_PAIR(take);
             if (!__any(take)) continue;
             const float alpha = take ? a : 0.f;
             // the blend recurrence (ags_blend_bwd_apply without its accumulation)
@@ -772,6 +778,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
     }
     AGS_TL(3, tl_w, 4);
     if (nb) { flush(); ++tl_flush; }
+    AGS_PROBE_FLUSH(1);
     AGS_TL(3, tl_w, 5);
     AGS_TL_VAL(3, tl_w, 6, tl_iters | ((unsigned long long)tl_flush << 32));
     AGS_TL_VAL(3, tl_w, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32));

@@ -1,0 +1,16 @@
+"""Host-side cProfile of the mapper loop (config 3), by CUMULATIVE time of this package's own functions: which phases of a
+keyframe the interpreter spends its time in.  usage: python profiles/experiments/mapper_cprofile_cum.py [top=70]"""
+import cProfile, os, pstats, sys
+import numpy as np, torch
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, R)
+from active_gs_amd.synthetic import make_keyframes, run_mapper_loop
+dev = torch.device("cuda:0")
+frames = make_keyframes(50, 512, 512, dev)
+run_mapper_loop(frames, warmup_frames=2)
+np.random.seed(0)
+pr = cProfile.Profile()
+pr.enable()
+out = run_mapper_loop(frames, warmup_frames=0)
+pr.disable()
+print(out["seconds"])
+st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats("active.gs.amd", int(sys.argv[1]) if len(sys.argv) > 1 else 70)
