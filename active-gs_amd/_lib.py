@@ -154,6 +154,17 @@ class AgsLossConfig(C.Structure):
                 ("gt_frame_index", C.c_void_p)]
 
 
+class AgsNextIteration(C.Structure):
+    _fields_ = [("uniforms", C.c_void_p), ("n_weights", C.c_int32), ("k", C.c_int32), ("first_random", C.c_int32),
+                ("views", C.c_int32), ("all_view", C.c_void_p), ("all_proj", C.c_void_p), ("dst_view", C.c_void_p),
+                ("dst_proj", C.c_void_p), ("msum", C.c_void_p)]
+
+
+class AgsMapArrays(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("means", "scales", "rotations", "opacities", "harmonics", "view_scores",
+                                          "view_supports", "view_means")]
+
+
 class AgsActivation(C.Structure):
     _fields_ = [("n", C.c_int32), ("scale_factor", C.c_float), ("max_scale", C.c_float), ("raw_scales", c_f32p),
                 ("raw_rotations", c_f32p), ("raw_opacities", c_f32p)]
@@ -174,9 +185,9 @@ class AgsCandidates(C.Structure):
 
 EXPORTS = ["ags_workspace_bytes", "ags_workspace_region", "ags_workspace_init", "ags_workspace_init_batch", "ags_workspace_discard_pass", "ags_forward", "ags_forward_batch",
            "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_backward_rows", "ags_backward_fused_next", "ags_forward_resume", "ags_read_status", "ags_read_status_async", "ags_adam_step",
-           "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_rows_index", "ags_adam_step_gathered", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_weighted_topk", "ags_facade_post", "ags_facade_post_batch", "ags_facade_post_backward", "ags_smooth_depth", "ags_densify_candidates",
+           "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_rows_index", "ags_adam_step_gathered", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_loss_finish_next", "ags_weighted_topk", "ags_facade_post", "ags_facade_post_batch", "ags_facade_post_backward", "ags_smooth_depth", "ags_densify_candidates",
            "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_view_stats_update", "ags_confidences", "ags_compact_plan_bytes", "ags_compact_plan",
-           "ags_compact_rows", "ags_profile_enable", "ags_profile_read",
+           "ags_compact_rows", "ags_map_append", "ags_map_compact", "ags_profile_enable", "ags_profile_read",
            "ags_error_string", "ags_version"]
 
 _lib = None
@@ -278,6 +289,9 @@ def load() -> C.CDLL:
     lib.ags_loss_finish.restype = C.c_int
     lib.ags_loss_finish.argtypes = [C.POINTER(AgsLossConfig), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]
+    lib.ags_loss_finish_next.restype = C.c_int
+    lib.ags_loss_finish_next.argtypes = [C.POINTER(AgsLossConfig), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(AgsNextIteration), C.c_void_p]
     lib.ags_smooth_depth.restype = C.c_int
     lib.ags_smooth_depth.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float,
                                      C.c_void_p]
@@ -301,6 +315,10 @@ def load() -> C.CDLL:
     lib.ags_compact_plan.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.ags_compact_rows.restype = C.c_int
     lib.ags_compact_rows.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ags_map_append.restype = C.c_int
+    lib.ags_map_append.argtypes = [C.c_int32, C.c_void_p, C.POINTER(AgsCandidates), C.c_float, C.POINTER(AgsMapArrays), C.c_void_p]
+    lib.ags_map_compact.restype = C.c_int
+    lib.ags_map_compact.argtypes = [C.c_int32, C.c_void_p, C.POINTER(AgsMapArrays), C.POINTER(AgsMapArrays), C.c_void_p]
     lib.ags_profile_enable.restype = C.c_int
     lib.ags_profile_enable.argtypes = [C.c_int32]
     lib.ags_profile_read.restype = C.c_int

@@ -254,6 +254,8 @@ void ags_launch_weighted_topk(const float* u, const float* w, int n, int k, long
 void ags_launch_stage_frames(int views, int hw, const long long* frame_index, const float* all_view, const float* all_proj,
                              const float* all_rgb, const float* all_depth, float* dst_view, float* dst_proj,
                              float* dst_rgb, float* dst_depth, int* msum, hipStream_t s);
+void ags_launch_loss_finish_next(const AgsLossConfig& cfg, float* accum, int views, long long* frame_index, float* frame_error,
+                                 float* total_loss, const AgsNextIteration& nx, hipStream_t s);
 void ags_launch_loss_finish(const AgsLossConfig& cfg, float* accum, int views, const long long* frame_index,
                             float* frame_error, float* total_loss, hipStream_t s);
 int ags_sort_passes(int num_tiles);
@@ -266,6 +268,8 @@ size_t ags_voxel_bytes(int n);
 void ags_launch_voxel_select(int n, const float* points, int32_t* select, float voxel, void* ws, hipStream_t s);
 size_t ags_compact_bytes(int n);
 void ags_launch_compact_plan(int n, const int32_t* keep, int32_t* dst_index, int32_t* total, void* scratch, hipStream_t s);
+void ags_launch_map_append(int P, const int32_t* dst_index, const AgsCandidates& c, float new_z, const AgsMapArrays& o, hipStream_t s);
+void ags_launch_map_compact(int n, const int32_t* dst_index, const AgsMapArrays& a, const AgsMapArrays& o, hipStream_t s);
 void ags_launch_compact_rows(int n, int width, const int32_t* dst_index, const float* src, float* dst, hipStream_t s);
 void ags_launch_view_stats(int n, const float* means, const float* raw_rotations, const float* campos, float far,
                            const int32_t* newest_count, int use_vd, float* view_supports, float* view_means,

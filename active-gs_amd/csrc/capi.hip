@@ -538,6 +538,22 @@ int ags_loss_finish(const AgsLossConfig* cfg, float* accum, int32_t views, const
     return ags_check_launch();
 }
 
+int ags_loss_finish_next(const AgsLossConfig* cfg, float* accum, int32_t views, int64_t* frame_index, float* frame_error,
+                         float* total_loss, const AgsNextIteration* next, ags_stream_t stream) {
+    if (!cfg || !accum || !next || !frame_index || views < 0 || cfg->accum_stride < 4 + 2 * views || cfg->accum_stride > 256 ||
+        cfg->batch_total < 1 || cfg->image_height <= 0 || cfg->image_width <= 0 ||
+        ((long long)cfg->image_height * cfg->image_width) % 4 != 0)
+        return AGS_E_INVALID;
+    if (next->views < 1 || next->views > 4096 || !next->all_view || !next->all_proj || !next->dst_view || !next->dst_proj || !next->msum)
+        return AGS_E_INVALID;
+    if (next->uniforms && next->k > 0 &&
+        (!frame_error || next->n_weights < 1 || next->n_weights > 8192 || next->k > next->n_weights || next->first_random < 0 ||
+         next->first_random + next->k > next->views))
+        return AGS_E_INVALID;
+    ags_launch_loss_finish_next(*cfg, accum, views, (long long*)frame_index, frame_error, total_loss, *next, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
 int ags_profile_enable(int32_t slots) {
     if (slots < 0) return AGS_E_INVALID;
     for (int st = 0; st < AGS_NUM_STAGES; ++st) {
@@ -651,6 +667,29 @@ int ags_compact_rows(int32_t n, int32_t width, const int32_t* dst_index, const f
     if (n == 0) return AGS_OK;
     if (!dst_index || !src || !dst) return AGS_E_INVALID;
     ags_launch_compact_rows(n, width, dst_index, src, dst, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+static bool ags_map_arrays_ok(const AgsMapArrays* a) {
+    return a && a->means && a->scales && a->rotations && a->opacities && a->harmonics && a->view_scores && a->view_supports &&
+           a->view_means;
+}
+
+int ags_map_append(int32_t candidates, const int32_t* dst_index, const AgsCandidates* c, float new_z_scale,
+                   const AgsMapArrays* first_new_row, ags_stream_t stream) {
+    if (candidates < 0) return AGS_E_INVALID;
+    if (candidates == 0) return AGS_OK;
+    if (!dst_index || !c || !c->means || !c->rotations || !c->harmonics || !ags_map_arrays_ok(first_new_row)) return AGS_E_INVALID;
+    ags_launch_map_append(candidates, dst_index, *c, new_z_scale, *first_new_row, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
+int ags_map_compact(int32_t n, const int32_t* dst_index, const AgsMapArrays* src, const AgsMapArrays* dst, ags_stream_t stream) {
+    if (n < 0) return AGS_E_INVALID;
+    if (n == 0) return AGS_OK;
+    if (!dst_index || !ags_map_arrays_ok(src) || !ags_map_arrays_ok(dst)) return AGS_E_INVALID;
+    if (src->means == dst->means || src->scales == dst->scales || src->rotations == dst->rotations) return AGS_E_INVALID;   // not in place
+    ags_launch_map_compact(n, dst_index, *src, *dst, (hipStream_t)stream);
     return ags_check_launch();
 }
 

@@ -344,6 +344,51 @@ __global__ __launch_bounds__(256) void ags_k_compact_rows(long long elems, int w
     if (d >= 0) dst[(size_t)d * width + col] = src[e];
 }
 
+// All eight arrays of the map in one launch each way (one lane per candidate / per row): the growth used to be eight
+// zero-fills, eight copies of the old map into fresh arrays, three row compactions and a strided fill per keyframe.
+__global__ __launch_bounds__(256) void ags_k_map_append(int P, const int32_t* __restrict__ dst_index, AgsCandidates c,
+                                                        float new_z, AgsMapArrays o) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int32_t d = dst_index[i];
+    if (d < 0) return;
+    const size_t r = (size_t)d;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o.means[3 * r + k] = c.means[3 * (size_t)i + k];
+        o.harmonics[3 * r + k] = c.harmonics[3 * (size_t)i + k];
+        o.view_means[3 * r + k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.rotations[4 * r + k] = c.rotations[4 * (size_t)i + k];
+    o.scales[3 * r] = 0.f; o.scales[3 * r + 1] = 0.f; o.scales[3 * r + 2] = new_z;
+    o.opacities[r] = 0.f; o.view_scores[r] = 0.f; o.view_supports[r] = 0.f;
+}
+__global__ __launch_bounds__(256) void ags_k_map_compact(int n, const int32_t* __restrict__ dst_index, AgsMapArrays a,
+                                                         AgsMapArrays o) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t d = dst_index[i];
+    if (d < 0) return;
+    const size_t r = (size_t)d, q = (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o.means[3 * r + k] = a.means[3 * q + k];
+        o.scales[3 * r + k] = a.scales[3 * q + k];
+        o.harmonics[3 * r + k] = a.harmonics[3 * q + k];
+        o.view_means[3 * r + k] = a.view_means[3 * q + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.rotations[4 * r + k] = a.rotations[4 * q + k];
+    o.opacities[r] = a.opacities[q]; o.view_scores[r] = a.view_scores[q]; o.view_supports[r] = a.view_supports[q];
+}
+void ags_launch_map_append(int P, const int32_t* dst_index, const AgsCandidates& c, float new_z, const AgsMapArrays& o, hipStream_t s) {
+    hipLaunchKernelGGL(ags_k_map_append, dim3((P + 255) / 256), dim3(256), 0, s, P, dst_index, c, new_z, o);
+}
+void ags_launch_map_compact(int n, const int32_t* dst_index, const AgsMapArrays& a, const AgsMapArrays& o, hipStream_t s) {
+    hipLaunchKernelGGL(ags_k_map_compact, dim3((n + 255) / 256), dim3(256), 0, s, n, dst_index, a, o);
+}
+
 // ---------------------------------------------------------------------------------------------
 void ags_launch_bilateral(int h, int w, const float* depth, float* out, int d, float sigma_color, float sigma_space,
                           hipStream_t s) {

@@ -16,7 +16,7 @@
 //   stage 2 (per pixel): TV gradient wrt n(p) gathered from the 4 neighbours (each unordered pair counted
 //                        from both sides), consistency gradient, chain rule through the normalisation ->
 //                        d_normal; consistency gradient wrt d2n(p) through the cross products onto the
-//                        depths of p and its 4 neighbours (atomicAdd into d_depth)
+//                        depths of p and its 4 neighbours (gathered per 32x8 tile through LDS, added to d_depth)
 #include "ags_internal.h"
 
 struct AgsLossDev {
@@ -36,10 +36,16 @@ __device__ __forceinline__ float3 operator*(float3 a, float s) { return f3(a.x *
 __device__ __forceinline__ float3 ags_point(float3 ray, float d) {
     return f3(__fmul_rn(ray.x, d), __fmul_rn(ray.y, d), __fmul_rn(ray.z, d));
 }
-__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// (this file is compiled with -ffp-contract=off for ags_point's sake; dot and cross products fuse explicitly: the stencil
+// kernels are bound by vector-instruction issue, and nothing downstream relies on an unfused rounding of these)
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
-    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    return f3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
+// b - a * s
+__device__ __forceinline__ float3 fnma3(float3 a, float s, float3 b) { return f3(fmaf(-a.x, s, b.x), fmaf(-a.y, s, b.y), fmaf(-a.z, s, b.z)); }
+// b + a * s
+__device__ __forceinline__ float3 fma3(float3 a, float s, float3 b) { return f3(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z)); }
 
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     v = ags_wave_sum(v);
@@ -106,23 +112,89 @@ __device__ __forceinline__ float3 load_n(const float* __restrict__ n_img, int HW
     return f3(n_img[q], n_img[HW + q], n_img[2 * HW + q]);
 }
 
+// Stage 2 works on 32x8-pixel tiles.  The consistency term's gradient reaches the depths of a pixel AND of its four
+// neighbours; until round 4 every pixel added its five contributions with atomics (14 M float atomics per batch of eleven
+// 512x512 views, half the kernel's time, and a last-bit dependence on their order).  Now a workgroup first evaluates the
+// stencil of every pixel of its tile and of the one-pixel ring around it (340 pixels: the ring's stencils reach into the
+// tile) into LDS - the five depth contributions and d2n - and every tile pixel then GATHERS what is addressed to it in a
+// fixed order (replicate padding: at an image border a pixel's "neighbour" is the pixel itself) and adds it to d_depth
+// with one plain read-modify-write.  1.33 x the stencil arithmetic, no atomics, deterministic.
+#define AGS_S2_TW 32
+#define AGS_S2_TH 8
+#define AGS_S2_RW (AGS_S2_TW + 2)
+#define AGS_S2_RN (AGS_S2_RW * (AGS_S2_TH + 2))
 __global__ __launch_bounds__(256) void ags_k_loss_stage2(
     AgsLossDev c, const float* __restrict__ depth, const float* __restrict__ opacity,
     const float* __restrict__ normal_raw, const float* __restrict__ n_img, const float* __restrict__ gt_depth,
     const int* __restrict__ msum, float* __restrict__ d_normal, float* __restrict__ d_depth,
     float* __restrict__ accum, int accum_stride) {
     __shared__ float sh[4];
+    __shared__ float st[8][AGS_S2_RN];      // [0..4]: contributions to the depths of (centre, up, left, right, below); [5..7]: d2n
     const int H = c.H, W = c.W, HW = H * W;
-    if (gridDim.y > 1) {
-        const size_t po = (size_t)blockIdx.y * (size_t)HW;
-        const size_t go = c.gt_index ? (size_t)c.gt_index[blockIdx.y] * (size_t)HW : po;
+    if (gridDim.z > 1) {
+        const size_t po = (size_t)blockIdx.z * (size_t)HW;
+        const size_t go = c.gt_index ? (size_t)c.gt_index[blockIdx.z] * (size_t)HW : po;
         depth += po; opacity += po; normal_raw += 3 * po; n_img += 3 * po; gt_depth += go;
         d_normal += 3 * po; d_depth += po;
     }
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int x0 = blockIdx.x * AGS_S2_TW, y0 = blockIdx.y * AGS_S2_TH;
+    const float k_c = c.w_cons / ((float)c.B * (float)c.B * (float)HW);
+    // the ray slopes of the tile's columns and rows (x0 - 2 .. x0 + 33, y0 - 2 .. y0 + 9, clamped to the image): 48 correctly
+    // rounded divisions per workgroup instead of six per pixel
+    __shared__ float rxs[AGS_S2_TW + 4], rys[AGS_S2_TH + 4];
+    if (threadIdx.x < AGS_S2_TW + 4) rxs[threadIdx.x] = ((float)min(max(x0 - 2 + (int)threadIdx.x, 0), W - 1) - 0.5f * (float)W) / c.fxq;
+    else if (threadIdx.x >= 64 && threadIdx.x < 64 + AGS_S2_TH + 4)
+        rys[threadIdx.x - 64] = ((float)min(max(y0 - 2 + (int)threadIdx.x - 64, 0), H - 1) - 0.5f * (float)H) / c.fyq;
+    __syncthreads();
+    // ---------------- depth -> normal (replicate padding) and the consistency term's gradient onto the five depths
+    for (int i = threadIdx.x; i < AGS_S2_RN; i += 256) {
+        const int x = x0 + (i % AGS_S2_RW) - 1, y = y0 + (i / AGS_S2_RW) - 1;
+        float gc = 0.f, gu = 0.f, gl = 0.f, gr = 0.f, gb = 0.f;
+        float3 d2n = f3(0.f, 0.f, 0.f);
+        if (x >= 0 && x < W && y >= 0 && y < H) {
+            const int p = y * W + x;
+            const float mn = opacity[p] > 1e-2f ? 1.f : 0.f;
+            const float ms = (float)msum[p];
+            if (mn > 0.f) {
+                const int yu = max(y - 1, 0), yb = min(y + 1, H - 1), xl = max(x - 1, 0), xr = min(x + 1, W - 1);
+                const int iu = yu * W + x, ib = yb * W + x, il = y * W + xl, ir = y * W + xr;
+                const float rx = rxs[x - x0 + 2], ry = rys[y - y0 + 2];
+                const float rxl = rxs[xl - x0 + 2], rxr = rxs[xr - x0 + 2], ryu = rys[yu - y0 + 2], ryb = rys[yb - y0 + 2];
+                const float dp = depth[p], du = depth[iu], db = depth[ib], dl = depth[il], dr = depth[ir];
+                const float Mu = opacity[iu] > 1e-2f ? 1.f : 0.f, Mb = opacity[ib] > 1e-2f ? 1.f : 0.f;
+                const float Ml = opacity[il] > 1e-2f ? 1.f : 0.f, Mr = opacity[ir] > 1e-2f ? 1.f : 0.f;
+                const float3 ray_c = f3(rx, ry, 1.f), ray_u = f3(rx, ryu, 1.f), ray_b = f3(rx, ryb, 1.f);
+                const float3 ray_l = f3(rxl, ry, 1.f), ray_r = f3(rxr, ry, 1.f);
+                const float3 pc = ags_point(ray_c, dp) * mn;
+                const float3 pu = (ags_point(ray_u, du) - pc) * Mu, pl = (ags_point(ray_l, dl) - pc) * Ml;
+                const float3 pb = (ags_point(ray_b, db) - pc) * Mb, pr = (ags_point(ray_r, dr) - pc) * Mr;
+                const float3 m = cross3(pu, pl) + cross3(pr, pu) + cross3(pb, pr) + cross3(pl, pb);
+                const float ml = fmaxf(sqrtf(dot3(m, m)), 1e-12f);
+                const float3 mh = m * (1.f / ml);
+                d2n = mh * mn;
+                // consistency gradient wrt d2n(p) -> m -> the five depths
+                if (sqrtf(dot3(m, m)) > 1e-12f && ms > 0.f) {
+                    const float3 G = load_n(n_img, HW, p) * (-k_c * ms);
+                    const float3 Gm = fnma3(mh, dot3(mh, G), G) * (1.f / ml);
+                    const float3 gpu = cross3(pl, Gm) + cross3(Gm, pr);
+                    const float3 gpl = cross3(Gm, pu) + cross3(pb, Gm);
+                    const float3 gpr = cross3(pu, Gm) + cross3(Gm, pb);
+                    const float3 gpb = cross3(pr, Gm) + cross3(Gm, pl);
+                    const float3 gpc = (gpu * Mu + gpl * Ml + gpr * Mr + gpb * Mb) * -1.f;
+                    gc = dot3(gpc, ray_c) * mn; gu = dot3(gpu, ray_u) * Mu; gl = dot3(gpl, ray_l) * Ml;
+                    gr = dot3(gpr, ray_r) * Mr; gb = dot3(gpb, ray_b) * Mb;
+                }
+            }
+        }
+        st[0][i] = gc; st[1][i] = gu; st[2][i] = gl; st[3][i] = gr; st[4][i] = gb;
+        st[5][i] = d2n.x; st[6][i] = d2n.y; st[7][i] = d2n.z;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & (AGS_S2_TW - 1), ly = threadIdx.x / AGS_S2_TW;
+    const int x = x0 + lx, y = y0 + ly;
     float s_cons = 0.f, s_tv = 0.f;
-    if (p < HW) {
-        const int y = p / W, x = p - y * W;
+    if (x < W && y < H) {
+        const int p = y * W + x, ri = (ly + 1) * AGS_S2_RW + lx + 1;
         const float3 n = load_n(n_img, HW, p);
         const float dp = depth[p];
         const float mdp = gt_depth[p] > 0.f ? 1.f : 0.f;
@@ -143,60 +215,37 @@ __global__ __launch_bounds__(256) void ags_k_loss_stage2(
                 s_tv += ex * nd * mdp;                                   // this pixel's own term
                 const float mdq = gt_depth[q] > 0.f ? 1.f : 0.f;
                 const float fp = ex * (1.f - nd * c.inv_2sig2) * (mdp + mdq) * 2.f * k_tv; // both orientations of the pair
-                gn = gn + df * fp;
+                gn = fma3(df, fp, gn);
             }
         }
-        // ---------------- depth -> normal (replicate padding) and the consistency term
+        // ---------------- the consistency term
         const float mn = opacity[p] > 1e-2f ? 1.f : 0.f;
-        const int yu = max(y - 1, 0), yb = min(y + 1, H - 1), xl = max(x - 1, 0), xr = min(x + 1, W - 1);
-        const int iu = yu * W + x, ib = yb * W + x, il = y * W + xl, ir = y * W + xr;
-        const float rx = ((float)x - 0.5f * (float)W) / c.fxq, ry = ((float)y - 0.5f * (float)H) / c.fyq;
-        const float rxl = ((float)xl - 0.5f * (float)W) / c.fxq, rxr = ((float)xr - 0.5f * (float)W) / c.fxq;
-        const float ryu = ((float)yu - 0.5f * (float)H) / c.fyq, ryb = ((float)yb - 0.5f * (float)H) / c.fyq;
-        const float du = depth[iu], db = depth[ib], dl = depth[il], dr = depth[ir];
-        const float Mu = opacity[iu] > 1e-2f ? 1.f : 0.f, Mb = opacity[ib] > 1e-2f ? 1.f : 0.f;
-        const float Ml = opacity[il] > 1e-2f ? 1.f : 0.f, Mr = opacity[ir] > 1e-2f ? 1.f : 0.f;
-        const float3 ray_c = f3(rx, ry, 1.f), ray_u = f3(rx, ryu, 1.f), ray_b = f3(rx, ryb, 1.f);
-        const float3 ray_l = f3(rxl, ry, 1.f), ray_r = f3(rxr, ry, 1.f);
-        const float3 pc = ags_point(ray_c, dp) * mn;
-        const float3 pu = (ags_point(ray_u, du) - pc) * Mu, pl = (ags_point(ray_l, dl) - pc) * Ml;
-        const float3 pb = (ags_point(ray_b, db) - pc) * Mb, pr = (ags_point(ray_r, dr) - pc) * Mr;
-        const float3 m = cross3(pu, pl) + cross3(pr, pu) + cross3(pb, pr) + cross3(pl, pb);
-        const float ml = fmaxf(sqrtf(dot3(m, m)), 1e-12f);
-        const float3 mh = m * (1.f / ml);
-        const float3 d2n = mh * mn;
+        const float3 d2n = f3(st[5][ri], st[6][ri], st[7][ri]);
         const float ms = (float)msum[p];
-        const float k_c = c.w_cons / ((float)c.B * (float)c.B * (float)HW);
         s_cons = (1.f - dot3(n, d2n)) * ms;
-        gn = gn + d2n * (-k_c * ms);
+        gn = fma3(d2n, -k_c * ms, gn);
         // chain rule through n = normalize(N) * mask
         const float3 N = f3(normal_raw[p], normal_raw[HW + p], normal_raw[2 * HW + p]);
         const float Nl = sqrtf(dot3(N, N));
         float3 dN = f3(0.f, 0.f, 0.f);
         if (mn > 0.f && Nl > 1e-12f) {
-            const float3 nh = N * (1.f / Nl);
-            dN = (gn - nh * dot3(nh, gn)) * (1.f / Nl);
+            const float iNl = 1.f / Nl;
+            const float3 nh = N * iNl;
+            dN = fnma3(nh, dot3(nh, gn), gn) * iNl;
         }
         d_normal[p] = dN.x; d_normal[HW + p] = dN.y; d_normal[2 * HW + p] = dN.z;
-        // consistency gradient wrt d2n(p) -> m -> the five depths
-        const float3 G = n * (-k_c * ms);
-        if (mn > 0.f && sqrtf(dot3(m, m)) > 1e-12f && ms > 0.f) {
-            const float3 Gm = (G - mh * dot3(mh, G)) * (1.f / ml);
-            const float3 gpu = cross3(pl, Gm) + cross3(Gm, pr);
-            const float3 gpl = cross3(Gm, pu) + cross3(pb, Gm);
-            const float3 gpr = cross3(pu, Gm) + cross3(Gm, pb);
-            const float3 gpb = cross3(pr, Gm) + cross3(Gm, pl);
-            const float3 gpc = (gpu * Mu + gpl * Ml + gpr * Mr + gpb * Mb) * -1.f;
-            atomicAdd(&d_depth[p], dot3(gpc, ray_c) * mn);
-            atomicAdd(&d_depth[iu], dot3(gpu, ray_u) * Mu);
-            atomicAdd(&d_depth[il], dot3(gpl, ray_l) * Ml);
-            atomicAdd(&d_depth[ir], dot3(gpr, ray_r) * Mr);
-            atomicAdd(&d_depth[ib], dot3(gpb, ray_b) * Mb);
-        }
+        // what the stencils of this pixel and of its neighbours address to this pixel's depth (replicate padding: at a
+        // border the pixel is its own neighbour)
+        float add = st[0][ri];
+        add += (y + 1 < H ? st[1][ri + AGS_S2_RW] : 0.f) + (y == 0 ? st[1][ri] : 0.f);       // "up" of the pixel below
+        add += (x + 1 < W ? st[2][ri + 1] : 0.f) + (x == 0 ? st[2][ri] : 0.f);               // "left" of the pixel to the right
+        add += (x > 0 ? st[3][ri - 1] : 0.f) + (x == W - 1 ? st[3][ri] : 0.f);               // "right" of the pixel to the left
+        add += (y > 0 ? st[4][ri - AGS_S2_RW] : 0.f) + (y == H - 1 ? st[4][ri] : 0.f);       // "below" of the pixel above
+        d_depth[p] += add;
     }
     const float t_c = block_sum_256(s_cons, sh), t_t = block_sum_256(s_tv, sh);
     if (threadIdx.x == 0) {
-        float* row = accum + (size_t)(blockIdx.x & (AGS_LOSS_ACCUM_ROWS - 1)) * accum_stride;
+        float* row = accum + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) & (AGS_LOSS_ACCUM_ROWS - 1)) * accum_stride;
         atomicAdd(&row[2], t_c); atomicAdd(&row[3], t_t);
     }
 }
@@ -368,11 +417,9 @@ void ags_launch_facade_post_bwd(int h, int w, float tanx, float tany, const floa
 // order (what torch.topk returned when this was log + clamp + div + topk + a slice assignment: five launches and
 // 0.26 ms of host time per iteration).
 #define AGS_WTOPK_MAX 8192
-__global__ __launch_bounds__(256) void ags_k_weighted_topk(const float* __restrict__ u, const float* __restrict__ w, int n,
-                                                           int k, long long* __restrict__ out) {
-    __shared__ float key[AGS_WTOPK_MAX];
-    __shared__ float best_v[4];
-    __shared__ int best_i[4];
+// (the body of ags_k_weighted_topk for one workgroup of 256 threads; key / best_v / best_i: its LDS)
+__device__ __forceinline__ void ags_wtopk_block(const float* __restrict__ u, const float* __restrict__ w, int n, int k,
+                                                long long* __restrict__ out, float* key, float* best_v, int* best_i) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     // every key stays FINITE (u = 0 from torch.rand would give log(0) = -inf, a NaN weight a NaN key: both become the lowest
     // finite key), so that a drawn slot can be marked with NaN and never be selected again: the k indices are distinct
@@ -410,6 +457,60 @@ __global__ __launch_bounds__(256) void ags_k_weighted_topk(const float* __restri
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(256) void ags_k_weighted_topk(const float* __restrict__ u, const float* __restrict__ w, int n,
+                                                           int k, long long* __restrict__ out) {
+    __shared__ float key[AGS_WTOPK_MAX];
+    __shared__ float best_v[4];
+    __shared__ int best_i[4];
+    ags_wtopk_block(u, w, n, k, out, key, best_v, best_i);
+}
+
+// The end of one batched training iteration and the set-up of the next in ONE launch (ags_loss_finish_next): workgroup 0
+// runs ags_k_loss_finish's sums, then the next iteration's weighted draw over the errors it has just written
+// (ags_k_weighted_topk), then gathers the drawn frames' matrices (ags_k_stage_frames without images); the other
+// workgroups clear the visibility count.  Three launches and a torch.rand fewer per iteration: each of them was a
+// single-workgroup kernel that the GPU finished before the next one arrived (~25 us of an 0.58-ms iteration).
+struct AgsNextDev {
+    const float* u; int n_w, k, first_random, views;
+    const float* all_view; const float* all_proj; float* dst_view; float* dst_proj; int* msum;
+};
+__global__ __launch_bounds__(256) void ags_k_loss_finish_next(AgsLossDev c, float* __restrict__ accum, int accum_stride,
+                                                              int views, long long* __restrict__ frame_index,
+                                                              float* __restrict__ frame_error, float* __restrict__ total_loss,
+                                                              AgsNextDev nx) {
+    __shared__ float key[AGS_WTOPK_MAX];
+    __shared__ float best_v[4];
+    __shared__ int best_i[4];
+    const int t = threadIdx.x;
+    if (blockIdx.x > 0) {            // the visibility count of the next iteration: (H*W / 4) int4 over gridDim.x - 1 workgroups
+        const int HW4 = (c.H * c.W) >> 2;
+        for (int q = (blockIdx.x - 1) * 256 + t; q < HW4; q += (gridDim.x - 1) * 256) reinterpret_cast<int4*>(nx.msum)[q] = make_int4(0, 0, 0, 0);
+        return;
+    }
+    float s = 0.f;
+    if (t < accum_stride) {
+        for (int r = 0; r < AGS_LOSS_ACCUM_ROWS; ++r) { s += accum[(size_t)r * accum_stride + t]; accum[(size_t)r * accum_stride + t] = 0.f; }
+    }
+    key[t] = s;                      // (the draw's key array doubles as the sums' scratch)
+    __syncthreads();
+    const float hw = (float)c.H * (float)c.W, b = (float)c.B;
+    if (t < views && frame_error) frame_error[frame_index[t]] = key[4 + 2 * t] / (3.f * hw) + key[5 + 2 * t] / hw;
+    if (t == 0 && total_loss)
+        *total_loss = c.w_rgb * key[0] / (b * 3.f * hw) + c.w_depth * key[1] / (b * hw) + c.w_cons * key[2] / (b * b * hw) +
+                      c.w_tv * key[3] / (b * 4.f * hw);
+    __threadfence_block();
+    __syncthreads();                 // the errors are written: the draw reads them
+    if (nx.u && nx.k > 0) ags_wtopk_block(nx.u, frame_error, nx.n_w, nx.k, frame_index + nx.first_random, key, best_v, best_i);
+    __threadfence_block();
+    __syncthreads();
+    for (int i = t; i < nx.views * 32; i += 256) {
+        const int v = i >> 5, e = i & 31;
+        const size_t f = (size_t)frame_index[v];
+        if (e < 16) nx.dst_view[v * 16 + e] = nx.all_view[f * 16 + e];
+        else nx.dst_proj[v * 16 + e - 16] = nx.all_proj[f * 16 + e - 16];
+    }
+}
+
 void ags_launch_weighted_topk(const float* u, const float* w, int n, int k, long long* out, hipStream_t s) {
     hipLaunchKernelGGL(ags_k_weighted_topk, dim3(1), dim3(256), 0, s, u, w, n, k, out);
 }
@@ -439,8 +540,10 @@ void ags_launch_loss_stage2(const AgsLossConfig& cfg, const AgsImages& img, cons
                             const int* msum, float* d_normal, float* d_depth, float* accum, hipStream_t s) {
     const int HW = cfg.image_height * cfg.image_width;
     const int views = cfg.num_views > 1 ? cfg.num_views : 1;
-    hipLaunchKernelGGL(ags_k_loss_stage2, dim3((HW + 255) / 256, views), dim3(256), 0, s, make_dev(cfg), img.depth,
-                       img.opacity, img.normal, n_img, gt_depth, msum, d_normal, d_depth, accum, cfg.accum_stride);
+    (void)HW;
+    hipLaunchKernelGGL(ags_k_loss_stage2, dim3((cfg.image_width + AGS_S2_TW - 1) / AGS_S2_TW, (cfg.image_height + AGS_S2_TH - 1) / AGS_S2_TH, views),
+                       dim3(256), 0, s, make_dev(cfg), img.depth, img.opacity, img.normal, n_img, gt_depth, msum, d_normal,
+                       d_depth, accum, cfg.accum_stride);
 }
 
 void ags_launch_stage_frames(int views, int hw, const long long* frame_index, const float* all_view, const float* all_proj,
@@ -449,6 +552,16 @@ void ags_launch_stage_frames(int views, int hw, const long long* frame_index, co
     // without image copies only view 0's workgroups have pixels to touch (the visibility count) - one workgroup per other view
     hipLaunchKernelGGL(ags_k_stage_frames, dim3(((hw >> 2) + 255) / 256, views), dim3(256), 0, s, hw, frame_index, all_view,
                        all_proj, all_rgb, all_depth, dst_view, dst_proj, dst_rgb, dst_depth, msum);
+}
+
+void ags_launch_loss_finish_next(const AgsLossConfig& cfg, float* accum, int views, long long* frame_index, float* frame_error,
+                                 float* total_loss, const AgsNextIteration& nx, hipStream_t s) {
+    const AgsNextDev d = {nx.uniforms, nx.n_weights, nx.k, nx.first_random, nx.views, nx.all_view, nx.all_proj, nx.dst_view,
+                          nx.dst_proj, nx.msum};
+    const int hw4 = (cfg.image_height * cfg.image_width) >> 2;
+    const int clear_blocks = (hw4 + 1023) / 1024 < 1 ? 1 : (hw4 + 1023) / 1024;     // four int4 per thread
+    hipLaunchKernelGGL(ags_k_loss_finish_next, dim3(1 + clear_blocks), dim3(256), 0, s, make_dev(cfg), accum, cfg.accum_stride,
+                       views, frame_index, frame_error, total_loss, d);
 }
 
 void ags_launch_loss_finish(const AgsLossConfig& cfg, float* accum, int views, const long long* frame_index,

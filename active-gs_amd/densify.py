@@ -109,15 +109,74 @@ def compact_rows(src: torch.Tensor, dst_index: torch.Tensor, dst: torch.Tensor) 
     _lib.check(_lib.load().ags_compact_rows(n, width, ptr(dst_index), ptr(src), ptr(dst), _stream()), "ags_compact_rows")
 
 
-def add_gaussians(state: Dict[str, torch.Tensor], frame: dict, pred: Optional[dict], error_thres: float
-                  ) -> Tuple[Dict[str, torch.Tensor], int]:
-    """``GaussianMap.add_gaussians`` (gaussian_map.py:294-462).  Returns (grown state, rows added)."""
+class MapArena:
+    """The map's eight per-surfel arrays with room behind the last row.  The reference grows the map with ``torch.cat``
+    and prunes it with boolean indexing (fresh tensors at every keyframe); here the arrays are views ``[:n]`` of buffers of
+    ``cap`` rows - growing writes the new rows behind the old ones (one launch, ``ags_map_append``), pruning compacts into
+    a second set of buffers (one launch, ``ags_map_compact``) and swaps.  Buffers double when they run out."""
+
+    TAILS = dict(means=(3,), scales=(3,), rotations=(4,), opacities=(), harmonics=(1, 3), view_scores=(), view_supports=(),
+                 view_means=(3,))
+
+    def __init__(self, cap: int, device):
+        self.cap, self.device = int(cap), device
+        self.bufs = self._alloc(self.cap)
+        self.alt = None                      # the buffers prune compacts into (made at the first prune)
+
+    def _alloc(self, cap: int) -> Dict[str, torch.Tensor]:
+        return {k: torch.empty((cap,) + t, device=self.device, dtype=torch.float32) for k, t in self.TAILS.items()}
+
+    def views(self, n: int) -> Dict[str, torch.Tensor]:
+        return {k: b[:n] for k, b in self.bufs.items()}
+
+    def holds(self, state: Dict[str, torch.Tensor]) -> bool:
+        """Are these tensors this arena's own leading rows?"""
+        return all(state[k].data_ptr() == self.bufs[k].data_ptr() and state[k].shape[0] <= self.cap
+                   and state[k].dtype == torch.float32 and state[k].is_contiguous() for k in STATE_KEYS)
+
+    def adopt(self, state: Dict[str, torch.Tensor], room: int) -> None:
+        """Make the arena hold ``state`` with at least ``room`` free rows behind it (copies only what it does not hold)."""
+        n = state["means"].shape[0]
+        held = self.holds(state)
+        if n + room > self.cap:
+            old = self.bufs if held else None
+            self.cap = max(2 * (n + room), 1 << 16)
+            self.bufs, self.alt = self._alloc(self.cap), None
+            src = {k: old[k][:n] for k in STATE_KEYS} if held else state
+            for k in STATE_KEYS:
+                self.bufs[k][:n].copy_(src[k].reshape((n,) + self.TAILS[k]))
+        elif not held:
+            for k in STATE_KEYS:
+                self.bufs[k][:n].copy_(state[k].reshape((n,) + self.TAILS[k]))
+
+    def arrays(self, bufs: Dict[str, torch.Tensor], row: int) -> "_lib.AgsMapArrays":
+        a = _lib.AgsMapArrays()
+        for k in STATE_KEYS:
+            width = 1
+            for t in self.TAILS[k]:
+                width *= t
+            setattr(a, k, bufs[k].data_ptr() + 4 * width * row)
+        return a
+
+
+def add_gaussians(state: Dict[str, torch.Tensor], frame: dict, pred: Optional[dict], error_thres: float,
+                  arena: Optional[MapArena] = None) -> Tuple[Dict[str, torch.Tensor], int]:
+    """``GaussianMap.add_gaussians`` (gaussian_map.py:294-462).  Returns (grown state, rows added).  With an ``arena`` the
+    grown state is the arena's leading rows (no copy of the old map when it already lives there)."""
     ds = smooth_depth(frame["depth"])
     c = candidates(frame, ds, pred, error_thres)
     voxel_select(c["means"], c["select"])
     dst_index, k = compact_plan(c["select"])
     n = state["means"].shape[0]
     dev = c["means"].device
+    if arena is not None:
+        arena.adopt(state, k)
+        if k:
+            cs = _lib.AgsCandidates(ptr(c["means"]), ptr(c["rotations"]), ptr(c["harmonics"]), ptr(c["select"]))
+            first = arena.arrays(arena.bufs, n)
+            _lib.check(_lib.load().ags_map_append(c["means"].shape[0], ptr(dst_index), C.byref(cs), NEW_Z_SCALE, C.byref(first),
+                                                  _stream()), "ags_map_append")
+        return arena.views(n + k), k
     out = {}
     for key in STATE_KEYS:
         old = state[key]
@@ -132,7 +191,8 @@ def add_gaussians(state: Dict[str, torch.Tensor], frame: dict, pred: Optional[di
     return out, k
 
 
-def prune(state: Dict[str, torch.Tensor], prune_mask: Optional[torch.Tensor]) -> Tuple[Dict[str, torch.Tensor], int]:
+def prune(state: Dict[str, torch.Tensor], prune_mask: Optional[torch.Tensor], arena: Optional[MapArena] = None
+          ) -> Tuple[Dict[str, torch.Tensor], int]:
     """``GaussianMap.prune`` (gaussian_map.py:234-246).  Returns (pruned state, rows deleted)."""
     lib = _lib.load()
     opac = _need_gpu(state["opacities"], "opacities")
@@ -142,6 +202,14 @@ def prune(state: Dict[str, torch.Tensor], prune_mask: Optional[torch.Tensor]) ->
     pm = None if prune_mask is None else _need_gpu(prune_mask.to(dev).float(), "prune_mask")
     _lib.check(lib.ags_prune_keep(n, ptr(pm), ptr(opac), MIN_OPACITY, ptr(keep), _stream()), "ags_prune_keep")
     dst_index, k = compact_plan(keep[:n])
+    if arena is not None and n > 0:
+        arena.adopt(state, 0)
+        if arena.alt is None:
+            arena.alt = arena._alloc(arena.cap)
+        src, dst = arena.arrays(arena.bufs, 0), arena.arrays(arena.alt, 0)
+        _lib.check(lib.ags_map_compact(n, ptr(dst_index), C.byref(src), C.byref(dst), _stream()), "ags_map_compact")
+        arena.bufs, arena.alt = arena.alt, arena.bufs
+        return arena.views(k), n - k
     out = {}
     for key in STATE_KEYS:
         old = state[key].contiguous()

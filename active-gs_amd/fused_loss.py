@@ -108,6 +108,16 @@ class FusedLoss:
                                                ptr(frame_error), ptr(total_loss),
                                                _lib.current_stream()), "ags_loss_finish")
 
+    def finish_next(self, views: int, frame_index, frame_error, total_loss, uniforms, n_weights: int, k: int,
+                    first_random: int, all_view, all_proj, dst_view, dst_proj) -> None:
+        """``finish`` + the NEXT iteration's draw (``uniforms``: n_weights numbers ~ U(0,1), None: the indices stay) +
+        its ``stage_frames`` (matrices only, ``msum`` zeroed) - one launch (``ags_loss_finish_next``)."""
+        nx = _lib.AgsNextIteration(ptr(uniforms), int(n_weights), int(k), int(first_random), int(views), ptr(all_view),
+                                   ptr(all_proj), ptr(dst_view), ptr(dst_proj), ptr(self.msum))
+        _lib.check(_lib.load().ags_loss_finish_next(C.byref(self.cfg), ptr(self.accum), int(views), ptr(frame_index),
+                                                    ptr(frame_error), ptr(total_loss), C.byref(nx),
+                                                    _lib.current_stream()), "ags_loss_finish_next")
+
     def total_loss(self) -> torch.Tensor:
         c, a, hw = self.cfg, self.accum.sum(0), float(self.h * self.w)
         b = float(c.batch_total)

@@ -85,6 +85,8 @@ class FusedMapTrainer(GaussianMapTrainer):
         self._uniform = None     # _uniform_frames()
         self._count_batch = None # _render_counts(): the chunk of views the prune pass renders at a time
         self._states = {}        # view slot -> ForwardState
+        self._arena = None       # _map_arena(): the buffers the map's arrays are views of
+        self._perf_buf = None    # _append_performance()
         self._loss = None
         self._loss_bufs = []
         self._cap = 0
@@ -145,36 +147,58 @@ class FusedMapTrainer(GaussianMapTrainer):
 
     def _make_camera(self, f: dict):
         """(api.Camera, fov_x, fov_y) of a frame.  The 4x4 / 3x3 algebra runs on the HOST (one small
-        read of the pose, two small uploads): on the GPU it is a dozen tiny launches and an inverse."""
+        read of the pose, ONE small upload): on the GPU it is a dozen tiny launches and an inverse."""
         h, w = f["rgb"].shape[-2:]
-        # camera.camera_matrices for one frame in numpy (float64, rounded to float32 at the end): the same algebra as ~40
-        # small torch ops took 0.34 ms of every keyframe
+        # camera.camera_matrices for one frame in float64 (rounded to float32 at the end) - the same algebra as ~40 small torch
+        # ops (0.34 ms of every keyframe), and with scalar arithmetic where numpy's per-call overhead dominated (the four
+        # unit rays and the 3x3 inverse: 75 -> 30 us; the GPU idles while this runs)
+        import math
+
         import numpy as np
         # (pose, intrinsics and the far bound in ONE read-back when the frame lives on the device)
         dr = f.get("depth_range")
-        parts = [f["extrinsic"].detach().reshape(-1).double(), f["intrinsic"].detach().reshape(-1).double()]
+        parts = [f["extrinsic"].detach().reshape(-1), f["intrinsic"].detach().reshape(-1)]
         if torch.is_tensor(dr):
-            parts.append(dr.detach().reshape(-1).double().to(parts[0].device))
-        host = torch.cat(parts).cpu().numpy()
-        c2w, Kinv = host[:16].reshape(4, 4), np.linalg.inv(host[16:25].reshape(3, 3))
+            parts.append(dr.detach().reshape(-1).to(parts[0].device))
+        dt = torch.float64 if any(p_.dtype == torch.float64 for p_ in parts) else torch.float32   # (no conversion launches for float32 frames)
+        host = torch.cat([p_.to(dt) for p_ in parts]).cpu().numpy().astype(np.float64)
+        host32 = host.astype(np.float32)
         if torch.is_tensor(dr):
             f["_far_host"] = float(host[25 + 1])
-        if "intrinsic_inv" not in f:       # what densify.candidates needs of the intrinsics: no second read-back for it
-            f["intrinsic_inv"] = self._upload(np.linalg.inv(host[16:25].astype(np.float32).reshape(3, 3))).reshape(3, 3)
-        ray = lambda u, v: (lambda d: d / np.linalg.norm(d))(Kinv @ np.array([u, v, 1.0]))
-        fov_x = float(np.arccos(np.clip(ray(0.0, 0.5) @ ray(1.0, 0.5), -1.0, 1.0)))
-        fov_y = float(np.arccos(np.clip(ray(0.5, 0.0) @ ray(0.5, 1.0), -1.0, 1.0)))
+        k = host[16:25].tolist()
+        det = (k[0] * (k[4] * k[8] - k[5] * k[7]) - k[1] * (k[3] * k[8] - k[5] * k[6]) + k[2] * (k[3] * k[7] - k[4] * k[6]))
+        Ki = [(k[4] * k[8] - k[5] * k[7]) / det, (k[2] * k[7] - k[1] * k[8]) / det, (k[1] * k[5] - k[2] * k[4]) / det,
+              (k[5] * k[6] - k[3] * k[8]) / det, (k[0] * k[8] - k[2] * k[6]) / det, (k[2] * k[3] - k[0] * k[5]) / det,
+              (k[3] * k[7] - k[4] * k[6]) / det, (k[1] * k[6] - k[0] * k[7]) / det, (k[0] * k[4] - k[1] * k[3]) / det]
+
+        def ray(u, v):
+            x, y, z = Ki[0] * u + Ki[1] * v + Ki[2], Ki[3] * u + Ki[4] * v + Ki[5], Ki[6] * u + Ki[7] * v + Ki[8]
+            n = math.sqrt(x * x + y * y + z * z)
+            return x / n, y / n, z / n
+
+        def angle(a, b):
+            return math.acos(min(1.0, max(-1.0, a[0] * b[0] + a[1] * b[1] + a[2] * b[2])))
+
+        fov_x, fov_y = angle(ray(0.0, 0.5), ray(1.0, 0.5)), angle(ray(0.5, 0.0), ray(0.5, 1.0))
         near, far = (float(x) for x in self.cfg["bound"])
-        tx, ty = float(np.tan(0.5 * fov_x)), float(np.tan(0.5 * fov_y))
+        tx, ty = math.tan(0.5 * fov_x), math.tan(0.5 * fov_y)
         P = np.zeros((4, 4))
         P[0, 0], P[1, 1], P[3, 2] = 1.0 / tx, 1.0 / ty, 1.0
         P[2, 2], P[2, 3] = far / (far - near), -(far * near) / (far - near)
-        view = np.linalg.inv(c2w).T
+        view = np.linalg.inv(host[:16].reshape(4, 4)).T
         proj = view @ P.T
-        mats = self._upload(np.stack([view, proj])).reshape(2, 4, 4)
+        up = np.empty(41, dtype=np.float32)
+        up[:16], up[16:32] = view.reshape(-1), proj.reshape(-1)
+        need_inv = "intrinsic_inv" not in f
+        if need_inv:     # what densify.candidates needs of the intrinsics (a float32 inverse like torch.linalg.inv's): no second read-back
+            up[32:] = np.linalg.inv(host32[16:25].reshape(3, 3)).reshape(-1)
+        dev_up = self._upload(up if need_inv else up[:32])
+        if need_inv:
+            f["intrinsic_inv"] = dev_up[32:41].reshape(3, 3)
+        mats = dev_up[:32].reshape(2, 4, 4)
         tanx, tany = float(np.float32(tx)), float(np.float32(ty))
         cam = api.Camera(h, w, tanx, tany, mats[0], mats[1], self.background)
-        return (cam, 2.0 * float(np.arctan(tanx)), 2.0 * float(np.arctan(tany)))
+        return (cam, 2.0 * math.atan(tanx), 2.0 * math.atan(tany))
 
     def _state(self, slot: int, n: int, h: int, w: int) -> api.ForwardState:
         st = self._states.get(slot)
@@ -296,6 +320,11 @@ class FusedMapTrainer(GaussianMapTrainer):
         sampler = make_frame_sampler(self.cfg, self.frames)
         self.last_losses = []
         self._cap = max(self._cap, 1 << 16, 2 * n)
+        sizes = {tuple(f["rgb"].shape[-2:]) for f in self.frames}
+        if len(sizes) > 1:
+            # the reference stacks the sampled frames (torch.stack, /root/reference/mapping/utils.py:220-221,253-254): frames of
+            # different sizes cannot be trained together there either
+            raise ValueError(f"keyframes of different image sizes cannot be trained together: {sorted(sizes)}")
         for it in range(self.cfg["optimization_steps"] if steps is None else steps):
             ids = sampler.next_ids(self.training_performance)
             B = len(ids)
@@ -340,8 +369,9 @@ class FusedMapTrainer(GaussianMapTrainer):
                 self._loss.stage1(st, f["rgb"], f["depth"], self._loss_bufs[slot], b, -1 if S > 1 else slot == 0, sh)
 
             def bwd_view(slot, b, sh):
-                cam, _, _ = self._camera(int(ids[b]))
+                cam, fxv, fyv = self._camera(int(ids[b]))
                 st, buf = self._states[slot], self._loss_bufs[slot]
+                self._loss.cfg.fov_x, self._loss.cfg.fov_y = float(fxv), float(fyv)   # depth -> normal with THIS view's intrinsics
                 self._loss.stage2(st, self.frames[int(ids[b])]["depth"], buf, sh)
                 api.backward(cam, g, st, buf.d_rgb, buf.d_normal, buf.d_depth, None, None, grads=slab.grads,
                              accumulate=2 if S > 1 else (slot > 0), stream=sh, touched=rows)
@@ -534,6 +564,10 @@ class FusedMapTrainer(GaussianMapTrainer):
         register the frame.  All per-pixel work and the compaction run in densify.hip.  Returns
         the number of surfels added."""
         frame = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in frame.items()}
+        if self.frames and tuple(frame["rgb"].shape[-2:]) != tuple(self.frames[0]["rgb"].shape[-2:]):
+            # (the reference stacks the sampled frames, /root/reference/mapping/utils.py:220-221,253-254: it cannot train such a set either)
+            raise ValueError(f"keyframes of different image sizes cannot be trained together: {tuple(frame['rgb'].shape[-2:])} "
+                             f"after {tuple(self.frames[0]['rgb'].shape[-2:])}")
         pred = None
         if self.is_init and self.means.shape[0] > 0:
             h, w = frame["rgb"].shape[-2:]
@@ -549,15 +583,35 @@ class FusedMapTrainer(GaussianMapTrainer):
                 st = self._state("densify", n, h, w)
                 api.forward(cam, g, st)
                 pred = dict(rgb=st.rgb, depth=st.depth[0], opacity=st.opacity[0])
-                state, added = densify.add_gaussians(self._map_state(), frame, pred, self.cfg["error_thres"])
+                state, added = densify.add_gaussians(self._map_state(), frame, pred, self.cfg["error_thres"], arena=self._map_arena())
                 if self._check_capacity(["densify"]):
                     break
         else:
-            state, added = densify.add_gaussians(self._map_state(), frame, pred, self.cfg["error_thres"])
+            state, added = densify.add_gaussians(self._map_state(), frame, pred, self.cfg["error_thres"], arena=self._map_arena())
         self._set_map_state(state)
         self.frames.append(frame)
-        self.training_performance = torch.cat((self.training_performance, torch.tensor([10.0], device=self.device)), 0)
+        self._append_performance(10.0)
         return added
+
+    def _map_arena(self) -> "densify.MapArena":
+        """The buffers the map's arrays are the leading rows of (densify.MapArena): made on first use, with room for a map
+        twice the current size."""
+        if self._arena is None:
+            self._arena = densify.MapArena(max(2 * self.means.shape[0], 1 << 18), self.device)
+        return self._arena
+
+    def _append_performance(self, value: float) -> None:
+        """training_performance = cat(training_performance, [value]) (gaussian_map.py:466-468) as one fill of the next
+        element of a buffer with room (the cat is an allocation, a copy and an upload from pageable memory per keyframe)."""
+        perf = self.training_performance
+        k = perf.shape[0]
+        buf = self._perf_buf
+        if buf is None or buf.data_ptr() != perf.data_ptr() or k + 1 > buf.shape[0] or perf.dtype != torch.float32:
+            buf = torch.empty(max(64, 2 * (k + 1)), device=self.device, dtype=torch.float32)
+            buf[:k].copy_(perf)
+            self._perf_buf = buf
+        buf[k:k + 1].fill_(float(value))
+        self.training_performance = buf[:k + 1]
 
     def update(self, frame: dict, steps: Optional[int] = None) -> None:
         """``GaussianMap.update`` (gaussian_map.py:62-64): grow the map from the keyframe, then train."""
@@ -566,7 +620,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         self.is_init = True
 
     def prune(self, mask):
-        state, deleted = densify.prune(self._map_state(), mask)
+        state, deleted = densify.prune(self._map_state(), mask, arena=self._map_arena())
         self._set_map_state(state)
         return deleted
 
@@ -651,11 +705,15 @@ class FusedMapTrainer(GaussianMapTrainer):
         optim.zero_grad = True          # the row-set Adam leaves the slab clean for the next iteration
         fast_stage = (h * w) % 4 == 0
 
-        def iteration(loss_out):
-            """everything of one optimisation step that runs on the GPU (11 launches); inputs:
-            state['idx'] (device), output: per-frame errors and the loss value"""
+        def iteration(loss_out, staged=False, next_uniforms=False):
+            """everything of one optimisation step that runs on the GPU (9-10 launches); inputs:
+            state['idx'] (device), output: per-frame errors and the loss value.  ``staged``: the previous iteration's last
+            launch has already drawn this one's frames and staged their matrices; ``next_uniforms`` (a row of uniforms,
+            None, or False = no): this iteration's last launch does that for the next one."""
             batch, idx, B = state["batch"], state["idx"], state["B"]
-            if fast_stage:
+            if staged:
+                pass
+            elif fast_stage:
                 # the sampled frames' matrices into the batch; their images stay where they are (the loss stages read view
                 # v's ground truth at frame idx[v] of the keyframe store: no 4 MB copy per view and iteration)
                 self._loss.stage_frames(B, idx, all_view, all_proj, None, None, batch.viewmats, batch.projmats, None, None)
@@ -679,13 +737,17 @@ class FusedMapTrainer(GaussianMapTrainer):
                 # separate optimiser kernel)
                 batch.backward(B, bufs.d_rgb, bufs.d_normal, bufs.d_depth, self._no_grads, adam_tick=optim.tick_args(),
                                defer_rows=True)
-                api.backward_rows([(batch.cams[v], batch.states[v]) for v in range(B)], batch.g, self._no_grads, rows,
+                api.backward_rows((batch.view_refs(), B), batch.g, self._no_grads, rows,
                                   adam_clock=optim.tick_args(), fused_adam=(optim.tensors_struct(slab.as_list()), optim.eps))
             else:
                 batch.backward(B, bufs.d_rgb, bufs.d_normal, bufs.d_depth, slab.grads, touched=rows,
                                adam_tick=optim.tick_args())
                 optim.step(slab.as_list(), device_clock=True, pre_ticked=True)
-            self._loss.finish(B, idx, self.training_performance, loss_out)
+            if next_uniforms is False:
+                self._loss.finish(B, idx, self.training_performance, loss_out)
+            else:
+                self._loss.finish_next(B, idx, self.training_performance, loss_out, next_uniforms, n_old, n_random, n_active,
+                                       all_view, all_proj, batch.viewmats, batch.projmats)
 
         def fits() -> bool:
             """forward-only probe of the staged batch: were the per-view workspaces large enough?"""
@@ -707,8 +769,21 @@ class FusedMapTrainer(GaussianMapTrainer):
         # (the device draw is the weighted one; the uniform sampler keeps torch.randperm's host stream)
         device_sampler = self._device_sampler()
         n_active, n_random = len(sampler.active_ids), sampler.num_random
+        n_old = len(sampler.older_ids)
+        will_graph = self.use_graph and total >= self.graph_min_steps
+        # the iterations of a call chained on the device: the last launch of one (ags_loss_finish_next) writes the frame
+        # errors, draws the next iteration's frames from them and stages their matrices; the uniforms of all the call's
+        # draws come from ONE torch.rand.  (A recorded graph replays a fixed launch sequence with fixed pointers: it keeps
+        # the separate draw in front of every replay.)
+        perf = self.training_performance
+        chained = (device_sampler and fast_stage and not will_graph and n_old <= 8192 and perf.dtype == torch.float32
+                   and perf.is_contiguous())
+        uniforms = torch.rand(total, max(n_old, 1), device=dev) if chained and n_random > 0 else None
         for it in range(total):
-            if device_sampler:
+            staged = chained and it > 0
+            if staged:
+                B = state["B"]
+            elif device_sampler:
                 # the same draw as np.random.choice(older, n_random, replace=False, p = error / sum) - successive
                 # sampling without replacement == the n_random largest log(u_i) / w_i (Efraimidis-Spirakis) -
                 # from torch's device generator, so the host never reads the errors back
@@ -716,8 +791,12 @@ class FusedMapTrainer(GaussianMapTrainer):
                 if state["idx"] is None or B != state["B"]:
                     state["idx"], state["B"], graph = torch.empty(B, device=dev, dtype=torch.long), B, None
                     state["idx"][:n_active] = torch.as_tensor(sampler.active_ids, dtype=torch.long)
-                if n_random > 0:
-                    n_old = len(sampler.older_ids)
+                if n_random > 0 and uniforms is not None:
+                    from . import _lib
+                    _lib.check(_lib.load().ags_weighted_topk(_lib.ptr(uniforms[0]), _lib.ptr(perf), n_old, n_random,
+                                                             _lib.ptr(state["idx"][n_active:]), _lib.current_stream()),
+                               "ags_weighted_topk")
+                elif n_random > 0:
                     weighted_choice_into(self.training_performance[:n_old], n_random, state["idx"][n_active:])
             else:
                 ids = sampler.next_ids(self.training_performance)   # host read of the errors
@@ -743,8 +822,11 @@ class FusedMapTrainer(GaussianMapTrainer):
                     state["batch"] = keep["batch"] = api.ViewBatch(
                         g, Bmax, h, w, cam0.tanfovx, cam0.tanfovy, self.background, self._cap,
                         binning_mode=self.binning_mode, capacity_n=ncap, tuning=self.tuning)
-                iteration(losses[it:it + 1])
-                if self.use_graph and total >= self.graph_min_steps and it + 1 < total:
+                nxt = False
+                if chained and it + 1 < total:
+                    nxt = None if uniforms is None else uniforms[it + 1]
+                iteration(losses[it:it + 1], staged=staged, next_uniforms=nxt)
+                if will_graph and it + 1 < total:
                     # for a given batch size the iteration is a fixed launch sequence: record it once
                     # (capture costs a few ms: it pays for long train() calls, not for the mapper's 10)
                     torch.cuda.synchronize()

@@ -344,13 +344,16 @@ def backward_rows(views: Sequence, g: Gaussians, grads: GaussianGrads, touched: 
     ``touched=None`` with ``row_range=(begin, end)``: no row set - the rows [begin, end) of the map, ``grads`` overwritten
     (the dense form of data-parallel ranks, cut into row chunks whose all-reduces overlap the next chunk's launch)."""
     lib = _lib.load()
-    n = len(views)
-    refs = (_lib.AgsViewRef * n)()
-    keep = []
-    for k, (cam, state) in enumerate(views):
-        cs, ws = cam.c_struct(), state.ws_struct()
-        keep.append((cs, ws))
-        refs[k].cam, refs[k].radii, refs[k].ws = C.pointer(cs), ptr(state.radii), C.pointer(ws)
+    if isinstance(views, tuple) and len(views) == 2 and isinstance(views[0], ViewRefs):
+        refs, n = views[0].refs, int(views[1])              # (ViewBatch.view_refs(), the first n of them)
+    else:
+        n = len(views)
+        refs = (_lib.AgsViewRef * n)()
+        keep = []
+        for k, (cam, state) in enumerate(views):
+            cs, ws = cam.c_struct(), state.ws_struct()
+            keep.append((cs, ws))
+            refs[k].cam, refs[k].radii, refs[k].ws = C.pointer(cs), ptr(state.radii), C.pointer(ws)
     gs = g.c_struct()
     din = _lib.AgsGaussianGrads(ptr(grads.means3D), ptr(grads.scales), ptr(grads.rotations), ptr(grads.opacities),
                                 ptr(grads.colors), ptr(grads.means2D), int(accumulate))
@@ -424,6 +427,14 @@ def forward_many(cams: Sequence[Camera], g: Gaussians, states: Sequence[ForwardS
     pool.join()
 
 
+class ViewRefs:
+    """A prebuilt ``AgsViewRef`` array (``ViewBatch.view_refs()``): what ``backward_rows`` builds from a list of
+    (Camera, ForwardState) at every call, kept for the life of a binding."""
+
+    def __init__(self, refs, keep):
+        self.refs, self.keep = refs, keep
+
+
 class ViewBatch:
     """``V`` forward-only views of one size and field of view rendered by ONE set of launches
     (``ags_forward_batch``: blockIdx.y = view).
@@ -485,12 +496,39 @@ class ViewBatch:
         self.importance = self._importance[:V * n].view(V, n)
         self.count = self._count[:V * n].view(V, n)
         self.radii = self._radii[:V * n].view(V, n)
-        self.states = [ForwardState(self.rgb[v], self.normal[v], self.depth[v], self.opacity[v], self.confidence[v],
-                                    self.importance[v], self.count[v], self.radii[v],
-                                    self.workspace[v * per:(v + 1) * per], self.max_instances, self.binning_mode, self.tuning)
-                       for v in range(V)]
+        self._states = None                    # per-view ForwardStates (slices of the batch buffers): made when somebody asks
+        self._refs = None                      # view_refs()
         ws = _lib.workspace(ptr(self.workspace), V * per, self.max_instances, self.binning_mode, self.tuning)
         _lib.check(_lib.load().ags_workspace_init_batch(C.byref(ws), V, n, h, w, _stream()), "ags_workspace_init_batch")
+
+    @property
+    def states(self):
+        """``states[v]``: view v's outputs and workspace as a ``ForwardState`` of slices (built on first use after a
+        ``bind``: a training loop that re-binds at every keyframe never needs them - ninety tensor slices)."""
+        if self._states is None:
+            per = self._per
+            self._states = [ForwardState(self.rgb[v], self.normal[v], self.depth[v], self.opacity[v], self.confidence[v],
+                                         self.importance[v], self.count[v], self.radii[v],
+                                         self.workspace[v * per:(v + 1) * per], self.max_instances, self.binning_mode,
+                                         self.tuning)
+                            for v in range(self.num_views)]
+        return self._states
+
+    def view_refs(self) -> "ViewRefs":
+        """The views of this batch as ``backward_rows`` takes them (``AgsViewRef`` array over cameras, radii and per-view
+        workspaces), from the batch buffers' addresses - no tensor slices; valid until the next ``bind``."""
+        if self._refs is None:
+            V, n, per = self.num_views, self.g.n, self._per
+            refs = (_lib.AgsViewRef * V)()
+            keep = []
+            base_ws, base_radii = ptr(self.workspace), ptr(self._radii)
+            for v in range(V):
+                cs = self.cams[v].c_struct()
+                ws = _lib.workspace(base_ws + v * per, per, self.max_instances, self.binning_mode, self.tuning)
+                keep.append((cs, ws))
+                refs[v].cam, refs[v].radii, refs[v].ws = C.pointer(cs), base_radii + 4 * v * n, C.pointer(ws)
+            self._refs = ViewRefs(refs, keep)
+        return self._refs
 
     def _structs(self, touched=None):
         im = _lib.AgsImages(ptr(self.rgb), ptr(self.normal), ptr(self.depth), ptr(self.opacity), ptr(self.confidence))

@@ -584,6 +584,26 @@ int ags_compact_plan(int32_t n, const int32_t* keep, int32_t* dst_index, int32_t
                      size_t scratch_bytes, ags_stream_t stream);
 int ags_compact_rows(int32_t n, int32_t width, const int32_t* dst_index, const float* src, float* dst,
                      ags_stream_t stream);
+/* The map's eight per-surfel arrays (gaussian_map.py:20-33: the five learnable tensors and the three view statistics). */
+typedef struct AgsMapArrays {
+    float* means;          /* (n,3) */
+    float* scales;         /* (n,3) raw */
+    float* rotations;      /* (n,4) raw */
+    float* opacities;      /* (n)   raw */
+    float* harmonics;      /* (n,3) */
+    float* view_scores;    /* (n) */
+    float* view_supports;  /* (n) */
+    float* view_means;     /* (n,3) */
+} AgsMapArrays;
+/* add_gaussians' torch.cat of the selected candidates (gaussian_map.py:402-462) into arrays that already hold the map
+ * with room behind it, ONE launch: new row dst_index[i] (>= 0) of `first_new_row` (pointers at row n of every array)
+ * takes candidate i's mean, rotation and colour, raw scales (0, 0, new_z_scale), raw opacity 0 and zeroed statistics.
+ * ags_map_compact: prune's boolean indexing of all eight arrays (gaussian_map.py:234-246), ONE launch:
+ * dst row dst_index[i] = src row i for the kept rows (src and dst must not overlap). */
+int ags_map_append(int32_t candidates, const int32_t* dst_index, const AgsCandidates* c, float new_z_scale,
+                   const AgsMapArrays* first_new_row, ags_stream_t stream);
+int ags_map_compact(int32_t n, const int32_t* dst_index, const AgsMapArrays* src, const AgsMapArrays* dst,
+                    ags_stream_t stream);
 
 /* Two helpers that keep a batched training iteration to a handful of launches:
  * ags_stage_frames gathers the sampled frames (frame_index: `views` int64 indices, device) of the
@@ -603,6 +623,26 @@ int ags_stage_frames(int32_t views, int32_t h, int32_t w, const int64_t* frame_i
                      float* dst_rgb, float* dst_depth, int32_t* msum, ags_stream_t stream);
 int ags_loss_finish(const AgsLossConfig* cfg, float* accum, int32_t views, const int64_t* frame_index,
                     float* frame_error, float* total_loss, ags_stream_t stream);
+/* The end of one batched training iteration and the set-up of the next in ONE launch: ags_loss_finish (frame_index is
+ * required), then - with the errors it has just written as the weights - the next iteration's draw
+ * (ags_weighted_topk(uniforms, frame_error, n_weights, k) into frame_index[first_random .. first_random + k); uniforms
+ * NULL or k == 0: the indices stay what they are), then ags_stage_frames of the matrices of frame_index[0 .. views)
+ * (no images: AgsLossConfig.gt_frame_index reads them in place) with msum cleared.  Replaces, per iteration of the
+ * mapper's train() (gaussian_map.py:88-139 with mapping/utils.py:190-228's sampler), three single-workgroup launches
+ * and the draw of the uniforms (one torch.rand for all iterations of a train() call instead). */
+typedef struct AgsNextIteration {
+    const float* uniforms;          /* n_weights numbers ~ U(0,1) for THIS draw, device */
+    int32_t n_weights, k;           /* draw k distinct frames of the first n_weights by frame_error */
+    int32_t first_random;           /* where in frame_index the drawn indices go */
+    int32_t views;                  /* views of the next iteration: frame_index[0 .. views) are staged */
+    const float* all_view;          /* (K,16) */
+    const float* all_proj;          /* (K,16) */
+    float* dst_view;                /* (views,16) */
+    float* dst_proj;                /* (views,16) */
+    int32_t* msum;                  /* (H,W) visibility count, cleared; H*W a multiple of 4 */
+} AgsNextIteration;
+int ags_loss_finish_next(const AgsLossConfig* cfg, float* accum, int32_t views, int64_t* frame_index, float* frame_error,
+                         float* total_loss, const AgsNextIteration* next, ags_stream_t stream);
 
 /* Optional stage timing with library-owned hipEvents (process-global, for bench/profiling
  * only; off by default so the normal path records nothing).  `slots` event pairs are kept

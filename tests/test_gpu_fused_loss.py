@@ -191,6 +191,57 @@ def test_stage_frames_and_loss_finish_match_torch(agslib):
     assert float(loss.accum.abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("k_random", [3, 0])
+def test_finish_next_equals_finish_then_draw_then_stage(agslib, k_random):
+    """ags_loss_finish_next == ags_loss_finish, then ags_weighted_topk over the errors just written, then ags_stage_frames
+    (matrices only, visibility count cleared): the same errors, loss, indices and staged matrices, bit for bit."""
+    from active_gs_amd import _lib
+    from active_gs_amd.fused_loss import FusedLoss
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    K, h, w, n_active = 40, 36, 52, 2
+    B = n_active + k_random
+    n_old = K - n_active
+    all_view = torch.randn(K, 4, 4, generator=gen).to(dev)
+    all_proj = torch.randn(K, 4, 4, generator=gen).to(dev)
+    u = torch.rand(n_old, generator=gen).to(dev)
+    acc0 = (torch.rand(64, 4 + 2 * 8, generator=gen) * 100).to(dev)
+    idx0 = torch.tensor([K - 1, K - 2, 7, 0, 21][:B], device=dev)
+    perf0 = (torch.rand(K, generator=gen) * 0.2 + 0.01).to(dev)
+
+    def separate():
+        loss = FusedLoss(h, w, 1.0, 0.9, B, 8, dev)
+        loss.accum.copy_(acc0); loss.msum.fill_(3)
+        idx, perf, total = idx0.clone(), perf0.clone(), torch.zeros(1, device=dev)
+        dv, dp = torch.zeros(8, 4, 4, device=dev), torch.zeros(8, 4, 4, device=dev)
+        loss.finish(B, idx, perf, total)
+        if k_random:
+            _lib.check(_lib.load().ags_weighted_topk(_lib.ptr(u), _lib.ptr(perf), n_old, k_random, _lib.ptr(idx[n_active:]),
+                                                     _lib.current_stream()), "ags_weighted_topk")
+        loss.stage_frames(B, idx, all_view, all_proj, None, None, dv, dp, None, None)
+        return idx, perf, total, dv, dp, loss
+
+    def fused():
+        loss = FusedLoss(h, w, 1.0, 0.9, B, 8, dev)
+        loss.accum.copy_(acc0); loss.msum.fill_(3)
+        idx, perf, total = idx0.clone(), perf0.clone(), torch.zeros(1, device=dev)
+        dv, dp = torch.zeros(8, 4, 4, device=dev), torch.zeros(8, 4, 4, device=dev)
+        loss.finish_next(B, idx, perf, total, u if k_random else None, n_old, k_random, n_active, all_view, all_proj, dv, dp)
+        return idx, perf, total, dv, dp, loss
+
+    a, b = separate(), fused()
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y)
+    assert int(b[5].msum.abs().sum()) == 0 and float(b[5].accum.abs().sum()) == 0.0
+    if k_random:
+        drawn = b[0][n_active:].tolist()
+        assert len(set(drawn)) == k_random and all(0 <= i < n_old for i in drawn)
+        assert not torch.equal(b[0], idx0)                    # (the draw happened)
+    else:
+        assert torch.equal(b[0], idx0)
+    assert torch.equal(b[3][:B], all_view[b[0]]) and torch.equal(b[4][:B], all_proj[b[0]])
+
+
 @pytest.mark.parametrize("h,w", [(64, 96), (97, 51), (16, 16)])
 def test_facade_post_kernel_matches_the_torch_statements(agslib, h, w):
     """render_cuda_core's two post-processing statements (operations.py:714-718: normalize(normal) * (opacity > 1e-2),
