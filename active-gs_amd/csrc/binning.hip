@@ -577,7 +577,11 @@ __global__ __launch_bounds__(256) void ags_k_tile_sort_direct_wave(uint2* __rest
     if (!live) return;
     const uint32_t cnt = tc[wave];
     const uint32_t K = cnt < tile_cap ? cnt : tile_cap;
+#ifdef AGS_EXP_IDENTITY_SLOTS   // experiment: tiles keep their natural order (no heaviest-first slots)
+    const uint32_t slot = (uint32_t)tile;
+#else
     const uint32_t slot = (uint32_t)band0 + part[0][wave] + part[1][wave] + part[2][wave] + part[3][wave];
+#endif
     if (lane == 0) {
         ranges[slot] = make_uint2((uint32_t)tile, K);
         if (cnt) {
