@@ -87,6 +87,8 @@ class FusedMapTrainer(GaussianMapTrainer):
         self._states = {}        # view slot -> ForwardState
         self._arena = None       # _map_arena(): the buffers the map's arrays are views of
         self._perf_buf = None    # _append_performance()
+        self._snap_bufs = None   # _snapshot()
+        self._state_bufs = {}    # _state(): view slot -> the buffers its ForwardState is a view of
         self._loss = None
         self._loss_bufs = []
         self._cap = 0
@@ -204,7 +206,17 @@ class FusedMapTrainer(GaussianMapTrainer):
         st = self._states.get(slot)
         if (st is None or st.max_instances < self._cap or st.radii.shape[0] != n or st.rgb.shape[-2:] != (h, w)
                 or st.binning_mode != self.binning_mode):
-            st = api.alloc_state(n, h, w, self._cap, self.device, self.binning_mode, tuning=self.tuning)
+            # the map changes size at every keyframe: the slot's buffers are allocated for twice the map and the state is a
+            # view of their leading rows, laid out again (one memset) - not nine allocations per slot and keyframe
+            full = self._state_bufs.get(slot)
+            if (full is None or full.max_instances < self._cap or full.radii.shape[0] < n or full.rgb.shape[-2:] != (h, w)
+                    or full.binning_mode != self.binning_mode or full.tuning is not self.tuning):
+                full = api.alloc_state(max(2 * n, 1 << 16), h, w, self._cap, self.device, self.binning_mode, tuning=self.tuning)
+                self._state_bufs[slot] = full
+            st = api.ForwardState(full.rgb, full.normal, full.depth, full.opacity, full.confidence, full.importance[:n],
+                                  full.count[:n], full.radii[:n], full.workspace, full.max_instances, full.binning_mode,
+                                  full.tuning)
+            api.init_workspace(st, n, h, w)
             self._states[slot] = st
         return st
 
@@ -266,8 +278,18 @@ class FusedMapTrainer(GaussianMapTrainer):
     # after the loop) and the call is then repeated from a snapshot with larger workspaces
     def _snapshot(self) -> dict:
         import numpy as np
-        snap = {k: getattr(self, k).clone() for k in ("means", "scales", "rotations", "opacities", "harmonics",
-                                                     "training_performance")}
+        # into buffers kept across calls, as ONE multi-tensor copy (six clones are six allocations and six launches with the
+        # GPU idle behind them)
+        keys = ("means", "scales", "rotations", "opacities", "harmonics", "training_performance")
+        src = [getattr(self, k) for k in keys]
+        bufs = self._snap_bufs
+        if (bufs is None or any(b.shape[0] < t.shape[0] or b.shape[1:] != t.shape[1:] or b.dtype != t.dtype or b.device != t.device
+                                for b, t in zip(bufs, src))):
+            bufs = self._snap_bufs = [torch.empty((max(2 * t.shape[0], 64),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                                      for t in src]
+        dst = [b[:t.shape[0]] for b, t in zip(bufs, src)]
+        torch._foreach_copy_(dst, src)
+        snap = dict(zip(keys, dst))
         # the random streams a repeated call has to draw from again: numpy's global one (the reference's weighted sampler)
         # only when the host sampler is in use - reading it costs 0.8 ms inside this loop, as much as the rest of the
         # call's set-up - torch's CPU generator (sampler_type "uniform": randperm), the device generator (cfg["sampler"]

@@ -162,10 +162,21 @@ class GaussianMap:
         return dict(bound=(float(self.scene_near), float(self.scene_far)), scale_factor=float(self.scale_factor),
                     optimization_steps=int(self.optimization_steps), prune_interval=int(self.prune_interval),
                     error_thres=float(self.error_thres), use_view_distribution=bool(self.use_view_distribution),
-                    background=tuple(float(x) for x in self.background_color.reshape(-1).tolist()),
+                    background=self._background_host(),
                     batch_size=int(_cfg_get(smp, "batch_size", DEFAULT_CFG["batch_size"])),
                     active_size=int(_cfg_get(smp, "active_size", DEFAULT_CFG["active_size"])),
                     sampler_type=str(_cfg_get(smp, "sampler_type", "weighted")), sampler=self.frame_sampler, lrs=lrs)
+
+    def _background_host(self) -> tuple:
+        """``background_color`` as host floats - read back when the attribute is another tensor or has been written to since
+        (a read-back per call is a wait for the GPU twice per keyframe)."""
+        t = self.background_color
+        key = (id(t), t._version) if torch.is_tensor(t) else None
+        c = getattr(self, "_bg_cache", None)
+        if c is None or key is None or c[0] != key or c[2] is not t:
+            vals = tuple(float(x) for x in (t.reshape(-1).tolist() if torch.is_tensor(t) else t))
+            c = self._bg_cache = (key, vals, t)
+        return c[1]
 
     def _fused(self):
         """The trainer (made on first use; needs a GPU) with the current attribute values as its configuration."""
