@@ -96,7 +96,8 @@ int ags_forward(const AgsCamera* cam, const AgsGaussians* in, const AgsImages* o
     if (!cam->viewmatrix || !cam->projmatrix || !cam->bg) return AGS_E_INVALID;
     if (in->n > 0 && !pg->radii) return AGS_E_INVALID;
     if (!out->rgb || !out->normal || !out->depth || !out->opacity || !out->confidence) return AGS_E_INVALID;
-    if (in->n > 0 && (cam->want_stats || cam->config) && (!pg->importance || !pg->count)) return AGS_E_INVALID;
+    if (in->n > 0 && (cam->want_stats || cam->config) && (!pg->count || (!pg->importance && (cam->want_stats != AGS_STATS_SEEN || cam->config))))
+        return AGS_E_INVALID;
     if (in->n > 0 && (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences))
         return AGS_E_INVALID;
     if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll || !ags_tuning_ok(ws)) return AGS_E_INVALID;
@@ -146,7 +147,8 @@ int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* i
     if (in->n <= 0 || cam->image_height <= 0 || cam->image_width <= 0) return AGS_E_INVALID;
     if (!cam->viewmatrix || !cam->projmatrix || !cam->bg || !pg->radii) return AGS_E_INVALID;
     if (!out->rgb || !out->normal || !out->depth || !out->opacity || !out->confidence) return AGS_E_INVALID;
-    if ((cam->want_stats || cam->config) && (!pg->importance || !pg->count)) return AGS_E_INVALID;
+    if ((cam->want_stats || cam->config) && (!pg->count || (!pg->importance && (cam->want_stats != AGS_STATS_SEEN || cam->config))))
+        return AGS_E_INVALID;
     if (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->colors || !in->confidences) return AGS_E_INVALID;
     if (ws->max_instances < 1 || ws->max_instances > 0xFFFFFFFFll || !ags_tuning_ok(ws)) return AGS_E_INVALID;
     if (ws->binning_mode != AGS_BIN_TILE_SORT && ws->binning_mode != AGS_BIN_DIRECT) return AGS_E_INVALID;

@@ -293,7 +293,13 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
                     if (STATS && stats_on) { const float wm = w * mk[s]; wsum += wm; wcnt += (wm > weight_thres) ? 1u : 0u; }
                 }
             }
-            if (STATS && stats_on) {
+            if (STATS && stats_on && importance == nullptr) {
+                // AGS_STATS_SEEN: the caller only asks WHETHER a surfel has a counted pixel (post_processing's `counts >= 1`):
+                // one vote and one plain store instead of two wave reductions and two atomics per surfel and wave
+                if constexpr (STATS) {
+                    if (__any(wcnt != 0u) && lane == 0) count[st.sid[k]] = 1;
+                }
+            } else if (STATS && stats_on) {
                 const float ts = ags_wave_sum(wsum);
                 const uint32_t tc = ags_wave_sum_u32(wcnt);
                 if constexpr (STATS) {
@@ -809,7 +815,7 @@ static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
     if (cam.want_stats || cam.config)   // (device-side configuration: config[3] decides inside the kernel)
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, true>), grid, block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
-                           pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
+                           (cam.want_stats == AGS_STATS_SEEN && !cam.config) ? nullptr : pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
                            (uint32_t*)(ws + L.tile_fill), fin, tile_cap, vs);
     else
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, false>), grid, block, 0, s, F, cam.normalize_depth,

@@ -472,7 +472,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         g = self._gaussians()
         cam0, _, _ = self._camera(k - 1)
         cam = api.Camera(h, w, cam0.tanfovx, cam0.tanfovy, cam0.viewmatrix, cam0.projmatrix, self.background,
-                         want_stats=True, front_only=True, render_mask=(depth_gt > 0.0).float().contiguous())
+                         want_stats=api.STATS_SEEN, front_only=True, render_mask=(depth_gt > 0.0).float().contiguous())
         st = self._state("count", n, h, w)
         api.forward(cam, g, st)
         return dict(cam=cam, g=g, n=n, hw=(h, w))
@@ -539,7 +539,7 @@ class FusedMapTrainer(GaussianMapTrainer):
                 if (batch is None or batch._count_key != key or batch.capacity_n < n or batch.max_instances < self._cap):
                     self._count_batch = None            # release before the larger one is made
                     batch = api.ViewBatch(g, CH, h, w, cam0.tanfovx, cam0.tanfovy, self.background, self._cap,
-                                          want_stats=True, front_only=True, render_masks=torch.zeros(CH, h, w, device=self.device),
+                                          want_stats=api.STATS_SEEN, front_only=True, render_masks=torch.zeros(CH, h, w, device=self.device),
                                           binning_mode=self.binning_mode, capacity_n=max(2 * n, 1 << 16), tuning=self.tuning)
                     batch._count_key = key
                     self._count_batch = batch
@@ -562,7 +562,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         for k, fid in enumerate(frame_ids):
             cam0, _, _ = self._camera(int(fid))
             cam = api.Camera(h, w, cam0.tanfovx, cam0.tanfovy, cam0.viewmatrix, cam0.projmatrix, self.background,
-                             want_stats=True, front_only=True, render_mask=(depth_gt[k] > 0.0).float().contiguous())
+                             want_stats=api.STATS_SEEN, front_only=True, render_mask=(depth_gt[k] > 0.0).float().contiguous())
             while True:
                 st = self._state("count", n, h, w)
                 api.forward(cam, g, st)

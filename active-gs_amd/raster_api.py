@@ -136,6 +136,9 @@ def workspace_bytes(n: int, h: int, w: int, max_instances: int) -> int:
 
 
 BIN_TILE_SORT, BIN_RADIX, BIN_DIRECT = 0, 1, 2
+# Camera.want_stats = STATS_SEEN (AGS_STATS_SEEN): count[i] = 1 for every surfel with a counted pixel, importance untouched -
+# all the mapper's post-processing reads of its count render
+STATS_SEEN = 2
 REGION_FINAL_T, REGION_N_CONTRIB, REGION_GEOM, REGION_RANGES, REGION_KEYS, REGION_IDS = range(6)
 
 
@@ -231,7 +234,8 @@ def forward(cam: Camera, g: Gaussians, state: ForwardState, stream: Optional[int
         for name in ("means3D", "scales", "rotations", "opacities", "colors", "confidences"):
             _require_cuda(getattr(g, name), name)
     if cam.want_stats and cam.config is None:     # (device-side configuration: the per-Gaussian kernel clears them)
-        state.importance.zero_()
+        if int(cam.want_stats) != STATS_SEEN:       # (seen flags: importance is not touched)
+            state.importance.zero_()
         state.count.zero_()
     cs, gs = cam.c_struct(), g.c_struct()
     im, pg, ws = state.images_struct(), state.per_gaussian_struct(touched), state.ws_struct()
@@ -539,7 +543,8 @@ class ViewBatch:
     def _enqueue_batched(self, views: Optional[int] = None, touched: Optional[RowSet] = None) -> None:
         lib = _lib.load()
         if self.want_stats:
-            self.importance.zero_()
+            if int(self.want_stats) != STATS_SEEN:
+                self.importance.zero_()
             self.count.zero_()
         cs, gs = self.cam.c_struct(), self.g.c_struct()
         im, pg, ws = self._structs(touched)

@@ -54,7 +54,7 @@ typedef struct AgsCamera {
     float weight_thres;      /* weight_thres: count_i counts pixels with blend weight > this */
     int32_t normalize_depth; /* config[1] */
     int32_t perpix_depth;    /* config[2] */
-    int32_t want_stats;      /* config[3]: fill importance / count */
+    int32_t want_stats;      /* config[3]: fill importance / count (1), or AGS_STATS_SEEN */
     int32_t front_only;      /* config[4] */
     const float* viewmatrix; /* viewmatrix, 16 floats */
     const float* projmatrix; /* projmatrix, 16 floats */
@@ -113,7 +113,12 @@ typedef struct AgsRowSet {
 } AgsRowSet;
 
 /* The three per-Gaussian outputs of the 8-tuple. importance/count are written only when
- * want_stats != 0 (they must be zero-filled by the caller before the call). */
+ * want_stats != 0 (they must be zero-filled by the caller before the call).
+ * want_stats == AGS_STATS_SEEN: only count is touched (importance may be NULL) and only as a flag - count[i] = 1 for
+ * every surfel with at least one pixel whose blend weight exceeds weight_thres (what the full count would make >= 1):
+ * all that post_processing reads of its count render (gaussian_map.py:193-194,228-231: `counts[-1] >= 1`,
+ * `sum(counts) >= 1`), at a third of the blend kernel's time.  Ignored with AgsCamera.config. */
+#define AGS_STATS_SEEN 2
 typedef struct AgsPerGaussian {
     float* importance; /* (n) */
     int32_t* count;    /* (n) */

@@ -617,6 +617,51 @@ def test_view_batch_equals_sequential(agslib, mode):
         assert float(got[0][0].abs().sum()) > 0
 
 
+def test_seen_flags_equal_the_full_count_at_least_one(agslib):
+    """want_stats = STATS_SEEN (what the mapper's post-processing renders with): count[i] == 1 exactly where the full
+    statistics count >= 1 - single views (with and without a render mask, front_only) and a batch - and the images are
+    the same; importance is not needed."""
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.synthetic import activate, make_room_scene
+    dev = torch.device("cuda:0")
+    n, h, w, V = 30000, 160, 208, 5
+    a = activate(make_room_scene(n, seed=3))
+    g = api.Gaussians(*(a[k].to(dev).contiguous() for k in ("means", "scales", "rotations", "opacities", "colors",
+                                                              "confidences")))
+    S = [room_case(16, h, w, view=v, seed=3)[1] for v in range(V)]
+    bg = S[0].bg.to(dev)
+    gen = torch.Generator().manual_seed(0)
+    masks = (torch.rand(V, h, w, generator=gen) > 0.3).float().to(dev)
+    full_counts = []
+    for v, s in enumerate(S):
+        for front in (False, True):
+            kw = dict(front_only=front, render_mask=masks[v].contiguous() if v % 2 else None)
+            cam_f = api.Camera(h, w, s.tanfovx, s.tanfovy, s.viewmatrix.to(dev), s.projmatrix.to(dev), bg, want_stats=True, **kw)
+            cam_s = api.Camera(h, w, s.tanfovx, s.tanfovy, s.viewmatrix.to(dev), s.projmatrix.to(dev), bg,
+                               want_stats=api.STATS_SEEN, **kw)
+            sf, ss = api.alloc_state(n, h, w, 1 << 19, dev), api.alloc_state(n, h, w, 1 << 19, dev)
+            ss.importance.fill_(7.0)
+            api.forward(cam_f, g, sf); api.forward(cam_s, g, ss)
+            torch.cuda.synchronize()
+            assert not api.read_status(sf)["overflow"]
+            assert torch.equal(sf.rgb, ss.rgb) and torch.equal(sf.depth, ss.depth) and torch.equal(sf.radii, ss.radii)
+            assert torch.equal(sf.count >= 1, ss.count == 1) and int(ss.count.max()) == 1 and int(ss.count.min()) == 0
+            assert float((ss.importance - 7.0).abs().max()) == 0.0            # untouched
+            if front:
+                full_counts.append(sf.count.clone())
+    # the batched launch, every view masked, front_only (the prune pass's shape)
+    batch = api.ViewBatch(g, V, h, w, S[0].tanfovx, S[0].tanfovy, bg, 1 << 19, want_stats=api.STATS_SEEN, front_only=True,
+                          render_masks=masks)
+    ref = api.ViewBatch(g, V, h, w, S[0].tanfovx, S[0].tanfovy, bg, 1 << 19, want_stats=True, front_only=True,
+                        render_masks=masks)
+    vm = torch.stack([s.viewmatrix for s in S]).to(dev)
+    pm = torch.stack([s.projmatrix for s in S]).to(dev)
+    batch.render(vm, pm); ref.render(vm, pm)
+    torch.cuda.synchronize()
+    assert torch.equal(ref.count >= 1, batch.count == 1) and int(batch.count.sum()) > 0
+    assert torch.equal(ref.rgb, batch.rgb)
+
+
 def test_alpha_clamp_near_plane_and_grazing_surfels(agslib):
     """Branches a random room scene rarely reaches: o*G > 0.99 (clamped alpha, zero gradient through
     the clamp), surfels on both sides of the z = 0.2 near cull, edge-on surfels (grazing clamp of the
