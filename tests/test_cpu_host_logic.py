@@ -180,7 +180,8 @@ def test_public_header_is_plain_c(tmp_path):
               "AgsStatus": _lib.AgsStatus,
               "AgsAdamTensors": _lib.AgsAdamTensors, "AgsActivation": _lib.AgsActivation,
               "AgsLossConfig": _lib.AgsLossConfig, "AgsRowSet": _lib.AgsRowSet, "AgsKeyframe": _lib.AgsKeyframe,
-              "AgsDensifyPred": _lib.AgsDensifyPred, "AgsCandidates": _lib.AgsCandidates}
+              "AgsDensifyPred": _lib.AgsDensifyPred, "AgsCandidates": _lib.AgsCandidates,
+              "AgsNextIteration": _lib.AgsNextIteration, "AgsMapArrays": _lib.AgsMapArrays}
     lines = ['#include "ags_raster.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
     for name, cls in fields.items():
         lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
