@@ -258,11 +258,12 @@ class GaussianMap:
 
     # ------------------------------------------------------------------ checkpoints (gaussian_map.py:491-527)
     def save(self, save_path, index="final"):
+        from .map_io import compact        # (the arrays are views of larger buffers: torch.save would write those whole)
         map_state = {
-            "means": self._means.detach(), "scales": self._scales.detach(), "harmonics": self._harmonics.detach(),
-            "opacities": self._opacities.detach(), "rotations": self._rotations.detach(),
-            "view_scores": self.view_scores.detach(), "view_supports": self.view_supports.detach(),
-            "view_means": self.view_means.detach(), "near": self.scene_near, "far": self.scene_far,
+            "means": compact(self._means), "scales": compact(self._scales), "harmonics": compact(self._harmonics),
+            "opacities": compact(self._opacities), "rotations": compact(self._rotations),
+            "view_scores": compact(self.view_scores), "view_supports": compact(self.view_supports),
+            "view_means": compact(self.view_means), "near": self.scene_near, "far": self.scene_far,
             "use_view_direction": self.use_view_distribution, "background_color": self.background_color,
             "scale_factor": self.scale_factor,
         }

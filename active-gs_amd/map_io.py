@@ -12,14 +12,23 @@ MAP_KEYS = ("means", "scales", "harmonics", "opacities", "rotations", "view_scor
             "near", "far", "use_view_direction", "background_color", "scale_factor")
 
 
+def compact(t: torch.Tensor) -> torch.Tensor:
+    """``t.detach()`` - as a tensor that owns exactly its elements: ``torch.save`` writes a tensor's WHOLE storage, and the
+    map's arrays are the leading rows of buffers with room behind them (densify.MapArena)."""
+    t = t.detach()
+    if t.untyped_storage().nbytes() > t.numel() * t.element_size():
+        t = t.clone()
+    return t
+
+
 def map_state(trainer) -> dict:
     """State dict of a ``GaussianMapTrainer`` / ``FusedMapTrainer`` in the reference's schema."""
     near, far = trainer.cfg["bound"]
     return {
-        "means": trainer.means.detach(), "scales": trainer.scales.detach(), "harmonics": trainer.harmonics.detach(),
-        "opacities": trainer.opacities.detach(), "rotations": trainer.rotations.detach(),
-        "view_scores": trainer.view_scores.detach(), "view_supports": trainer.view_supports.detach(),
-        "view_means": trainer.view_means.detach(), "near": near, "far": far,
+        "means": compact(trainer.means), "scales": compact(trainer.scales), "harmonics": compact(trainer.harmonics),
+        "opacities": compact(trainer.opacities), "rotations": compact(trainer.rotations),
+        "view_scores": compact(trainer.view_scores), "view_supports": compact(trainer.view_supports),
+        "view_means": compact(trainer.view_means), "near": near, "far": far,
         "use_view_direction": trainer.cfg["use_view_distribution"], "background_color": trainer.background,
         "scale_factor": trainer.cfg["scale_factor"],
     }

@@ -84,6 +84,9 @@ def test_voxel_map_properties_recorder_save_and_planner_inputs(agslib, tmp_path)
     st = torch.load(path)
     assert sorted(st) == sorted(["means", "scales", "harmonics", "opacities", "rotations", "view_scores", "view_supports",
                                  "view_means", "near", "far", "use_view_direction", "background_color", "scale_factor"])
+    # the file holds the map's rows, not the larger buffers they are the leading rows of
+    n = gm.get_means.shape[0]
+    assert st["means"].untyped_storage().nbytes() == n * 3 * 4 and os.path.getsize(path) < 4 * 19 * n + (1 << 16)
     g2 = GaussianMap(None, DEV)
     g2.load(path)
     for k, (a, b) in enumerate(zip(gm.get_attr(), g2.get_attr())):
