@@ -130,6 +130,52 @@ def test_add_gaussians_and_prune_match_reference_fixture(agslib):
         assert torch.equal(pruned[k].cpu(), g["after_prune"][k]), k
 
 
+def test_map_arena_equals_fresh_tensors_through_growth_regrowth_and_prune(agslib):
+    """densify.MapArena (the map's arrays as the leading rows of buffers with room; growth = ags_map_append, prune =
+    ags_map_compact into a second set of buffers) gives bit for bit what the fresh-tensor path (torch.zeros + copies +
+    ags_compact_rows per array) gives - with an arena that starts far too small (every growth reallocates), with a foreign
+    state handed in (adopted by copy), across two prunes (the buffer sets swap twice) - and never writes behind the rows
+    it owns."""
+    from active_gs_amd import densify
+    g = _gold()
+    frames = [_to_dev(g["frames"][k]) for k in range(2)]
+    pred = g["second"]["pred"]
+    p2 = _to_dev(dict(rgb=pred["rgb"][0], depth=pred["depth"][0], opacity=pred["opacity"][0]))
+    arena = densify.MapArena(8, DEV)                    # (8 rows: the first growth already reallocates)
+    plain, held = _empty_state(), _empty_state()
+    same = lambda a, b: all(torch.equal(a[k], b[k].reshape(a[k].shape)) for k in densify.STATE_KEYS)
+    gen = torch.Generator().manual_seed(0)
+    for step, (f, p) in enumerate([(frames[0], None), (frames[1], p2), (frames[0], p2)]):
+        plain, k1 = densify.add_gaussians(plain, f, p, g["error_thres"])
+        held, k2 = densify.add_gaussians(held, f, p, g["error_thres"], arena=arena)
+        assert k1 == k2 and same(plain, held) and arena.holds(held)
+        n = plain["means"].shape[0]
+        assert held["harmonics"].shape == (n, 1, 3) and all(held[k].is_contiguous() for k in densify.STATE_KEYS)
+        # training writes the rows in place (both copies alike), then some rows are pruned
+        for k in ("opacities", "means"):
+            noise = torch.randn(plain[k].shape, generator=gen).to(DEV)
+            plain[k] += noise; held[k] += noise
+        mask = (torch.rand(n, generator=gen) < 0.2).to(DEV)
+        if step < 2:
+            plain, d1 = densify.prune(plain, mask)
+            held, d2 = densify.prune(held, mask, arena=arena)
+            assert d1 == d2 > 0 and same(plain, held) and arena.holds(held)
+    # a state that lives elsewhere (GaussianMap.load, a caller's assignment) is adopted by copy; the caller's tensors stay theirs
+    foreign = {k: v.clone() for k, v in plain.items()}
+    before = {k: v.clone() for k, v in foreign.items()}
+    grown, k3 = densify.add_gaussians(foreign, frames[1], p2, g["error_thres"], arena=arena)
+    ref, k4 = densify.add_gaussians(plain, frames[1], p2, g["error_thres"])
+    assert k3 == k4 and same(ref, grown) and arena.holds(grown) and all(torch.equal(foreign[k], before[k]) for k in before)
+    # room behind the last row is never written by a growth of zero rows / a prune of nothing
+    n = grown["means"].shape[0]
+    assert arena.alt is not None
+    for b in arena.alt.values():
+        b.fill_(-7.0)                                   # the set the next prune compacts into
+    kept, d = densify.prune(grown, torch.zeros(n, device=DEV), arena=arena)
+    assert arena.holds(kept) and kept["means"].shape[0] == n - d and d > 0     # (rows whose opacity fell under 0.1)
+    assert all(bool((b[n - d:] == -7.0).all()) for b in arena.bufs.values())   # nothing written behind the kept rows
+
+
 @pytest.mark.parametrize("sampler", ["host", "device"])
 def test_mapper_loop_grows_trains_and_prunes(agslib, sampler):
     """GaussianMap.update() for a few keyframes starting from an EMPTY map: add_gaussians -> train ->
