@@ -812,7 +812,12 @@ class FusedMapTrainer(GaussianMapTrainer):
                 B = n_active + n_random
                 if state["idx"] is None or B != state["B"]:
                     state["idx"], state["B"], graph = torch.empty(B, device=dev, dtype=torch.long), B, None
-                    state["idx"][:n_active] = torch.as_tensor(sampler.active_ids, dtype=torch.long)
+                    act = [int(x) for x in sampler.active_ids]
+                    if act and act == list(range(act[0], act[0] + len(act))):
+                        # (the newest frames: written on the device - an upload from pageable memory waits for the stream)
+                        torch.arange(act[0], act[0] + len(act), out=state["idx"][:n_active])
+                    else:
+                        state["idx"][:n_active] = torch.as_tensor(sampler.active_ids, dtype=torch.long)
                 if n_random > 0 and uniforms is not None:
                     from . import _lib
                     _lib.check(_lib.load().ags_weighted_topk(_lib.ptr(uniforms[0]), _lib.ptr(perf), n_old, n_random,
