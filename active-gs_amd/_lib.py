@@ -185,7 +185,7 @@ class AgsCandidates(C.Structure):
 
 EXPORTS = ["ags_workspace_bytes", "ags_workspace_region", "ags_workspace_init", "ags_workspace_init_batch", "ags_workspace_discard_pass", "ags_forward", "ags_forward_batch",
            "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_backward_rows", "ags_backward_fused_next", "ags_forward_resume", "ags_read_status", "ags_read_status_async", "ags_adam_step",
-           "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_rows_index", "ags_adam_step_gathered", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_loss_finish_next", "ags_weighted_topk", "ags_facade_post", "ags_facade_post_batch", "ags_facade_post_backward", "ags_smooth_depth", "ags_densify_candidates",
+           "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_rows_index", "ags_adam_step_gathered", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_loss_finish_next", "ags_zero_many", "ags_weighted_topk", "ags_facade_post", "ags_facade_post_batch", "ags_facade_post_backward", "ags_smooth_depth", "ags_densify_candidates",
            "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_view_stats_update", "ags_confidences", "ags_compact_plan_bytes", "ags_compact_plan",
            "ags_compact_rows", "ags_map_append", "ags_map_compact", "ags_profile_enable", "ags_profile_read",
            "ags_error_string", "ags_version"]
@@ -289,6 +289,8 @@ def load() -> C.CDLL:
     lib.ags_loss_finish.restype = C.c_int
     lib.ags_loss_finish.argtypes = [C.POINTER(AgsLossConfig), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]
+    lib.ags_zero_many.restype = C.c_int
+    lib.ags_zero_many.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
     lib.ags_loss_finish_next.restype = C.c_int
     lib.ags_loss_finish_next.argtypes = [C.POINTER(AgsLossConfig), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(AgsNextIteration), C.c_void_p]
@@ -345,6 +347,20 @@ def current_stream() -> int:
 def check(code: int, what: str) -> None:
     if code != 0:
         raise RuntimeError(f"{what} failed: {load().ags_error_string(code).decode()} ({code})")
+
+
+def zero_many(tensors) -> None:
+    """Zero the given (contiguous, 16-byte aligned) device tensors with ONE launch per sixteen of them (``ags_zero_many``)."""
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    lib = load()
+    for a in range(0, len(ts), 16):
+        part = ts[a:a + 16]
+        for t in part:
+            if not t.is_contiguous() or not t.is_cuda or (t.data_ptr() & 15) or (t.numel() * t.element_size()) & 3:
+                raise ValueError("zero_many: contiguous GPU tensors at 16-byte aligned addresses, sizes in whole words")
+        regions = (C.c_void_p * len(part))(*[t.data_ptr() for t in part])
+        sizes = (C.c_size_t * len(part))(*[t.numel() * t.element_size() for t in part])
+        check(lib.ags_zero_many(len(part), regions, sizes, current_stream()), "ags_zero_many")
 
 
 def ptr(t) -> int | None:

@@ -174,6 +174,7 @@ void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGau
                            const AgsLayout& L, const AgsPerGaussian& pg, int emit,
                            const AgsViewStride& vs, hipStream_t s);
 void ags_launch_direct_sort(char* ws, const AgsLayout& L, const AgsViewStride& vs, hipStream_t s);
+void ags_launch_zero_many(int count, void* const* regions, const size_t* bytes, hipStream_t s);
 void ags_launch_clear_regions(char* base, size_t stride, size_t offset, size_t bytes, int views, hipStream_t s);
 // AGS_BIN_DIRECT bookkeeping, kept in the (otherwise radix-only) digit-total words of the workspace: 64 partial
 // sums of the tiles' list lengths, 64 partial maxima, 64 partial counts of visible surfels - spread so that the

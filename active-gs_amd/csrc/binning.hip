@@ -627,6 +627,27 @@ void ags_launch_clear_regions(char* base, size_t stride, size_t offset, size_t b
     hipLaunchKernelGGL(ags_k_clear_regions, dim3(blocks < 1 ? 1 : blocks, views), dim3(256), 0, s, base, stride, offset, bytes);
 }
 
+// ags_zero_many: blockIdx.y = region; 16-byte stores where the size allows, the tail in words
+struct AgsZeroMany { char* p[AGS_ZERO_MANY_MAX]; size_t bytes[AGS_ZERO_MANY_MAX]; };
+__global__ __launch_bounds__(256) void ags_k_zero_many(AgsZeroMany z) {
+    char* p = z.p[blockIdx.y];
+    const size_t bytes = z.bytes[blockIdx.y], n16 = bytes >> 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        reinterpret_cast<uint4*>(p)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0) {
+        const size_t words = (bytes & 15) >> 2;
+        if (threadIdx.x < words) reinterpret_cast<uint32_t*>(p + (n16 << 4))[threadIdx.x] = 0u;
+    }
+}
+void ags_launch_zero_many(int count, void* const* regions, const size_t* bytes, hipStream_t s) {
+    AgsZeroMany z = {};
+    size_t most = 0;
+    for (int k = 0; k < count; ++k) { z.p[k] = (char*)regions[k]; z.bytes[k] = bytes[k]; most = bytes[k] > most ? bytes[k] : most; }
+    size_t blocks = ((most >> 4) + 1023) / 1024;     // four 16-byte stores per thread for the largest region
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(ags_k_zero_many, dim3((unsigned)blocks, count), dim3(256), 0, s, z);
+}
+
 void ags_launch_direct_sort(char* ws, const AgsLayout& L, const AgsViewStride& vs, hipStream_t s) {
     const bool no_wave = L.tune.tile_sort_no_wave != 0;   // AgsTuning: always the 256-thread form
     const uint32_t tile_cap = ags_direct_tile_cap(L);

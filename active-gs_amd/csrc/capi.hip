@@ -540,6 +540,16 @@ int ags_loss_finish(const AgsLossConfig* cfg, float* accum, int32_t views, const
     return ags_check_launch();
 }
 
+int ags_zero_many(int32_t count, void* const* regions, const size_t* bytes, ags_stream_t stream) {
+    if (count < 0 || count > AGS_ZERO_MANY_MAX) return AGS_E_INVALID;
+    if (count == 0) return AGS_OK;
+    if (!regions || !bytes) return AGS_E_INVALID;
+    for (int k = 0; k < count; ++k)
+        if ((bytes[k] && !regions[k]) || ((uintptr_t)regions[k] & 15) || (bytes[k] & 3)) return AGS_E_INVALID;
+    ags_launch_zero_many(count, regions, bytes, (hipStream_t)stream);
+    return ags_check_launch();
+}
+
 int ags_loss_finish_next(const AgsLossConfig* cfg, float* accum, int32_t views, int64_t* frame_index, float* frame_error,
                          float* total_loss, const AgsNextIteration* next, ags_stream_t stream) {
     if (!cfg || !accum || !next || !frame_index || views < 0 || cfg->accum_stride < 4 + 2 * views || cfg->accum_stride > 256 ||

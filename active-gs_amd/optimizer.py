@@ -16,7 +16,9 @@ from ._lib import ptr
 
 
 class FusedAdam:
-    def __init__(self, params: Sequence[torch.Tensor], lrs: Sequence[float], betas=(0.9, 0.999), eps: float = 1e-15):
+    def __init__(self, params: Sequence[torch.Tensor], lrs: Sequence[float], betas=(0.9, 0.999), eps: float = 1e-15,
+                 zero: bool = True):
+        """``zero=False``: the caller zeroes ``state_buffers()`` itself (``_lib.zero_many`` together with its other buffers)."""
         if len(params) != 5 or len(lrs) != 5:
             raise ValueError("FusedAdam takes the five map tensors (means, scales, rotations, opacities, harmonics)")
         for p in params:
@@ -34,7 +36,7 @@ class FusedAdam:
         n = params[3].numel()
         self.state_rows = None
         if [p.numel() for p in params] == [3 * n, 3 * n, 4 * n, n, 3 * n] and n > 0:
-            self.state_rows = torch.zeros(n, 28, device=params[0].device, dtype=torch.float32)
+            self.state_rows = (torch.zeros if zero else torch.empty)(n, 28, device=params[0].device, dtype=torch.float32)
             cols = ((0, 3), (3, 6), (6, 10), (10, 11), (11, 14))
             self.exp_avg = [self.state_rows[:, a:b].view(*p.shape) if p.dim() != 1 else self.state_rows[:, a]
                             for (a, b), p in zip(cols, params)]
@@ -45,13 +47,17 @@ class FusedAdam:
             self.exp_avg_sq = [torch.zeros_like(p) for p in params]
         self.step_count = 0
         # device-resident clock {int step; float step_size[5]; float inv_sqrt_bc2; int skipped; ...} for graph replay
-        self.device_clock = torch.zeros(16, device=params[0].device, dtype=torch.int32)
+        self.device_clock = (torch.zeros if zero else torch.empty)(16, device=params[0].device, dtype=torch.int32)
         self._clock_on_device = None   # where the ONE logical step counter currently lives (see use_clock)
         # optional raster_api.RowSet: update only the surfels this optimiser's views have shown
         # (exact: the others have zero gradient and zero moments, so the dense update is 0)
         self.touched = None
         # with ``touched``: gradient rows are zeroed as they are consumed (slabs the views add into atomically)
         self.zero_grad = False
+
+    def state_buffers(self):
+        """What a fresh optimiser needs zeroed (``zero=False``)."""
+        return [self.device_clock] + ([self.state_rows] if self.state_rows is not None else self.exp_avg + self.exp_avg_sq)
 
     def use_clock(self, device: bool) -> None:
         """There is one logical step counter; it lives either in ``step_count`` (host, ``ags_adam_step``) or in

@@ -78,8 +78,8 @@ class RowSet:
     rows.  ``reset()`` empties it - do that together with zeroing the gradient slab and the Adam
     moments (the reference re-creates its optimiser per train() call, gaussian_map.py:259-292)."""
 
-    def __init__(self, n: int, device):
-        self.buf = torch.zeros(2 * n + 1, device=device, dtype=torch.int32)
+    def __init__(self, n: int, device, zero: bool = True):
+        self.buf = (torch.zeros if zero else torch.empty)(2 * n + 1, device=device, dtype=torch.int32)
         self.n = n
         self.member, self.rows, self.count = self.buf[:n], self.buf[n:2 * n], self.buf[2 * n:]
 

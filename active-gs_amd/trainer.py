@@ -37,13 +37,13 @@ class GradSlab:
     """One contiguous buffer for the five gradients (segments start on 16-byte
     boundaries) so the data-parallel exchange is a single collective."""
 
-    def __init__(self, n: int, device):
+    def __init__(self, n: int, device, zero: bool = True):
         sizes = [3 * n, 3 * n, 4 * n, n, 3 * n]
         offs, o = [], 0
         for s in sizes:
             offs.append(o)
             o += _pad4(s)
-        self.flat = torch.zeros(max(o, 4), device=device, dtype=torch.float32)
+        self.flat = (torch.zeros if zero else torch.empty)(max(o, 4), device=device, dtype=torch.float32)
         v = [self.flat[a:a + s] for a, s in zip(offs, sizes)]
         self.grads = api.GaussianGrads(v[0].view(n, 3), v[1].view(n, 3), v[2].view(n, 4), v[3], v[4].view(n, 3))
 

@@ -646,6 +646,11 @@ typedef struct AgsNextIteration {
     float* dst_proj;                /* (views,16) */
     int32_t* msum;                  /* (H,W) visibility count, cleared; H*W a multiple of 4 */
 } AgsNextIteration;
+/* Zero up to AGS_ZERO_MANY_MAX device regions in ONE launch (16-byte aligned addresses, sizes multiples of 4 bytes): the
+ * buffers a train() call starts from - Adam moments, row set, gradient slab, loss accumulators, step clock - are separate
+ * allocations, and a fill per buffer is a launch per buffer with the GPU idle in between. */
+#define AGS_ZERO_MANY_MAX 16
+int ags_zero_many(int32_t count, void* const* regions, const size_t* bytes, ags_stream_t stream);
 int ags_loss_finish_next(const AgsLossConfig* cfg, float* accum, int32_t views, int64_t* frame_index, float* frame_error,
                          float* total_loss, const AgsNextIteration* next, ags_stream_t stream);
 

@@ -191,6 +191,25 @@ def test_stage_frames_and_loss_finish_match_torch(agslib):
     assert float(loss.accum.abs().sum()) == 0.0
 
 
+def test_zero_many_clears_exactly_the_given_regions(agslib):
+    """ags_zero_many: regions of any whole-word size (16-byte body + word tail), up to sixteen per launch (more: several
+    launches), nothing touched outside them; misaligned / odd-sized regions are refused."""
+    from active_gs_amd import _lib
+    dev = torch.device("cuda:0")
+    sizes = [1, 3, 4, 5, 16, 17, 1023, 4096, 100_003, 7, 64, 2, 33, 255, 256, 257, 9, 1_000_001]      # floats (18 regions)
+    bufs = [torch.full((s + 8,), 3.0, device=dev) for s in sizes]
+    views = [b[4:4 + s] for b, s in zip(bufs, sizes)]                                # 16-byte aligned starts inside guards
+    _lib.zero_many(views + [None, torch.empty(0, device=dev)])
+    torch.cuda.synchronize()
+    for b, s in zip(bufs, sizes):
+        assert float(b[4:4 + s].abs().sum()) == 0.0 and bool((b[:4] == 3.0).all()) and bool((b[4 + s:] == 3.0).all()), s
+    with pytest.raises(ValueError):
+        _lib.zero_many([bufs[0][1:3]])                                               # not 16-byte aligned
+    h = torch.zeros(8, device=dev, dtype=torch.float16)
+    with pytest.raises(ValueError):
+        _lib.zero_many([h[:3]])                                                      # 6 bytes
+
+
 @pytest.mark.parametrize("k_random", [3, 0])
 def test_finish_next_equals_finish_then_draw_then_stage(agslib, k_random):
     """ags_loss_finish_next == ags_loss_finish, then ags_weighted_topk over the errors just written, then ags_stage_frames
