@@ -326,13 +326,10 @@ class SurfelRenderer:
                                                          ptr(r["opacity"]), ptr(normal), ptr(d2n),
                                                          _lib.current_stream()), "ags_facade_post_batch")
             r["normal_post"], r["d2n"], r["seen"] = normal, d2n, r["radii"] > 0
-            b = self._batched[key] = dict(raw=r, views={})
-        v = b["views"].get(i)
-        if v is None:
-            r = b["raw"]
-            v = b["views"][i] = (r["rgb"][i], r["depth"][i], r["normal_post"][i], r["opacity"][i], r["d2n"][i], r["confidence"][i],
-                                 r["importance"][i], r["count"][i], r["seen"][i])
-        return v
+            # the 9-tuples of all views from nine unbind() calls (a slice per output and view is 900 tensor ops per planning step)
+            cols = [r[k].unbind(0) for k in ("rgb", "depth", "normal_post", "opacity", "d2n", "confidence", "importance", "count", "seen")]
+            b = self._batched[key] = dict(raw=r, views=list(zip(*cols)))
+        return b["views"][i]
 
     def render_view(self, i=0, require_grad=False, require_importance=False, front_only=False):
         if not require_grad and self._batchable():
