@@ -681,10 +681,11 @@ class FusedMapTrainer(GaussianMapTrainer):
         raise RuntimeError("train(): the rasterizer workspace kept overflowing after six enlargements")
 
     def _train_batched(self, steps: Optional[int] = None, defer: bool = False):
-        """``train`` with the B views of an iteration in ONE set of launches: 4 forward kernels, 2 loss
-        kernels, 2 backward kernels and the row-set Adam per ITERATION instead of per view (a 512x512
-        view is 1024 tiles - a quarter of what the GPU holds).  The sampled frames' poses and
-        ground truth are staged into the batch's buffers with four index_select launches."""
+        """``train`` with the B views of an iteration in ONE set of launches per ITERATION instead of per view (a 512x512
+        view is 1024 tiles - a quarter of what the GPU holds): per-Gaussian stage, tile sort, blend, two loss stages, blend
+        backward, ONE per-Gaussian backward + Adam over the rows the views showed, and a last launch that writes the frame
+        errors, draws the next iteration's frames and stages their matrices (eight launches).  The sampled frames' images
+        are read where they are, in the keyframe store."""
         lrs = self.cfg["lrs"]
         for name in ("means", "scales", "rotations", "opacities", "harmonics"):
             setattr(self, name, getattr(self, name).contiguous())
