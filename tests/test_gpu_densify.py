@@ -341,7 +341,7 @@ def test_weighted_frame_draw_kernel_equals_the_torch_statement(agslib):
     log / clamp / div / topk gave from the same uniforms - and every older frame is drawn with the frequency its error
     weight asks for."""
     from active_gs_amd.fused_map_trainer import weighted_choice_into, weighted_choice_without_replacement
-    for n, k in ((1, 1), (5, 5), (40, 8), (300, 8), (5000, 64)):
+    for n, k in ((1, 1), (5, 5), (40, 8), (64, 64), (65, 8), (300, 8), (5000, 64)):     # (<= 64: the one-wave form)
         w = (torch.rand(n, device=DEV) * 3 + 0.01)
         w[::7] = 0.0                                                    # frames with zero error: drawn last
         for rep in range(5):
