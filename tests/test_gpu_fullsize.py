@@ -130,3 +130,48 @@ def test_reference_checkpoint_renders_at_mesh_resolution(agslib):
     assert float((rgb.cpu() - ref[0]).abs().mean()) < 1e-4 and float((opacity.cpu() - ref[3]).abs().mean()) < 1e-4
     assert float((depth.cpu() - ref[2]).abs().mean()) < 1e-3
     assert torch.equal(in_view.cpu(), ref[7] > 0)
+
+
+def test_c3_size_fused_iterations_match_the_autograd_mirror(agslib):
+    """Configuration 3's shape (512x512 keyframes, batch 8 + 3, a mapper-grown map of ~200 k surfels): three iterations of
+    the fused batched loop (HIP loss head, one per-Gaussian backward + Adam over the rows the views showed, iterations
+    chained on the device) against the same three iterations through the reference-shaped mirror (facade + drop-in module
+    under autograd + the torch loss head, dense Adam) from the same state and the same frame draws: losses, per-frame
+    errors and where the parameters land."""
+    import numpy as np
+    from active_gs_amd.fused_map_trainer import FusedMapTrainer
+    from active_gs_amd.gaussian_map import GaussianMap
+    from active_gs_amd.map_trainer import GaussianMapTrainer
+    from active_gs_amd.synthetic import make_keyframes, mapper_cfg
+    dev = torch.device("cuda:0")
+    frames = make_keyframes(12, 512, 512, dev, gt_surfels=400_000)
+    np.random.seed(0)
+    gm = GaussianMap(mapper_cfg(10, "device"), dev)
+    for f in frames:
+        gm.update(f)
+    tr0 = gm._trainer
+    n = tr0.means.shape[0]
+    assert n > 100_000
+    keys = ("means", "scales", "rotations", "opacities", "harmonics", "view_scores", "view_supports", "view_means")
+    raw = {k: getattr(tr0, k).detach().clone() for k in keys}
+    cfg = dict(tr0.cfg, optimization_steps=3, sampler="host", prune_interval=10 ** 9)
+    perf0 = tr0.training_performance.clone()
+    out = []
+    for cls in (FusedMapTrainer, GaussianMapTrainer):
+        t = cls({k: v.clone() for k, v in raw.items()}, list(tr0.frames), dict(cfg))
+        t.training_performance = perf0.clone()
+        np.random.seed(3)
+        if cls is FusedMapTrainer:
+            assert t._uniform_frames()
+            assert t._train_batched(3) is True          # (the loop alone: no post-processing on either side)
+        else:
+            t.train(3)                                   # (its post-processing touches the view statistics only)
+        torch.cuda.synchronize()
+        out.append(({k: getattr(t, k).detach().clone() for k in keys[:5]}, t.training_performance.clone(), [float(x) for x in t.last_losses]))
+    (pa, ea, la), (pb, eb, lb) = out
+    assert len(la) == len(lb) == 3 and np.allclose(la, lb, rtol=2e-4), (la, lb)
+    assert torch.allclose(ea, eb, rtol=1e-3, atol=1e-5)
+    for k in keys[:5]:
+        travel = (pb[k] - raw[k]).abs().mean()
+        diff = (pa[k] - pb[k]).abs()
+        assert float(travel) > 0 and float(diff.mean()) < 5e-3 * float(travel), (k, float(diff.mean()), float(travel))
