@@ -902,8 +902,11 @@ __device__ __forceinline__ void ags_rows_body(
 // member row; the row's inputs are loaded and activated once; every view that shows the row adds its chain rule (in the
 // space of the ACTIVATED parameters: the activations' own chain rule is view-independent and applied once to the sum);
 // then the tail of the single-view row kernel: MODE 1 fused Adam, MODE 2 exchange segment, MODE 0 gradient arrays.
+#ifndef AGS_ROWS_MULTI_WAVES
+#define AGS_ROWS_MULTI_WAVES 3   // resident waves per SIMD the register budget is cut for (512 / 3 -> 168 VGPRs; 4 spills: measured slower)
+#endif
 template <int MODE>
-__global__ __launch_bounds__(AGS_ROWS_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void ags_k_rows_multi(AgsRowViews rv, AgsGaussians in, AgsGaussianGrads out,
+__global__ __launch_bounds__(AGS_ROWS_THREADS) __attribute__((amdgpu_waves_per_eu(AGS_ROWS_MULTI_WAVES, AGS_ROWS_MULTI_WAVES))) void ags_k_rows_multi(AgsRowViews rv, AgsGaussians in, AgsGaussianGrads out,
                                                                     AgsAdamArgs adam) {
     // MODE 3 (data-parallel ranks that exchange the dense gradient slab in row chunks): no row set - the rows
     // [out.row_begin, out.row_end) of the MAP, gradient arrays overwritten (zeros where no view shows the row)
