@@ -337,7 +337,7 @@ int ags_backward_rows(const AgsViewRef* views, int32_t num_views, const AgsGauss
     const bool ranged = !din->touched.member && !din->touched.rows && !din->touched.count;   // rows [row_begin, row_end) of the map
     if (ranged) {
         if (din->row_begin < 0 || din->row_end <= din->row_begin || din->row_end > in->n) return AGS_E_INVALID;
-        if (din->fused_adam || din->pack_segment || din->accumulate != 0) return AGS_E_INVALID;
+        if (din->fused_adam || din->pack_segment || (din->accumulate != 0 && din->accumulate != 1)) return AGS_E_INVALID;   // 1: += (a further group of views)
         if (!din->d_means3D || !din->d_scales || !din->d_rotations || !din->d_opacities || !din->d_colors) return AGS_E_INVALID;
     } else if (!din->touched.member || !din->touched.rows || !din->touched.count || din->accumulate == 2) {
         return AGS_E_INVALID;

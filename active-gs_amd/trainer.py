@@ -212,6 +212,7 @@ class SurfelTrainer:
     # share scratch buffers between views and must consume what it allocates on that stream - a callback written for the
     # one-stream step (the default) need not know any of this.
     VIEW_STREAMS = int(os.environ.get("AGS_VIEW_STREAMS", "1"))
+    MAX_ROW_VIEWS = 16       # AGS_MAX_ROW_VIEWS (include/ags_raster.h): views one ags_backward_rows launch joins
     MULTI_VIEW_ROWS = True   # several views per step: one per-Gaussian backward launch for all of them (ags_backward_rows)
     # Data-parallel ranks that exchange the DENSE gradient slab (row sets covering most of the map: configuration 4): the
     # per-Gaussian backward, the all-reduce and the Adam update are cut into this many row chunks; chunk k's all-reduce
@@ -317,7 +318,7 @@ class SurfelTrainer:
         # launch (ags_backward_rows) turns them all into parameter gradients - the member list is walked once, a row's
         # inputs are loaded once, the views' gradients meet in registers (no read-modify-write of the gradient rows per
         # view), and the optimiser step / exchange segment is its tail
-        if len(cams) > 1 and len(cams) <= 16 and self.rows is not None and self.MULTI_VIEW_ROWS:
+        if len(cams) > 1 and self.rows is not None and self.MULTI_VIEW_ROWS:
             self._drop_prepared()
             done = []
             lanes = self._view_streams(len(cams))
@@ -336,8 +337,15 @@ class SurfelTrainer:
             for s in lanes:
                 main.wait_stream(s)
             fused = (self.optim.tensors_struct(self.slab.as_list()), self.optim.eps) if (ticked and fuse_adam) else None
-            api.backward_rows(done, g, self._no_grads if fused is not None else self.slab.grads, self.rows,
-                              adam_clock=self.optim.tick_args() if fused is not None else None, fused_adam=fused, pack=pack)
+            # (one launch joins at most MAX_ROW_VIEWS views: a rank with more - all 32 views of configuration 4 on one GPU -
+            # sums the earlier groups into the gradient rows and gives the tail to the last group)
+            groups = [done[k:k + self.MAX_ROW_VIEWS] for k in range(0, len(done), self.MAX_ROW_VIEWS)]
+            for j, grp in enumerate(groups[:-1]):
+                api.backward_rows(grp, g, self.slab.grads, self.rows, accumulate=(j > 0))
+            many = len(groups) > 1
+            api.backward_rows(groups[-1], g, self._no_grads if (fused is not None and not many) else self.slab.grads, self.rows,
+                              accumulate=many, adam_clock=self.optim.tick_args() if fused is not None else None,
+                              fused_adam=fused, pack=pack)
             self.adam_fused = fused is not None
             if not self.fused_activations:
                 self.activate_backward()
@@ -392,7 +400,7 @@ class SurfelTrainer:
 
     def _dense_chunked(self, cams) -> bool:
         return (self._distributed() and self.rows is None and self.fused_activations and self.MULTI_VIEW_ROWS
-                and len(cams) <= 16 and self.DENSE_CHUNKS >= 1)
+                and self.DENSE_CHUNKS >= 1)
 
     def _dense_step(self, cams, image_grads, max_instances, device_clock: bool) -> None:
         """The data-parallel step with the dense slab: blend passes of this rank's views, then per ROW CHUNK the
@@ -434,30 +442,69 @@ class SurfelTrainer:
         segs = [t.view(-1) for t in self.slab.as_list()]
         if getattr(self, "_comm", None) is None:
             self._comm = torch.cuda.Stream()
+        # ``tail_probe`` (a list, set by a measuring caller on EAGER steps): timing events of this tail are appended -
+        # how long the chain rule, every chunk's all-reduce and the Adam updates took and how long the main stream
+        # waited for sums that had not arrived (``tail_timeline`` turns them into milliseconds)
+        probe = getattr(self, "tail_probe", None)
+        if probe is not None and torch.cuda.is_current_stream_capturing():
+            probe = None
+
+        def stamp(stream):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            return e
+        rec = dict(start=stamp(main), rows=[], ar=[], adam=[], chunks=K, bounds=bounds) if probe is not None else None
+        groups = [done[k:k + self.MAX_ROW_VIEWS] for k in range(0, len(done), self.MAX_ROW_VIEWS)]
         arrived = []
         for c in range(K):
             a, b = bounds[c], bounds[c + 1]
-            if done:
-                api.backward_rows(done, g, self.slab.grads, None, row_range=(a, b))
-            elif c == 0:
+            for j, grp in enumerate(groups):      # (more than MAX_ROW_VIEWS views on a rank: later groups add to the chunk)
+                api.backward_rows(grp, g, self.slab.grads, None, row_range=(a, b), accumulate=(j > 0))
+            if not done and c == 0:
                 self.slab.flat.zero_()            # a rank without views this step contributes zeros
+            if rec is not None:
+                rec["rows"].append(stamp(main))
             if K == 1:
+                t0 = stamp(main) if rec is not None else None
                 all_reduce_(self.slab.flat, group=self.pg)
+                if rec is not None:
+                    rec["ar"].append((t0, stamp(main)))
                 continue
             ready = torch.cuda.Event()
             ready.record(main)
             with torch.cuda.stream(self._comm):
                 self._comm.wait_event(ready)
+                t0 = stamp(self._comm) if rec is not None else None
                 for seg, width in zip(segs, (3, 3, 4, 1, 3)):
                     all_reduce_(seg[a * width:b * width], group=self.pg)
                 ev = torch.cuda.Event()
                 ev.record(self._comm)
+                if rec is not None:
+                    rec["ar"].append((t0, stamp(self._comm)))
             arrived.append(ev)
         for c in range(K):
             if K > 1:
                 main.wait_event(arrived[c])
+            t0 = stamp(main) if rec is not None else None
             self.optim.step_range(self.slab.as_list(), bounds[c], bounds[c + 1], device_clock=device_clock,
                                   pre_ticked=ticked, first=(c == 0))
+            if rec is not None:
+                rec["adam"].append((t0, stamp(main)))
+        if rec is not None:
+            probe.append(rec)
+
+    @staticmethod
+    def tail_timeline(rec: dict) -> dict:
+        """Host-synchronous: one ``tail_probe`` record in milliseconds.  ``exposed_ms`` = what the main stream spent
+        between the last chunk's chain rule and the last Adam update that was NOT an Adam update: the wait for sums
+        still on the wire (with one chunk: the whole all-reduce)."""
+        torch.cuda.synchronize()
+        rows_ms = rec["start"].elapsed_time(rec["rows"][-1])
+        ar = [a.elapsed_time(b) for a, b in rec["ar"]]
+        adam = [a.elapsed_time(b) for a, b in rec["adam"]]
+        tail_ms = rec["start"].elapsed_time(rec["adam"][-1][1])
+        return dict(chunks=rec["chunks"], rows_ms=rows_ms, all_reduce_ms=ar, all_reduce_sum_ms=sum(ar), adam_ms=sum(adam),
+                    tail_ms=tail_ms, exposed_ms=max(0.0, tail_ms - rows_ms - sum(adam)))
 
     def _step_once(self, cams, image_grads, max_instances, device_clock, next_cam=None) -> None:
         dist_on = self._distributed()
@@ -467,7 +514,17 @@ class SurfelTrainer:
         ticked = self._local_pass(cams, image_grads, max_instances, tick=device_clock, fuse_adam=not dist_on,
                                   next_cam=None if dist_on else next_cam)
         if dist_on:
-            self._exchange_gradients(device_clock)
+            # ``exchange_probe`` (a list, set by a measuring caller on eager steps): an event pair around the exchange -
+            # in this form of the step the collective sits on the main stream, all of it is exposed
+            probe = getattr(self, "exchange_probe", None)
+            if probe is not None and not torch.cuda.is_current_stream_capturing():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._exchange_gradients(device_clock)
+                e1.record()
+                probe.append((e0, e1))
+            else:
+                self._exchange_gradients(device_clock)
         self._optimizer_step(device_clock, ticked)
 
     # -- overflow: noted on the device, looked at every few steps, repaired without losing a gradient row ----

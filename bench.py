@@ -254,6 +254,156 @@ def measure_config(tag, n, h, w, views, room, steps, dev, lrs=None, binning_mode
     return out
 
 
+STRONG_CONFIGS = {
+    # BASELINE.json configs[3]: "room0, 1.5M Gaussians, 32 training views sharded view-parallel over 8 x MI355X, RCCL grad
+    # all-reduce" and configs[4]: "5M-Gaussian scene, 2048x2048 ..., 1->8 GPU roofline sweep" (8 views, so that 8 ranks have
+    # one each): the TOTAL work is fixed, rank r renders views r::N - "scaling": "strong" inside these objects
+    "c4": dict(n=1_500_000, views=32, h=680, w=1200, room="room0",
+               what="config 4: room0 stand-in, 1.5 M surfels, 32 views @1200x680 per optimisation step, 32/N per rank"),
+    "c5": dict(n=5_000_000, views=8, h=2048, w=2048, room="office0",
+               what="config 5: 5 M surfels, 8 views @2048x2048 per optimisation step, 8/N per rank"),
+}
+
+
+def strong_configs():
+    """STRONG_CONFIGS, or the sizes a test asks for: AGS_BENCH_STRONG="c4=150000,8,680,1200;c5=400000,4,1024,1024"."""
+    out = {k: dict(v) for k, v in STRONG_CONFIGS.items()}
+    spec = os.environ.get("AGS_BENCH_STRONG")
+    if spec:
+        for part in spec.split(";"):
+            k, v = part.split("=")
+            n, views, h, w = (int(x) for x in v.split(","))
+            out[k].update(n=n, views=views, h=h, w=w, reduced=True)
+    return out
+
+
+def replica_checksums(trainer, dist_on):
+    """Are the replicas bit-identical?  Per parameter tensor the int64 sum of its bits, MIN and MAX over the ranks."""
+    sums = torch.stack([t.detach().view(torch.int32).to(torch.int64).sum() for t in trainer.params])
+    if not dist_on:
+        return True, [int(x) for x in sums.tolist()]
+    from active_gs_amd.dist_util import all_reduce_
+    lo, hi = sums.clone(), sums.clone()
+    all_reduce_(lo, torch.distributed.ReduceOp.MIN)
+    all_reduce_(hi, torch.distributed.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi)), [int(x) for x in sums.tolist()]
+
+
+def measure_strong(key, cfg, steps, dev, world, rank, dist_on, check_only=False, samples=7, probe_steps=6):
+    """One optimisation step of a STRONG-scaled configuration on `world` ranks: the configuration's views are dealt out
+    round-robin (rank r renders views r::world), every rank holds the whole map and the Adam state, ONE exchange of the
+    gradients per step (the path `RowExchange.agree()` picks from the ranks' row coverage: all-gather of member rows, or
+    the dense slab all-reduced in DENSE_CHUNKS row chunks on a communication stream under the next chunk's chain rule,
+    /root/reference/mapping/gaussian_map.py:113-125 is the sum it shards), then the replicated Adam step.  Timed like
+    the headline (samples of `steps` steps, barrier + synchronize on both sides, max over ranks, median); the exposed
+    part of the exchange comes from HIP events on the main / communication streams of `probe_steps` eager steps."""
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.camera import camera_matrices
+    from active_gs_amd.dist_util import all_reduce_
+    from active_gs_amd.synthetic import make_camera, make_room_scene
+    from active_gs_amd.trainer import SurfelTrainer
+    n, total, h, w = cfg["n"], cfg["views"], cfg["h"], cfg["w"]
+    mine = list(range(rank, total, world))
+    raw = {k: v.to(dev) for k, v in make_room_scene(n, room=cfg["room"], seed=0).items()}
+    trainer = SurfelTrainer(raw, view_streams=int(os.environ.get("AGS_VIEW_STREAMS", "4")))
+    cams = []
+    for v in mine:
+        c2w, K = make_camera(v, h, w)
+        cm = camera_matrices(c2w[None].to(dev), K[None].to(dev), 0.001, 10.0)
+        tan = cm["tanfov"][0].cpu()
+        cams.append(api.Camera(h, w, float(tan[0]), float(tan[1]), cm["viewmatrix"][0].contiguous(),
+                               cm["projmatrix"][0].contiguous(), torch.zeros(4, device=dev)))
+    gen = torch.Generator().manual_seed(4)
+    d_img = [(torch.randn(c, h, w, generator=gen) / (h * w * total)).to(dev) for c in (3, 3, 1)]
+    fn = lambda v, st: (d_img[0], d_img[1], d_img[2], None, None)
+    # size the workspaces from forward-only probes of this rank's views; every rank takes the largest need (one agreement)
+    g = trainer.gaussians()
+    cap, V, I = 1 << 22, 0, 0
+    while True:
+        probe = api.alloc_state(n, h, w, cap, dev)
+        need, V, I = 0, 0, 0
+        for cam in cams:
+            api.forward(cam, g, probe)
+            info = api.read_status(probe)
+            need, V, I = max(need, info["needed"]), V + info["num_visible"], I + info["num_instances"]
+        del probe
+        t = torch.tensor([need], device=dev, dtype=torch.int64)
+        if dist_on:
+            all_reduce_(t, torch.distributed.ReduceOp.MAX)
+        need = int(t.item())
+        if need <= cap:
+            break
+        cap = int(need * 1.25) + 4096
+    del g
+    for _ in range(2):
+        trainer.step(cams, fn, cap)              # the first step of a data-parallel trainer agrees on the exchange
+    trainer.check_overflow()
+    x = trainer.exchange
+    slab_bytes = 4 * trainer.slab.flat.numel()
+    if not dist_on:
+        path, xbytes = "single rank: no exchange, row-set Adam fused into the per-Gaussian backward", 0
+    elif x is not None and x.capacity:
+        path, xbytes = f"rows: all-gather of {x.capacity}-row segments (64 B per row)", 4 * x.send.numel()
+    else:
+        K = max(1, min(int(trainer.DENSE_CHUNKS), n // trainer.DENSE_CHUNK_MIN_ROWS))
+        path = (f"dense: all-reduce of the {slab_bytes / 1e6:.0f} MB gradient slab in {K} row chunks on a communication stream, "
+                "chunk k under chunk k+1's chain rule, Adam per chunk" if trainer._dense_chunked(cams)
+                else f"dense: one all-reduce of the {slab_bytes / 1e6:.0f} MB gradient slab")
+        xbytes = slab_bytes
+    out = dict(config=key, what=cfg["what"], scaling="strong", surfels=n, image=[h, w], views_total=total,
+               views_this_rank=len(mine), world_size=world, exchange_path=path, exchange_bytes_per_rank=xbytes,
+               dense_chunks=(max(1, min(int(trainer.DENSE_CHUNKS), n // trainer.DENSE_CHUNK_MIN_ROWS))
+                             if dist_on and trainer.rows is None else None),
+               member_rows_this_rank=None if trainer.rows is None else int(trainer.rows.count.item()),
+               visible_per_view=V // max(1, len(mine)), tile_instances_per_view=I // max(1, len(mine)),
+               view_streams=min(int(trainer.VIEW_STREAMS), max(1, len(mine))), reduced_size=bool(cfg.get("reduced")))
+    if dist_on:                                     # every rank must have taken the same path
+        paths = [None] * world
+        torch.distributed.all_gather_object(paths, path)
+        if len(set(paths)) != 1:
+            raise RuntimeError(f"ranks disagree on the exchange path of {key}: {paths}")
+    if not check_only:
+        replay = trainer.capture(cams, fn, cap)
+        for _ in range(3):
+            replay()
+        torch.cuda.synchronize()
+        sm = summarise(time_samples(lambda: [replay() for _ in range(steps)], samples, dist_on, dev), steps)
+        out.update(ms_per_step=round(sm["median"], 4), ms_per_step_min=round(sm["min"], 4), ms_per_step_max=round(sm["max"], 4),
+                   samples=sm["samples"], steps_per_sample=steps, gaussians_per_s=n * total / (sm["median"] * 1e-3),
+                   launch=("hipGraph replay" + (", exchange recorded in the graph" if getattr(replay, "collective_in_graph", False)
+                                                else (": graph | collective | graph" if dist_on and trainer.rows is not None
+                                                      else (", eager chunks (host-driven collectives)" if dist_on else "")))))
+        if dist_on:
+            # where the exchange sits in the step: events of a few EAGER steps (a replayed graph cannot be timed inside)
+            trainer.tail_probe, trainer.exchange_probe = [], []
+            for _ in range(probe_steps):
+                trainer.step(cams, fn, cap)
+            torch.cuda.synchronize()
+            if trainer.tail_probe:
+                tl = [SurfelTrainer.tail_timeline(r) for r in trainer.tail_probe]
+                med = lambda k: statistics.median(t[k] for t in tl)
+                out["exchange_timeline_ms"] = dict(chain_rule=round(med("rows_ms"), 4), all_reduce_sum=round(med("all_reduce_sum_ms"), 4),
+                                                   adam=round(med("adam_ms"), 4), tail=round(med("tail_ms"), 4),
+                                                   all_reduce_per_chunk=[round(statistics.median(t["all_reduce_ms"][c] for t in tl), 4)
+                                                                         for c in range(len(tl[0]["all_reduce_ms"]))])
+                out["all_reduce_exposed_ms"] = round(med("exposed_ms"), 4)
+            elif trainer.exchange_probe:
+                ex = [a.elapsed_time(b) for a, b in trainer.exchange_probe]
+                out["all_reduce_exposed_ms"] = round(statistics.median(ex), 4)
+                out["exchange_timeline_ms"] = dict(note="the all-gather sits on the main stream between the per-Gaussian backward and "
+                                                        "the gathered Adam: all of it is exposed")
+            trainer.tail_probe = trainer.exchange_probe = None
+            out["exposed_note"] = ("HIP events on the main and communication streams of eager steps: what the main stream waited "
+                                   "between the last chunk's chain rule and the last Adam update beyond the Adam updates themselves")
+        trainer.check_overflow()
+    ok, sums = replica_checksums(trainer, dist_on)
+    out["replicas_identical"] = ok
+    out["parameter_checksums"] = sums
+    del trainer, raw, cams, d_img
+    torch.cuda.empty_cache()
+    return out
+
+
 def measure_c3(dev):
     """BASELINE.json configs[2]: "full mapper loop (densify/prune + Adam), 1 MI355X, 500 iters" - 50 keyframes x 10
     iterations from an empty map through ``active_gs_amd.gaussian_map.GaussianMap.update`` (the class an untouched
@@ -542,9 +692,20 @@ def main():
             torch.distributed.all_gather_object(paths, path)
             if len(set(paths)) != 1:
                 raise SystemExit(f"bench.py --check: ranks disagree on the exchange path: {paths}")
+        refused0 = trainer.refused_steps() if dist_on else 0
+        strong = None
+        if dist_on and not args.no_extras:
+            # the path every rank takes for the strong-scaled configurations 4 and 5 (one sizing pass + two eager steps each)
+            del trainer
+            torch.cuda.empty_cache()
+            strong = {}
+            for key, cfg in strong_configs().items():
+                r = measure_strong(key, cfg, 0, dev, world, rank, dist_on, check_only=True)
+                strong[key] = {k: r[k] for k in ("exchange_path", "exchange_bytes_per_rank", "views_this_rank", "surfels",
+                                                 "member_rows_this_rank", "replicas_identical")}
         if rank == 0:
             print(json.dumps({"check": "ok", "n_gpus": world, "backend": backend if dist_on else None, "exchange_path": path,
-                              "ranks": identity, "refused_steps": trainer.refused_steps() if dist_on else 0}))
+                              "ranks": identity, "refused_steps": refused0, "strong_configs": strong}))
         if dist_on:
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
@@ -665,6 +826,18 @@ def main():
     stage_ms, stage_mean_ms = read_stage_times(lib)
     lib.ags_profile_enable(0)
 
+    strong = None
+    if dist_on and not args.no_extras and not args.eager:
+        # BASELINE.json's configurations 4 and 5 at THIS number of ranks (strong scaling: the views of a step are dealt out
+        # over the ranks); every rank takes part (collectives), rank 0 reports
+        strong = {}
+        for key, cfg in strong_configs().items():
+            try:
+                strong[key] = measure_strong(key, cfg, 10, dev, world, rank, dist_on)
+            except Exception as e:                      # (deterministic across ranks: same software, same sizes)
+                strong[key] = f"{type(e).__name__}: {e}"
+                torch.cuda.synchronize()
+
     if rank == 0:
         T = ((H + 15) // 16) * ((W + 15) // 16)
         rows = int(trainer.rows.count.item()) if getattr(trainer, "rows", None) is not None else None
@@ -776,6 +949,10 @@ def main():
         out.update(extras)
         if valu is not None:
             out["roofline_valu"] = valu
+        if strong is not None:
+            out["config"]["secondary"] = {"strong": strong, **strong,
+                                          "note": "configurations 4 and 5 strong-scaled over this run's ranks, measured after the "
+                                                  "timed region; `value` / `ms_per_step` above are weak-scaled configuration 2"}
         if not dist_on and not args.no_extras and not args.eager:
             # -- the same step with the blend backward's per-surfel sums on the bf16 matrix pipe (hi/lo splits, f32
             #    accumulation: AgsTuning.bwd_reduce = AGS_BWD_BF16_SPLIT, an opt-in per workspace) - same process, same
@@ -847,6 +1024,18 @@ def main():
                                                          "busy 0.80 (profiles/r04_a_c5_sq_counters.md)"}
             except Exception as e:
                 out["config"]["secondary"] = f"{type(e).__name__}: {e}"
+            # -- the one-rank end of the strong-scaled forms of configurations 4 and 5 (ALL the step's views on this GPU):
+            #    what `bench.py --gpus N` reports as config.secondary.c4 / .c5 at N ranks
+            try:
+                torch.cuda.empty_cache()
+                st_ = {key: measure_strong(key, cfg, 10, dev, 1, 0, False) for key, cfg in strong_configs().items()}
+                if isinstance(out["config"].get("secondary"), dict):
+                    out["config"]["secondary"]["strong"] = st_
+                else:
+                    out["config"]["secondary_strong"] = st_
+            except Exception as e:
+                out["config"]["secondary_strong"] = f"{type(e).__name__}: {e}"
+                torch.cuda.synchronize()
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only (contract)
             d_cpu = [t.cpu() for t in d_img]
 

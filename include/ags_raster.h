@@ -181,7 +181,8 @@ typedef struct AgsGaussianGrads {
     /* ags_backward_rows WITHOUT a row set (touched all NULL): the rows [row_begin, row_end) of the map - what a data-parallel
      * rank that exchanges the dense gradient slab uses to cut its per-Gaussian backward into row chunks, so that chunk k's
      * all-reduce (on another stream) runs under chunk k + 1's chain rule.  The five gradient arrays are required and
-     * OVERWRITTEN for those rows (zeros where no view shows the row); no fused_adam, no pack_segment.  Ignored elsewhere. */
+     * OVERWRITTEN for those rows (zeros where no view shows the row; accumulate 1: added to - a rank with more than
+     * AGS_MAX_ROW_VIEWS views calls once per group of views); no fused_adam, no pack_segment.  Ignored elsewhere. */
     int32_t row_begin, row_end;
 } AgsGaussianGrads;
 

@@ -88,6 +88,12 @@ def mapper_cfg(steps):
 
 
 def main():
+    # AGS_GOLDEN_ONLY="mapper_loop.pt,..." : run everything (the sections feed each other and share RNG streams) but
+    # write only the named files - the other fixtures stay byte-identical
+    only = [x for x in os.environ.get("AGS_GOLDEN_ONLY", "").split(",") if x]
+    if only:
+        real_save = torch.save
+        torch.save = lambda obj, path, *a, **kw: real_save(obj, path, *a, **kw) if os.path.basename(path) in only else None
     ops, gm, Rast = install_reference()
     from active_gs_amd.synthetic import activate, make_camera, make_room_scene
     torch.manual_seed(0)
@@ -231,19 +237,47 @@ def main():
     torch.randperm = lambda n, device=None: torch.arange(n)
     np.random.seed(11)
     history = []
+    # Where every row of the map comes from: growth appends rows and prune is a stable compaction, so an ORIGIN id
+    # (keyframe << 32 | index among the rows that keyframe added) can ride along from outside - recorded by wrapping the
+    # instance's add_gaussians / prune (the latter ORs the opacity rule into the mask it is handed, in place), so that a
+    # test can compare the final parameters row by row even when a threshold pixel made the two maps differ in a row.
+    origin = torch.zeros(0, dtype=torch.int64)
+    track = dict(k=0, added=None, pruned=None)
+    ref_add, ref_prune = m.add_gaussians, m.prune
+
+    def add_rec(frame):
+        nonlocal origin
+        n0 = m._means.shape[0]
+        out = ref_add(frame)
+        n1 = m._means.shape[0]
+        track["added"] = m._means.detach()[n0:n1].clone()           # the new rows as spawned (before any training)
+        origin = torch.cat([origin, (track["k"] << 32) + torch.arange(n1 - n0, dtype=torch.int64)])
+        return out
+
+    def prune_rec(mask):
+        nonlocal origin
+        out = ref_prune(mask)
+        track["pruned"] = mask.bool().clone()
+        origin = origin[~mask.bool()]
+        return out
+    m.add_gaussians, m.prune = add_rec, prune_rec
     try:
         for k in range(4):
             n_before = m._means.shape[0]
+            track.update(k=k, added=None, pruned=None)
             m.update(dict(dframes[k % 2]))
+            assert origin.shape[0] == m._means.shape[0]
             history.append(dict(n_before=n_before, n_after=m._means.shape[0],
                                 training_performance=m.training_performance.clone(),
                                 opacity_mean=float(torch.sigmoid(m._opacities.detach()).mean()),
-                                supports=m.view_supports.clone(), scores_mean=float(m.view_scores.mean())))
+                                supports=m.view_supports.clone(), scores_mean=float(m.view_scores.mean()),
+                                added_means=track["added"], pruned=track["pruned"]))
     finally:
         torch.randperm = real_randperm
     torch.save(dict(frames=dframes, cfg=json.loads(json.dumps(loop_cfg)), seed=11, history=history,
                     final=dict(means=m._means.detach().clone(), opacities=m._opacities.detach().clone(),
-                               harmonics=m._harmonics.detach().clone(), scales=m._scales.detach().clone())),
+                               harmonics=m._harmonics.detach().clone(), scales=m._scales.detach().clone(),
+                               rotations=m._rotations.detach().clone(), origin=origin.clone())),
                os.path.join(HERE, "mapper_loop.pt"))
 
     # ---------------------------------------------------------------- adam.pt

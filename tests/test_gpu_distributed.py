@@ -125,7 +125,7 @@ def test_two_ranks_equal_single_process_two_views(agslib, use_graph, sparse_rows
         assert moved >= 4                                          # the optimiser did move the map (scales may sit on their clamp)
 
 
-def _dense_worker(rank, world, port, chunks, use_graph, ret):
+def _dense_worker(rank, world, port, chunks, use_graph, row_views, ret):
     _watchdog()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -134,6 +134,7 @@ def _dense_worker(rank, world, port, chunks, use_graph, ret):
     try:
         from active_gs_amd.trainer import SurfelTrainer
         SurfelTrainer.DENSE_CHUNKS, SurfelTrainer.DENSE_CHUNK_MIN_ROWS = chunks, 1024      # 8000 rows: 4 chunks of ~2000
+        SurfelTrainer.MAX_ROW_VIEWS = row_views      # 1: every view is its own group - later groups ADD to the chunk's rows
         raw, cams, grads = _setup([rank, rank + world])                                    # two views per rank
         tr = SurfelTrainer(raw, sparse_rows=False)
         fn = lambda v, st: (grads[v][0], grads[v][1], grads[v][2], None, None)
@@ -155,16 +156,18 @@ def _dense_worker(rank, world, port, chunks, use_graph, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_chunked_dense_exchange_keeps_the_replicas_identical(agslib, use_graph):
+@pytest.mark.parametrize("use_graph,row_views", [(False, 16), (True, 16), (False, 1)])
+def test_chunked_dense_exchange_keeps_the_replicas_identical(agslib, use_graph, row_views):
     """Data-parallel ranks that exchange the dense slab (configuration 4's shape: the row sets cover most of the map) cut
     the per-Gaussian backward, the all-reduce and the Adam update into row chunks, chunk k's all-reduce on a communication
     stream under chunk k + 1's chain rule (SurfelTrainer.DENSE_CHUNKS).  Two ranks, two views each, four chunks: the
     replicas' parameters, both moments and the reduced slab are bit-identical, and they are the single-process result
-    over the four views.  (That the chunked tail gives the SAME BITS as one all-reduce of the whole slab is checked from
+    over the four views.  ``row_views`` 1: a rank with more views than one ``ags_backward_rows`` launch joins
+    (AGS_MAX_ROW_VIEWS: all 32 views of configuration 4 on one or two GPUs) goes through its views in groups, the later
+    groups adding to the chunk's gradient rows - here every view is its own group.  (That the chunked tail gives the SAME BITS as one all-reduce of the whole slab is checked from
     identical gradient records in tests/tools/rccl_one_rank.py - two separate runs of the blend backward differ in the
     order of its float atomics.)"""
-    four = _spawn_two(_dense_worker, (4, use_graph))
+    four = _spawn_two(_dense_worker, (4, use_graph, row_views))
     assert four[0]["step"] == four[1]["step"] == STEPS
     for key in ("params", "m", "v"):
         for c, d in zip(four[0][key], four[1][key]):

@@ -240,3 +240,37 @@ def test_every_binning_mode_replays_from_a_graph(agslib):
                 assert float((got[k] - ref[k]).abs().sum()) <= 1e-5 * float(ref[k].abs().sum()) + 1e-12, (mode, replay, k)
             again = api.read_status(st)
             assert again["num_instances"] == info["num_instances"] and again["overflow_passes"] == 0
+
+
+def test_more_views_than_one_rows_launch_joins(agslib):
+    """A single-rank step over more views than ``ags_backward_rows`` joins in one launch (AGS_MAX_ROW_VIEWS = 16: e.g. all
+    32 views of BASELINE.json's configuration 4 on one GPU) goes through its views in groups - the earlier groups sum into
+    the gradient rows, the last group adds what they left and runs the fused Adam step.  Here: 4 views in groups of
+    16 (one launch), 3 (two launches) and 1 (four): the same parameters and moments up to the order of the float sums."""
+    from active_gs_amd.trainer import SurfelTrainer
+    n, h, w = 9000, 136, 240
+    dev, cams, fn = _setup(n, h, w)
+    res = {}
+    was = SurfelTrainer.MAX_ROW_VIEWS
+    try:
+        for groups in (16, 3, 1):
+            SurfelTrainer.MAX_ROW_VIEWS = groups
+            tr = _trainer(n, dev)
+            init = [p.clone() for p in tr.params]
+            for _ in range(3):
+                tr.step(cams, fn, 1 << 21)
+            tr.check_overflow()
+            torch.cuda.synchronize()
+            res[groups] = ([p.clone() for p in tr.params], [m.clone() for m in tr.optim.exp_avg], init, int(tr.rows.count.item()))
+    finally:
+        SurfelTrainer.MAX_ROW_VIEWS = was
+    ref_p, ref_m, init, rows = res[16]
+    assert rows > 1000
+    for groups in (3, 1):
+        p, m, _, r = res[groups]
+        assert r == rows
+        for a, b, i0 in zip(p, ref_p, init):
+            travel = (b - i0).abs().mean()
+            assert (a - b).abs().mean() <= 2e-3 * travel + 1e-9, groups
+        for a, b in zip(m, ref_m):
+            assert (a - b).abs().sum() <= 1e-4 * b.abs().sum() + 1e-12, groups
