@@ -418,8 +418,10 @@ void ags_launch_facade_post_bwd(int h, int w, float tanx, float tany, const floa
 // 0.26 ms of host time per iteration).
 #define AGS_WTOPK_MAX 8192
 // (the body of ags_k_weighted_topk for one workgroup of 256 threads; key / best_v / best_i: its LDS)
-__device__ __forceinline__ void ags_wtopk_block(const float* __restrict__ u, const float* __restrict__ w, int n, int k,
-                                                long long* __restrict__ out, float* key, float* best_v, int* best_i) {
+// (w and out carry no __restrict__: ags_k_loss_finish_next hands in the per-frame errors it has just written through another
+// pointer, and reads the indices written here through its own)
+__device__ __forceinline__ void ags_wtopk_block(const float* __restrict__ u, const float* w, int n, int k,
+                                                long long* out, float* key, float* best_v, int* best_i) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     // every key stays FINITE (u = 0 from torch.rand would give log(0) = -inf, a NaN weight a NaN key: both become the lowest
     // finite key), so that a drawn slot can be marked with NaN and never be selected again: the k indices are distinct
@@ -475,8 +477,8 @@ struct AgsNextDev {
     const float* all_view; const float* all_proj; float* dst_view; float* dst_proj; int* msum;
 };
 __global__ __launch_bounds__(256) void ags_k_loss_finish_next(AgsLossDev c, float* __restrict__ accum, int accum_stride,
-                                                              int views, long long* __restrict__ frame_index,
-                                                              float* __restrict__ frame_error, float* __restrict__ total_loss,
+                                                              int views, long long* frame_index,
+                                                              float* frame_error, float* __restrict__ total_loss,
                                                               AgsNextDev nx) {
     __shared__ float key[AGS_WTOPK_MAX];
     __shared__ float best_v[4];

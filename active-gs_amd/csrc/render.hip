@@ -187,7 +187,9 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
     int id_stride, const AgsGeom* __restrict__ geom, AgsImages out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ importance, int* __restrict__ count, int num_tiles,
     uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_fill, AgsFinalize fin,
-    uint32_t tile_cap, AgsViewStride vs) {
+    uint32_t tile_cap, AgsViewStride vs, int seen_only) {
+    // seen_only (AGS_STATS_SEEN, an explicit argument - not a null `importance`, which the batched prologue below would
+    // shift into a non-null bogus pointer for the views y >= 1): count[i] = 1 for every surfel with a counted pixel
     { // batched forward: this workgroup's view // (offsets are 0 for a single view)
         const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws, po = (size_t)blockIdx.y * (size_t)vs.px;
         AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(vals, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(final_T, wo);
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
         if (fin.status) { AGS_WS_SHIFT(fin.status, wo); AGS_WS_SHIFT(fin.partial, wo); }
         if (mask) mask += po;
         out.rgb += 3 * po; out.normal += 3 * po; out.depth += po; out.opacity += po; out.confidence += po;
-        if (STATS) { importance += (size_t)blockIdx.y * (size_t)vs.n; count += (size_t)blockIdx.y * (size_t)vs.n; }
+        if (STATS) { if (importance) importance += (size_t)blockIdx.y * (size_t)vs.n; count += (size_t)blockIdx.y * (size_t)vs.n; }
     }
     __shared__ AgsWaveStageQ<SLOTS, 64, STATS> st;
     const int lane = threadIdx.x;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
                     if (STATS && stats_on) { const float wm = w * mk[s]; wsum += wm; wcnt += (wm > weight_thres) ? 1u : 0u; }
                 }
             }
-            if (STATS && stats_on && importance == nullptr) {
+            if (STATS && stats_on && seen_only) {
                 // AGS_STATS_SEEN: the caller only asks WHETHER a surfel has a counted pixel (post_processing's `counts >= 1`):
                 // one vote and one plain store instead of two wave reductions and two atomics per surfel and wave
                 if constexpr (STATS) {
@@ -812,16 +814,17 @@ static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
     float* fT = (float*)(ws + L.final_T);
     uint32_t* nc = (uint32_t*)(ws + L.n_contrib);
     const dim3 block(64), grid(8 * ags_wave_blocks_per_xcd(L.num_tiles, 4 / SLOTS), vs.views);
+    const int seen_only = (cam.want_stats == AGS_STATS_SEEN && !cam.config) ? 1 : 0;
     if (cam.want_stats || cam.config)   // (device-side configuration: config[3] decides inside the kernel)
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, true>), grid, block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
-                           (cam.want_stats == AGS_STATS_SEEN && !cam.config) ? nullptr : pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
-                           (uint32_t*)(ws + L.tile_fill), fin, tile_cap, vs);
+                           seen_only ? nullptr : pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
+                           (uint32_t*)(ws + L.tile_fill), fin, tile_cap, vs, seen_only);
     else
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, false>), grid, block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
-                           (uint32_t*)(ws + L.tile_fill), fin, tile_cap, vs);
+                           (uint32_t*)(ws + L.tile_fill), fin, tile_cap, vs, 0);
 }
 
 template <int SLOTS>

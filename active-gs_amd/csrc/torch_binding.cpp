@@ -316,7 +316,14 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                 { std::lock_guard<std::mutex> g(mu); eslot = take_slot(); }
                 wss.early_status_host = eslot.host; wss.early_status_event = eslot.ev;
             }
-            check_rc(abi.forward(&cs, &gs, &im, &pg, &wss, stream), "ags_forward");
+            // host-side flags asking for statistics: importance / count were zero-filled once above, and an abandoned
+            // (truncated) pass still ADDS into them - a repeat starts from zeros again, ordered behind that pass on the stream
+            // (with device-side flags the per-Gaussian kernel clears them itself)
+            const bool host_stats = !cfg.defined() && flags[2] && n > 0;
+            if (host_stats && attempts > 0) { importance.zero_(); count.zero_(); }
+            const int rc_fwd = abi.forward(&cs, &gs, &im, &pg, &wss, stream);
+            if (rc_fwd != 0 && early) { std::lock_guard<std::mutex> g(mu); free_slots.push_back(eslot); }   // the slot goes back before the throw
+            check_rc(rc_fwd, "ags_forward");
             if (early) {
                 HIP_OK(hipEventSynchronize(eslot.ev));
                 const uint32_t longest = eslot.host->early_tile_need;

@@ -131,13 +131,19 @@ class FusedMapTrainer(GaussianMapTrainer):
         a = np.ascontiguousarray(array, dtype=np.float32).reshape(-1)
         ring = getattr(self, "_ring", None)
         if ring is None:
-            ring = self._ring = dict(buf=torch.empty(128, 64, dtype=torch.float32).pin_memory(), k=0)
+            ring = self._ring = dict(buf=torch.empty(128, 64, dtype=torch.float32).pin_memory(), k=0, ev=[None] * 128)
         if a.size > 64:
             return torch.from_numpy(a).to(self.device)
-        slot = ring["buf"][ring["k"] % 128]
+        j = ring["k"] % 128
+        slot = ring["buf"][j]
         ring["k"] += 1
+        if ring["ev"][j] is not None:
+            ring["ev"][j].synchronize()        # the copy that last read this slot (128 uploads ago) has executed: no wait in practice
         slot[:a.size] = torch.from_numpy(a)
-        return slot[:a.size].to(self.device, non_blocking=True)
+        out = slot[:a.size].to(self.device, non_blocking=True)
+        ev = ring["ev"][j] = ring["ev"][j] or torch.cuda.Event()
+        ev.record()
+        return out
 
     # ---- cached per-frame camera (the intrinsics -> fov step needs host scalars once per frame)
     def _camera(self, idx: int):

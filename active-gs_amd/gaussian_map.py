@@ -282,6 +282,12 @@ class GaussianMap:
         self.is_init = True
 
     # ------------------------------------------------------------------ activations (gaussian_map.py:529-590)
+    # LIFETIME (differs from the reference, whose growth / prune make fresh tensors): ``_means``, ``_harmonics``, ... and what
+    # ``get_means`` / ``get_harmonics`` / ``get_params`` return are VIEWS of the leading rows of the map's buffers
+    # (densify.MapArena) - valid until the next ``update()`` / ``add_gaussians()`` / ``prune()``; growth appends in place,
+    # prune compacts into the second buffer set and swaps, so a view kept across a prune shows other rows.  A caller that
+    # keeps map data across keyframes (a GUI packet, a voxel map) takes ``.clone()``; the activated getters
+    # (``get_scales``, ``get_opacities``, ``get_rotations``, ``get_confidences``, ``get_normals``) return fresh tensors.
     @property
     def get_means(self):
         return self._means

@@ -17,10 +17,16 @@ NAMES = ("rgb", "normal", "depth", "opacity", "confidence")
 
 def _compare(n, h, w, room_seed, view, max_tiles, fullest, grads=True, scale_mult=1.0, config=(1, 1, 1, 0, 0), focal=None,
              last_contributor=False):
+    a, S = room_case(n, h, w, view=view, seed=room_seed, scale_mult=scale_mult, config=config, focal_px=focal)
+    return _compare_case(a, S, f"{n} surfels {w}x{h} view {view} x{scale_mult}", max_tiles, fullest, grads, last_contributor)
+
+
+def _compare_case(a, S, label, max_tiles, fullest, grads=True, last_contributor=False):
+    """``a``: activated surfels (means, scales, rotations, opacities, colors, confidences) on the CPU; ``S``: the view."""
     from diff_gaussian_rasterization_2d import GaussianRasterizer, check_overflow
     dev = torch.device("cuda:0")
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    a, S = room_case(n, h, w, view=view, seed=room_seed, scale_mult=scale_mult, config=config, focal_px=focal)
+    n, h, w = a["means"].shape[0], S.image_height, S.image_width
     ins = oracle_inputs(a, requires_grad=grads)
     gen = torch.Generator().manual_seed(11)
     d_img = [torch.randn(c, h, w, generator=gen) / (h * w) for c in (3, 3, 1, 1, 1)]
@@ -36,7 +42,7 @@ def _compare(n, h, w, room_seed, view, max_tiles, fullest, grads=True, scale_mul
     out = GaussianRasterizer(product_settings(S, dev))(gin[0], gin[1], gin[2], gin[3], None, gin[4], gin[5], gin[6], None)
     check_overflow()
     m = covered.to(dev)
-    what = f"{n} surfels {w}x{h} view {view} x{scale_mult}, {len(aux['tiles'])} of {aux['nonempty']} tiles"
+    what = f"{label}, {len(aux['tiles'])} of {aux['nonempty']} tiles"
     # contract mean-L1, largest pixel error, worst-tile mean L1, regression gate - over the compared tiles
     err = _parity.check_images(ref, {k: o.detach().cpu() for k, o in zip(NAMES, out[:5])}, covered, what=what)
     # integer output: exact but for rows on a rounding boundary, every one of them counted and explained
@@ -130,6 +136,38 @@ def test_reference_checkpoint_renders_at_mesh_resolution(agslib):
     assert float((rgb.cpu() - ref[0]).abs().mean()) < 1e-4 and float((opacity.cpu() - ref[3]).abs().mean()) < 1e-4
     assert float((depth.cpu() - ref[2]).abs().mean()) < 1e-3
     assert torch.equal(in_view.cpu(), ref[7] > 0)
+
+
+def test_c3_size_mapper_grown_map_matches_oracle_on_tile_subset(agslib):
+    """Configuration 3's own workload against the ORACLE: a map GROWN by the mapper loop (``GaussianMap.update`` over 40
+    keyframes @512x512: ~200 k surfels, spatially coherent rows, the scales / opacities / rotations training left, the
+    confidences post_processing left - not the seeded room of the other cases), one of its keyframe views at the
+    reference's 512x512 (config/simulator/habitat.yaml:8-9): 5 images, 6 gradients, radii, on ~160 spread tiles plus the
+    12 fullest - the rasterizer calls one fused iteration makes for a view, held to the same gates as C2 / C4 / C5."""
+    import numpy as np
+    from active_gs_amd.camera import camera_matrices
+    from active_gs_amd.gaussian_map import GaussianMap
+    from active_gs_amd.synthetic import make_keyframes, mapper_cfg
+    from oracle.surfel_oracle import OracleSettings
+    dev = torch.device("cuda:0")
+    frames = make_keyframes(40, 512, 512, dev, gt_surfels=400_000)
+    np.random.seed(0)
+    gm = GaussianMap(mapper_cfg(10, "device"), dev)
+    for f in frames:
+        gm.update(f)
+    n = gm.get_means.shape[0]
+    assert n > 150_000
+    means, harmonics, opac, conf, scales, rot = (t.detach().float().cpu().contiguous() for t in gm.get_attr())
+    a = dict(means=means, scales=scales, rotations=rot, opacities=opac, colors=harmonics[:, 0, :].contiguous(), confidences=conf)
+    f = frames[17]
+    cm = camera_matrices(f["extrinsic"][None].cpu(), f["intrinsic"][None].cpu(), 0.001, 10.0)
+    S = OracleSettings(512, 512, cm["tanfov"][0, 0].item(), cm["tanfov"][0, 1].item(), torch.zeros(4), 1.0,
+                       cm["viewmatrix"][0].contiguous(), cm["projmatrix"][0].contiguous(), campos=cm["campos"][0],
+                       render_mask=None, config=torch.tensor([1.0, 1.0, 1.0, 0.0, 0.0]))
+    del gm
+    torch.cuda.empty_cache()
+    err, aux = _compare_case(a, S, f"mapper-grown map, {n} surfels 512x512 keyframe 17", max_tiles=160, fullest=12)
+    assert aux["nonempty"] > 900 and aux["instances"] > 200_000
 
 
 def test_c3_size_fused_iterations_match_the_autograd_mirror(agslib):
