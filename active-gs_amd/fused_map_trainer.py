@@ -586,11 +586,28 @@ class FusedMapTrainer(GaussianMapTrainer):
             setattr(self, k, state[k])
         self._states.clear()          # per-view workspaces are sized by the number of surfels
 
+    # Where a keyframe's time goes, measured in ONE run: a caller may set ``phase_hook`` (callable(label)); the loop calls it at
+    # its phase boundaries - "grow" (add_gaussians), "set-up" (a train() call up to its first iteration), "iterations",
+    # "post" (count render, the wait of the call, view statistics / prune), "between".  synthetic.run_mapper_loop(phases=True)
+    # records a HIP event and the host clock there.
+    phase_hook = None
+
+    def _phase(self, label: str) -> None:
+        if self.phase_hook is not None:
+            self.phase_hook(label)
+
     def add_gaussians(self, frame: dict) -> int:
         """``GaussianMap.add_gaussians`` (gaussian_map.py:294-468): spawn surfels from a new RGB-D
         keyframe where the map's own render is wrong / empty / occluding, one per 2 cm voxel, then
         register the frame.  All per-pixel work and the compaction run in densify.hip.  Returns
         the number of surfels added."""
+        self._phase("grow")
+        try:
+            return self._add_gaussians(frame)
+        finally:
+            self._phase("between")
+
+    def _add_gaussians(self, frame: dict) -> int:
         frame = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in frame.items()}
         if self.frames and tuple(frame["rgb"].shape[-2:]) != tuple(self.frames[0]["rgb"].shape[-2:]):
             # (the reference stacks the sampled frames, /root/reference/mapping/utils.py:220-221,253-254: it cannot train such a set either)
@@ -675,12 +692,15 @@ class FusedMapTrainer(GaussianMapTrainer):
         """All-or-nothing like every train() here, with ONE wait at its end: the loop's iterations and the count render of
         post_processing are enqueued back to back, then the sticky status words of the loop's views and the count
         render's status are read together (round 3 waited for the loop, then again for the count render)."""
+        self._phase("set-up")
         snap = self._snapshot()
         for _ in range(6):
             settle = self._train_batched(steps, defer=True)
+            self._phase("post")
             pending = self._post_processing_begin()
             if settle():
                 self._post_processing_end(pending)
+                self._phase("between")
                 return
             self.overflow_retries = getattr(self, "overflow_retries", 0) + 1
             self._restore(snap)
@@ -814,6 +834,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         chained = (device_sampler and fast_stage and not will_graph and n_old <= 8192 and perf.dtype == torch.float32
                    and perf.is_contiguous())
         uniforms = torch.rand(total, max(n_old, 1), device=dev) if chained and n_random > 0 else None
+        self._phase("iterations")
         for it in range(total):
             staged = chained and it > 0
             if staged:

@@ -161,11 +161,16 @@ def mapper_cfg(optimization_steps: int = 10, draw: str = "device"):
               optimizer=NS(mean_lr=0.0005, rotation_lr=0.0005, opacity_lr=0.01, scale_lr=0.01, harmonic_lr=0.0001))
 
 
-def run_mapper_loop(frames, steps: int = 10, draw: str = "device", warmup_frames: int = 2, split: bool = False):
+def run_mapper_loop(frames, steps: int = 10, draw: str = "device", warmup_frames: int = 2, split: bool = False,
+                    phases: bool = False):
     """BASELINE.json configuration 3: what /root/reference/mapping/mapper.py:98-104 does per keyframe -
     ``gaussian_map.update(dataframe)`` - from an EMPTY map over ``frames``, through the drop-in ``GaussianMap`` class.
     ``warmup_frames`` keyframes first go through a scratch map so that every kernel module is loaded before the timed
     loop.  ``split``: synchronise around growth and training to report them separately (two more waits per keyframe).
+    ``phases``: a HIP event and the host clock at every phase boundary of the loop (FusedMapTrainer.phase_hook; ~7 event
+    records per keyframe) -> ``phases``: per phase the GPU-timeline time between its marks (idle included) and the host
+    time to enqueue it, from THIS run.  A phase whose GPU time is about its host time is host-bound (the GPU waits for
+    launches); the iterations' GPU time is kernel time (their host time is a fifth of it).
     -> dict(seconds, iterations, ms_per_iteration, final_surfels, ...)."""
     import time
     from .gaussian_map import GaussianMap
@@ -177,6 +182,13 @@ def run_mapper_loop(frames, steps: int = 10, draw: str = "device", warmup_frames
         del warm
     torch.cuda.synchronize(dev)
     gm = GaussianMap(mapper_cfg(steps, draw), dev)
+    marks = []
+    if phases:
+        def mark(label):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((label, e, time.perf_counter()))
+        gm._fused().phase_hook = mark
     ms0 = torch.cuda.memory_stats(dev)
     t_grow = t_train = 0.0
     sizes = []
@@ -204,6 +216,18 @@ def run_mapper_loop(frames, steps: int = 10, draw: str = "device", warmup_frames
                mean_frame_error=round(float(gm.training_performance.mean()), 5), last_loss=round(tr.last_losses[-1], 5),
                device_mallocs=int(torch.cuda.memory_stats(dev)["num_device_alloc"] - ms0["num_device_alloc"]),
                overflow_retries=int(getattr(tr, "overflow_retries", 0)))
+    if phases and len(marks) > 1:
+        tr.phase_hook = None
+        acc = {}
+        for (la, ea, ta), (lb, eb, tb) in zip(marks[:-1], marks[1:]):
+            a = acc.setdefault(la, dict(gpu_timeline_ms=0.0, host_enqueue_ms=0.0, times=0))
+            a["gpu_timeline_ms"] += ea.elapsed_time(eb); a["host_enqueue_ms"] += (tb - ta) * 1e3; a["times"] += 1
+        for a in acc.values():
+            a["gpu_timeline_ms"], a["host_enqueue_ms"] = round(a["gpu_timeline_ms"], 2), round(a["host_enqueue_ms"], 2)
+        out["phases"] = acc
+        it_ms = acc.get("iterations", {}).get("gpu_timeline_ms", 0.0)
+        out["iterations_gpu_ms"] = it_ms
+        out["gpu_bound_frac"] = round(it_ms / (dt * 1e3), 4)      # share of THIS run's wall time the GPU-bound phase covers
     if split:
         out.update(grow_ms_per_keyframe=round(1e3 * t_grow / len(frames), 3), train_ms_per_keyframe=round(1e3 * t_train / len(frames), 3))
     return out

@@ -112,13 +112,15 @@ def read_stage_times(lib):
     return med, mean
 
 
-def measure_dropin(dev, n, h, w, views, iters=30, focal=None, deferred=False):
+def measure_dropin(dev, n, h, w, views, iters=30, focal=None, deferred=False, samples=9):
     """The path an UNMODIFIED caller takes (operations.py:682-713, :854): ``GaussianRasterizer(settings)(...)`` per view
     under autograd + one backward through all of them - the module alone (no facade post-processing, no loss head,
     no optimiser).  ``deferred`` False: the module's default - every call reads its status block back and repairs an
     outgrown workspace before it returns (what the CUDA extension's num_rendered read-back does; safe for a caller that
     has no retry).  True: the opt-in for loops that settle once per iteration (``check_overflow()`` after the backward,
-    inside the timed loop).  -> (ms per view, host synchronisations the module itself issued per view)."""
+    inside the timed loop).  Sampled like the headline: `samples` timings of `iters` iterations each, median + min / max
+    (one unsampled loop once read 0.49 ms on the driver's box against 0.09-0.13 in seven other sessions - a host stall
+    nothing recorded).  -> dict(ms per view: median / min / max, host enqueue time, module waits per view)."""
     from active_gs_amd.camera import camera_matrices
     from active_gs_amd.synthetic import activate, make_camera, make_room_scene
     import active_gs_amd.rasterizer as R
@@ -155,20 +157,26 @@ def measure_dropin(dev, n, h, w, views, iters=30, focal=None, deferred=False):
         torch.cuda.synchronize()
         check_overflow()
         syncs0, early0 = R.counters()["status_syncs"], R.counters().get("early_waits", 0)
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            iteration()
-            if deferred:
-                check_overflow()          # one wait per iteration for the views' status copies (they have long landed)
-        host_s = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        per, host = [], []
+        for _ in range(samples):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                iteration()
+                if deferred:
+                    check_overflow()      # one wait per iteration for the views' status copies (they have long landed)
+            host_s = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t0) / (iters * views) * 1e3)
+            host.append(host_s / (iters * views) * 1e3)
         check_overflow()
     finally:
         R.set_option("always_check", was)
-    return dict(ms_per_view=dt / (iters * views) * 1e3, host_enqueue_ms_per_view=host_s / (iters * views) * 1e3,
-                module_syncs_per_view=(R.counters()["status_syncs"] - syncs0) / (iters * views),
-                module_event_waits_per_view=(R.counters().get("early_waits", 0) - early0) / (iters * views),
+    calls = samples * iters * views
+    return dict(ms_per_view=statistics.median(per), ms_per_view_min=min(per), ms_per_view_max=max(per), samples=samples,
+                iterations_per_sample=iters, host_enqueue_ms_per_view=statistics.median(host),
+                module_syncs_per_view=(R.counters()["status_syncs"] - syncs0) / calls,
+                module_event_waits_per_view=(R.counters().get("early_waits", 0) - early0) / calls,
                 workspace_checks="deferred, settled once per iteration (opt-in)" if deferred else
                                  "every call, before it returns (default): the call waits for the event behind its per-Gaussian "
                                  "kernel (the pass's overflow is known there), not for the stream")
@@ -409,7 +417,7 @@ def measure_c3(dev):
     iterations from an empty map through ``active_gs_amd.gaussian_map.GaussianMap.update`` (the class an untouched
     mapping.Mapper constructs and calls), frames rendered from the room stand-in.  The fraction of the loop during which
     kernels run comes from a committed rocprofv3 kernel trace of examples/mapper_loop.py (it cannot be collected from
-    inside this process) and is labelled as such."""
+    inside this process) and is labelled as such; the share of the wall time the GPU-bound phase covers is measured here."""
     from active_gs_amd.synthetic import make_keyframes, run_mapper_loop
     res = {}
     for tag, (h, w) in (("512x512", (512, 512)), ("1200x680", (680, 1200))):
@@ -420,16 +428,31 @@ def measure_c3(dev):
                         device_mallocs=r["device_mallocs"])
         del frames
         torch.cuda.empty_cache()
+    # Where the loop's wall time goes, from ONE run (no figure of a profiled run is divided by another run's clock): the
+    # same 512x512 loop once more with a HIP event + the host clock at every phase boundary.  The iterations are the
+    # GPU-bound phase (their GPU time is kernel time, the host enqueues them in a fifth of it); growth, a call's set-up and
+    # post-processing are host-bound (GPU-timeline time ~ host time: launches with the GPU waiting between them).
     busy = None
     try:
-        kb = json.load(open(os.path.join(ROOT, "profiles", "c3_kernels_busy.json")))
-        busy = dict(kernels_busy_frac=round(min(1.0, kb["busy_ms"] / (res["512x512"]["seconds"] * 1e3)), 3),
-                    kernels_busy_frac_under_profiler=kb.get("kernels_busy_frac"), kernel_ms_profiled=kb.get("busy_ms"),
-                    source=f"kernel time of the same loop from profiles/c3_kernels_busy.json (rocprofv3 --kernel-trace of "
-                           f"examples/mapper_loop.py, session {kb.get('_session', '?')}: union of the kernel intervals; not collected in "
-                           "this run) / this run's wall time; under the profiler itself the host side is slower")
-    except Exception:
-        pass
+        frames = make_keyframes(50, 512, 512, dev)
+        r = run_mapper_loop(frames, steps=10, draw="device", warmup_frames=0, phases=True)
+        del frames
+        torch.cuda.empty_cache()
+        busy = dict(seconds_with_marks=r["seconds"], gpu_bound_frac=r["gpu_bound_frac"], iterations_gpu_ms=r["iterations_gpu_ms"],
+                    phases=r["phases"],
+                    what="this run, second pass of the 512x512 loop with event marks at the phase boundaries (~7 records per "
+                         "keyframe): gpu_bound_frac = GPU-timeline time of the iterations / that pass's wall time - a LOWER bound "
+                         "of the kernels-busy fraction (the host-bound phases also run kernels)")
+        try:
+            kb = json.load(open(os.path.join(ROOT, "profiles", "c3_kernels_busy.json")))
+            busy["kernels_busy_frac_under_profiler"] = kb.get("kernels_busy_frac")
+            busy["under_profiler_source"] = (f"profiles/c3_kernels_busy.json (rocprofv3 --kernel-trace of examples/mapper_loop.py, session "
+                                             f"{kb.get('_session', '?')}): union of the kernel intervals / that profiled run's own wall time")
+        except Exception:
+            pass
+    except Exception as e:
+        busy = f"{type(e).__name__}: {e}"
+        torch.cuda.synchronize()
     return dict(seconds=res["512x512"]["seconds"], ms_per_iteration=res["512x512"]["ms_per_iteration"],
                 final_surfels=res["512x512"]["final_surfels"], kernels_busy=busy, **res,
                 what="GaussianMap(cfg, device).update(dataframe) x 50 keyframes (10 iterations each, batch 8 with 3 active frames, "
@@ -980,10 +1003,10 @@ def main():
                 torch.cuda.synchronize()
             # -- the path an UNMODIFIED caller takes: the drop-in module under autograd, per view
             try:
-                d1 = measure_dropin(dev, N_GAUSS, H, W, 1, iters=100)
-                d2 = measure_dropin(dev, N_GAUSS, 512, 512, 8, iters=25, focal=0.5 * 512 / 0.57735)
-                d1d = measure_dropin(dev, N_GAUSS, H, W, 1, iters=100, deferred=True)
-                d2d = measure_dropin(dev, N_GAUSS, 512, 512, 8, iters=25, focal=0.5 * 512 / 0.57735, deferred=True)
+                d1 = measure_dropin(dev, N_GAUSS, H, W, 1, iters=40)
+                d2 = measure_dropin(dev, N_GAUSS, 512, 512, 8, iters=8, focal=0.5 * 512 / 0.57735)
+                d1d = measure_dropin(dev, N_GAUSS, H, W, 1, iters=40, deferred=True)
+                d2d = measure_dropin(dev, N_GAUSS, 512, 512, 8, iters=8, focal=0.5 * 512 / 0.57735, deferred=True)
                 out["config"]["dropin_ms_per_view"] = round(d1["ms_per_view"], 4)
                 out["config"]["dropin"] = {"c2_1200x680_1_view": d1, "reference_shape_512x512_8_views": d2,
                                            "c2_1200x680_1_view_deferred": d1d, "reference_shape_512x512_8_views_deferred": d2d,

@@ -100,8 +100,20 @@ def test_bench_single_rank_contract_fields(agslib):
     c3 = d["config"]["c3"]
     assert c3["512x512"]["iterations"] == 500 and 0 < c3["seconds"] < 5 and c3["final_surfels"] > 50_000
     assert c3["1200x680"]["seconds"] > 0 and c3["512x512"]["overflow_retries"] == 0
+    # where the loop's wall time goes comes from ONE run (event marks at the phase boundaries), not from a profiled run's
+    # kernel time over this run's clock
+    kb = c3["kernels_busy"]
+    assert 0.4 < kb["gpu_bound_frac"] <= 1.0 and kb["phases"]["iterations"]["times"] == 50 and "kernels_busy_frac" not in kb
+    # the drop-in figures are sampled like the headline
+    for v in dr.values():
+        if isinstance(v, dict):
+            assert v["samples"] >= 9 and v["ms_per_view_min"] <= v["ms_per_view"] <= v["ms_per_view_max"]
     sec = d["config"]["secondary"]
     assert sec["c4_share_ms"] > 0 and sec["c5_ms"] > 0 and set(sec["c5"]["stage_hbm_frac"]) >= {"preprocess", "render_bwd"}
+    # the one-rank end of the strong-scaled configurations 4 and 5 (what --gpus N reports as config.secondary.c4 / .c5)
+    s4, s5 = sec["strong"]["c4"], sec["strong"]["c5"]
+    assert s4["views_total"] == s4["views_this_rank"] == 32 and s4["surfels"] == 1_500_000 and s4["ms_per_step"] > 0
+    assert s5["views_total"] == 8 and s5["surfels"] == 5_000_000 and s5["image"] == [2048, 2048] and s5["scaling"] == "strong"
     assert d["roofline"]["traffic_read"] is not None and d["roofline"]["traffic_write"] is not None
     assert d["roofline"]["c5"]["kernel"] == "render_bwd" and 0.05 < d["roofline"]["c5"]["frac"] < 0.5
     dr = d["config"]["derived_rates"]

@@ -231,10 +231,13 @@ def test_mapper_loop_grows_trains_and_prunes(agslib, sampler):
 # test_gpu_gaussian_map.py::test_class_api_replays_the_reference_mapper_loop_capture): ~10x the margins measured on the
 # GPU (profiles/r05_parity_margins.json, "capture" records), like every other gate of tests/_parity.py.
 CAPTURE_GATES = dict(rows=2,                 # |rows - reference rows| after a keyframe (threshold pixels; measured 0)
-                     perf_rel=3e-3,          # per-frame training errors, relative
-                     opacity_mean=2e-4, supports_rel=2e-3, scores_rel=2e-3,
-                     common_frac=0.995,      # rows spawned at the same place by the same keyframe and kept by both maps
-                     means=2e-5, harmonics=2e-5, scales=2e-3, opacities=2e-3, rotations=2e-4)   # mean |final - reference's|
+                     perf_rel=7e-4,          # per-frame training errors, relative (measured <= 7.1e-5)
+                     opacity_mean=7e-5,      # (measured <= 7.0e-6)
+                     supports_rel=1.5e-3, scores_rel=1.6e-3,            # (measured <= 1.5e-4 / 1.6e-4)
+                     common_frac=0.995,      # rows spawned at the same place by the same keyframe and kept by both maps (measured 1.0)
+                     # mean |final - reference's| over the common rows after 16 sign-like Adam steps (measured 1.35e-5, 9.7e-7,
+                     # 1.15e-4, 1.6e-4, 8.6e-6)
+                     means=1.4e-4, harmonics=1e-5, scales=1.2e-3, opacities=1.6e-3, rotations=9e-5)
 
 
 def check_capture_keyframe(k, ref, n_after, perf, opacity_mean, supports_mean, scores_mean):

@@ -167,7 +167,7 @@ def test_c3_size_mapper_grown_map_matches_oracle_on_tile_subset(agslib):
     del gm
     torch.cuda.empty_cache()
     err, aux = _compare_case(a, S, f"mapper-grown map, {n} surfels 512x512 keyframe 17", max_tiles=160, fullest=12)
-    assert aux["nonempty"] > 900 and aux["instances"] > 200_000
+    assert aux["nonempty"] > 900 and aux["instances"] > 100_000
 
 
 def test_c3_size_fused_iterations_match_the_autograd_mirror(agslib):
