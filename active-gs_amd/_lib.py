@@ -58,8 +58,7 @@ class AgsGaussianGrads(C.Structure):
 
 class AgsTuning(C.Structure):
     _fields_ = [("bwd_reduce", C.c_int32), ("render_slots", C.c_int32), ("cull_first_min_n", C.c_int32),
-                ("tile_sort_no_wave", C.c_int32), ("bucket_no_scan", C.c_int32), ("blend_group", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("tile_sort_no_wave", C.c_int32), ("bucket_no_scan", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 BWD_F32, BWD_BF16_SPLIT, BWD_VALU = 0, 1, 2
@@ -70,8 +69,7 @@ def tuning_from_env(env=None) -> AgsTuning:
     """The library reads no environment variable (AgsTuning travels with the workspace); THIS binding fills the struct
     from the AGS_* variables INTEGRATION.md lists, once per process, for experiments and the tests that select kernels:
       AGS_BWD_REDUCE=f32|bf16|valu  (AGS_BWD_BF16=1 = bf16, AGS_BWD_MFMA=0 = valu)   blend backward's per-surfel sums
-      AGS_RENDER_SLOTS=1|2|4, AGS_PRE_CULL_MIN_N=<rows> (0: always), AGS_TSORT_NO_WAVE, AGS_BUCKET_NO_SCAN,
-      AGS_BLEND_GROUP=16|64   lanes that share a surfel in the blend loops (16: four surfels in flight per wave)"""
+      AGS_RENDER_SLOTS=1|2|4, AGS_PRE_CULL_MIN_N=<rows> (0: always), AGS_TSORT_NO_WAVE, AGS_BUCKET_NO_SCAN"""
     env = os.environ if env is None else env
     t = AgsTuning()
     mode = env.get("AGS_BWD_REDUCE")
@@ -90,8 +88,6 @@ def tuning_from_env(env=None) -> AgsTuning:
         t.cull_first_min_n = 1 if v <= 0 else min(v, 0x7FFFFFFF)
     t.tile_sort_no_wave = int(env.get("AGS_TSORT_NO_WAVE") is not None)
     t.bucket_no_scan = int(env.get("AGS_BUCKET_NO_SCAN") is not None)
-    if env.get("AGS_BLEND_GROUP") in ("16", "64"):
-        t.blend_group = int(env["AGS_BLEND_GROUP"])
     return t
 
 
@@ -107,12 +103,10 @@ def default_tuning() -> AgsTuning:
     return _default_tuning
 
 
-def make_tuning(bwd_reduce=None, render_slots=None, cull_first_min_n=None, blend_group=None) -> AgsTuning:
+def make_tuning(bwd_reduce=None, render_slots=None, cull_first_min_n=None) -> AgsTuning:
     """A copy of the default selection with some fields replaced (bwd_reduce: "f32" | "bf16" | "valu" or AGS_BWD_*)."""
     d = default_tuning()
-    t = AgsTuning(d.bwd_reduce, d.render_slots, d.cull_first_min_n, d.tile_sort_no_wave, d.bucket_no_scan, d.blend_group)
-    if blend_group is not None:
-        t.blend_group = int(blend_group)
+    t = AgsTuning(d.bwd_reduce, d.render_slots, d.cull_first_min_n, d.tile_sort_no_wave, d.bucket_no_scan)
     if bwd_reduce is not None:
         t.bwd_reduce = _BWD_NAMES[bwd_reduce] if isinstance(bwd_reduce, str) else int(bwd_reduce)
     if render_slots is not None:

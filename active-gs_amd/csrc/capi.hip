@@ -86,7 +86,6 @@ static bool ags_tuning_ok(const AgsWorkspace* ws) {
     const AgsTuning* t = ws->tuning;
     if (!t) return true;
     if (t->bwd_reduce < AGS_BWD_F32 || t->bwd_reduce > AGS_BWD_VALU) return false;
-    if (t->blend_group != 0 && t->blend_group != 16 && t->blend_group != 64) return false;
     return t->render_slots == 0 || t->render_slots == 1 || t->render_slots == 2 || t->render_slots == 4;
 }
 

@@ -343,143 +343,6 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
     AGS_TL(2, tl_w, 4);
 }
 
-// ---------------------------------------------------------------------------------------
-// Forward blend with FOUR surfels in flight per wave (AgsTuning.blend_group = 16).
-//
-// ags_k_render_fwd<1> walks the surfels that reach its 8x8 quadrant one at a time with all 64 lanes; a mapper-grown map at
-// the reference's 512x512 (config/simulator/habitat.yaml:8-9) has surfels of a few pixels: a blended (surfel, quadrant)
-// pair is taken by 24.6 of the 64 pixels and touches 2.5 of the quadrant's four 4x4 blocks (profiles/r04_h_lane_occupancy
-// .jsonl).  Here the wave's four 16-lane groups own one 4x4 block each and walk their OWN lists: the staging lane of a
-// surfel computes its reach per block (four exact box tests instead of one), a round's four block ballots become every
-// group's 64-bit work mask (a VGPR pair, group-uniform), and an iteration serves each group the next surfel of its own
-// mask - its record read from LDS with a group-uniform address, the list position (n_contrib) per group.  A round takes
-// as many iterations as its LONGEST block list instead of the union of the four.  Same images bit for bit: every pixel
-// still sees exactly the surfels that can reach it, in list order (the reach test is conservative and exact).
-// Price per iteration: the walk is vector work (find-first, clear, address: ~10 instructions the scalar unit did for free).
-template <int N>
-__device__ __forceinline__ uint32_t ags_stage_commit_g16(AgsWaveStageQ<1, N, false>& st, int lane, const AgsRec4& r, float qx0,
-                                                         float qy0, float2* oxy = nullptr) {
-    AgsGeom g;
-    g.mx = r.r0.x; g.my = r.r0.y; g.ca = r.r0.z; g.cb = r.r0.w; g.cc = r.r1.x; g.o = r.r1.y; g.dc = r.r1.z; g.gx = r.r1.w;
-    g.gy = r.r2.x;
-    AgsQuadShared sh;
-    ags_quad_shared(g, sh);
-    AgsStagedRec<1>& d = st.sg[lane];
-    d.a = make_float4(sh.E3, sh.E4, sh.E5, g.gx);
-    d.b = r.r2;
-    d.c = r.r3;
-    AgsQuadCoef q;
-    ags_quad_coeffs(g, qx0 + 3.5f, qy0 + 3.5f, q);
-    d.slot[0] = make_float4(q.E0, q.E1, q.E2, q.D0);
-    if (oxy) *oxy = make_float2(g.mx - (qx0 + 3.5f), g.my - (qy0 + 3.5f));
-    uint32_t m = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {            // block b of the quadrant sits at (b & 1, b >> 1), 4x4 pixels
-        const float x0 = qx0 + 4.f * (float)(b & 1), y0 = qy0 + 4.f * (float)(b >> 1);
-        m |= ags_reaches_box(g, x0, x0 + 3.f, y0, y0 + 3.f) ? (1u << b) : 0u;
-    }
-    return m;
-}
-
-// the 64-bit work mask of the lane's group from the round's four block ballots (group-uniform VGPR pair); `dm` = ballot of
-// the pixels that have stopped: a group whose 16 pixels all have takes nothing more.  `iters` (wave-uniform): the longest of
-// the four lists = the iterations the round needs.
-__device__ __forceinline__ unsigned long long ags_group_mask(uint32_t m, int grp, unsigned long long dm, int& iters) {
-    unsigned long long b0 = __ballot((m & 1u) != 0u), b1 = __ballot((m & 2u) != 0u), b2 = __ballot((m & 4u) != 0u),
-                       b3 = __ballot((m & 8u) != 0u);
-    if ((dm & 0xFFFFull) == 0xFFFFull) b0 = 0ull;
-    if (((dm >> 16) & 0xFFFFull) == 0xFFFFull) b1 = 0ull;
-    if (((dm >> 32) & 0xFFFFull) == 0xFFFFull) b2 = 0ull;
-    if ((dm >> 48) == 0xFFFFull) b3 = 0ull;
-    iters = max(max(__builtin_popcountll(b0), __builtin_popcountll(b1)), max(__builtin_popcountll(b2), __builtin_popcountll(b3)));
-    return (grp & 2) ? ((grp & 1) ? b3 : b2) : ((grp & 1) ? b1 : b0);
-}
-
-__global__ __launch_bounds__(64) void ags_k_render_fwd_g16(
-    AgsFrame F, int normalize_depth, const float* __restrict__ bgp, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom, AgsImages out,
-    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int num_tiles, uint32_t* __restrict__ tile_count,
-    uint32_t* __restrict__ tile_fill, AgsFinalize fin, uint32_t tile_cap, AgsViewStride vs) {
-    {
-        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws, po = (size_t)blockIdx.y * (size_t)vs.px;
-        AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(vals, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(final_T, wo);
-        AGS_WS_SHIFT(n_contrib, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(tile_fill, wo);
-        if (fin.status) { AGS_WS_SHIFT(fin.status, wo); AGS_WS_SHIFT(fin.partial, wo); }
-        out.rgb += 3 * po; out.normal += 3 * po; out.depth += po; out.opacity += po; out.confidence += po;
-    }
-    __shared__ AgsWaveStageQ<1, 64, false> st;
-    const int lane = threadIdx.x;
-    int slot, wave;
-    if (!ags_wave_block(blockIdx.x, num_tiles, 4, slot, wave)) return;
-    normalize_depth = ags_cfg_flag(F.cfg, 1, normalize_depth);
-    AGS_PRIO_HIGH();
-    if (fin.status && blockIdx.x == 0) ags_finalize_status(fin, num_tiles, lane);   // wave-uniform
-    uint32_t spec_id = 0;
-    if (tile_cap && (uint32_t)lane < tile_cap)
-        spec_id = vals[((size_t)slot * tile_cap + lane) * id_stride];
-    uint2 rg;
-    const int tile = ags_slot_tile(ranges, slot, tile_cap, rg);
-    const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
-    // quadrant `wave` of the tile sits at (wave & 1, wave >> 1); group g = lane >> 4 owns its 4x4 block (g & 1, g >> 1);
-    // lane j = lane & 15 of the group is pixel (j & 3, j >> 2) of the block
-    const int grp = lane >> 4, j = lane & 15;
-    const int lx = 4 * (grp & 1) + (j & 3), ly = 4 * (grp >> 1) + (j >> 2);
-    const int px = tx * AGS_TILE + 8 * (wave & 1) + lx, py = ty * AGS_TILE + 8 * (wave >> 1) + ly;
-    const float qx0 = (float)(tx * AGS_TILE + 8 * (wave & 1)), qy0 = (float)(ty * AGS_TILE + 8 * (wave >> 1));
-    if (wave == 0 && lane == 0) { tile_count[(size_t)tile * (tile_cap ? fin.tc_stride : 1u)] = 0u; tile_fill[tile] = 0u; }
-    const float qx = (float)lx - 3.5f, qy = (float)ly - 3.5f;
-    AgsPix pix;
-    const bool inside = (px < F.W) && (py < F.H);
-    ags_pix_init(pix, inside);
-    for (uint32_t base = rg.x; base < rg.y; base += 64) {
-        const unsigned long long dm = __ballot(pix.done != 0);
-        if (dm == ~0ull) break;
-        ags_wave_lds_sync();
-        const uint32_t idx = base + lane;
-        uint32_t m = 0;
-        if (idx < rg.y) {
-            const uint32_t gid = (tile_cap && base == rg.x) ? spec_id : vals[(size_t)idx * id_stride];
-            m = ags_stage_commit_g16<64>(st, lane, ags_stage_issue(geom, gid), qx0, qy0);
-        }
-        ags_wave_lds_sync();
-        int iters;
-        unsigned long long act = ags_group_mask(m, grp, dm, iters);
-        AGS_PRIO_LOOP();
-        const uint32_t pos_base = base - rg.x + 1;
-        for (int it = 0; it < iters; ++it) {     // (a scalar trip count: the longest of the four lists)
-            const bool has = act != 0ull;
-            const int k = has ? (__ffsll((long long)act) - 1) : 0;
-            act &= act - 1ull;
-            const AgsStagedRec<1>& g = st.sg[k];
-            const float4 ga = ags_lds_read16(&g.a), gs = ags_lds_read16(&g.slot[0]);   // E3, E4, E5, gx | E0, E1, E2, D0
-            const AgsQuadShared sh = {ga.x, ga.y, ga.z};
-            const AgsQuadCoef qc = {gs.x, gs.y, gs.z, gs.w};
-            const float a = ags_alpha_quad(sh, qc, qx, qy);
-            const bool take = has && a >= AGS_ALPHA_MIN && !pix.done;
-            // (straight-line: with four surfels in flight "no lane takes it" is rare, and a skip branch costs a register
-            // shuffle per accumulator on both paths)
-            const float al = take ? a : 0.f;
-            const float4 gb = ags_lds_read16(&g.b), gc = ags_lds_read16(&g.c);         // gy, r, g, b | nx, ny, nz, conf
-            const float dq = fmaf(gb.x, qy, ga.w * qx);
-            ags_blend_apply_q(pix, gb.y, gb.z, gb.w, gc.x, gc.y, gc.z, gc.w, gs.w + dq, al, pos_base + (uint32_t)k);
-        }
-    }
-    AGS_PRIO_HIGH();
-    if (inside) {
-        const float bg0 = bgp[0], bg1 = bgp[1], bg2 = bgp[2];
-        const size_t HW = (size_t)F.H * F.W;
-        const size_t o = (size_t)py * F.W + px;
-        const float T = pix.T, A = 1.f - T;
-        out.rgb[o] = pix.c0 + T * bg0; out.rgb[HW + o] = pix.c1 + T * bg1; out.rgb[2 * HW + o] = pix.c2 + T * bg2;
-        out.normal[o] = pix.n0; out.normal[HW + o] = pix.n1; out.normal[2 * HW + o] = pix.n2;
-        out.depth[o] = normalize_depth ? pix.d / fmaxf(A, AGS_DEPTH_A_EPS) : pix.d;
-        out.opacity[o] = A;
-        out.confidence[o] = pix.cf;
-        final_T[o] = T;
-        n_contrib[o] = pix.last;
-    }
-}
-
 #ifdef AGS_BWD_WAVES   // experiment knob: force a register budget for N resident waves per SIMD
 #define AGS_BWD_ATTR __attribute__((amdgpu_waves_per_eu(AGS_BWD_WAVES, AGS_BWD_WAVES)))
 #else
@@ -929,231 +792,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
     AGS_TL_VAL(3, tl_w, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32));
 }
 
-// ---------------------------------------------------------------------------------------
-// Blend backward with FOUR surfels in flight per wave (AgsTuning.blend_group = 16, exact f32 matrix form).
-//
-// Same idea as ags_k_render_fwd_g16 on the gather side: the wave's four 16-lane groups own one 4x4 block of the 8x8
-// quadrant each and walk their own back-to-front lists (32-bit work masks: a round stages 32 records), each trimmed to the
-// positions the block's pixels reached at all (the group's largest n_contrib).  The matrix-core reduction changes shape
-// with it: a parked row still holds one iteration's factor of all 64 pixels, but its four 16-pixel spans now belong to
-// four DIFFERENT surfels, so the contraction over pixels must not mix spans - accumulator g takes the four
-// v_mfma_f32_16x16x4_f32 whose K lanes are the pixels 16 g + 4 k + t (t = 0..3) of span g only: the same sixteen matrix
-// instructions per flush as ags_k_render_bwd_mfma<false>, four accumulators instead of two chains, and a flush covers
-// 8 iterations x 4 groups = 32 (surfel, block) pairs instead of 8 (surfel, quadrant) pairs.  Each pair leaves as its own
-// 64-byte atomic record (eight atomic instructions of four records per flush): the price of the scheme is MORE records
-// for surfels that span several blocks of a quadrant.  id and (mean - quadrant centre) of a staged surfel sit beside the
-// staged records (`extra`), the group's first lane copies them to the pair's slot when it parks the factors.
-struct AgsWaveBatchG {      // one per wave, in LDS: 2048 + 512 + 4352 + 512 = 7424 B -> six 1280-byte granules, 21 waves per CU
-    AgsStagedRec<1> sg[AGS_MFMA_STAGE];
-    float4 extra[AGS_MFMA_STAGE];   // staged surfel: {mean.x - quadrant centre.x, mean.y - centre.y, id (bits), -}
-    float gw[16][68];               // row 2 i: gp of iteration slot i (64 pixels = 4 spans of 4 surfels), row 2 i + 1: its w
-    float4 pairs[8][4];             // (iteration slot, group): {ox, oy, id (bits; ~0 = nothing parked), -}
-};
-
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void ags_k_render_bwd_mfma_g16(
-    AgsFrame F, int normalize_depth, const float* __restrict__ bgp, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
-    const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
-    const uint32_t* __restrict__ n_contrib, AgsImageGrads dout, float* __restrict__ dgeom, int num_tiles,
-    AgsTick tick, uint32_t tile_cap, AgsViewStride vs) {
-    {
-        const size_t wo = (size_t)blockIdx.y * (size_t)vs.ws, po = (size_t)blockIdx.y * (size_t)vs.px;
-        AGS_WS_SHIFT(ranges, wo); AGS_WS_SHIFT(vals, wo); AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(final_T, wo);
-        AGS_WS_SHIFT(n_contrib, wo); AGS_WS_SHIFT(dgeom, wo);
-        depth_out += po; opac_out += po;
-        if (dout.d_rgb) dout.d_rgb += 3 * po;
-        if (dout.d_normal) dout.d_normal += 3 * po;
-        if (dout.d_depth) dout.d_depth += po;
-        if (dout.d_opacity) dout.d_opacity += po;
-        if (dout.d_confidence) dout.d_confidence += po;
-    }
-    __shared__ AgsWaveBatchG wb;
-    static_assert(sizeof(AgsWaveBatchG) <= 7680, "the grouped blend backward's LDS per wave: six 1280-byte granules");
-    static_assert(AGS_MFMA_STAGE == 32, "32-bit work masks: a round stages 32 records");
-    const int lane = threadIdx.x;
-    int slot, wave;
-    if (!ags_wave_block(blockIdx.x, num_tiles, 4, slot, wave)) return;
-    normalize_depth = ags_cfg_flag(F.cfg, 1, normalize_depth);
-    AgsWaveStageQ<1, AGS_MFMA_STAGE, false>& st = *reinterpret_cast<AgsWaveStageQ<1, AGS_MFMA_STAGE, false>*>(&wb.sg[0]);
-    if (tick.clock && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        ags_adam_tick(tick.clock, tick.lr, tick.beta1, tick.beta2);
-        if (tick.count_snap) *tick.count_snap = (uint32_t)*tick.rows_count;
-    }
-    AGS_PRIO_HIGH();
-    uint32_t gid_early = 0;
-    if (tile_cap && lane < AGS_MFMA_STAGE && (uint32_t)lane < tile_cap)
-        gid_early = vals[((size_t)slot * tile_cap + lane) * id_stride];
-    uint2 rg;
-    const int tile = ags_slot_tile(ranges, slot, tile_cap, rg);
-    if (rg.y <= rg.x) return;
-    const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
-    // group g = lane >> 4 owns block (g & 1, g >> 1) of quadrant `wave`; lane j of the group is pixel (j & 3, j >> 2)
-    const int grp = lane >> 4, j = lane & 15;
-    const int lx = 4 * (grp & 1) + (j & 3), ly = 4 * (grp >> 1) + (j >> 2);
-    const int px = tx * AGS_TILE + 8 * (wave & 1) + lx, py = ty * AGS_TILE + 8 * (wave >> 1) + ly;
-    const float qx0 = (float)(tx * AGS_TILE + 8 * (wave & 1)), qy0 = (float)(ty * AGS_TILE + 8 * (wave >> 1));
-    const float bg[3] = {bgp[0], bgp[1], bgp[2]};
-    const size_t HW = (size_t)F.H * F.W;
-    const uint32_t list_len = rg.y - rg.x;
-    const bool early = AGS_EARLY_GATHER && list_len <= (uint32_t)AGS_MFMA_STAGE;   // wave-uniform
-    if (!tile_cap && early && lane < (int)list_len) gid_early = vals[(size_t)(rg.x + lane) * id_stride];
-    AgsPixGrad pg;
-    AgsRec4 rec_early = {};
-    {
-        float dC[3] = {0, 0, 0}, dN[3] = {0, 0, 0}, dD = 0, dO = 0, dCf = 0, dep = 0, opa = 0, Tf = 1.f;
-        uint32_t last = 0;
-        if (px < F.W && py < F.H) {
-            const size_t o = (size_t)py * F.W + px;
-            last = n_contrib[o];
-            if (dout.d_rgb) { dC[0] = dout.d_rgb[o]; dC[1] = dout.d_rgb[HW + o]; dC[2] = dout.d_rgb[2 * HW + o]; }
-            if (dout.d_normal) { dN[0] = dout.d_normal[o]; dN[1] = dout.d_normal[HW + o]; dN[2] = dout.d_normal[2 * HW + o]; }
-            if (dout.d_depth) dD = dout.d_depth[o];
-            if (dout.d_opacity) dO = dout.d_opacity[o];
-            if (dout.d_confidence) dCf = dout.d_confidence[o];
-            dep = depth_out[o]; opa = opac_out[o]; Tf = final_T[o];
-        }
-        if (early && lane < (int)list_len) rec_early = ags_stage_issue(geom, gid_early);
-        if (!last) { dC[0] = dC[1] = dC[2] = dN[0] = dN[1] = dN[2] = dD = dO = dCf = dep = opa = 0.f; Tf = 1.f; }
-        ags_pixgrad_init(pg, dC, dN, dD, dO, dCf, dep, opa, Tf, last, bg, normalize_depth);
-    }
-    uint32_t m_early = 0;
-    if (early && lane < (int)list_len) {
-        float2 oxy;
-        m_early = ags_stage_commit_g16<AGS_MFMA_STAGE>(st, lane, rec_early, qx0, qy0, &oxy);
-        wb.extra[lane] = make_float4(oxy.x, oxy.y, __uint_as_float(gid_early), 0.f);
-    }
-    const uint32_t maxlast = ags_wave_max_u32(pg.last);
-    if (maxlast == 0) return; // wave-uniform
-    // the largest list position any pixel of the lane's BLOCK reached: the group walks nothing behind it
-    uint32_t gmax = pg.last;
-    gmax = max(gmax, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gmax, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    gmax = max(gmax, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gmax, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    gmax = max(gmax, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gmax, 0x141, 0xF, 0xF, true));  // row_half_mirror
-    gmax = max(gmax, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gmax, 0x140, 0xF, 0xF, true));  // row_mirror
-
-    // ---- B operands: feature (lane & 15) of the pixels 16 g + 4 (lane >> 4) + t, t = 0..3, for the four spans g ----
-    const int fld = lane & 15, kgrp = lane >> 4;
-    const float qx = (float)lx - 3.5f, qy = (float)ly - 3.5f;   // the lane's pixel about the quadrant centre
-    float FE[16] = {};
-    {
-        float* ex = &wb.gw[0][0];
-        const float feat[16] = {qx, qy, qx * qx, qx * qy, qy * qy, 1.f, pg.dDn, pg.dDn * qx, pg.dDn * qy,
-                                pg.dC0, pg.dC1, pg.dC2, pg.dN0, pg.dN1, pg.dN2, 0.f};
-#pragma unroll
-        for (int f = 0; f < 15; ++f) ex[f * 68 + lane] = feat[f];
-        ags_wave_lds_sync();
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (fld < 15) v = *reinterpret_cast<const float4*>(ex + fld * 68 + 16 * g + 4 * kgrp);
-            FE[4 * g] = v.x; FE[4 * g + 1] = v.y; FE[4 * g + 2] = v.z; FE[4 * g + 3] = v.w;
-        }
-        ags_wave_lds_sync();
-    }
-    const float gx1 = fld == 0 ? 1.f : 0.f, gy1 = fld == 1 ? 1.f : 0.f;
-    const float kxx = fld == 2 ? 1.f : 0.f, kxy = fld == 3 ? 1.f : 0.f, kyy = fld == 4 ? 1.f : 0.f;
-    const float mYx = fld == 2 ? 2.f : 0.f, mYy = fld == 3 ? 1.f : 0.f, mZx = fld == 3 ? 1.f : 0.f, mZy = fld == 4 ? 2.f : 0.f;
-    const float wx1 = fld == 7 ? 1.f : 0.f, wy1 = fld == 8 ? 1.f : 0.f;
-    int nb = 0; // filled iteration slots (wave-uniform)
-
-    auto flush = [&]() {
-        ags_wave_lds_sync();
-        ags_f32x4 acc[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = ags_f32x4{0.f, 0.f, 0.f, 0.f};
-        float4 col[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) col[g] = *reinterpret_cast<const float4*>(&wb.gw[fld][16 * g + 4 * kgrp]);
-        // t-major: four independent accumulators back to back (a dependent matrix instruction waits longer)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(col[g].x, FE[4 * g], acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(col[g].y, FE[4 * g + 1], acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(col[g].z, FE[4 * g + 2], acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(col[g].w, FE[4 * g + 3], acc[g], 0, 0, 0);
-        // lane: field fld of rows 4 kgrp + r = (gp, w) of iteration slots 2 kgrp and 2 kgrp + 1, for each span g
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int sl = 2 * kgrp + h;
-                const float4 pr = wb.pairs[sl][g];
-                const float ox = pr.x, oy = pr.y;
-                const uint32_t sid = __float_as_uint(pr.z);
-                const float gpv = acc[g][2 * h];
-                const float R0 = ags_dpp_f<0x150 + 5>(gpv);
-                const float R1x = ags_dpp_f<0x150 + 0>(gpv);
-                const float R1y = ags_dpp_f<0x150 + 1>(gpv);
-                const float c0 = gx1 * ox + gy1 * oy - (kxx * ox * ox + kxy * ox * oy + kyy * oy * oy);
-                const float outg = gpv - c0 * R0 - (mYx * ox + mYy * oy) * R1x - (mZx * ox + mZy * oy) * R1y;
-                const float wv = acc[g][2 * h + 1];
-                const float Q0 = ags_dpp_f<0x150 + 6>(wv);
-                const float outw = wv - (wx1 * ox + wy1 * oy) * Q0;
-                if (sl < nb && sid != 0xFFFFFFFFu && fld < 15) unsafeAtomicAdd(dgeom + (size_t)sid * 16 + fld, fld < 6 ? outg : outw);
-            }
-        }
-        ags_wave_lds_sync();
-        nb = 0;
-    };
-
-    for (int r = (int)((maxlast - 1) >> 5); r >= 0; --r) {
-        const uint32_t k0 = (uint32_t)r << 5;
-        ags_wave_lds_sync();
-        uint32_t m = 0;
-        if (early) {
-            if (lane < (int)maxlast) m = m_early;
-        } else if (lane < AGS_MFMA_STAGE && k0 + lane < maxlast) {
-            const uint32_t gid = vals[(size_t)(rg.x + k0 + lane) * id_stride];
-            float2 oxy;
-            m = ags_stage_commit_g16<AGS_MFMA_STAGE>(st, lane, ags_stage_issue(geom, gid), qx0, qy0, &oxy);
-            wb.extra[lane] = make_float4(oxy.x, oxy.y, __uint_as_float(gid), 0.f);
-        }
-        ags_wave_lds_sync();
-        // the group's work mask (32 staged records), trimmed to the positions its block reached
-        const uint32_t b0 = (uint32_t)__ballot((m & 1u) != 0u), b1 = (uint32_t)__ballot((m & 2u) != 0u),
-                       b2 = (uint32_t)__ballot((m & 4u) != 0u), b3 = (uint32_t)__ballot((m & 8u) != 0u);
-        uint32_t act = (grp & 2) ? ((grp & 1) ? b3 : b2) : ((grp & 1) ? b1 : b0);
-        const uint32_t room = gmax > k0 ? gmax - k0 : 0u;                  // staged positions k < room are within reach
-        act &= room >= 32u ? 0xFFFFFFFFu : ((1u << room) - 1u);
-        const int iters = (int)ags_wave_max_u32((uint32_t)__builtin_popcount(act));   // the longest of the four lists
-        AGS_PRIO_LOOP();
-        for (int it = 0; it < iters; ++it) {
-            const bool has = act != 0u;
-            const int k = has ? (31 - __builtin_clz(act)) : 0;           // back to front: highest staged position first
-            act &= ~(1u << k);
-            const AgsStagedRec<1>& g = st.sg[k];
-            const uint32_t pos1 = k0 + (uint32_t)k + 1u;
-            const float4 ga = ags_lds_read16(&g.a), gs = ags_lds_read16(&g.slot[0]);   // E3, E4, E5, gx | E0, E1, E2, D0
-            const AgsQuadShared sh = {ga.x, ga.y, ga.z};
-            const AgsQuadCoef qc = {gs.x, gs.y, gs.z, gs.w};
-            const float a = ags_alpha_quad(sh, qc, qx, qy);
-            const bool take = has && a >= AGS_ALPHA_MIN && pos1 <= pg.last;
-            const float alpha = take ? a : 0.f;
-            const float iom = ags_rcp(1.f - alpha);
-            pg.T = pg.T * iom;
-            const float w = alpha * pg.T;
-            const float4 gb = ags_lds_read16(&g.b), gc = ags_lds_read16(&g.c);         // gy, r, g, b | nx, ny, nz, conf
-            const float dpix = fmaf(gb.x, qy, fmaf(ga.w, qx, gs.w));
-            const float gsum = pg.dC0 * gb.y + pg.dC1 * gb.z + pg.dC2 * gb.w + pg.dN0 * gc.x + pg.dN1 * gc.y + pg.dN2 * gc.z
-                             + pg.dDn * dpix + pg.dCf * gc.w + pg.dA;
-            const float dalpha = pg.T * gsum - pg.S * iom;
-            pg.S += w * gsum;
-            const float gp = (alpha < AGS_ALPHA_MAX) ? alpha * dalpha : 0.f;
-            wb.gw[2 * nb][lane] = gp;
-            wb.gw[2 * nb + 1][lane] = w;
-            if (j == 0) {          // the group's first lane: id and offset of the group's surfel ride with the parked factors
-                float4 e = wb.extra[k];
-                if (!has) e.z = __uint_as_float(0xFFFFFFFFu);
-                wb.pairs[nb][grp] = e;
-            }
-            if (++nb == 8) flush();
-        }
-    }
-    if (nb) flush();
-}
-
 // How many strips per wave: one wave per tile when the image has enough tiles to fill the
 // 1024 SIMDs several times over, otherwise split tiles over more waves.
 static int ags_pick_slots(int num_tiles, const AgsTuning& tune) {
@@ -1202,16 +840,6 @@ static void launch_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs,
                            bool direct, hipStream_t s) {
-    // AgsTuning.blend_group = 16: four surfels in flight per wave, one per 4x4 block (views without statistics)
-    if (L.tune.blend_group == 16 && !cam.want_stats && !cam.config) {
-        AgsFinalize fin = {nullptr, nullptr, 0u, 1u};
-        if (direct) fin = AgsFinalize{(uint32_t*)(ws + L.status), (uint32_t*)(ws + L.totals), ags_direct_tile_cap(L), (uint32_t)L.tc_stride};
-        hipLaunchKernelGGL(ags_k_render_fwd_g16, dim3(8 * ags_wave_blocks_per_xcd(L.num_tiles, 4), vs.views), dim3(64), 0, s, F,
-                           cam.normalize_depth, cam.bg, (const uint2*)(ws + L.ranges), ids.ids, ids.stride,
-                           (const AgsGeom*)(ws + L.geom), out, (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib), L.num_tiles,
-                           (uint32_t*)(ws + L.tile_count), (uint32_t*)(ws + L.tile_fill), fin, direct ? ags_direct_tile_cap(L) : 0u, vs);
-        return;
-    }
     // strips per wave by the number of tiles in flight: a batch of views fills the GPU like one big image
     switch (ags_pick_slots(L.num_tiles * vs.views, L.tune)) {
         case 1: launch_fwd<1>(F, cam, ws, L, ids, out, pg, vs, direct, s); break;
@@ -1225,13 +853,6 @@ void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
                            const AgsViewStride& vs, bool direct, hipStream_t s) {
     const uint32_t tile_cap = direct ? ags_direct_tile_cap(L) : 0u;
     // AgsTuning.bwd_reduce: exact f32 matrix instructions (default), the bf16 hi/lo split, or no matrix instructions
-    if (L.tune.blend_group == 16 && L.tune.bwd_reduce == AGS_BWD_F32) {   // four surfels in flight per wave (exact f32 form only)
-        hipLaunchKernelGGL(ags_k_render_bwd_mfma_g16, dim3(8 * ags_wave_blocks_per_xcd(L.num_tiles, 4), vs.views), dim3(64), 0, s, F,
-                           cam.normalize_depth, cam.bg, (const uint2*)(ws + L.ranges), ids.ids, ids.stride,
-                           (const AgsGeom*)(ws + L.geom), fwd.depth, fwd.opacity, (const float*)(ws + L.final_T),
-                           (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick, tile_cap, vs);
-        return;
-    }
     if (L.tune.bwd_reduce != AGS_BWD_VALU) {
 #define AGS_LAUNCH_BWD_MFMA(BF16)                                                                                         \
     hipLaunchKernelGGL(ags_k_render_bwd_mfma<BF16>, dim3(8 * ags_wave_blocks_per_xcd(L.num_tiles, 4), vs.views), dim3(64), 0, s, F, \

@@ -102,7 +102,7 @@ def _load_binding():
     mod.set_option("always_check", 0.0 if mode == "deferred" else 1.0)
     # the library reads no environment variable: this binding hands it the process's kernel selection (AgsTuning)
     t = _lib.default_tuning()
-    mod.set_tuning(t.bwd_reduce, t.render_slots, t.cull_first_min_n, t.tile_sort_no_wave, t.bucket_no_scan, t.blend_group)
+    mod.set_tuning(t.bwd_reduce, t.render_slots, t.cull_first_min_n, t.tile_sort_no_wave, t.bucket_no_scan)
     _binding = mod
     return mod
 
@@ -144,7 +144,7 @@ def check_overflow() -> None:
 def set_tuning(tuning: "_lib.AgsTuning") -> None:
     """The kernel selection the module hands to the library with every workspace (default: _lib.default_tuning())."""
     _load_binding().set_tuning(tuning.bwd_reduce, tuning.render_slots, tuning.cull_first_min_n, tuning.tile_sort_no_wave,
-                               tuning.bucket_no_scan, tuning.blend_group)
+                               tuning.bucket_no_scan)
 
 
 import threading as _threading

@@ -211,11 +211,7 @@ typedef struct AgsTuning {
                                 * culls on the means first; < 0 = never; 1 = always */
     int32_t tile_sort_no_wave; /* != 0: AGS_BIN_DIRECT always sorts with the 256-thread kernel (never one wave per tile) */
     int32_t bucket_no_scan;    /* != 0: AGS_BIN_TILE_SORT always runs the separate tile-scan launch */
-    int32_t blend_group;       /* lanes that share a surfel in the blend loops: 0 / 64 = the whole wave (one surfel per iteration over
-                                * an 8x8 quadrant); 16 = four surfels in flight per wave, each over one 4x4 block - for views whose
-                                * surfels are a few pixels wide (a mapper-grown map at 512x512); same images, same gradients up to
-                                * the order of the float sums */
-    int32_t reserved[2];       /* 0 */
+    int32_t reserved[3];       /* 0 */
 } AgsTuning;
 
 typedef struct AgsWorkspace {

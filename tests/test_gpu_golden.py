@@ -246,7 +246,7 @@ def test_bf16_split_backward_passes_the_same_fixtures(agslib):
     env = dict(os.environ, AGS_BWD_REDUCE="bf16")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_golden.py"),
                         os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
-                        "not valu_backward and not two_quadrants and not bf16_split and not blend_group and (oracle or train or properties or c4_size or c5_size "
+                        "not valu_backward and not two_quadrants and not bf16_split and (oracle or train or properties or c4_size or c5_size "
                         "or row_set or batched_backward or overfull or alpha_clamp)"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
@@ -264,7 +264,7 @@ def test_valu_backward_passes_the_same_fixtures(agslib):
     env = dict(os.environ, AGS_BWD_MFMA="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_golden.py"),
                         os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
-                        "not valu_backward and not two_quadrants and not bf16_split and not blend_group and (oracle or train or properties or c4_size or c5_size or row_set or batched_backward "
+                        "not valu_backward and not two_quadrants and not bf16_split and (oracle or train or properties or c4_size or c5_size or row_set or batched_backward "
                         "or overfull or alpha_clamp)"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
@@ -284,55 +284,8 @@ def test_two_quadrants_per_wave_kernels_pass_the_same_fixtures(agslib):
     env = dict(os.environ, AGS_RENDER_SLOTS="2")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_golden.py"),
                         os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
-                        "not valu_backward and not two_quadrants and not bf16_split and not blend_group and (oracle or train or properties or c4_size or c5_size or row_set "
+                        "not valu_backward and not two_quadrants and not bf16_split and (oracle or train or properties or c4_size or c5_size or row_set "
                         "or batched_backward or overfull or alpha_clamp or argument_variants)"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert " passed" in r.stdout
-
-
-def test_blend_group_16_kernels_pass_the_same_fixtures(agslib):
-    """AgsTuning.blend_group = 16: the blend loops keep FOUR surfels in flight per wave, one per 4x4 block of the wave's 8x8
-    quadrant (every 16-lane group walks its own list of the surfels that reach its block) instead of one surfel over all 64
-    lanes - for views whose surfels are a few pixels wide (a mapper-grown map at the reference's 512x512).  In-process: the
-    forward's images, n_contrib and final_T are BIT-IDENTICAL to the default's on scenes with small and with large
-    footprints (every pixel still blends exactly the surfels that reach it, in list order), the backward's gradients agree
-    up to the order of the float sums.  Then the reference fixtures and every oracle comparison re-run with the switch on
-    (read once per process, hence the subprocess)."""
-    import subprocess
-    import sys
-    from active_gs_amd import _lib, raster_api as api
-    from _scenes import oracle_inputs, room_case
-    dev = torch.device("cuda:0")
-    for (n, h, w, view, mult) in ((5000, 170, 300, 1, 2.0), (20000, 512, 512, 2, 0.6), (3000, 96, 128, 0, 8.0)):
-        a, S = room_case(n, h, w, view=view, seed=view + 3, scale_mult=mult)
-        ins = [t.to(dev) for t in oracle_inputs(a, requires_grad=False)]
-        g = api.Gaussians(ins[0], ins[5].contiguous(), ins[6], ins[2].reshape(-1).contiguous(), ins[4], ins[3])
-        cam = api.Camera(h, w, S.tanfovx, S.tanfovy, S.viewmatrix.to(dev), S.projmatrix.to(dev), S.bg.to(dev))
-        gen = torch.Generator().manual_seed(0)
-        d = [torch.randn(c, h, w, generator=gen).to(dev) for c in (3, 3, 1)]
-        res = {}
-        for grp in (64, 16):
-            st = api.alloc_state(n, h, w, 1 << 21, dev, tuning=_lib.make_tuning(blend_group=grp))
-            api.forward(cam, g, st)
-            assert not api.read_status(st)["overflow"]
-            imgs = [getattr(st, k).clone() for k in ("rgb", "normal", "depth", "opacity", "confidence")]
-            imgs.append(api.workspace_region(st, n, h, w, api.REGION_N_CONTRIB, torch.int32).clone())
-            imgs.append(api.workspace_region(st, n, h, w, api.REGION_FINAL_T, torch.float32).clone())
-            res[grp] = (imgs, api.backward(cam, g, st, *d))
-        for x, y in zip(res[16][0], res[64][0]):
-            assert torch.equal(x, y)
-        assert float(res[64][0][3].max()) > 0.5
-        for name in ("means3D", "scales", "rotations", "opacities", "colors"):
-            x, y = getattr(res[16][1], name), getattr(res[64][1], name)
-            rel = float((x - y).abs().sum() / y.abs().sum())
-            assert rel < 2e-5, (name, rel)
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, AGS_BLEND_GROUP="16")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_golden.py"),
-                        os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
-                        "not valu_backward and not two_quadrants and not bf16_split and not blend_group and (oracle or train or "
-                        "properties or c4_size or c5_size or row_set or batched_backward or overfull or alpha_clamp or argument_variants)"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout
