@@ -87,8 +87,9 @@ def voxel_select(points: torch.Tensor, select: torch.Tensor, voxel: float = VOXE
     return select
 
 
-def compact_plan(keep: torch.Tensor) -> Tuple[torch.Tensor, int]:
-    """(dst_index, number of kept rows) - the one host read of the operation."""
+def compact_plan(keep: torch.Tensor, before_sync=None) -> Tuple[torch.Tensor, int]:
+    """(dst_index, number of kept rows) - the one host read of the operation.  ``before_sync``: see add_gaussians
+    (True -> (dst_index, None))."""
     lib = _lib.load()
     n = keep.shape[0]
     dst = torch.empty(max(n, 1), device=keep.device, dtype=torch.int32)
@@ -96,6 +97,8 @@ def compact_plan(keep: torch.Tensor) -> Tuple[torch.Tensor, int]:
     scratch = torch.empty(int(lib.ags_compact_plan_bytes(n)), device=keep.device, dtype=torch.uint8)
     _lib.check(lib.ags_compact_plan(n, ptr(keep), ptr(dst), ptr(total), ptr(scratch), scratch.numel(), _stream()),
                "ags_compact_plan")
+    if before_sync is not None and before_sync():
+        return dst, None
     return dst, int(total.item())
 
 
@@ -160,13 +163,18 @@ class MapArena:
 
 
 def add_gaussians(state: Dict[str, torch.Tensor], frame: dict, pred: Optional[dict], error_thres: float,
-                  arena: Optional[MapArena] = None) -> Tuple[Dict[str, torch.Tensor], int]:
+                  arena: Optional[MapArena] = None, before_sync=None):
     """``GaussianMap.add_gaussians`` (gaussian_map.py:294-462).  Returns (grown state, rows added).  With an ``arena`` the
-    grown state is the arena's leading rows (no copy of the old map when it already lives there)."""
+    grown state is the arena's leading rows (no copy of the old map when it already lives there).
+    ``before_sync`` (optional callable -> bool): called right before the one host read of the operation (the row count),
+    when everything up to it is enqueued; if it returns True the map has changed under this call and nothing is appended
+    (returns None: the caller starts over)."""
     ds = smooth_depth(frame["depth"])
     c = candidates(frame, ds, pred, error_thres)
     voxel_select(c["means"], c["select"])
-    dst_index, k = compact_plan(c["select"])
+    dst_index, k = compact_plan(c["select"], before_sync=before_sync)
+    if k is None:
+        return None
     n = state["means"].shape[0]
     dev = c["means"].device
     if arena is not None:

@@ -7,6 +7,8 @@ no per-view host synchronisation in the loop.
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional
 
 import torch
@@ -47,6 +49,7 @@ class FusedMapTrainer(GaussianMapTrainer):
     # the losses of the last train() call: kept on the device by the batched loop and read when somebody asks
     @property
     def last_losses(self):
+        self.settle()
         if self._losses_dev is not None:
             self._losses_host, self._losses_dev = [float(x) for x in self._losses_dev.cpu()], None
         return self._losses_host
@@ -93,6 +96,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         self._loss_bufs = []
         self._cap = 0
         self._last_need, self._last_need_n = None, 0   # most tile instances a view of the last train() call needed, and the map size then
+        self._pending_check = None   # settle(): a train() call whose workspace check has not been looked at yet
         self.is_init = len(frames) > 0 and self.means.shape[0] > 0   # gaussian_map.py:35,130
 
     # ---- the keyframes' images and matrices as ONE growing set of arrays the sampled batch is gathered from on the
@@ -286,10 +290,15 @@ class FusedMapTrainer(GaussianMapTrainer):
         import numpy as np
         # into buffers kept across calls, as ONE multi-tensor copy (six clones are six allocations and six launches with the
         # GPU idle behind them)
-        keys = ("means", "scales", "rotations", "opacities", "harmonics", "training_performance")
+        # (the view statistics too: a call whose check is deferred has its post-processing enqueued before anybody knows
+        # whether the call stands - settle())
+        keys = ("means", "scales", "rotations", "opacities", "harmonics", "training_performance", "view_supports", "view_means",
+                "view_scores")
+        for k in keys[6:]:
+            setattr(self, k, getattr(self, k).float().contiguous())
         src = [getattr(self, k) for k in keys]
         bufs = self._snap_bufs
-        if (bufs is None or any(b.shape[0] < t.shape[0] or b.shape[1:] != t.shape[1:] or b.dtype != t.dtype or b.device != t.device
+        if (bufs is None or len(bufs) != len(src) or any(b.shape[0] < t.shape[0] or b.shape[1:] != t.shape[1:] or b.dtype != t.dtype or b.device != t.device
                                 for b, t in zip(bufs, src))):
             bufs = self._snap_bufs = [torch.empty((max(2 * t.shape[0], 64),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
                                       for t in src]
@@ -310,7 +319,8 @@ class FusedMapTrainer(GaussianMapTrainer):
 
     def _restore(self, snap: dict) -> None:
         import numpy as np
-        for k in ("means", "scales", "rotations", "opacities", "harmonics", "training_performance"):
+        for k in ("means", "scales", "rotations", "opacities", "harmonics", "training_performance", "view_supports", "view_means",
+                  "view_scores"):
             getattr(self, k).copy_(snap[k])
         if snap["np_rng"] is not None:
             np.random.set_state(snap["np_rng"])
@@ -328,6 +338,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         raise RuntimeError("train(): the rasterizer workspace kept overflowing after six enlargements")
 
     def train(self, steps: Optional[int] = None):
+        self.settle()
         if self.batched and self._uniform_frames():
             return self.train_batched(steps)
         self._all_or_nothing(self._train_views, steps)
@@ -455,6 +466,10 @@ class FusedMapTrainer(GaussianMapTrainer):
         return out
 
     def post_processing(self):
+        self.settle()
+        return self._post_processing()
+
+    def _post_processing(self):
         """The reference's rule (count render of the newest keyframe, or of ALL keyframes every prune_interval-th frame;
         supports / view means / view scores of the surfels the newest frame sees; prune what no keyframe sees) with the
         per-surfel bookkeeping as one launch (``ags_view_stats_update``) and the ground-truth depths taken from the
@@ -483,7 +498,8 @@ class FusedMapTrainer(GaussianMapTrainer):
         api.forward(cam, g, st)
         return dict(cam=cam, g=g, n=n, hw=(h, w))
 
-    def _post_processing_end(self, pending):
+    def _post_processing_end(self, pending, check: bool = True):
+        """``check`` False (a call whose workspace check is deferred, settle()): the count render's status is not read here."""
         if self.world > 1 or not self.means.is_cuda or self.means.shape[0] == 0 or not self._uniform_frames():
             return super().post_processing()
         from . import _lib
@@ -492,7 +508,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         prune_now = k % self.cfg["prune_interval"] == 0
         n = self.means.shape[0]
         if pending is not None and not prune_now and pending["n"] == n:
-            while not self._check_capacity(["count"]):       # (the GPU has drained by now: this read does not wait)
+            while check and not self._check_capacity(["count"]):       # (the GPU has drained by now: this read does not wait)
                 st = self._state("count", n, *pending["hw"])
                 api.forward(pending["cam"], pending["g"], st)
             newest = self._states["count"].count
@@ -624,14 +640,22 @@ class FusedMapTrainer(GaussianMapTrainer):
             g = self._gaussians()
             while True:
                 # the render's capacity check rides on the read-back densify needs anyway (its row count): one wait for
-                # the GPU per keyframe here instead of two; an outgrown workspace (rare) repeats both
+                # the GPU per keyframe here instead of two; an outgrown workspace (rare) repeats both.  The previous train()
+                # call's pending check (settle()) is looked at at that same wait: everything up to here - the render, the
+                # smoothing, the candidates, the voxel filter - was enqueued behind that call's iterations without waiting.
                 st = self._state("densify", n, h, w)
                 api.forward(cam, g, st)
                 pred = dict(rgb=st.rgb, depth=st.depth[0], opacity=st.opacity[0])
-                state, added = densify.add_gaussians(self._map_state(), frame, pred, self.cfg["error_thres"], arena=self._map_arena())
+                grown = densify.add_gaussians(self._map_state(), frame, pred, self.cfg["error_thres"], arena=self._map_arena(),
+                                              before_sync=self.settle)
+                if grown is None:            # the pending call was repeated: the map is not what this render showed
+                    g = self._gaussians()
+                    continue
+                state, added = grown
                 if self._check_capacity(["densify"]):
                     break
         else:
+            self.settle()
             state, added = densify.add_gaussians(self._map_state(), frame, pred, self.cfg["error_thres"], arena=self._map_arena())
         self._set_map_state(state)
         self.frames.append(frame)
@@ -665,6 +689,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         self.is_init = True
 
     def prune(self, mask):
+        self.settle()
         state, deleted = densify.prune(self._map_state(), mask, arena=self._map_arena())
         self._set_map_state(state)
         return deleted
@@ -692,12 +717,37 @@ class FusedMapTrainer(GaussianMapTrainer):
         """All-or-nothing like every train() here, with ONE wait at its end: the loop's iterations and the count render of
         post_processing are enqueued back to back, then the sticky status words of the loop's views and the count
         render's status are read together (round 3 waited for the loop, then again for the count render)."""
+        self.settle()
         self._phase("set-up")
         snap = self._snapshot()
-        for _ in range(6):
+        self._train_batched_checked(steps, snap, 6, defer_ok=True)
+
+    # The wait of a train() call - did any pass of any iteration, or the count render, outgrow its workspace? - keeps the
+    # GPU idle for as long as the host then needs to enqueue what follows it: the view statistics, and the next keyframe's
+    # render / candidates up to ITS read-back.  On keyframes that do not prune the call therefore returns with the check
+    # PENDING: the status words are copied to page-locked memory behind the count render, the view-statistics update is
+    # enqueued at once, and ``settle()`` looks at the words at the next point that waits for the GPU anyway (the row count
+    # of the next add_gaussians) - or when anybody reads the map (GaussianMap's attributes, last_losses, save).  A call
+    # that did overflow (rare: workspaces carry head-room) is then repeated from its snapshot - parameters, per-frame
+    # errors, view statistics, random streams - exactly as the immediate check would have repeated it.
+    DEFER_SETTLE = os.environ.get("AGS_MAPPER_DEFER_SETTLE", "1") != "0"
+
+    def _train_batched_checked(self, steps, snap, attempts: int, defer_ok: bool = False) -> None:
+        for attempt in range(attempts):
             settle = self._train_batched(steps, defer=True)
             self._phase("post")
             pending = self._post_processing_begin()
+            if defer_ok and attempt == 0 and self.DEFER_SETTLE and pending is not None and settle.batch is not None:
+                words_b = self._words_async(settle.batch.status_words())
+                count_state = self._states["count"]
+                words_c = self._words_async(count_state.workspace[:32].view(torch.int32).view(1, 8))
+                self._post_processing_end(pending, check=False)          # the view statistics, enqueued unchecked
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending_check = dict(event=ev, words_b=words_b, words_c=words_c, count_cap=count_state.max_instances,
+                                           snap=snap, steps=steps, settle=settle)
+                self._phase("between")
+                return
             if settle():
                 self._post_processing_end(pending)
                 self._phase("between")
@@ -705,6 +755,33 @@ class FusedMapTrainer(GaussianMapTrainer):
             self.overflow_retries = getattr(self, "overflow_retries", 0) + 1
             self._restore(snap)
         raise RuntimeError("train(): the rasterizer workspace kept overflowing after six enlargements")
+
+    def _words_async(self, words_dev: torch.Tensor) -> torch.Tensor:
+        """(V, 8) int32 status words -> page-locked host tensor, copy enqueued on the current stream (no wait)"""
+        host = torch.empty(tuple(words_dev.shape), dtype=torch.int32).pin_memory()
+        host.copy_(words_dev, non_blocking=True)
+        return host
+
+    def settle(self) -> bool:
+        """Look at the workspace check a train() call left pending (see DEFER_SETTLE); repeats the call if it overflowed.
+        Returns True when a call was repeated (the map's parameters are then not what they were a moment ago).  Cheap when
+        nothing is pending; waits for the GPU otherwise."""
+        p = self._pending_check
+        if p is None:
+            return False
+        self._pending_check = None
+        p["event"].synchronize()
+        ok = p["settle"].evaluate((p["words_b"].to(torch.int64)) & 0xFFFFFFFF)
+        wc = (p["words_c"].to(torch.int64)) & 0xFFFFFFFF
+        if int(wc[0, 7]) > p["count_cap"]:               # the count render's lists were truncated
+            self._grow_cap(int(wc[0, 7]), int(wc[0, 0]))
+            ok = False
+        if ok:
+            return False
+        self.overflow_retries = getattr(self, "overflow_retries", 0) + 1
+        self._restore(p["snap"])
+        self._train_batched_checked(p["steps"], p["snap"], 5, defer_ok=False)
+        return True
 
     def _train_batched(self, steps: Optional[int] = None, defer: bool = False):
         """``train`` with the B views of an iteration in ONE set of launches per ITERATION instead of per view (a 512x512
@@ -903,17 +980,20 @@ class FusedMapTrainer(GaussianMapTrainer):
         batch = state["batch"]
         self._losses_host, self._losses_dev = [], losses[:total]      # (read when somebody asks: last_losses)
 
+        def evaluate(status) -> bool:
+            """status: (views, 8) words of every slot of the batch (sticky: any pass of any iteration)"""
+            self._last_need, self._last_need_n = int(status[:, 4].max()), n
+            if bool(status[:, 5].any()):
+                self._grow_cap(self._last_need, int(status[:, 0].max()))
+                self._last_need = None
+                keep["batch"] = None                      # too small: the repeat allocates a larger one
+                return False
+            return True
+
         def settle() -> bool:
             """the wait of the call: did any pass of any iteration outgrow its workspace?"""
-            if batch is not None:
-                status = batch.statuses()                     # every slot, sticky words: any pass of any iteration
-                self._last_need, self._last_need_n = int(status[:, 4].max()), n
-                if bool(status[:, 5].any()):
-                    self._grow_cap(self._last_need, int(status[:, 0].max()))
-                    self._last_need = None
-                    keep["batch"] = None                      # too small: the repeat allocates a larger one
-                    return False
-            return True
+            return evaluate(batch.statuses()) if batch is not None else True
+        settle.batch, settle.evaluate = batch, evaluate
         return settle if defer else settle()
 
     # ------------------------------------------------------------------ hipGraph iteration

@@ -55,10 +55,14 @@ def _cfg_get(node, name, default=None):
 
 def _state_property(name):
     def get(self):
-        return getattr(self._trainer, name) if self._trainer is not None else self._cold[name]
+        if self._trainer is not None:
+            self._trainer.settle()       # (a train() call whose workspace check is still pending: FusedMapTrainer.settle)
+            return getattr(self._trainer, name)
+        return self._cold[name]
 
     def set_(self, value):
         if self._trainer is not None:
+            self._trainer.settle()
             setattr(self._trainer, name, value)
             self._trainer._states.clear()        # per-view workspaces are laid out for the row count
         else:
@@ -128,6 +132,18 @@ class GaussianMap:
         self.optimizer = None
 
     # ------------------------------------------------------------------ trainer plumbing
+    @property
+    def num_gaussians(self) -> int:
+        """Rows of the map, without waiting for the GPU (every state attribute / getter first settles a training call
+        whose workspace check is pending - FusedMapTrainer.settle; the row count does not depend on it)."""
+        return int(self._trainer.means.shape[0]) if self._trainer is not None else int(self._cold["means"].shape[0])
+
+    def settle(self) -> None:
+        """Wait for / look at what the last ``update()`` left pending (nothing to do for callers that read the map through
+        its attributes: they settle themselves)."""
+        if self._trainer is not None:
+            self._trainer.settle()
+
     @property
     def training_data(self):
         return self._trainer.frames if self._trainer is not None else self._frames

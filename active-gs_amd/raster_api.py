@@ -604,6 +604,13 @@ class ViewBatch:
         self._graph.replay()
         return self.states
 
+    def status_words(self, views: Optional[int] = None) -> torch.Tensor:
+        """The first eight words of every view's status block as a (views, 8) int32 DEVICE tensor (a copy enqueued on the
+        current stream; ``statuses`` reads it back)."""
+        V = self.num_views if views is None else int(views)
+        per = self._per
+        return self.workspace[:self.num_views * per].view(self.num_views, per)[:V, :32].contiguous().view(torch.int32).view(V, 8)
+
     def statuses(self, views: Optional[int] = None) -> torch.Tensor:
         """Blocking: the first eight words of every view's status block (``AgsStatus``) in ONE transfer ->
         (views, 8) int64 on the host: [0] tile instances, [1] instances sorted, [2] overflow flag, [3] visible,

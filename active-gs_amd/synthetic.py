@@ -203,7 +203,8 @@ def run_mapper_loop(frames, steps: int = 10, draw: str = "device", warmup_frames
             t_grow += b - a; t_train += c - b
         else:
             gm.update(f)
-        sizes.append(gm.get_means.shape[0])
+        sizes.append(gm.num_gaussians)       # (the row count: a read of the map itself would settle the call first)
+    gm.settle()                              # the last call's pending workspace check belongs to the loop
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     iters = len(frames) * steps

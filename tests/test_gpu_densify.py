@@ -308,6 +308,61 @@ def test_mapper_loop_matches_reference_capture(agslib):
                                          rotations=tr.rotations))
 
 
+def test_deferred_workspace_check_repeats_an_overflowed_call(agslib):
+    """``FusedMapTrainer.DEFER_SETTLE``: on keyframes that do not prune, train() returns with its workspace check PENDING
+    (status words copied to page-locked memory, the view statistics enqueued unchecked) and ``settle()`` looks at it at the
+    next wait - inside the next add_gaussians, or when somebody reads the map.  (a) the deferred loop lands where the
+    immediate one does; (b) a call whose check FAILS (injected here: the first deferred check of the second keyframe is
+    made to report an overflowed pass) is repeated from its snapshot - parameters, per-frame errors, the view statistics
+    the speculative post-processing had already updated, the random streams - and the loop again lands where the
+    immediate one does, with the supports counted once."""
+    from active_gs_amd.fused_map_trainer import FusedMapTrainer
+    g = _gold()
+    z = lambda *s: torch.zeros(*s, device=DEV)
+
+    def run(defer, inject):
+        raw = dict(means=z(0, 3), scales=z(0, 3), rotations=z(0, 4), opacities=z(0), harmonics=z(0, 1, 3))
+        np.random.seed(3)
+        torch.manual_seed(3)
+        torch.cuda.manual_seed(3)
+        tr = FusedMapTrainer(raw, [], dict(optimization_steps=5, prune_interval=3, batch_size=4, active_size=2, sampler="device"),
+                             use_graph=False, num_streams=1)
+        tr.DEFER_SETTLE = defer
+        deferred = []
+        if inject:
+            real = tr._words_async
+            calls = {"n": 0}
+
+            def words(dev_words):
+                host = real(dev_words)
+                calls["n"] += 1
+                if calls["n"] == 3:                     # keyframe 2's batch words (keyframe 1: calls 1 and 2)
+                    torch.cuda.synchronize()
+                    host[0, 5] = 1                      # "one pass overflowed"
+                    host[0, 4] = 1 << 20
+                return host
+            tr._words_async = words
+        for k in range(4):                              # prune_interval 3: keyframes 1, 2, 4 defer, keyframe 3 prunes
+            tr.update(dict(g["frames"][k % 2]))
+            deferred.append(tr._pending_check is not None)
+        tr.settle()
+        torch.cuda.synchronize()
+        return tr, deferred
+
+    a, da = run(False, False)
+    b, db = run(True, False)
+    c, dc = run(True, True)
+    assert da == [False] * 4 and db == dc == [True, True, False, True]
+    assert getattr(a, "overflow_retries", 0) == 0 and getattr(b, "overflow_retries", 0) == 0 and c.overflow_retries == 1
+    for other in (b, c):
+        assert other.means.shape[0] == a.means.shape[0] and len(other.frames) == 4
+        assert torch.equal(other.view_supports, a.view_supports)            # counted once, also for the repeated call
+        assert torch.allclose(other.training_performance, a.training_performance, rtol=2e-3, atol=1e-5)
+        for key in ("means", "harmonics", "opacities", "scales"):
+            assert float((getattr(other, key) - getattr(a, key)).abs().mean()) < 2e-4, key
+        assert torch.allclose(other.view_scores, a.view_scores, rtol=1e-3, atol=1e-4)
+
+
 def test_frame_store_and_chunked_count_render(agslib):
     """A long mapping session: the keyframes live in ONE growing set of arrays (FusedMapTrainer._frame_store: appended
     to as frames arrive, rebuilt when the list is edited) instead of being stacked at every train() call, and the
