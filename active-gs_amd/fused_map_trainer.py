@@ -757,8 +757,14 @@ class FusedMapTrainer(GaussianMapTrainer):
         raise RuntimeError("train(): the rasterizer workspace kept overflowing after six enlargements")
 
     def _words_async(self, words_dev: torch.Tensor) -> torch.Tensor:
-        """(V, 8) int32 status words -> page-locked host tensor, copy enqueued on the current stream (no wait)"""
-        host = torch.empty(tuple(words_dev.shape), dtype=torch.int32).pin_memory()
+        """(V, 8) int32 status words -> page-locked host tensor, copy enqueued on the current stream (no wait).  The host
+        buffers are kept (page-locking memory costs more than the wait it saves): two per shape, used in turn - a pending
+        check is always settled before the next train() call makes another."""
+        key = tuple(words_dev.shape)
+        pool = self.__dict__.setdefault("_words_pool", {})
+        slot = pool.setdefault(key, [[torch.empty(key, dtype=torch.int32).pin_memory() for _ in range(2)], 0])
+        host = slot[0][slot[1] & 1]
+        slot[1] += 1
         host.copy_(words_dev, non_blocking=True)
         return host
 
