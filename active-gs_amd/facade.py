@@ -268,7 +268,10 @@ class SurfelRenderer:
         cap, mode = st.get(ckey, (max(1 << 16, 2 * n), api.BIN_DIRECT))
         cap = max(cap, 1 << 16, 2 * n)
         o = dict(device=dev, dtype=torch.float32)
-        # (without statistics every view's importance / count are zeros, like the extension's: ONE row, shown V times)
+        # (without statistics every view's importance / count are zeros, like the extension's: ONE row, shown V times -
+        # an ``expand``ed view: READ-ONLY for the caller (torch refuses an in-place write on the batch; a write through a
+        # per-view slice would show in every view).  The reference never writes to them: operations.py:845-851 stacks
+        # and returns them, gaussian_map.py:195,229-232 only compares)
         stat_rows = V if require_importance else 1
         out = dict(rgb=torch.empty(V, 3, h, w, **o), normal=torch.empty(V, 3, h, w, **o), depth=torch.empty(V, 1, h, w, **o),
                    opacity=torch.empty(V, 1, h, w, **o), confidence=torch.empty(V, 1, h, w, **o),

@@ -36,6 +36,7 @@ H, W = 680, 1200
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PMC_HBM_FILE = "pmc_hbm_bytes.json"   # per-stage HBM bytes per launch of this command (rocprofv3 --pmc, committed)
 PMC_SQ_FILE = "sq_counters.json"      # per-stage SQ instruction counters per launch of this command
+PMC5_HBM_FILE = "pmc5_hbm_bytes.json"  # the same HBM bytes for configuration 5's steady-state launches (c5_counters.sh)
 DTYPE = "f32"   # every stage computes in fp32, like the reference's extension (the blend backward's per-surfel sums run on
                 # exact f32 matrix instructions; the bf16 hi/lo-split form is an opt-in, timed as ms_per_step_bf16_split)
 
@@ -1041,10 +1042,18 @@ def main():
                 out["roofline"]["c5"] = {"bound": "hbm", "kernel": dom5, "achieved": c5["stage_algorithmic_bytes"][dom5] / t5 / 1e9,
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c5["stage_algorithmic_bytes"][dom5] / t5 / 1e9 / HBM_PEAK_GBS,
                                          "algorithmic_bytes_per_launch": c5["stage_algorithmic_bytes"][dom5], "launch_ms": c5["stage_ms_per_view"][dom5],
-                                         "traffic": None,
-                                         "traffic_note": "profiles/r04_a_c5_pmc_hbm.md (rocprofv3 --pmc, not collected in this run): render_bwd reads "
-                                                         "536 MB (2 x FETCH_SIZE) and writes 499 MB per launch against 793 MB algorithmic; VALU issue "
-                                                         "busy 0.80 (profiles/r04_a_c5_sq_counters.md)"}
+                                         "traffic": None}
+                try:      # counter figures of configuration 5's steady-state launches: a committed rocprofv3 --pmc run of
+                          # profiles/experiments/c5_counters.sh (eager steps on a frozen scene; not collected in this run)
+                    pm5 = json.load(open(os.path.join(ROOT, "profiles", PMC5_HBM_FILE)))
+                    e5 = pm5.get(dom5, {})
+                    out["roofline"]["c5"].update(traffic=e5.get("traffic"), traffic_read=2 * e5.get("fetch_raw", 0) or None,
+                                                 traffic_write=e5.get("write"),
+                                                 traffic_source=f"profiles/{PMC5_HBM_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                                                f"eager steps of configuration 5, session {pm5.get('_session', '?')}; not collected "
+                                                                "in this run; read = 2 x FETCH_SIZE)")
+                except Exception:
+                    pass
             except Exception as e:
                 out["config"]["secondary"] = f"{type(e).__name__}: {e}"
             # -- the one-rank end of the strong-scaled forms of configurations 4 and 5 (ALL the step's views on this GPU):

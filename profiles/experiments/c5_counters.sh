@@ -12,7 +12,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/c5_$c
   rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/c5_$c -o p -- python3 $S > /dev/null 2>&1
 done
-python3 $R/profiles/pmc_summary.py $R/gpurun_out/c5_FETCH_SIZE/p_counter_collection.csv $R/gpurun_out/c5_WRITE_SIZE/p_counter_collection.csv > $R/gpurun_out/${TAG}_c5_pmc_hbm.md
+python3 $R/profiles/pmc_summary.py $R/gpurun_out/c5_FETCH_SIZE/p_counter_collection.csv $R/gpurun_out/c5_WRITE_SIZE/p_counter_collection.csv $R/gpurun_out/pmc5_hbm_bytes.json ${TAG}_c5 > $R/gpurun_out/${TAG}_c5_pmc_hbm.md
 rm -rf $R/gpurun_out/c5_sq1 $R/gpurun_out/c5_sq2
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/c5_sq1 -o p -- python3 $S > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS --output-format csv -d $R/gpurun_out/c5_sq2 -o p -- python3 $S > $R/gpurun_out/${TAG}_c5_sq2.log 2>&1
