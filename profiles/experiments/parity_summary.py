@@ -24,4 +24,17 @@ out = {"comparisons": len(rows),
        "radii_mismatch_total": sum(r["mismatch"] for r in rows if r["kind"] == "radii"),
        "count": [dict(test=r["test"].split("::")[-1], **{k: r[k] for k in ("rows", "rows_differ", "max_row_diff", "total", "total_diff")}) for r in rows if r["kind"] == "count"],
        "last_contributor": [dict(test=r["test"].split("::")[-1], what=r["what"], pixels=r["pixels"], differ=r["differ"]) for r in rows if r["kind"] == "last_contributor"]}
+# the reference-capture replays (tests/test_gpu_densify.py, test_gpu_gaussian_map.py): worst margin per quantity over the
+# keyframes, and the final row-by-row comparison (rows aligned by origin) - what CAPTURE_GATES are 10x of
+cap = collections.defaultdict(float)
+for r in rows:
+    if r["kind"] == "capture":
+        for k in ("rows", "perf_rel", "opacity_mean", "supports_rel", "scores_rel"):
+            cap[k] = max(cap[k], abs(r[k]))
+out["capture_worst"] = dict(cap)
+out["capture_final"] = [dict(test=r["test"].split("::")[-1], rows_ref=r["rows_ref"], rows_mine=r["rows_mine"], common=r["common"],
+                             common_frac=r["common_frac"], mean_abs_diff=r["mean_abs_diff"], pruned=r["pruned_mine"])
+                        for r in rows if r["kind"] == "capture_final"]
+out["densify_fixture"] = [dict(what=r["what"], rows_mine=r["rows_mine"], rows_ref=r["rows_ref"], paired=r["paired"],
+                               max_abs_diff=r["max_abs_diff"]) for r in rows if r["kind"] == "densify_fixture"]
 json.dump(out, sys.stdout, indent=1)
