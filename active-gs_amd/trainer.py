@@ -159,6 +159,7 @@ class SurfelTrainer:
         if view_streams is not None:
             self.VIEW_STREAMS = max(1, int(view_streams))
         self.tuning = tuning     # _lib.AgsTuning handed over with every workspace this trainer makes (None: process default)
+        self._tuning_pinned = tuning is not None      # a caller's selection is not adapted (_adapt_kernels)
         lrs = {**DEFAULT_LRS, **(lrs or {})}
         self.raw = {k: v.contiguous() for k, v in raw.items()}
         dev = self.raw["means"].device
@@ -536,11 +537,40 @@ class SurfelTrainer:
     def workspace_overflows(self) -> dict:
         """Host-synchronous: per view size, (overflowed passes, peak tile instances) since the workspace was made."""
         out = {}
+        vis, views = 0, 0
         for key, st in self._state.items():
             info = api.read_status(st)
             if info["overflow_passes"]:
                 out[key] = (info["overflow_passes"], info["peak_instances"])
+            vis, views = vis + info["num_visible"], views + 1
+        if views:
+            self._adapt_kernels(vis / views)
         return out
+
+    # Which per-Gaussian forward kernel: the cull-first form (cull on the means alone, project the survivors on full waves:
+    # ags_k_preprocess_cull) is the library's choice from 2^20 rows up; below that the plain kernel's single pass is the
+    # shorter chain - unless a view shows little of the map: at C2 (200 k rows in random order, 7 % visible) nearly every
+    # wave of the plain kernel still has a visible lane and runs the ~900-instruction projection at a tenth of its lanes,
+    # and the cull-first kernel is 1.1-3.9 us faster (step -3.5 %, profiles/r05_h_preprocess_c2.md); a mapper-grown map
+    # seen from inside (a third of its rows visible, neighbours in a wave) is 3.5 % SLOWER with it
+    # (profiles/r05_i_mapper_cull.txt).  The trainer reads its views' status blocks every CHECK_EVERY steps anyway: it asks
+    # for the cull-first kernel while the views show less than CULL_FIRST_BELOW of the rows.
+    CULL_FIRST_BELOW, CULL_FIRST_MIN_ROWS = 0.20, 1 << 16
+
+    def _adapt_kernels(self, visible_per_view: float) -> None:
+        if self.n < self.CULL_FIRST_MIN_ROWS or not self.fused_activations or getattr(self, "_tuning_pinned", False):
+            return
+        if os.environ.get("AGS_PRE_CULL_MIN_N") is not None or os.environ.get("AGS_CULL_ADAPT") == "0":
+            return                                    # the process's explicit choice stands
+        want = 1 if visible_per_view < self.CULL_FIRST_BELOW * self.n else 0      # AgsTuning.cull_first_min_n: 1 = always, 0 = default
+        if self.tuning is None:
+            if want == 0:
+                return
+            self.tuning = _lib.make_tuning()          # this trainer's own copy of the process default
+            for st in self._state.values():
+                st.tuning = self.tuning
+        if self.tuning.cull_first_min_n in (0, 1):    # (a caller's explicit threshold is left alone)
+            self.tuning.cull_first_min_n = want
 
     def regrow_exchange(self) -> int:
         """Collective.  If the gathered Adam has refused steps, agree on a larger segment (or fall back to the

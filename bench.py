@@ -984,6 +984,7 @@ def main():
             try:
                 t2 = SurfelTrainer({k: v.to(dev) for k, v in raw_cpu.items()}, binning_mode=bin_mode,
                                    tuning=_lib.make_tuning(bwd_reduce="bf16"))
+                t2._tuning_pinned = False          # (the per-Gaussian kernel is chosen from the views like the headline's)
                 for _ in range(3):
                     t2.step([cam], grads_fn, cap)
                 torch.cuda.synchronize()

@@ -274,3 +274,34 @@ def test_more_views_than_one_rows_launch_joins(agslib):
             assert (a - b).abs().mean() <= 2e-3 * travel + 1e-9, groups
         for a, b in zip(m, ref_m):
             assert (a - b).abs().sum() <= 1e-4 * b.abs().sum() + 1e-12, groups
+
+
+def test_trainer_asks_for_the_cull_first_kernel_when_its_views_show_little(agslib):
+    """``SurfelTrainer._adapt_kernels``: every CHECK_EVERY steps the trainer reads its views' status blocks anyway; while they
+    show less than a fifth of the map (here: 80 k rows in random order, a view of ~7 %) it asks for the cull-first
+    per-Gaussian kernel (``AgsTuning.cull_first_min_n`` = 1; the library's own threshold is 2^20 rows) - bit-identical
+    records, so training lands where the plain kernel's does; a caller's explicit selection is left alone."""
+    import os
+    from active_gs_amd import _lib
+    from active_gs_amd.synthetic import make_room_scene
+    from active_gs_amd.trainer import SurfelTrainer
+    if os.environ.get("AGS_PRE_CULL_MIN_N") is not None:
+        pytest.skip("the process pins the kernel choice")
+    n, h, w = 80_000, 340, 600
+    dev, cams, fn = _setup(n, h, w, views=1)
+    res = {}
+    for mode in ("adaptive", "pinned"):
+        raw = {k: v.to(dev) for k, v in make_room_scene(n, seed=5).items()}
+        tr = SurfelTrainer(raw, tuning=_lib.make_tuning(cull_first_min_n=-1) if mode == "pinned" else None)
+        for _ in range(SurfelTrainer.CHECK_EVERY + 4):
+            tr.step(cams, fn, 1 << 21)
+        tr.check_overflow()
+        torch.cuda.synchronize()
+        res[mode] = (tr, [p.clone() for p in tr.params])
+    ta, tp = res["adaptive"][0], res["pinned"][0]
+    assert ta.tuning is not None and ta.tuning.cull_first_min_n == 1 and tp.tuning.cull_first_min_n == -1
+    assert 0 < int(ta.rows.count.item()) == int(tp.rows.count.item()) < 0.2 * n
+    init = make_room_scene(n, seed=5)
+    for a, b, key in zip(res["adaptive"][1], res["pinned"][1], ("means", "scales", "rotations", "opacities", "harmonics")):
+        travel = float((b - init[key].to(dev).reshape(b.shape)).abs().mean())
+        assert float((a - b).abs().mean()) <= 5e-3 * travel + 1e-9, key      # (the blend backward's float atomics are unordered)
