@@ -550,13 +550,17 @@ def launch_ranks(args) -> int:
         if have < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s)", file=sys.stderr)
             return 2
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool
     env.setdefault("OMP_NUM_THREADS", "8")
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    for attempt in (0, 1):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        # the port was free when it was picked; if another socket took it before the store bound it, once more on another
+        if r.returncode == 0 or attempt == 1 or not any(m in r.stderr for m in ("Address already in use", "EADDRINUSE")):
+            break
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     other = [l for l in r.stdout.splitlines() if not l.startswith("{")]
     if other:
