@@ -463,3 +463,84 @@ def test_drop_in_classes_cover_the_reference_classes_public_surface():
         for a in want["instance_attributes"]:
             assert hasattr(inst, a), (name, a)
     assert instances["GaussianRenderer"][1].raydir_map.shape == (3, 16, 16)
+
+
+def test_row_range_form_of_backward_rows_accepts_a_further_group_of_views(agslib):
+    """Round 5: a data-parallel rank with more views than one ``ags_backward_rows`` launch joins (AGS_MAX_ROW_VIEWS = 16: all
+    32 views of configuration 4 on one or two GPUs) calls the row-range form once per group, the later groups ADDING to the
+    chunk's rows (accumulate 1).  The argument checks run before any HIP call: with a view whose workspace is too small the
+    call gets as far as that size check (AGS_E_WORKSPACE = -2) exactly when the range form's own checks let it through -
+    accumulate 0 and 1 do, accumulate 2, a fused tail or a range outside the map do not (AGS_E_INVALID = -1)."""
+    from active_gs_amd import _lib
+    buf = (C.c_float * 400)()
+    addr = C.cast(buf, C.c_void_p).value
+    cam = _lib.AgsCamera()
+    cam.image_height, cam.image_width, cam.viewmatrix, cam.projmatrix = 32, 32, addr, addr
+    ws = _lib.AgsWorkspace(addr, 1, 1 << 16, 2)                        # one byte of workspace: too small for anything
+    refs = (_lib.AgsViewRef * 1)()
+    refs[0].cam, refs[0].radii, refs[0].ws = C.pointer(cam), addr, C.pointer(ws)
+    g, gg = _lib.AgsGaussians(), _lib.AgsGaussianGrads()
+    g.n = 100
+    for f in ("means3D", "scales", "rotations", "opacities"):
+        setattr(g, f, addr)
+    for f in ("d_means3D", "d_scales", "d_rotations", "d_opacities", "d_colors"):
+        setattr(gg, f, addr)
+    gg.row_begin, gg.row_end = 0, 64
+    for acc, want in ((0, -2), (1, -2), (2, -1)):
+        gg.accumulate = acc
+        assert agslib.ags_backward_rows(refs, 1, C.byref(g), C.byref(gg), None) == want, acc
+    gg.accumulate, gg.row_end = 1, 101                                 # a range that leaves the map
+    assert agslib.ags_backward_rows(refs, 1, C.byref(g), C.byref(gg), None) == -1
+    gg.row_end, gg.pack_segment = 64, addr                             # no exchange segment in the range form
+    assert agslib.ags_backward_rows(refs, 1, C.byref(g), C.byref(gg), None) == -1
+
+
+def test_rows_of_two_grown_maps_are_paired_by_origin():
+    """tests/_origin.py: the final parameters of two maps that were GROWN are compared over the rows both hold - spawned by
+    the same keyframe at the same place and kept by both - whatever the two row counts are."""
+    from _origin import common_rows
+    gen = torch.Generator().manual_seed(0)
+    k0 = torch.rand(50, 3, generator=gen)
+    k1 = torch.rand(30, 3, generator=gen) + 2.0
+    # mine: keyframe 0 spawned the same rows in another order and one extra row; keyframe 1 misses a row
+    perm = torch.randperm(50, generator=gen)
+    mine0 = torch.cat([k0[perm] + 1e-6, torch.tensor([[9.0, 9.0, 9.0]])])
+    mine1 = k1[1:]
+    ref_origin = torch.cat([torch.arange(50), (1 << 32) + torch.arange(30)])
+    ref_origin = ref_origin[ref_origin != 7]                                   # the reference pruned its row (0, 7)
+    my_origin = torch.cat([torch.arange(51), (1 << 32) + torch.arange(29)])
+    ri, mi, stats = common_rows([k0, k1], ref_origin, [mine0, mine1], my_origin)
+    assert stats[0]["same_place"] == 50 and stats[1]["same_place"] == 29
+    assert ri.numel() == mi.numel() == 49 + 29                                 # (0, 7) is gone on one side, (1, 0) was never spawned on the other
+    ref_rows = torch.cat([k0, k1])[torch.cat([torch.arange(50) != 7, torch.ones(30, dtype=torch.bool)])]
+    my_rows = torch.cat([mine0, mine1])
+    assert float((ref_rows[ri] - my_rows[mi]).abs().max()) < 1e-5              # every pair IS the same spawned row
+
+
+def test_bench_strong_configurations_and_replica_checksums():
+    """bench.py's strong-scaled configurations 4 and 5: BASELINE.json's sizes by default (32 views of 1.5 M surfels @1200x680, 8
+    views of 5 M @2048x2048), a test's reduced sizes from AGS_BENCH_STRONG; the replica check is a bit checksum per tensor."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    was = os.environ.pop("AGS_BENCH_STRONG", None)
+    try:
+        c = bench.strong_configs()
+        assert (c["c4"]["n"], c["c4"]["views"], c["c4"]["h"], c["c4"]["w"]) == (1_500_000, 32, 680, 1200)
+        assert (c["c5"]["n"], c["c5"]["views"], c["c5"]["h"], c["c5"]["w"]) == (5_000_000, 8, 2048, 2048) and "reduced" not in c["c5"]
+        os.environ["AGS_BENCH_STRONG"] = "c4=150000,8,680,1200"
+        c = bench.strong_configs()
+        assert c["c4"]["n"] == 150000 and c["c4"]["views"] == 8 and c["c4"]["reduced"] and c["c5"]["n"] == 5_000_000
+    finally:
+        os.environ.pop("AGS_BENCH_STRONG", None)
+        if was is not None:
+            os.environ["AGS_BENCH_STRONG"] = was
+
+    class T:
+        params = [torch.arange(6, dtype=torch.float32).reshape(2, 3), torch.ones(4)]
+    ok, sums = bench.replica_checksums(T, False)
+    assert ok and sums == [int(t.view(torch.int32).to(torch.int64).sum()) for t in T.params]
+    T.params[1][2] = 1.0000001                                                 # one ulp: another checksum
+    assert bench.replica_checksums(T, False)[1] != sums
