@@ -157,51 +157,7 @@ class FusedMapTrainer(GaussianMapTrainer):
             self._cams[idx] = c
         return c
 
-    # A new keyframe's pose and intrinsics are device tensors (mapper.py:95 moves the whole dataframe to the GPU) and the
-    # camera needs them as host scalars (tan(fov) travels by value in every launch).  Read in stream order, that read waits
-    # for everything this loop has queued - the previous keyframe's iterations - and the render / filter / candidates of the
-    # growth phase are then enqueued behind a wait.  SPECULATIVE_POSE: the 26 floats are read on a side stream AT ONCE (the
-    # frame was produced before update() was called; normally long before), the camera is built from them, and the main
-    # stream - in order - compares what the frame's tensors hold when IT gets there with what was used; the flag is looked at
-    # at the growth phase's own wait (the row count): a mismatch (the producer had not finished) repeats the phase with a
-    # stream-ordered read.  Correct whatever the producer did; no wait in the usual case.
-    SPECULATIVE_POSE = os.environ.get("AGS_MAPPER_SPECULATIVE_POSE", "1") != "0"
-
-    def _read_pose(self, parts, speculative: bool):
-        import numpy as np
-        self._pose_check = None
-        if not (speculative and self.SPECULATIVE_POSE and all(p_.is_cuda for p_ in parts)):
-            return torch.cat(parts).cpu().numpy()
-        main = torch.cuda.current_stream()
-        side = self.__dict__.setdefault("_pose_stream", torch.cuda.Stream())
-        n = sum(p_.numel() for p_ in parts)
-        pool = self.__dict__.setdefault("_pose_host", {})
-        key = (n, parts[0].dtype)
-        if key not in pool:
-            pool[key] = (torch.empty(n, dtype=parts[0].dtype).pin_memory(), torch.empty(1, dtype=torch.uint8).pin_memory())
-        host, flag = pool[key]
-        with torch.cuda.stream(side):
-            packed = torch.cat(parts)                     # reads the frame's tensors NOW, not behind the main stream's queue
-            host.copy_(packed, non_blocking=True)
-        side.synchronize()
-        used = host.numpy().copy()
-        packed.record_stream(main)
-        changed = (torch.cat(parts) != packed).any().to(torch.uint8).reshape(1)      # in order on the main stream
-        flag.copy_(changed, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._pose_check = dict(event=ev, flag=flag)
-        return used
-
-    def _pose_was_stale(self) -> bool:
-        """Waits for the in-order comparison of a speculatively read pose (it sits in front of the growth phase's launches)."""
-        pc, self._pose_check = getattr(self, "_pose_check", None), None
-        if pc is None:
-            return False
-        pc["event"].synchronize()
-        return bool(int(pc["flag"][0]))
-
-    def _make_camera(self, f: dict, speculative: bool = False):
+    def _make_camera(self, f: dict):
         """(api.Camera, fov_x, fov_y) of a frame.  The 4x4 / 3x3 algebra runs on the HOST (one small
         read of the pose, ONE small upload): on the GPU it is a dozen tiny launches and an inverse."""
         h, w = f["rgb"].shape[-2:]
@@ -217,7 +173,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         if torch.is_tensor(dr):
             parts.append(dr.detach().reshape(-1).to(parts[0].device))
         dt = torch.float64 if any(p_.dtype == torch.float64 for p_ in parts) else torch.float32   # (no conversion launches for float32 frames)
-        host = self._read_pose([p_.to(dt) for p_ in parts], speculative).astype(np.float64)
+        host = torch.cat([p_.to(dt) for p_ in parts]).cpu().numpy().astype(np.float64)
         host32 = host.astype(np.float32)
         if torch.is_tensor(dr):
             f["_far_host"] = float(host[25 + 1])
@@ -677,7 +633,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         if self.is_init and self.means.shape[0] > 0:
             h, w = frame["rgb"].shape[-2:]
             n = self.means.shape[0]
-            made = self._make_camera(frame, speculative=True)
+            made = self._make_camera(frame)
             self._cams[len(self.frames)] = made          # the frame is registered below under this index
             cam = made[0]
             self._cap = max(self._cap, 1 << 16, 2 * n)
@@ -690,20 +646,9 @@ class FusedMapTrainer(GaussianMapTrainer):
                 st = self._state("densify", n, h, w)
                 api.forward(cam, g, st)
                 pred = dict(rgb=st.rgb, depth=st.depth[0], opacity=st.opacity[0])
-                stale = {}
-
-                def before_count_read():
-                    stale["pose"] = self._pose_was_stale()
-                    return self.settle() or stale["pose"]
                 grown = densify.add_gaussians(self._map_state(), frame, pred, self.cfg["error_thres"], arena=self._map_arena(),
-                                              before_sync=before_count_read)
-                if grown is None:            # the pending call was repeated (the map is not what this render showed), or the
-                    if stale.get("pose"):    # frame's pose was not in place yet when it was read: once more, in stream order
-                        frame.pop("intrinsic_inv", None); frame.pop("_far_host", None)
-                        made = self._make_camera(frame)
-                        self._cams[len(self.frames)] = made
-                        cam = made[0]
-                        self.pose_rereads = getattr(self, "pose_rereads", 0) + 1
+                                              before_sync=self.settle)
+                if grown is None:            # the pending call was repeated: the map is not what this render showed
                     g = self._gaussians()
                     continue
                 state, added = grown

@@ -363,49 +363,6 @@ def test_deferred_workspace_check_repeats_an_overflowed_call(agslib):
         assert torch.allclose(other.view_scores, a.view_scores, rtol=1e-3, atol=1e-4)
 
 
-def test_speculative_pose_read_is_verified_in_stream_order(agslib):
-    """``FusedMapTrainer.SPECULATIVE_POSE``: a new keyframe's pose is read on a side stream at once (not behind the previous
-    keyframe's queued iterations) and the main stream - in order - compares what the frame's tensors hold when it gets there
-    with what was used.  Here the second keyframe's pose tensor is STILL BEING PRODUCED when update() is called (a copy
-    enqueued behind ~50 ms of other work on the stream; until then the tensor holds the first keyframe's pose): the
-    speculative read sees the stale pose, the in-order comparison notices, the growth phase is repeated with a
-    stream-ordered read - and the map is the one the non-speculative trainer builds."""
-    from active_gs_amd.fused_map_trainer import FusedMapTrainer
-    g = _gold()
-    z = lambda *s: torch.zeros(*s, device=DEV)
-
-    def run(speculative):
-        raw = dict(means=z(0, 3), scales=z(0, 3), rotations=z(0, 4), opacities=z(0), harmonics=z(0, 1, 3))
-        np.random.seed(4)
-        torch.manual_seed(4)
-        torch.cuda.manual_seed(4)
-        tr = FusedMapTrainer(raw, [], dict(optimization_steps=4, prune_interval=5, batch_size=4, active_size=2, sampler="device"),
-                             use_graph=False, num_streams=1)
-        tr.SPECULATIVE_POSE = speculative
-        f0, f1 = _to_dev(dict(g["frames"][0])), _to_dev(dict(g["frames"][1]))
-        tr.update(f0)
-        late = dict(f1)
-        late["extrinsic"] = f0["extrinsic"].clone()                 # what the tensor holds until its producer gets there
-        torch.cuda.synchronize()
-        busy = torch.randn(4096, 4096, device=DEV)
-        for _ in range(40):                                         # ~50 ms of work the stream has to get through first
-            busy = busy @ busy * 1e-4
-        late["extrinsic"].copy_(f1["extrinsic"], non_blocking=True)  # the producer: enqueued, not yet executed
-        tr.update(late)
-        tr.settle()
-        torch.cuda.synchronize()
-        return tr
-
-    a, b = run(False), run(True)
-    assert getattr(a, "pose_rereads", 0) == 0 and b.pose_rereads == 1
-    assert a.means.shape[0] == b.means.shape[0] > 4000 and len(b.frames) == 2
-    assert torch.equal(b.frames[1]["extrinsic"], _to_dev(dict(g["frames"][1]))["extrinsic"])
-    assert torch.equal(a._camera(1)[0].viewmatrix, b._camera(1)[0].viewmatrix)      # the camera of the pose that arrived
-    for key in ("means", "harmonics", "opacities", "scales"):
-        assert float((getattr(a, key) - getattr(b, key)).abs().mean()) < 2e-4, key
-    assert torch.equal(a.view_supports, b.view_supports)
-
-
 def test_frame_store_and_chunked_count_render(agslib):
     """A long mapping session: the keyframes live in ONE growing set of arrays (FusedMapTrainer._frame_store: appended
     to as frames arrive, rebuilt when the list is edited) instead of being stacked at every train() call, and the
