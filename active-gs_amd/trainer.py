@@ -324,10 +324,14 @@ class SurfelTrainer:
             done = []
             lanes = self._view_streams(len(cams))
             main = torch.cuda.current_stream()
+            # (every view's workspace exists BEFORE the streams fork: a workspace made inside the loop is initialised by a
+            # launch on the main stream that a view stream, already told to wait for the main stream's EARLIER position,
+            # would not wait for - its forward could then meet tile counters that are not zeroed yet)
+            states = [self.state_for(cam.image_height, cam.image_width, max_instances, slot=v) for v, cam in enumerate(cams)]
             for s in lanes:
                 s.wait_stream(main)
             for v, cam in enumerate(cams):
-                st = self.state_for(cam.image_height, cam.image_width, max_instances, slot=v)
+                st = states[v]
                 with torch.cuda.stream(lanes[v % len(lanes)]) if lanes else contextlib.nullcontext():
                     api.forward(cam, g, st, touched=self.rows)
                     d = image_grads(v, st)
@@ -418,10 +422,11 @@ class SurfelTrainer:
         done, ticked = [], False
         main = torch.cuda.current_stream()
         lanes = self._view_streams(len(cams))
+        states = [self.state_for(cam.image_height, cam.image_width, max_instances, slot=v) for v, cam in enumerate(cams)]   # before the fork (see _local_pass)
         for s_ in lanes:
             s_.wait_stream(main)
         for v, cam in enumerate(cams):
-            st = self.state_for(cam.image_height, cam.image_width, max_instances, slot=v)
+            st = states[v]
             with torch.cuda.stream(lanes[v % len(lanes)]) if lanes else contextlib.nullcontext():
                 api.forward(cam, g, st)
                 d = image_grads(v, st)

@@ -298,6 +298,12 @@ def replica_checksums(trainer, dist_on):
     return bool(torch.equal(lo, hi)), [int(x) for x in sums.tolist()]
 
 
+def note(msg):
+    """progress on stderr with AGS_BENCH_VERBOSE=1 (where a run is when a rank faults or hangs)"""
+    if os.environ.get("AGS_BENCH_VERBOSE") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def measure_strong(key, cfg, steps, dev, world, rank, dist_on, check_only=False, samples=7, probe_steps=6):
     """One optimisation step of a STRONG-scaled configuration on `world` ranks: the configuration's views are dealt out
     round-robin (rank r renders views r::world), every rank holds the whole map and the Adam state, ONE exchange of the
@@ -312,6 +318,7 @@ def measure_strong(key, cfg, steps, dev, world, rank, dist_on, check_only=False,
     from active_gs_amd.synthetic import make_camera, make_room_scene
     from active_gs_amd.trainer import SurfelTrainer
     n, total, h, w = cfg["n"], cfg["views"], cfg["h"], cfg["w"]
+    note(f"strong {key}: {n} surfels, {total} views")
     mine = list(range(rank, total, world))
     raw = {k: v.to(dev) for k, v in make_room_scene(n, room=cfg["room"], seed=0).items()}
     trainer = SurfelTrainer(raw, view_streams=int(os.environ.get("AGS_VIEW_STREAMS", "4")))
@@ -344,6 +351,7 @@ def measure_strong(key, cfg, steps, dev, world, rank, dist_on, check_only=False,
             break
         cap = int(need * 1.25) + 4096
     del g
+    note(f"strong {key}: sized, cap {cap}")
     for _ in range(2):
         trainer.step(cams, fn, cap)              # the first step of a data-parallel trainer agrees on the exchange
     trainer.check_overflow()
@@ -372,10 +380,12 @@ def measure_strong(key, cfg, steps, dev, world, rank, dist_on, check_only=False,
         if len(set(paths)) != 1:
             raise RuntimeError(f"ranks disagree on the exchange path of {key}: {paths}")
     if not check_only:
+        note(f"strong {key}: {path}; capturing")
         replay = trainer.capture(cams, fn, cap)
         for _ in range(3):
             replay()
         torch.cuda.synchronize()
+        note(f"strong {key}: replays ok; timing")
         sm = summarise(time_samples(lambda: [replay() for _ in range(steps)], samples, dist_on, dev), steps)
         out.update(ms_per_step=round(sm["median"], 4), ms_per_step_min=round(sm["min"], 4), ms_per_step_max=round(sm["max"], 4),
                    samples=sm["samples"], steps_per_sample=steps, gaussians_per_s=n * total / (sm["median"] * 1e-3),
@@ -384,6 +394,7 @@ def measure_strong(key, cfg, steps, dev, world, rank, dist_on, check_only=False,
                                                       else (", eager chunks (host-driven collectives)" if dist_on else "")))))
         if dist_on:
             # where the exchange sits in the step: events of a few EAGER steps (a replayed graph cannot be timed inside)
+            note(f"strong {key}: timed; probing the exchange")
             trainer.tail_probe, trainer.exchange_probe = [], []
             for _ in range(probe_steps):
                 trainer.step(cams, fn, cap)
@@ -405,6 +416,7 @@ def measure_strong(key, cfg, steps, dev, world, rank, dist_on, check_only=False,
             out["exposed_note"] = ("HIP events on the main and communication streams of eager steps: what the main stream waited "
                                    "between the last chunk's chain rule and the last Adam update beyond the Adam updates themselves")
         trainer.check_overflow()
+    note(f"strong {key}: checksums")
     ok, sums = replica_checksums(trainer, dist_on)
     out["replicas_identical"] = ok
     out["parameter_checksums"] = sums
