@@ -12,4 +12,5 @@ bash profiles/experiments/evidence.sh $TAG
 bash profiles/experiments/c5_counters.sh $TAG
 bash profiles/experiments/mapper_gaps.sh $TAG
 bash profiles/experiments/pmc_preprocess_c2.sh $TAG
+python examples/mission_loop.py 2>&1 | tail -1 > gpurun_out/${TAG}_mission_loop.json; cut -c1-300 gpurun_out/${TAG}_mission_loop.json
 python profiles/experiments/mapper_phases_r05.py > gpurun_out/${TAG}_mapper_phases.jsonl 2>&1; cat gpurun_out/${TAG}_mapper_phases.jsonl
