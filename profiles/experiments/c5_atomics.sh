@@ -4,6 +4,11 @@
 #  2. same-box A/B against an experiment build whose atomic instruction is never executed (scratch/libags_noatom.so:
 #     the condition is data-dependent and never true - everything else of the flush still runs), per kernel under
 #     rocprofv3: config 5 (frozen scene), C2, the mapper loop
+# The two builds (scratch/ is not tracked; made in the build container before the call):
+#   scratch/libags_base5.so  = a copy of active-gs_amd/lib/libags_raster.so
+#   scratch/libags_noatom.so = the same sources with, in render.hip's ags_k_render_bwd_mfma flush,
+#       if (slot < nb && fld < 15) unsafeAtomicAdd(rec, ...)   ->   if (slot < nb && fld < 15 && (fld < 6 ? outg : outw) == 1.2345e38f) unsafeAtomicAdd(rec, ...)
+#     compiled with the flags of active-gs_amd/build.py (copy csrc/ to scratch/exp_noatom, patch, hipcc each .hip, link)
 # bash profiles/experiments/c5_atomics.sh <tag>   -> gpurun_out/<tag>_c5_atomics.md
 TAG=${1:-r00}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
