@@ -24,10 +24,16 @@ for v in range(views):
 gen = torch.Generator().manual_seed(4)
 d_img = [(torch.randn(c, h, w, generator=gen) / (h * w * 32)).to(dev) for c in (3, 3, 1)]
 fn = lambda v, st: (d_img[0], d_img[1], d_img[2], None, None)
-for K_ in (1, 2, 4, 8):
-    SurfelTrainer.DENSE_CHUNKS = K_
+# (the same scene, views, capacity and zero learning rates for every form of the step)
+for K_ in ("fused", "rows", 1, 2, 4, 8):
+    # "fused": the single-rank step (row-set Adam fused into the per-Gaussian backward, no exchange); "rows": the
+    # data-parallel step with the row all-gather; 1..8: the data-parallel step with the dense slab in that many chunks
+    os.environ["AGS_DP_FORCE"] = "0" if K_ == "fused" else "1"
+    if isinstance(K_, int):
+        SurfelTrainer.DENSE_CHUNKS = K_
     raw = {k: v.to(dev) for k, v in make_room_scene(n, room="room0", seed=0).items()}
-    tr = SurfelTrainer(raw, sparse_rows=False, view_streams=4, lrs=dict(mean=0.0, scale=0.0, rotation=0.0, opacity=0.0, harmonic=0.0))
+    tr = SurfelTrainer(raw, sparse_rows=not isinstance(K_, int), view_streams=4,
+                       lrs=dict(mean=0.0, scale=0.0, rotation=0.0, opacity=0.0, harmonic=0.0))
     cap = 6_000_000
     for _ in range(3):
         tr.step(cams, fn, cap)
@@ -45,8 +51,9 @@ for K_ in (1, 2, 4, 8):
     for _ in range(8):
         tr.step(cams, fn, cap)
     tl = [SurfelTrainer.tail_timeline(r) for r in tr.tail_probe]
-    med = lambda k: round(statistics.median(t[k] for t in tl), 4)
-    print(json.dumps(dict(dense_chunks=K_, ms_per_step_graph=round(e0.elapsed_time(e1) / 50, 4), chain_rule_ms=med("rows_ms"), all_reduce_sum_ms=med("all_reduce_sum_ms"),
+    med = lambda k: round(statistics.median(t[k] for t in tl), 4) if tl else None
+    print(json.dumps(dict(form=K_ if isinstance(K_, str) else f"dense, {K_} chunk(s)", ms_per_step_graph=round(e0.elapsed_time(e1) / 50, 4),
+                          chain_rule_ms=med("rows_ms"), all_reduce_sum_ms=med("all_reduce_sum_ms"),
                           adam_ms=med("adam_ms"), tail_ms=med("tail_ms"), exposed_ms=med("exposed_ms"))), flush=True)
     del tr, replay, raw
     torch.cuda.empty_cache()
