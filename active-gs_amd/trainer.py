@@ -557,10 +557,12 @@ class SurfelTrainer:
     # shorter chain - unless a view shows little of the map: at C2 (200 k rows in random order, 7 % visible) nearly every
     # wave of the plain kernel still has a visible lane and runs the ~900-instruction projection at a tenth of its lanes,
     # and the cull-first kernel is 1.1-3.9 us faster (step -3.5 %, profiles/r05_h_preprocess_c2.md); a mapper-grown map
-    # seen from inside (a third of its rows visible, neighbours in a wave) is 3.5 % SLOWER with it
-    # (profiles/r05_i_mapper_cull.txt).  The trainer reads its views' status blocks every CHECK_EVERY steps anyway: it asks
-    # for the cull-first kernel while the views show less than CULL_FIRST_BELOW of the rows.
-    CULL_FIRST_BELOW, CULL_FIRST_MIN_ROWS = 0.20, 1 << 16
+    # (neighbours in a wave: the visible rows fill few waves well) is 3.5-5 % SLOWER with it although a view shows only
+    # 14-18 % of it (profiles/r05_i_mapper_cull.txt, r05_ag_mapper_cull_sizes.txt) - what decides is how the visible rows are
+    # spread over the waves, which the host cannot see; the visible FRACTION is the proxy it has.  The trainer reads its
+    # views' status blocks every CHECK_EVERY steps anyway: it asks for the cull-first kernel while the views show less than
+    # CULL_FIRST_BELOW of the rows - a tenth: below what a map grown by the mapper shows from inside, above C2's 7 %.
+    CULL_FIRST_BELOW, CULL_FIRST_MIN_ROWS = 0.10, 1 << 16
 
     def _adapt_kernels(self, visible_per_view: float) -> None:
         if self.n < self.CULL_FIRST_MIN_ROWS or not self.fused_activations or getattr(self, "_tuning_pinned", False):

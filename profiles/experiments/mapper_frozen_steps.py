@@ -20,7 +20,9 @@ from active_gs_amd.synthetic import make_keyframes, mapper_cfg  # noqa: E402
 dev = torch.device("cuda:0")
 mode, path = sys.argv[1], sys.argv[2]
 if mode == "make":
-    frames = make_keyframes(30, 512, 512, dev, gt_surfels=400_000)
+    # AGS_FROZEN_ROOM / AGS_FROZEN_KEYFRAMES: another room stand-in / a longer mission (a larger map of which a view shows less)
+    frames = make_keyframes(int(os.environ.get("AGS_FROZEN_KEYFRAMES", "30")), 512, 512, dev, gt_surfels=int(os.environ.get("AGS_FROZEN_GT", "400000")),
+                            room=os.environ.get("AGS_FROZEN_ROOM", "office0"))
     np.random.seed(0)
     gm = GaussianMap(mapper_cfg(10, "device"), dev)
     for f in frames:
@@ -42,9 +44,12 @@ else:
     tr.training_performance = d["perf"].to(dev)
     np.random.seed(1); torch.manual_seed(1)
     assert tr._uniform_frames()
+    st0 = None
     for rep in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         assert tr._train_batched(iters) is True
         e1.record(); torch.cuda.synchronize()
-        print("ms/iteration %.4f" % (e0.elapsed_time(e1) / iters), tr.means.shape[0], "surfels", flush=True)
+        b = tr._batched_cache["batch"]
+        vis = b.statuses()[:, 3].float().mean().item() if b is not None else float("nan")
+        print("ms/iteration %.4f" % (e0.elapsed_time(e1) / iters), tr.means.shape[0], "surfels, visible per view %.0f (%.1f %%)" % (vis, 100 * vis / tr.means.shape[0]), flush=True)
