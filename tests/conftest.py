@@ -13,6 +13,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+# Collection order of the GPU suite (it is run with -x): the single-process HIP-vs-oracle parity files come first, the
+# files that start other processes (ranks sharing the GPU over gloo, bench.py as a child) last - a fault in that plumbing
+# must never stop the run before the parity evidence has been produced.
+_ORDER = ["test_gpu_parity", "test_gpu_golden", "test_gpu_fullsize", "test_gpu_fused_loss", "test_gpu_gaussian_map",
+          "test_gpu_dropin", "test_gpu_consumers", "test_gpu_cull_kernel", "test_gpu_binning", "test_gpu_densify",
+          "test_gpu_pipeline"]
+_LAST = ["test_gpu_bench_multirank", "test_gpu_distributed"]
+# inside those two files: the tests that stay in one process (or start ONE child) before the ones that start several ranks
+_MULTI_RANK = ("two_ranks", "check_mode", "hung_rank", "chunked_dense", "moving_cameras", "four_ranks", "rccl_collectives")
+
+
+def _rank_of(item):
+    name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    if name in _ORDER:
+        return _ORDER.index(name)
+    if name in _LAST:
+        return 1000 + _LAST.index(name) + (10 if any(k in item.name for k in _MULTI_RANK) else 0)
+    return 500                                              # CPU files and any new GPU file: between the two groups
+
+
+def pytest_collection_modifyitems(session, config, items):
+    items.sort(key=_rank_of)                                # stable: the order inside a file is kept
+
+
 @pytest.fixture(scope="session")
 def agslib():
     """The product library; built in-tree if the .so is stale (hipcc cross-compiles)."""

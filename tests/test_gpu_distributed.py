@@ -6,8 +6,8 @@ import socket
 
 import pytest
 import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
+
+from _spawn import spawn_ranks
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,84 +34,36 @@ def _setup(views):
     return raw, cams, grads
 
 
-def _watchdog(seconds=150):
-    """Two processes sharing ONE GPU over gloo is a test-only arrangement and has stalled on some nodes of
-    the pool: a worker that is still running after `seconds` dumps its stacks and exits with code 1, and
-    _spawn_two tries ONCE more in fresh processes.  A second stall FAILS the test (a deadlock between
-    mismatched collectives looks exactly like this); set AGS_TEST_STALL_XFAIL=1 to report it as xfail."""
-    import faulthandler
-    faulthandler.dump_traceback_later(seconds, exit=True)
-
-
-RENDEZVOUS_ERRORS = ("Address already in use", "EADDRINUSE", "address already in use", "Connection refused", "Connection reset",
-                     "failed to connect", "The server socket has failed")
-
-
 def _spawn_two(worker, args):
-    from torch.multiprocessing.spawn import ProcessExitedException, ProcessRaisedException
-    last = None
-    for attempt in (0, 1):
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-        with mp.Manager() as mgr:
-            ret = mgr.dict()
-            try:
-                mp.spawn(worker, args=(2, port) + tuple(args) + (ret,), nprocs=2, join=True)
-                return dict(ret)
-            except ProcessRaisedException as e:
-                # the port was free when it was picked and taken when the store bound it (another process's ephemeral
-                # socket): test plumbing, not the product - once more on another port.  Anything else a worker raises
-                # (an assertion, a library error) propagates at once.
-                if attempt == 0 and any(m in str(e) for m in RENDEZVOUS_ERRORS):
-                    last = e
-                    continue
-                out = os.path.join(ROOT, "gpurun_out")
-                if os.path.isdir(out):                        # keep the worker's traceback where a batch run's `tail` cannot lose it
-                    with open(os.path.join(out, "distributed_worker_failure.log"), "a") as f:
-                        f.write(f"==== {os.environ.get('PYTEST_CURRENT_TEST', '?')}\n{e}\n")
-                raise
-            except ProcessExitedException as e:
-                # only the faulthandler watchdog's signature (exit code 1, no signal) counts as a stall and is
-                # retried; a worker killed by a signal (SIGSEGV, abort) is a crash and propagates at once.
-                # Assertion failures inside a worker arrive as ProcessRaisedException and propagate too.
-                if getattr(e, "signal_name", None) or getattr(e, "exit_code", 1) != 1:
-                    raise
-                last = e
-    msg = f"two ranks sharing the GPU over gloo stalled twice (watchdog exits): {last}"
-    if os.environ.get("AGS_TEST_STALL_XFAIL") == "1":
-        pytest.xfail(msg)
-    pytest.fail(msg)
+    """Two processes sharing ONE GPU over gloo is a test-only arrangement and has stalled on some nodes of the pool: a
+    worker still running after 150 s dumps its stacks and exits with code 1 (tests/_spawn.py), and the pair is started
+    ONCE more in fresh processes.  A second stall fails the test - a deadlock between mismatched collectives looks
+    exactly like this.  Anything a worker raises, and any worker killed by a signal, propagates at once."""
+    return spawn_ranks(worker, args, world=2, watchdog_s=150, stall_retries=1)
 
 
-def _worker(rank, world, port, use_graph, sparse_rows, per_rank, ret):
-    _watchdog()
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # both ranks are on this host: never pick a NIC by hostname
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from active_gs_amd.trainer import RowExchange, SurfelTrainer
-        RowExchange.GROWTH, RowExchange.SLACK = 1.25, 64   # small map: the production slack alone would exceed it
-        raw, cams, grads = _setup([rank + world * k for k in range(per_rank)])   # rank r renders views r, r + world, ...
-        tr = SurfelTrainer(raw, sparse_rows=sparse_rows)
-        fn = lambda v, st: (grads[v][0], grads[v][1], grads[v][2], None, None)
-        tr.step(cams, fn, CAP, device_clock=True)
-        assert (tr.exchange is not None and tr.exchange.capacity > 0) == sparse_rows, (tr.rows, tr.exchange)
-        if use_graph:
-            replay = tr.capture(cams, fn, CAP)
-            for _ in range(STEPS - 1):
-                replay()
-        else:
-            for _ in range(STEPS - 1):
-                tr.step(cams, fn, CAP, device_clock=True)
-        torch.cuda.synchronize()
-        if sparse_rows:
-            assert not tr.exchange.overflowed()
-            own, uni = int(tr.rows.count.item()), int(tr.exchange.union.count.item())
-            assert 0 < own <= uni <= N and uni < 2 * tr.exchange.capacity
-            assert float(tr.slab.flat.abs().max()) == 0.0          # consumed rows are re-zeroed every step
-        ret[rank] = [p.cpu() for p in tr.params]
-    finally:
-        dist.destroy_process_group()
+def _worker(rank, world, use_graph, sparse_rows, per_rank):
+    from active_gs_amd.trainer import RowExchange, SurfelTrainer
+    RowExchange.GROWTH, RowExchange.SLACK = 1.25, 64   # small map: the production slack alone would exceed it
+    raw, cams, grads = _setup([rank + world * k for k in range(per_rank)])   # rank r renders views r, r + world, ...
+    tr = SurfelTrainer(raw, sparse_rows=sparse_rows)
+    fn = lambda v, st: (grads[v][0], grads[v][1], grads[v][2], None, None)
+    tr.step(cams, fn, CAP, device_clock=True)
+    assert (tr.exchange is not None and tr.exchange.capacity > 0) == sparse_rows, (tr.rows, tr.exchange)
+    if use_graph:
+        replay = tr.capture(cams, fn, CAP)
+        for _ in range(STEPS - 1):
+            replay()
+    else:
+        for _ in range(STEPS - 1):
+            tr.step(cams, fn, CAP, device_clock=True)
+    torch.cuda.synchronize()
+    if sparse_rows:
+        assert not tr.exchange.overflowed()
+        own, uni = int(tr.rows.count.item()), int(tr.exchange.union.count.item())
+        assert 0 < own <= uni <= N and uni < 2 * tr.exchange.capacity
+        assert float(tr.slab.flat.abs().max()) == 0.0          # consumed rows are re-zeroed every step
+    return [p.cpu() for p in tr.params]
 
 
 @pytest.mark.parametrize("use_graph,sparse_rows,per_rank", [(False, True, 1), (True, True, 1), (False, False, 1),
@@ -130,46 +82,37 @@ def test_two_ranks_equal_single_process_two_views(agslib, use_graph, sparse_rows
     torch.cuda.synchronize()
     ref = [p.cpu() for p in tr.params]
     ret = _spawn_two(_worker, (use_graph, sparse_rows, per_rank))
-    if True:
-        for a, b in zip(ret[0], ret[1]):
-            assert torch.equal(a, b)                               # replicas stay identical
-        moved = 0
-        for a, r, i0 in zip(ret[0], ref, init):
-            travel = (r - i0).abs().mean()
-            moved += int(travel > 1e-6)
-            assert (a - r).abs().mean() < 5e-3 * travel + 1e-9     # Adam eps=1e-15: sign flips on ~0 gradients
-        assert moved >= 4                                          # the optimiser did move the map (scales may sit on their clamp)
+    for a, b in zip(ret[0], ret[1]):
+        assert torch.equal(a, b)                               # replicas stay identical
+    moved = 0
+    for a, r, i0 in zip(ret[0], ref, init):
+        travel = (r - i0).abs().mean()
+        moved += int(travel > 1e-6)
+        assert (a - r).abs().mean() < 5e-3 * travel + 1e-9     # Adam eps=1e-15: sign flips on ~0 gradients
+    assert moved >= 4                                          # the optimiser did move the map (scales may sit on their clamp)
 
 
-def _dense_worker(rank, world, port, chunks, use_graph, row_views, ret):
-    _watchdog()
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from active_gs_amd.trainer import SurfelTrainer
-        SurfelTrainer.DENSE_CHUNKS, SurfelTrainer.DENSE_CHUNK_MIN_ROWS = chunks, 1024      # 8000 rows: 4 chunks of ~2000
-        SurfelTrainer.MAX_ROW_VIEWS = row_views      # 1: every view is its own group - later groups ADD to the chunk's rows
-        raw, cams, grads = _setup([rank, rank + world])                                    # two views per rank
-        tr = SurfelTrainer(raw, sparse_rows=False)
-        fn = lambda v, st: (grads[v][0], grads[v][1], grads[v][2], None, None)
-        tr.step(cams, fn, CAP, device_clock=True)
-        assert tr.rows is None and tr.exchange is None and tr._dense_chunked(cams)
-        if use_graph:
-            replay = tr.capture(cams, fn, CAP)
-            for _ in range(STEPS - 1):
-                replay()
-        else:
-            for _ in range(STEPS - 1):
-                tr.step(cams, fn, CAP, device_clock=True)
-        tr.check_overflow()
-        torch.cuda.synchronize()
-        ret[rank] = dict(params=[p.cpu() for p in tr.params], m=[t.cpu() for t in tr.optim.exp_avg],
-                         v=[t.cpu() for t in tr.optim.exp_avg_sq], step=int(tr.optim.device_clock[0].item()),
-                         slab=tr.slab.flat.cpu())
-    finally:
-        dist.destroy_process_group()
+def _dense_worker(rank, world, chunks, use_graph, row_views):
+    from active_gs_amd.trainer import SurfelTrainer
+    SurfelTrainer.DENSE_CHUNKS, SurfelTrainer.DENSE_CHUNK_MIN_ROWS = chunks, 1024      # 8000 rows: 4 chunks of ~2000
+    SurfelTrainer.MAX_ROW_VIEWS = row_views      # 1: every view is its own group - later groups ADD to the chunk's rows
+    raw, cams, grads = _setup([rank, rank + world])                                    # two views per rank
+    tr = SurfelTrainer(raw, sparse_rows=False)
+    fn = lambda v, st: (grads[v][0], grads[v][1], grads[v][2], None, None)
+    tr.step(cams, fn, CAP, device_clock=True)
+    assert tr.rows is None and tr.exchange is None and tr._dense_chunked(cams)
+    if use_graph:
+        replay = tr.capture(cams, fn, CAP)
+        for _ in range(STEPS - 1):
+            replay()
+    else:
+        for _ in range(STEPS - 1):
+            tr.step(cams, fn, CAP, device_clock=True)
+    tr.check_overflow()
+    torch.cuda.synchronize()
+    return dict(params=[p.cpu() for p in tr.params], m=[t.cpu() for t in tr.optim.exp_avg],
+                     v=[t.cpu() for t in tr.optim.exp_avg_sq], step=int(tr.optim.device_clock[0].item()),
+                     slab=tr.slab.flat.cpu())
 
 
 @pytest.mark.parametrize("use_graph,row_views", [(False, 16), (True, 16), (False, 1)])
@@ -208,33 +151,25 @@ def test_chunked_dense_exchange_keeps_the_replicas_identical(agslib, use_graph, 
 MOVE_STEPS = 7
 
 
-def _moving_worker(rank, world, port, tail, ret):
+def _moving_worker(rank, world, tail):
     """every step each rank renders a NEW view: the sticky row sets keep growing past the (tightly) agreed segment"""
-    _watchdog()
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from active_gs_amd.trainer import RowExchange, SurfelTrainer
-        RowExchange.GROWTH, RowExchange.SLACK, RowExchange.TAIL = 1.0, 4, tail   # no head-room at all
-        SurfelTrainer.CHECK_EVERY = 3
-        raw, cams, grads = _setup([world * s + rank for s in range(MOVE_STEPS)])
-        tr = SurfelTrainer(raw)
-        caps = []
-        for s in range(MOVE_STEPS):
-            fn = lambda v, st, s=s: (grads[s][0], grads[s][1], grads[s][2], None, None)
-            tr.step([cams[s]], fn, CAP)
-            caps.append(tr.exchange.capacity if tr.exchange is not None else -1)
-        redone = tr.check_overflow()
-        torch.cuda.synchronize()
-        assert tr.refused_steps() == 0
-        if tr.exchange is not None:
-            assert not tr.exchange.overflowed() and tr.exchange.capacity >= int(tr.rows.count.item())
-        ret[rank] = dict(params=[p.cpu() for p in tr.params], regrowths=tr.exchange_regrowths, caps=caps,
-                         step=int(tr.optim.device_clock[0].item()), m=[t.cpu() for t in tr.optim.exp_avg])
-    finally:
-        dist.destroy_process_group()
+    from active_gs_amd.trainer import RowExchange, SurfelTrainer
+    RowExchange.GROWTH, RowExchange.SLACK, RowExchange.TAIL = 1.0, 4, tail   # no head-room at all
+    SurfelTrainer.CHECK_EVERY = 3
+    raw, cams, grads = _setup([world * s + rank for s in range(MOVE_STEPS)])
+    tr = SurfelTrainer(raw)
+    caps = []
+    for s in range(MOVE_STEPS):
+        fn = lambda v, st, s=s: (grads[s][0], grads[s][1], grads[s][2], None, None)
+        tr.step([cams[s]], fn, CAP)
+        caps.append(tr.exchange.capacity if tr.exchange is not None else -1)
+    redone = tr.check_overflow()
+    torch.cuda.synchronize()
+    assert tr.refused_steps() == 0
+    if tr.exchange is not None:
+        assert not tr.exchange.overflowed() and tr.exchange.capacity >= int(tr.rows.count.item())
+    return dict(params=[p.cpu() for p in tr.params], regrowths=tr.exchange_regrowths, caps=caps,
+                     step=int(tr.optim.device_clock[0].item()), m=[t.cpu() for t in tr.optim.exp_avg])
 
 
 @pytest.mark.parametrize("tail", ["indexed", "unpack"])
@@ -277,47 +212,34 @@ def _fused_cfg(d):
                          harmonic=cfg["optimizer"]["harmonic_lr"]))
 
 
-def _fused_worker(rank, world, port, ret):
-    _watchdog()
-    import sys
-    for p in (ROOT, os.path.join(ROOT, "tests")):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+def _fused_worker(rank, world):
     import numpy as np
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # both ranks are on this host: never pick a NIC by hostname
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from active_gs_amd.fused_map_trainer import FusedMapTrainer
-        dev = torch.device("cuda:0")
-        d = torch.load(os.path.join(ROOT, "tests", "golden", "train.pt"))
-        raw = {k: v.to(dev) for k, v in d["raw_init"].items()}
-        frames = [{k: v.to(dev) for k, v in f.items()} for f in d["frames"]]
-        t = FusedMapTrainer(raw, frames, _fused_cfg(d))
-        assert t.world == world
-        np.random.seed(7)
-        t.train()
-        torch.cuda.synchronize()
-        ret[rank] = dict(params={k: getattr(t, k).cpu() for k in d["raw_final"]}, perf=t.training_performance.cpu(),
-                         supports=t.view_supports.cpu(), losses=list(t.last_losses))
-    finally:
-        dist.destroy_process_group()
+    from active_gs_amd.fused_map_trainer import FusedMapTrainer
+    dev = torch.device("cuda:0")
+    d = torch.load(os.path.join(ROOT, "tests", "golden", "train.pt"))
+    raw = {k: v.to(dev) for k, v in d["raw_init"].items()}
+    frames = [{k: v.to(dev) for k, v in f.items()} for f in d["frames"]]
+    t = FusedMapTrainer(raw, frames, _fused_cfg(d))
+    assert t.world == world
+    np.random.seed(7)
+    t.train()
+    torch.cuda.synchronize()
+    return dict(params={k: getattr(t, k).cpu() for k in d["raw_final"]}, perf=t.training_performance.cpu(),
+                     supports=t.view_supports.cpu(), losses=list(t.last_losses))
 
 
 def test_fused_map_trainer_two_ranks_match_reference_capture(agslib):
     """Fused loss + view-parallel DP: visibility-count, gradient and error collectives."""
     d = torch.load(os.path.join(ROOT, "tests", "golden", "train.pt"))
     ret = _spawn_two(_fused_worker, ())
-    if True:
-        r0, r1 = ret[0], ret[1]
-        for k, ref in d["raw_final"].items():
-            assert torch.equal(r0["params"][k], r1["params"][k]), k
-            diff, travel = (r0["params"][k] - ref).abs(), (ref - d["raw_init"][k]).abs().mean()
-            assert diff.mean() < 2e-3 * travel, (k, float(diff.mean()), float(travel))
-        assert torch.allclose(r0["perf"], d["training_performance"], rtol=1e-3, atol=1e-5)
-        assert (r0["supports"] != d["view_supports"]).float().mean() < 2e-3
-        assert r0["losses"] == r1["losses"]
+    r0, r1 = ret[0], ret[1]
+    for k, ref in d["raw_final"].items():
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
+        diff, travel = (r0["params"][k] - ref).abs(), (ref - d["raw_init"][k]).abs().mean()
+        assert diff.mean() < 2e-3 * travel, (k, float(diff.mean()), float(travel))
+    assert torch.allclose(r0["perf"], d["training_performance"], rtol=1e-3, atol=1e-5)
+    assert (r0["supports"] != d["view_supports"]).float().mean() < 2e-3
+    assert r0["losses"] == r1["losses"]
 
 
 def test_row_segments_pack_unpack(agslib):
