@@ -61,16 +61,16 @@ class AgsTuning(C.Structure):
                 ("tile_sort_no_wave", C.c_int32), ("bucket_no_scan", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
-BWD_F32, BWD_BF16_SPLIT, BWD_VALU = 0, 1, 2
-_BWD_NAMES = {"f32": BWD_F32, "bf16": BWD_BF16_SPLIT, "bf16_split": BWD_BF16_SPLIT, "valu": BWD_VALU}
+BWD_F32, BWD_BF16_SPLIT, BWD_VALU, BWD_BF16X3 = 0, 1, 2, 3
+_BWD_NAMES = {"f32": BWD_F32, "bf16": BWD_BF16_SPLIT, "bf16_split": BWD_BF16_SPLIT, "valu": BWD_VALU, "bf16x3": BWD_BF16X3}
 
 
-def tuning_from_env(env=None) -> AgsTuning:
-    """The library reads no environment variable (AgsTuning travels with the workspace); THIS binding fills the struct
-    from the AGS_* variables INTEGRATION.md lists, once per process, for experiments and the tests that select kernels:
-      AGS_BWD_REDUCE=f32|bf16|valu  (AGS_BWD_BF16=1 = bf16, AGS_BWD_MFMA=0 = valu)   blend backward's per-surfel sums
+def tuning_from_env(env) -> AgsTuning:
+    """Neither the library nor this package reads an environment variable (AgsTuning travels with the workspace).  This
+    is a pure function of the mapping it is given: a launcher that wants the AGS_* variables INTEGRATION.md lists
+    honoured (bench.py, the tests' conftest, experiment scripts) passes ``os.environ`` through ``env_config.apply_env``:
+      AGS_BWD_REDUCE=f32|bf16|bf16x3|valu  (AGS_BWD_BF16=1 = bf16, AGS_BWD_MFMA=0 = valu)   blend backward's per-surfel sums
       AGS_RENDER_SLOTS=1|2|4, AGS_PRE_CULL_MIN_N=<rows> (0: always), AGS_TSORT_NO_WAVE, AGS_BUCKET_NO_SCAN"""
-    env = os.environ if env is None else env
     t = AgsTuning()
     mode = env.get("AGS_BWD_REDUCE")
     if mode is not None:
@@ -92,15 +92,22 @@ def tuning_from_env(env=None) -> AgsTuning:
 
 
 _default_tuning = None
+cull_choice_pinned = False     # set_default_tuning(..., cull_pinned=True): trainers leave the per-Gaussian kernel choice alone
 
 
 def default_tuning() -> AgsTuning:
-    """The process's default selection (from the environment, see tuning_from_env); kept alive for the structs that
-    point at it."""
+    """The process's default selection: the library's own defaults (all zero) unless a launcher has set another
+    (``set_default_tuning``); kept alive for the structs that point at it."""
     global _default_tuning
     if _default_tuning is None:
-        _default_tuning = tuning_from_env()
+        _default_tuning = AgsTuning()
     return _default_tuning
+
+
+def set_default_tuning(t: AgsTuning, cull_pinned: bool = False) -> None:
+    """Replace the process's default selection (before the first workspace is made: structs made earlier keep the old one)."""
+    global _default_tuning, cull_choice_pinned
+    _default_tuning, cull_choice_pinned = t, bool(cull_pinned)
 
 
 def make_tuning(bwd_reduce=None, render_slots=None, cull_first_min_n=None) -> AgsTuning:
@@ -193,9 +200,11 @@ EXPORTS = ["ags_workspace_bytes", "ags_workspace_region", "ags_workspace_init", 
 _lib = None
 
 
+lib_path_override = None       # an alternative build of the same library (kernel experiments; env_config: AGS_LIB_PATH)
+
+
 def library_path() -> str:
-    # AGS_LIB_PATH: load an alternative build of the same library (kernel experiments)
-    return os.environ.get("AGS_LIB_PATH") or _build.LIB
+    return lib_path_override or _build.LIB
 
 
 def load() -> C.CDLL:

@@ -85,7 +85,7 @@ static const AgsViewStride kOneView = {0, 0, 0, 1};
 static bool ags_tuning_ok(const AgsWorkspace* ws) {
     const AgsTuning* t = ws->tuning;
     if (!t) return true;
-    if (t->bwd_reduce < AGS_BWD_F32 || t->bwd_reduce > AGS_BWD_VALU) return false;
+    if (t->bwd_reduce < AGS_BWD_F32 || t->bwd_reduce > AGS_BWD_BF16X3) return false;
     return t->render_slots == 0 || t->render_slots == 1 || t->render_slots == 2 || t->render_slots == 4;
 }
 

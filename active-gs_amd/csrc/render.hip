@@ -503,6 +503,13 @@ struct AgsWaveBatch {       // one per wave, in LDS: 2048 + 4352 = 6400 B = five
 // the 8 bytes behind the 64 pixels of batch row `row` (hi rows of the bf16 form / the f32 rows): where a slot's
 // (mean - quadrant centre) [even row] and surfel id [odd row] ride along
 #define AGS_BWD_PAD(row) (BF16 ? (void*)&wb.gh[(row)][64] : (void*)&wb.gw[(row)][64])
+// RED (AgsTuning.bwd_reduce): AGS_BWD_F32, AGS_BWD_BF16_SPLIT, or AGS_BWD_BF16X3 - the THREE-way split x = hi + mid + lo
+// (bf16 each by truncation: 8 + 8 + 8 significand bits, so the split of an f32 is EXACT) with the six products of
+// relative size >= 2^-16 formed on the bf16 pipe and accumulated in f32: hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi.
+// The dropped terms (mid.lo, lo.mid, lo.lo) are below 2^-24 of the product - the size of ONE f32 rounding, of which the
+// exact-f32 form makes one per multiply-add.  The factors are parked as f32 (the f32 form's buffer and two stores per
+// pair) and split when the flush reads them as the A operand - 16 values per lane and flush either way, but no extra
+// LDS stores and no larger buffer.  Twelve matrix instructions per flush (f32 form: sixteen, each ~1.3x as long).
 typedef __bf16 ags_bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned int ags_u4 __attribute__((ext_vector_type(4)));
 // two floats -> one register of two truncated bf16 (lo half = a, hi half = b)
@@ -514,8 +521,21 @@ __device__ __forceinline__ float ags_bf16_residual(float x) { return x - __uint_
 #ifndef AGS_MFMA_WAVES
 #define AGS_MFMA_WAVES 6      // register budget: 512 / 6 -> 80 VGPRs
 #endif
-template <bool BF16>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAVES, AGS_MFMA_WAVES))) void ags_k_render_bwd_mfma(
+#ifndef AGS_MFMA_WAVES_X3
+#define AGS_MFMA_WAVES_X3 5   // the three-way split keeps 24 registers of B operands (f32 / two-way: 16): 512 / 5 -> 96 VGPRs
+#endif
+#define AGS_MFMA_WAVES_OF(RED) ((RED) == AGS_BWD_BF16X3 ? AGS_MFMA_WAVES_X3 : AGS_MFMA_WAVES)
+// eight consecutive f32 -> their bf16 hi parts, and the residuals in place
+__device__ __forceinline__ ags_u4 ags_split8_bf16(float x[8]) {
+    const ags_u4 h = {ags_pack_bf16_trunc(x[0], x[1]), ags_pack_bf16_trunc(x[2], x[3]), ags_pack_bf16_trunc(x[4], x[5]),
+                      ags_pack_bf16_trunc(x[6], x[7])};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = ags_bf16_residual(x[k]);
+    return h;
+}
+
+template <int RED>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAVES_OF(RED), AGS_MFMA_WAVES_OF(RED)))) void ags_k_render_bwd_mfma(
     AgsFrame F, int normalize_depth, const float* __restrict__ bgp, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ vals, int id_stride, const AgsGeom* __restrict__ geom,
     const float* __restrict__ depth_out, const float* __restrict__ opac_out, const float* __restrict__ final_T,
@@ -533,6 +553,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
         if (dout.d_confidence) dout.d_confidence += po;
     }
     constexpr int SLOTS = 1;
+    constexpr bool BF16 = RED == AGS_BWD_BF16_SPLIT, X3 = RED == AGS_BWD_BF16X3;
     __shared__ AgsWaveBatch wb;
     const int lane = threadIdx.x;
     int slot, wave;
@@ -606,9 +627,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
     // B operands of v_mfma_f32_16x16x32_bf16: lane = (feature fld, k-group kgrp) holds the feature of pixels
     // 32 b + 8 kgrp .. + 7 for the two K blocks b, as bf16 hi and lo parts: 2 x 4 + 2 x 4 registers
     // (f32 form: FE = the feature of pixels t + 16 kgrp, 16 registers; only one of the two sets is live)
-    ags_u4 BH[2] = {}, BL[2] = {};
+    ags_u4 BH[2] = {}, BL[2] = {}, BM[2] = {};
     float FE[16] = {};
-    if constexpr (BF16) {
+    if constexpr (X3) {
+        float* ex = &wb.gw[0][0];
+        const float feat[16] = {qx, qy, qx * qx, qx * qy, qy * qy, 1.f, pg.dDn, pg.dDn * qx, pg.dDn * qy,
+                                pg.dC0, pg.dC1, pg.dC2, pg.dN0, pg.dN1, pg.dN2, 0.f};
+#pragma unroll
+        for (int f = 0; f < 15; ++f) ex[f * 68 + lane] = feat[f];
+        ags_wave_lds_sync();
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float4* row = reinterpret_cast<const float4*>(ex + fld * 68 + 32 * b + 8 * kgrp);
+            float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+            if (fld < 15) { u = row[0]; v = row[1]; }
+            float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            BH[b] = ags_split8_bf16(x);
+            BM[b] = ags_split8_bf16(x);
+            BL[b] = ags_u4{ags_pack_bf16_trunc(x[0], x[1]), ags_pack_bf16_trunc(x[2], x[3]), ags_pack_bf16_trunc(x[4], x[5]),
+                           ags_pack_bf16_trunc(x[6], x[7])};      // (eight significand bits are left: exact)
+        }
+        ags_wave_lds_sync();
+    } else if constexpr (BF16) {
         float* ex = reinterpret_cast<float*>(&wb.gh[0][0]);       // [feature][pixel] f32, rows of 68 floats: 4080 B of the 4352
         const float feat[16] = {qx, qy, qx * qx, qx * qy, qy * qy, 1.f, pg.dDn, pg.dDn * qx, pg.dDn * qy,
                                 pg.dC0, pg.dC1, pg.dC2, pg.dN0, pg.dN1, pg.dN2, 0.f};
@@ -674,7 +714,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGS_MFMA_WAV
             slot_sid[h] = *reinterpret_cast<const uint32_t*>(AGS_BWD_PAD(4 * kgrp + 2 * h + 1));
         }
         ags_f32x4 d = {0.f, 0.f, 0.f, 0.f}, d_odd = {0.f, 0.f, 0.f, 0.f}; // two chains: a dependent MFMA waits 40 cycles, an independent one 32
-        if constexpr (BF16) {
+        if constexpr (X3) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            // A operand: row fld, pixels 32 b + 8 kgrp .. + 7 as f32 (two 16-byte reads), split three ways in registers
+            const float4* pa = reinterpret_cast<const float4*>(&wb.gw[fld][32 * b + 8 * kgrp]);
+            const float4 u = pa[0], v = pa[1];
+            float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            const ags_bf8 ah = __builtin_bit_cast(ags_bf8, ags_split8_bf16(x));
+            const ags_bf8 am = __builtin_bit_cast(ags_bf8, ags_split8_bf16(x));
+            const ags_bf8 al = __builtin_bit_cast(ags_bf8, ags_u4{ags_pack_bf16_trunc(x[0], x[1]), ags_pack_bf16_trunc(x[2], x[3]),
+                                                                  ags_pack_bf16_trunc(x[4], x[5]), ags_pack_bf16_trunc(x[6], x[7])});
+            const ags_bf8 bh = __builtin_bit_cast(ags_bf8, BH[b]), bm = __builtin_bit_cast(ags_bf8, BM[b]),
+                          bl = __builtin_bit_cast(ags_bf8, BL[b]);
+            // the leading products in one chain, the five corrections (<= 2^-8 of them) in the other
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
+            d_odd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d_odd, 0, 0, 0);
+            d_odd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d_odd, 0, 0, 0);
+            d_odd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, d_odd, 0, 0, 0);
+            d_odd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, d_odd, 0, 0, 0);
+            d_odd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, d_odd, 0, 0, 0);
+        }
+        } else if constexpr (BF16) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             // A operand: row fld, pixels 32 b + 8 kgrp .. + 7 as eight bf16 = two 8-byte reads (136-byte rows are 8-byte aligned)
@@ -854,12 +915,14 @@ void ags_launch_render_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, co
     const uint32_t tile_cap = direct ? ags_direct_tile_cap(L) : 0u;
     // AgsTuning.bwd_reduce: exact f32 matrix instructions (default), the bf16 hi/lo split, or no matrix instructions
     if (L.tune.bwd_reduce != AGS_BWD_VALU) {
-#define AGS_LAUNCH_BWD_MFMA(BF16)                                                                                         \
-    hipLaunchKernelGGL(ags_k_render_bwd_mfma<BF16>, dim3(8 * ags_wave_blocks_per_xcd(L.num_tiles, 4), vs.views), dim3(64), 0, s, F, \
+#define AGS_LAUNCH_BWD_MFMA(RED)                                                                                          \
+    hipLaunchKernelGGL(ags_k_render_bwd_mfma<RED>, dim3(8 * ags_wave_blocks_per_xcd(L.num_tiles, 4), vs.views), dim3(64), 0, s, F, \
                        cam.normalize_depth, cam.bg, (const uint2*)(ws + L.ranges), ids.ids, ids.stride,                    \
                        (const AgsGeom*)(ws + L.geom), fwd.depth, fwd.opacity, (const float*)(ws + L.final_T),             \
                        (const uint32_t*)(ws + L.n_contrib), dout, (float*)(ws + L.dgeom), L.num_tiles, tick, tile_cap, vs)
-        if (L.tune.bwd_reduce == AGS_BWD_BF16_SPLIT) AGS_LAUNCH_BWD_MFMA(true); else AGS_LAUNCH_BWD_MFMA(false);
+        if (L.tune.bwd_reduce == AGS_BWD_BF16_SPLIT) AGS_LAUNCH_BWD_MFMA(AGS_BWD_BF16_SPLIT);
+        else if (L.tune.bwd_reduce == AGS_BWD_BF16X3) AGS_LAUNCH_BWD_MFMA(AGS_BWD_BF16X3);
+        else AGS_LAUNCH_BWD_MFMA(AGS_BWD_F32);
 #undef AGS_LAUNCH_BWD_MFMA
         return;
     }

@@ -7,7 +7,6 @@ no per-view host synchronisation in the loop.
 """
 from __future__ import annotations
 
-import os
 
 from typing import List, Optional
 
@@ -233,7 +232,7 @@ class FusedMapTrainer(GaussianMapTrainer):
     def _gaussians(self) -> api.Gaussians:
         n = self.means.shape[0]
         return api.Gaussians(self.means, self.scales, self.rotations, self.opacities, self.harmonics.view(n, 3),
-                             self.confidences().contiguous(), raw_params=True, scale_factor=self.cfg["scale_factor"],
+                             self._confidences().contiguous(), raw_params=True, scale_factor=self.cfg["scale_factor"],
                              max_scale=0.05)
 
     # One-pass binning needs tiles x the LONGEST tile list of key slots; with badly skewed lists (a distant or
@@ -288,6 +287,7 @@ class FusedMapTrainer(GaussianMapTrainer):
     # after the loop) and the call is then repeated from a snapshot with larger workspaces
     def _snapshot(self) -> dict:
         import numpy as np
+        self.settle()      # a pending check's snapshot lives in the buffers overwritten below: look at it first
         # into buffers kept across calls, as ONE multi-tensor copy (six clones are six allocations and six launches with the
         # GPU idle behind them)
         # (the view statistics too: a call whose check is deferred has its post-processing enqueued before anybody knows
@@ -328,6 +328,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         torch.cuda.set_rng_state(snap["cuda_rng"], self.device)
 
     def _all_or_nothing(self, run, steps) -> None:
+        self.settle()
         snap = self._snapshot()
         for _ in range(6):
             if run(steps):
@@ -452,6 +453,12 @@ class FusedMapTrainer(GaussianMapTrainer):
 
     # ---- post_processing (gaussian_map.py:141-232) and get_confidences (:552-565) without their ~30 torch ops
     def confidences(self):
+        """(public readers see a settled map; the loop's own launches use ``_confidences`` - the view statistics do not
+        change inside a train() call, and add_gaussians settles at its own wait)"""
+        self.settle()
+        return self._confidences()
+
+    def _confidences(self):
         n = self.means.shape[0]
         if n == 0 or not self.means.is_cuda:
             return super().confidences()
@@ -730,7 +737,7 @@ class FusedMapTrainer(GaussianMapTrainer):
     # of the next add_gaussians) - or when anybody reads the map (GaussianMap's attributes, last_losses, save).  A call
     # that did overflow (rare: workspaces carry head-room) is then repeated from its snapshot - parameters, per-frame
     # errors, view statistics, random streams - exactly as the immediate check would have repeated it.
-    DEFER_SETTLE = os.environ.get("AGS_MAPPER_DEFER_SETTLE", "1") != "0"
+    DEFER_SETTLE = True
 
     def _train_batched_checked(self, steps, snap, attempts: int, defer_ok: bool = False) -> None:
         for attempt in range(attempts):
@@ -1011,6 +1018,7 @@ class FusedMapTrainer(GaussianMapTrainer):
     def train_graph(self, steps: Optional[int] = None):
         """Same iteration as ``train`` replayed from a hipGraph (single rank, frames of one shape
         and one field of view).  Falls back to ``train`` when those conditions do not hold."""
+        self.settle()
         if not self._graph_ok():
             return self.train(steps)
         self._all_or_nothing(self._train_graph, steps)
@@ -1036,7 +1044,7 @@ class FusedMapTrainer(GaussianMapTrainer):
         self._loss = FusedLoss(h, w, fx, fy, B, self.cfg["batch_size"], dev)
         bufs = [self._loss.alloc_view() for _ in range(B)]
         self._cap = max(self._cap, 1 << 16, 2 * n)
-        conf = self.confidences().contiguous()     # constant during train(): view stats change in post_processing
+        conf = self._confidences().contiguous()     # constant during train(): view stats change in post_processing
         g = api.Gaussians(self.means, self.scales, self.rotations, self.opacities, self.harmonics.view(n, 3), conf,
                           raw_params=True, scale_factor=self.cfg["scale_factor"], max_scale=0.05)
 

@@ -26,7 +26,6 @@ reference's one-line torch expressions), but ``update / train / add_gaussians / 
 """
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import torch
@@ -82,6 +81,8 @@ class GaussianMap:
     view_means = _state_property("view_means")
     training_performance = _state_property("training_performance")
 
+    FRAME_SAMPLER = "device"     # where the error-weighted frames of a batch are drawn unless cfg.sampler.draw says otherwise
+
     def __init__(self, cfg, device, process_group=None):
         """``cfg``, ``device``: the reference's arguments (gaussian_map.py:18).  ``process_group`` (not in the reference, which
         is single process): a torch.distributed group over which the views of every training iteration are sharded
@@ -121,8 +122,8 @@ class GaussianMap:
         # distribution (successive sampling without replacement) from torch's device generator, no read-back of the
         # per-frame errors per iteration; "host" = np.random.choice on the host, the reference's own stream (the
         # reference seeds nothing - main.py, mapper.py - so no caller can depend on that stream; fixtures replayed
-        # against a seeded capture set this to "host").  cfg.sampler.draw / AGS_FRAME_SAMPLER override.
-        self.frame_sampler = str(_cfg_get(_cfg_get(cfg, "sampler"), "draw", None) or os.environ.get("AGS_FRAME_SAMPLER", "device"))
+        # against a seeded capture set this to "host").  cfg.sampler.draw overrides the class default.
+        self.frame_sampler = str(_cfg_get(_cfg_get(cfg, "sampler"), "draw", None) or self.FRAME_SAMPLER)
         # activation functions (gaussian_map.py:53-60), kept as attributes like the reference
         self.scaling_activation = torch.exp
         self.scaling_inverse_activation = torch.log

@@ -23,6 +23,7 @@ def compact(t: torch.Tensor) -> torch.Tensor:
 
 def map_state(trainer) -> dict:
     """State dict of a ``GaussianMapTrainer`` / ``FusedMapTrainer`` in the reference's schema."""
+    getattr(trainer, "settle", lambda: False)()      # a train() call whose workspace check is still pending (FusedMapTrainer)
     near, far = trainer.cfg["bound"]
     return {
         "means": compact(trainer.means), "scales": compact(trainer.scales), "harmonics": compact(trainer.harmonics),

@@ -77,6 +77,9 @@ class GaussianRasterizationSettings(NamedTuple):
 _binding = None
 
 
+DROPIN_STATUS = "always"     # or "deferred"; read when the binding is first loaded (set_option("always_check", ..) afterwards)
+
+
 def _load_binding():
     """lib/ags_torch_binding.so (built by active_gs_amd.build.build_torch_binding); raises if it is missing."""
     global _binding
@@ -94,11 +97,11 @@ def _load_binding():
     mod.init(_lib.library_path())
     # Default: every call reads its status block back before it returns and repairs an outgrown workspace on the spot
     # (one stream synchronisation per view - what the CUDA extension's num_rendered read-back costs): an unmodified
-    # caller never sees truncated tile lists.  AGS_DROPIN_STATUS=deferred: checks one call late, for loops that call
+    # caller never sees truncated tile lists.  DROPIN_STATUS = "deferred" (set before the first call): checks one call late, for loops that call
     # check_overflow() every iteration (see torch_binding.cpp); deferred_status() does the same for one block of code.
-    mode = os.environ.get("AGS_DROPIN_STATUS", "always")
+    mode = DROPIN_STATUS
     if mode not in ("always", "deferred"):
-        raise ValueError(f"AGS_DROPIN_STATUS={mode!r}: 'always' (default) or 'deferred'")
+        raise ValueError(f"DROPIN_STATUS={mode!r}: 'always' (default) or 'deferred'")
     mod.set_option("always_check", 0.0 if mode == "deferred" else 1.0)
     # the library reads no environment variable: this binding hands it the process's kernel selection (AgsTuning)
     t = _lib.default_tuning()

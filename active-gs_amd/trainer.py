@@ -17,7 +17,6 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
-import os
 from typing import Callable, Optional, Sequence
 
 import torch
@@ -209,18 +208,21 @@ class SurfelTrainer:
     CHECK_EVERY = 16     # optimisation steps between two reads of the overflow notes (one 64-byte D2H each)
     # Views of a multi-view step can run on several streams (their launches overlap each other's ramps and tails: config 4's
     # four 1200x680 views 1.82 -> 1.53 ms per step on 4 streams; 2: 1.57, 3: 1.54).  OPT-IN (``view_streams=`` / this
-    # attribute / AGS_VIEW_STREAMS): the caller's ``image_grads(v, st)`` then runs under the view's stream, so it must not
+    # attribute): the caller's ``image_grads(v, st)`` then runs under the view's stream, so it must not
     # share scratch buffers between views and must consume what it allocates on that stream - a callback written for the
     # one-stream step (the default) need not know any of this.
-    VIEW_STREAMS = int(os.environ.get("AGS_VIEW_STREAMS", "1"))
+    VIEW_STREAMS = 1
     MAX_ROW_VIEWS = 16       # AGS_MAX_ROW_VIEWS (include/ags_raster.h): views one ags_backward_rows launch joins
     MULTI_VIEW_ROWS = True   # several views per step: one per-Gaussian backward launch for all of them (ags_backward_rows)
     # Data-parallel ranks that exchange the DENSE gradient slab (row sets covering most of the map: configuration 4): the
     # per-Gaussian backward, the all-reduce and the Adam update are cut into this many row chunks; chunk k's all-reduce
     # runs on a communication stream under chunk k + 1's chain rule and the Adam update of the chunks that have arrived.
     # Every element is summed over the ranks exactly as in one all-reduce, so the replicas stay bit-identical; 1 = one
-    # all-reduce of the whole slab behind the whole backward.  AGS_DENSE_CHUNKS overrides.
-    DENSE_CHUNKS = int(os.environ.get("AGS_DENSE_CHUNKS", "4"))
+    # all-reduce of the whole slab behind the whole backward.
+    DENSE_CHUNKS = 4
+    DP_FORCE = False             # tests / measurements: take the data-parallel step in a one-rank process group too
+    GRAPH_COLLECTIVES = True     # False: never record collectives inside the step graph
+    CULL_ADAPT = True            # False: never switch the per-Gaussian forward kernel from what the views show
     DENSE_CHUNK_MIN_ROWS = 1 << 14
 
     def reset_optimizer(self) -> None:
@@ -269,10 +271,9 @@ class SurfelTrainer:
     def _distributed(self) -> bool:
         if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             return False
-        # AGS_DP_FORCE=1 (tests): take the data-parallel path in a one-rank group too, which is how the RCCL
+        # DP_FORCE (tests): take the data-parallel path in a one-rank group too, which is how the RCCL
         # collectives and their capture into the step graph are exercised on a single-GPU box
-        import os
-        return torch.distributed.get_world_size(self.pg) > 1 or os.environ.get("AGS_DP_FORCE") == "1"
+        return torch.distributed.get_world_size(self.pg) > 1 or self.DP_FORCE
 
     def gaussians(self) -> api.Gaussians:
         if self.fused_activations:
@@ -567,7 +568,7 @@ class SurfelTrainer:
     def _adapt_kernels(self, visible_per_view: float) -> None:
         if self.n < self.CULL_FIRST_MIN_ROWS or not self.fused_activations or getattr(self, "_tuning_pinned", False):
             return
-        if os.environ.get("AGS_PRE_CULL_MIN_N") is not None or os.environ.get("AGS_CULL_ADAPT") == "0":
+        if _lib.cull_choice_pinned or not self.CULL_ADAPT:
             return                                    # the process's explicit choice stands
         want = 1 if visible_per_view < self.CULL_FIRST_BELOW * self.n else 0      # AgsTuning.cull_first_min_n: 1 = always, 0 = default
         if self.tuning is None:
@@ -687,8 +688,7 @@ class SurfelTrainer:
         if getattr(self, "_capturable", None) is not None:
             return self._capturable
         ok = False
-        import os
-        if os.environ.get("AGS_DP_GRAPH_COLLECTIVES", "1") != "0" and torch.distributed.get_backend(self.pg) == "nccl":
+        if self.GRAPH_COLLECTIVES and torch.distributed.get_backend(self.pg) == "nccl":
             try:
                 world = torch.distributed.get_world_size(self.pg)
                 t = torch.ones(1, device=self.device)

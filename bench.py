@@ -473,6 +473,41 @@ def measure_c3(dev):
                      "frame draw on the device (the same distribution as the reference's np.random.choice)")
 
 
+def flatten_scalars(out) -> None:
+    """The driver's record keeps the SCALAR keys of `config`; the other workloads of the line live in nested objects
+    (config.c3, config.dropin, config.secondary...).  Their headline figures are repeated here as top-level scalars of
+    `config` so that they are in the record - the nested objects stay, these are copies."""
+    cfg = out.get("config", {})
+
+    def dig(obj, *path):
+        for k in path:
+            if not isinstance(obj, dict) or k not in obj:
+                return None
+            obj = obj[k]
+        return obj if isinstance(obj, (int, float)) and not isinstance(obj, bool) else None
+
+    flat = {"c3_seconds_512": dig(cfg, "c3", "512x512", "seconds"), "c3_seconds_1200x680": dig(cfg, "c3", "1200x680", "seconds"),
+            "c3_ms_per_iteration_512": dig(cfg, "c3", "512x512", "ms_per_iteration"),
+            "c3_final_surfels_512": dig(cfg, "c3", "512x512", "final_surfels"),
+            "c3_device_mallocs_512": dig(cfg, "c3", "512x512", "device_mallocs"),
+            "c3_gpu_bound_frac": dig(cfg, "c3", "kernels_busy", "gpu_bound_frac"),
+            "c4_share_ms": dig(cfg, "secondary", "c4_share_ms"), "c5_ms": dig(cfg, "secondary", "c5_ms"),
+            "c4_strong_ms": dig(cfg, "secondary", "strong", "c4", "ms_per_step"),
+            "c5_strong_ms": dig(cfg, "secondary", "strong", "c5", "ms_per_step"),
+            "c4_strong_gaussians_per_s": dig(cfg, "secondary", "strong", "c4", "gaussians_per_s"),
+            "c5_strong_gaussians_per_s": dig(cfg, "secondary", "strong", "c5", "gaussians_per_s"),
+            "c5_roofline_frac_render_bwd": dig(out, "roofline", "c5", "frac"),
+            "dropin_ms_per_view_512": dig(cfg, "dropin", "reference_shape_512x512_8_views", "ms_per_view"),
+            "dropin_ms_per_view_1200x680": dig(cfg, "dropin", "c2_1200x680_1_view", "ms_per_view"),
+            "ms_per_step_bf16_split": out.get("ms_per_step_bf16_split"), "ms_per_step_bf16x3": out.get("ms_per_step_bf16x3"),
+            "ms_per_step_f32_mfma": out.get("ms_per_step_f32_mfma"), "ms_per_step_pipelined": out.get("ms_per_step_pipelined"),
+            "parity_rgb_L1": dig(out, "parity", "parity_rgb_L1"), "parity_grad_rel": dig(out, "parity", "parity_grad_rel"),
+            "cpu_baseline_gaussians_per_s": dig(out, "cpu_baseline", "value")}
+    for k, v in flat.items():
+        if v is not None and k not in cfg:
+            cfg[k] = v
+
+
 def cpu_baseline(raw_cpu, cam_cpu, d_img_cpu, gpu_check, budget_s=15.0, max_threads=16):
     """The oracle (oracle/surfel_oracle.py, PyTorch CPU, fp32) timed on this host: the full
     per-Gaussian stage + binning of the same view, then fwd+bwd of strided batches of tiles
@@ -637,6 +672,9 @@ def main():
         faulthandler.dump_traceback_later(wd, exit=True)
     if os.environ.get("AGS_BENCH_TEST_HANG") == str(rank) and world > 1:      # test hook: this rank stalls (see the tests)
         time.sleep(10 ** 6)
+    # the package reads no environment variable: this launcher hands it the documented AGS_* selection variables
+    from active_gs_amd import env_config
+    env_config.apply_env(os.environ)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
@@ -691,6 +729,7 @@ def main():
     cam = api.Camera(H, W, tanx, tany, cm["viewmatrix"][0].to(dev), cm["projmatrix"][0].to(dev), bg.to(dev))
     bin_mode = {"direct": api.BIN_DIRECT, "tile_sort": api.BIN_TILE_SORT, "radix": api.BIN_RADIX}[args.binning]
     trainer = SurfelTrainer(raw, binning_mode=bin_mode)
+    headline_reduce = int(_lib.default_tuning().bwd_reduce)     # which form of the blend backward's sums the timed region runs
 
     # size the workspace from one probing forward (outside the timed region)
     g = trainer.gaussians()
@@ -997,28 +1036,39 @@ def main():
             # -- the same step with the blend backward's per-surfel sums on the bf16 matrix pipe (hi/lo splits, f32
             #    accumulation: AgsTuning.bwd_reduce = AGS_BWD_BF16_SPLIT, an opt-in per workspace) - same process, same
             #    library, a second trainer on a fresh copy of the scene, sampled like the headline
-            try:
-                t2 = SurfelTrainer({k: v.to(dev) for k, v in raw_cpu.items()}, binning_mode=bin_mode,
-                                   tuning=_lib.make_tuning(bwd_reduce="bf16"))
-                t2._tuning_pinned = False          # (the per-Gaussian kernel is chosen from the views like the headline's)
-                for _ in range(3):
-                    t2.step([cam], grads_fn, cap)
-                torch.cuda.synchronize()
-                rep = max(d for d in range(1, max(1, args.graph_steps) + 1) if args.steps % d == 0)
-                many2 = t2.capture([cam], grads_fn, cap, repeat=rep, pipeline=pipe)
-                run2 = lambda: [many2() for _ in range(args.steps // many2.steps)]
-                for _ in range(max(1, args.warmup // max(args.steps, 1))):
-                    run2()
-                out["ms_per_step_bf16_split"] = summarise(time_samples(run2, max(5, n_samples // 3), False, dev), args.steps)["median"]
-                out["bf16_split_note"] = ("opt-in (AgsTuning.bwd_reduce = AGS_BWD_BF16_SPLIT): the blend backward's per-surfel sums "
-                                          "from bf16 hi/lo splits of both operands, f32 accumulation; gradients move by ~1e-5 "
-                                          "relative; `value` / `ms_per_step` are the exact-f32 default")
-                t2.check_overflow()
-                del t2, many2
-            except Exception as e:
-                out["ms_per_step_bf16_split"] = None
-                out["bf16_split_note"] = f"{type(e).__name__}: {e}"
-                torch.cuda.synchronize()
+            notes = {"bf16": ("ms_per_step_bf16_split", "bf16_split_note",
+                              "opt-in (AgsTuning.bwd_reduce = AGS_BWD_BF16_SPLIT): the blend backward's per-surfel sums "
+                              "from bf16 hi/lo splits of both operands, f32 accumulation; gradients move by ~1e-5 "
+                              "relative; `value` / `ms_per_step` are the default form"),
+                     "bf16x3": ("ms_per_step_bf16x3", "bf16x3_note",
+                                "AgsTuning.bwd_reduce = AGS_BWD_BF16X3: the same sums from an exact three-way bf16 split of both "
+                                "operands (six products, f32 accumulation; every multiply-add within 2^-24 of the exact product); "
+                                "error against fp64 gradients: profiles/r06_bwd_reduce_error.md"),
+                     "f32": ("ms_per_step_f32_mfma", "f32_mfma_note",
+                             "AgsTuning.bwd_reduce = AGS_BWD_F32: exact f32 matrix instructions")}
+            for mode, (key, note_key, text) in notes.items():
+                if _lib._BWD_NAMES[mode] == headline_reduce:
+                    continue                                   # (that form IS the headline)
+                try:
+                    t2 = SurfelTrainer({k: v.to(dev) for k, v in raw_cpu.items()}, binning_mode=bin_mode,
+                                       tuning=_lib.make_tuning(bwd_reduce=mode))
+                    t2._tuning_pinned = False          # (the per-Gaussian kernel is chosen from the views like the headline's)
+                    for _ in range(3):
+                        t2.step([cam], grads_fn, cap)
+                    torch.cuda.synchronize()
+                    rep = max(d for d in range(1, max(1, args.graph_steps) + 1) if args.steps % d == 0)
+                    many2 = t2.capture([cam], grads_fn, cap, repeat=rep, pipeline=pipe)
+                    run2 = lambda: [many2() for _ in range(args.steps // many2.steps)]
+                    for _ in range(max(1, args.warmup // max(args.steps, 1))):
+                        run2()
+                    out[key] = summarise(time_samples(run2, max(5, n_samples // 3), False, dev), args.steps)["median"]
+                    out[note_key] = text
+                    t2.check_overflow()
+                    del t2, many2
+                except Exception as e:
+                    out[key] = None
+                    out[note_key] = f"{type(e).__name__}: {e}"
+                    torch.cuda.synchronize()
             # -- the path an UNMODIFIED caller takes: the drop-in module under autograd, per view
             try:
                 d1 = measure_dropin(dev, N_GAUSS, H, W, 1, iters=40)
@@ -1108,6 +1158,7 @@ def main():
 
             out["cpu_baseline"], out["parity"] = cpu_baseline(
                 raw_cpu, dict(tanx=tanx, tany=tany, bg=bg, view=cm["viewmatrix"][0], proj=cm["projmatrix"][0]), d_cpu, gpu_check)
+        flatten_scalars(out)
         print(json.dumps(out))
     if dist_on:
         torch.distributed.barrier()  # rank 0 may still be in the CPU-baseline leg; leave together

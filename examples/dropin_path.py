@@ -17,6 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd import raster_api as api  # noqa: E402
 from active_gs_amd.camera import camera_matrices  # noqa: E402
 from active_gs_amd.facade import SurfelRenderer  # noqa: E402

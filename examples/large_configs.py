@@ -16,6 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run(tag, n, h, w, views, room, steps, warmup):
+    from active_gs_amd import env_config
+    env_config.apply_env(os.environ)   # the package itself reads no environment variable
     from active_gs_amd import raster_api as api
     from active_gs_amd.camera import camera_matrices
     from active_gs_amd.synthetic import make_camera, make_room_scene

@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--split", action="store_true", help="synchronise around growth and training to time them separately")
     args = ap.parse_args()
 
+    from active_gs_amd import env_config
+    env_config.apply_env(os.environ)   # the package itself reads no environment variable
     from active_gs_amd.synthetic import make_keyframes, run_mapper_loop
     dev = torch.device("cuda:0")
     h, w = args.size

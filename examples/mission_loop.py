@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--candidates", type=int, default=100)
     ap.add_argument("--save-every", type=int, default=10)
     args = ap.parse_args()
+    from active_gs_amd import env_config
+    env_config.apply_env(os.environ)   # the package itself reads no environment variable
     from active_gs_amd.facade import SurfelRenderer as GaussianRenderer
     from active_gs_amd.gaussian_map import GaussianMap
     from active_gs_amd.synthetic import make_camera, make_keyframes, mapper_cfg

@@ -204,6 +204,9 @@ typedef struct AgsGaussianGrads {
                               * hi.lo, f32 accumulation; every dropped term < 2^-16 of its product): ~4 % faster step,
                               * gradients move by ~1e-5 relative.  Opt-in. */
 #define AGS_BWD_VALU 2       /* no matrix instructions: per-lane sums + transposed wave reduction (exact f32) */
+#define AGS_BWD_BF16X3 3     /* the sums on the bf16 matrix pipe from an EXACT three-way split of both operands (8 + 8 + 8
+                              * significand bits), the six products >= 2^-16 of the leading one, f32 accumulation: every
+                              * multiply-add is within 2^-24 of the exact product - one f32 rounding, as in AGS_BWD_F32. */
 typedef struct AgsTuning {
     int32_t bwd_reduce;        /* AGS_BWD_* */
     int32_t render_slots;      /* 0 = by the number of tiles in flight; 1 / 2 / 4 = 8x8 quadrants per wave in the blend kernels */

@@ -1,5 +1,7 @@
 import os, subprocess, sys
 sys.path.insert(0, '.')
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 import active_gs_amd.build as b
 def build(tag, defs):
     objdir = f"scratch/exp_{tag}"; os.makedirs(objdir, exist_ok=True)

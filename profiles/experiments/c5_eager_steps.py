@@ -2,6 +2,8 @@
 Used for A/B runs of library builds: AGS_LIB_PATH=scratch/libags_<tag>.so python profiles/experiments/c5_eager_steps.py"""
 import sys, os, torch
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, R)
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd import raster_api as api
 from active_gs_amd.camera import camera_matrices
 from active_gs_amd.synthetic import make_camera, make_room_scene

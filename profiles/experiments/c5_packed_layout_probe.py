@@ -3,6 +3,8 @@
 (PACK=0, product build); prints the per-stage medians.  The probe build is not kept: the layout was not adopted."""
 import sys, os, torch, time
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, R)
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd import raster_api as api, _lib
 from active_gs_amd.camera import camera_matrices
 from active_gs_amd.synthetic import make_camera, make_room_scene

@@ -4,6 +4,8 @@ Steps config 5 eagerly, times ags_k_preprocess_bwd_rows with the library's stage
 (torch.sort of rows[:count]: membership and results are unchanged, only the order the kernel walks it in) and times again."""
 import sys, os, ctypes as C, torch
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, R)
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd import _lib, raster_api as api
 from active_gs_amd.camera import camera_matrices
 from active_gs_amd.synthetic import make_camera, make_room_scene

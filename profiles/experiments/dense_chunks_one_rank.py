@@ -8,6 +8,8 @@ os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
 import torch, torch.distributed as dist
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd import raster_api as api
 from active_gs_amd.camera import camera_matrices
 from active_gs_amd.synthetic import make_camera, make_room_scene

@@ -34,6 +34,8 @@ def read(lib, reset=True):
 
 
 def step_config(tag, n, h, w, views, room):
+    from active_gs_amd import env_config
+    env_config.apply_env(os.environ)   # the package itself reads no environment variable
     from active_gs_amd import raster_api as api
     from active_gs_amd.camera import camera_matrices
     from active_gs_amd.synthetic import make_camera, make_room_scene

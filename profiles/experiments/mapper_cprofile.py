@@ -3,6 +3,8 @@ usage: python profiles/experiments/mapper_cprofile.py [top=45]"""
 import cProfile, os, pstats, sys
 import numpy as np, torch
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, R)
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd.synthetic import make_keyframes, run_mapper_loop
 dev = torch.device("cuda:0")
 frames = make_keyframes(50, 512, 512, dev)

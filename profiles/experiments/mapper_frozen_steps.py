@@ -13,6 +13,8 @@ import torch
 
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, R)
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd.fused_map_trainer import FusedMapTrainer  # noqa: E402
 from active_gs_amd.gaussian_map import GaussianMap  # noqa: E402
 from active_gs_amd.synthetic import make_keyframes, mapper_cfg  # noqa: E402

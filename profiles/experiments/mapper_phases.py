@@ -15,6 +15,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 
 
 def main():
+    from active_gs_amd import env_config
+    env_config.apply_env(os.environ)   # the package itself reads no environment variable
     from active_gs_amd import fused_map_trainer as fmt
     from active_gs_amd import raster_api as api
     from active_gs_amd.gaussian_map import GaussianMap

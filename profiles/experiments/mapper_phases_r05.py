@@ -4,6 +4,8 @@ boundary), with the deferred workspace check on and off.  Prints one JSON line p
 import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd.fused_map_trainer import FusedMapTrainer
 from active_gs_amd.synthetic import make_keyframes, run_mapper_loop
 dev = torch.device("cuda:0")

@@ -6,6 +6,8 @@ import torch
 sys.argv = [sys.argv[0]]
 import importlib.util
 spec = importlib.util.spec_from_file_location("ml", "examples/mapper_loop.py"); ml = importlib.util.module_from_spec(spec); spec.loader.exec_module(ml)
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd import fused_map_trainer as fmt, optimizer, trainer, raster_api as api, map_trainer
 acc = collections.defaultdict(float); cnt = collections.defaultdict(int)
 def wrap(obj, name, label):

@@ -8,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch
 import bench
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 import active_gs_amd.synthetic as syn
 
 def morton_perm(p, bits=10):

@@ -4,6 +4,8 @@ import sys, os, cProfile, pstats, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd.camera import camera_matrices
 from active_gs_amd.synthetic import activate, make_camera, make_room_scene
 from diff_gaussian_rasterization_2d import GaussianRasterizationSettings, GaussianRasterizer

@@ -2,6 +2,8 @@
 at map sizes far beyond BASELINE.json's 5 M?   python profiles/experiments/scale_probe.py 60000000"""
 import sys, os, torch, time
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, R)
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd import raster_api as api
 from active_gs_amd.camera import camera_matrices
 from active_gs_amd.synthetic import make_camera, make_room_scene

@@ -6,6 +6,8 @@ os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
 import torch, torch.distributed as dist
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd.trainer import RowExchange
 def agree_dense(self, local_rows, slab_floats):      # what agree() decides at 8 ranks for configuration 4: the dense slab
     self.agreements += 1

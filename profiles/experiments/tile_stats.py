@@ -1,6 +1,8 @@
 import sys, os, json
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd import raster_api as api
 from active_gs_amd.camera import camera_matrices
 from active_gs_amd.fused_map_trainer import FusedMapTrainer

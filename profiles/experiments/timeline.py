@@ -25,6 +25,8 @@ ap.add_argument("--pipeline", action="store_true", help="software-pipelined step
 ap.add_argument("--graph", type=int, default=0, help="stamp the LAST step of a hipGraph of this many steps (0: one eager step)")
 args = ap.parse_args()
 
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd import _lib, raster_api as api  # noqa: E402
 from active_gs_amd.camera import camera_matrices  # noqa: E402
 from active_gs_amd.synthetic import make_camera, make_room_scene  # noqa: E402

@@ -11,6 +11,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the package reads no environment variable; the suite honours the documented AGS_* selection variables (the tests
+    # that hold the other kernel forms to the same fixtures re-run files of this suite in a child process with them set)
+    from active_gs_amd import env_config
+    env_config.apply_env(os.environ)
 
 
 # Collection order of the GPU suite (it is run with -x): the single-process HIP-vs-oracle parity files come first, the

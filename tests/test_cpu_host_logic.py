@@ -544,3 +544,27 @@ def test_bench_strong_configurations_and_replica_checksums():
     assert ok and sums == [int(t.view(torch.int32).to(torch.int64).sum()) for t in T.params]
     T.params[1][2] = 1.0000001                                                 # one ulp: another checksum
     assert bench.replica_checksums(T, False)[1] != sums
+
+
+def test_the_package_reads_no_environment_variable():
+    """Kernel selection travels as AgsTuning, everything else is an argument or a class attribute: no module of the
+    package (nor the drop-in module) touches os.environ; launchers call env_config.apply_env(mapping) explicitly, and
+    that function maps the documented AGS_* variables without reading the process environment itself."""
+    import ast
+    import glob
+    files = glob.glob(os.path.join(ROOT, "active-gs_amd", "*.py")) + glob.glob(os.path.join(ROOT, "diff_gaussian_rasterization_2d", "*.py"))
+    assert len(files) > 15
+    for f in files:
+        for node in ast.walk(ast.parse(open(f).read())):
+            assert not (isinstance(node, ast.Attribute) and node.attr in ("environ", "getenv", "environb", "putenv")), (f, node.lineno)
+    from active_gs_amd import _lib, env_config
+    from active_gs_amd.trainer import SurfelTrainer
+    saved = (_lib._default_tuning, _lib.cull_choice_pinned, SurfelTrainer.DENSE_CHUNKS, SurfelTrainer.CULL_ADAPT)
+    try:
+        ch = env_config.apply_env({"AGS_BWD_REDUCE": "bf16", "AGS_PRE_CULL_MIN_N": "0", "AGS_DENSE_CHUNKS": "2", "AGS_CULL_ADAPT": "0"})
+        assert _lib.default_tuning().bwd_reduce == _lib.BWD_BF16_SPLIT and _lib.default_tuning().cull_first_min_n == 1
+        assert _lib.cull_choice_pinned and SurfelTrainer.DENSE_CHUNKS == 2 and SurfelTrainer.CULL_ADAPT is False
+        assert set(ch) == {"tuning", "DENSE_CHUNKS", "CULL_ADAPT"}
+        assert env_config.apply_env({}) == {}
+    finally:
+        _lib._default_tuning, _lib.cull_choice_pinned, SurfelTrainer.DENSE_CHUNKS, SurfelTrainer.CULL_ADAPT = saved

@@ -123,6 +123,12 @@ def test_bench_single_rank_contract_fields(agslib):
     p = d["parity"]
     assert p["ok"] and p["parity_rgb_L1"] < 1e-5 and p["parity_grad_rel"] < 3e-4 and p["tiles_compared"] > 100
     assert max(p["image_max_abs"].values()) < 3e-2 and max(p["image_worst_tile_L1"].values()) < 2.5e-4
+    # the other workloads' headline figures are repeated as SCALAR keys of `config` (the driver's record keeps scalars only)
+    cf = d["config"]
+    assert cf["c3_seconds_512"] == c3["512x512"]["seconds"] and cf["c3_seconds_1200x680"] == c3["1200x680"]["seconds"]
+    assert cf["c3_gpu_bound_frac"] == kb["gpu_bound_frac"] and cf["c4_strong_ms"] == s4["ms_per_step"] and cf["c5_strong_ms"] == s5["ms_per_step"]
+    assert cf["dropin_ms_per_view_512"] > 0 and cf["c5_ms"] == sec["c5_ms"] and cf["ms_per_step_bf16x3"] == d["ms_per_step_bf16x3"]
+    assert 0.8 * d["ms_per_step"] < d["ms_per_step_bf16x3"] < 1.1 * d["ms_per_step"]
 
 
 def test_torch_free_cabi_demo(agslib):
@@ -158,6 +164,27 @@ def test_bench_check_mode_reports_the_exchange_path(agslib):
     sc = d["strong_configs"]
     assert sc["c4"]["exchange_path"].startswith("dense") and sc["c4"]["views_this_rank"] == 4 and sc["c4"]["replicas_identical"]
     assert sc["c5"]["exchange_path"].startswith(("dense", "rows")) and sc["c5"]["replicas_identical"]
+
+
+def test_bench_check_mode_four_ranks(agslib):
+    """The same readiness probe with FOUR ranks sharing the GPU over gloo (the dry run of profiles/r05_q_gloo_ranks.md kept
+    in the suite): four identities, one exchange path agreed by all, the strong-scaled configurations dealt out four ways
+    (configuration 4's 8 reduced views -> 2 per rank) with bit-identical replicas."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(AGS_BENCH_SHARE_GPU="1", AGS_BENCH_BACKEND="gloo", AGS_BENCH_WATCHDOG="200", AGS_BENCH_STRONG=STRONG_REDUCED)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--check"], env=env, capture_output=True,
+                       text=True, timeout=500)
+    if r.returncode != 0 and "Timeout" in r.stderr:
+        _stall_report(r, "bench_check4_stall.log")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["check"] == "ok" and d["n_gpus"] == 4 and d["backend"] == "gloo" and d["refused_steps"] == 0
+    assert [e["rank"] for e in d["ranks"]] == [0, 1, 2, 3]
+    sc = d["strong_configs"]
+    assert sc["c4"]["views_this_rank"] == 2 and sc["c4"]["replicas_identical"] and sc["c5"]["views_this_rank"] == 1
+    assert sc["c5"]["replicas_identical"]
 
 
 def test_a_hung_rank_ends_the_job_with_stacks_not_a_silent_timeout(agslib):

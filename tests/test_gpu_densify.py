@@ -363,6 +363,53 @@ def test_deferred_workspace_check_repeats_an_overflowed_call(agslib):
         assert torch.allclose(other.view_scores, a.view_scores, rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("reader", ["save_map", "train_graph", "confidences"])
+def test_readers_of_the_map_settle_a_pending_check_first(agslib, reader, tmp_path):
+    """Everything that reads or rewrites the map's state looks at a pending workspace check before it does: a checkpoint
+    (map_io.map_state), ``train_graph`` (its snapshot would overwrite the pending call's), ``confidences()``.  The
+    check of the second keyframe is made to fail: the reader must repeat that call (overflow_retries 1) before it
+    proceeds, and nothing may be pending afterwards."""
+    from active_gs_amd import map_io
+    from active_gs_amd.fused_map_trainer import FusedMapTrainer
+    g = _gold()
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    raw = dict(means=z(0, 3), scales=z(0, 3), rotations=z(0, 4), opacities=z(0), harmonics=z(0, 1, 3))
+    np.random.seed(3)
+    torch.manual_seed(3)
+    torch.cuda.manual_seed(3)
+    tr = FusedMapTrainer(raw, [], dict(optimization_steps=5, prune_interval=30, batch_size=4, active_size=2, sampler="device"),
+                         use_graph=True, num_streams=1)
+    tr.DEFER_SETTLE = True
+    real, calls = tr._words_async, {"n": 0}
+
+    def words(dev_words):
+        host = real(dev_words)
+        calls["n"] += 1
+        if calls["n"] == 3:                             # keyframe 2's batch words
+            torch.cuda.synchronize()
+            host[0, 5] = 1
+            host[0, 4] = 1 << 20
+        return host
+    tr._words_async = words
+    tr.update(dict(g["frames"][0]))
+    tr.update(dict(g["frames"][1]))
+    assert tr._pending_check is not None and getattr(tr, "overflow_retries", 0) == 0
+    if reader == "save_map":
+        path = map_io.save_map(tr, str(tmp_path))
+        assert tr.overflow_retries == 1 and tr._pending_check is None
+        saved = torch.load(path)
+        assert torch.equal(saved["means"].to(DEV), tr.means) and torch.equal(saved["view_supports"].to(DEV), tr.view_supports)
+    elif reader == "train_graph":
+        tr.train_graph(3)
+        assert tr.overflow_retries == 1
+        tr.settle()
+    else:
+        c = tr.confidences()
+        assert tr.overflow_retries == 1 and tr._pending_check is None and c.shape[0] == tr.means.shape[0]
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.means).all() and len(tr.frames) == 2
+
+
 def test_frame_store_and_chunked_count_render(agslib):
     """A long mapping session: the keyframes live in ONE growing set of arrays (FusedMapTrainer._frame_store: appended
     to as frames arrive, rebuilt when the list is edited) instead of being stacked at every train() call, and the

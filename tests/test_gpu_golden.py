@@ -231,11 +231,11 @@ def test_bf16_split_backward_passes_the_same_fixtures(agslib):
     gen = torch.Generator().manual_seed(0)
     d = [torch.randn(c, 170, 300, generator=gen).to(dev) for c in (3, 3, 1)]
     res = {}
-    for mode in ("f32", "bf16", "valu"):
+    for mode in ("f32", "bf16", "valu", "bf16x3"):
         st = api.alloc_state(5000, 170, 300, 1 << 20, dev, tuning=_lib.make_tuning(bwd_reduce=mode))
         api.forward(cam, g, st)
         res[mode] = (st.rgb.clone(), api.backward(cam, g, st, *d))
-    for mode in ("bf16", "valu"):
+    for mode in ("bf16", "valu", "bf16x3"):
         assert torch.equal(res[mode][0], res["f32"][0])
         for name in ("means3D", "scales", "rotations", "opacities", "colors"):
             x, y = getattr(res[mode][1], name), getattr(res["f32"][1], name)

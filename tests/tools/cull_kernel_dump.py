@@ -9,10 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from active_gs_amd import raster_api as api  # noqa: E402
+from active_gs_amd import env_config, raster_api as api  # noqa: E402
 from active_gs_amd.camera import camera_matrices  # noqa: E402
 from active_gs_amd.synthetic import make_camera, make_room_scene  # noqa: E402
 
+env_config.apply_env(os.environ)
 dev = torch.device("cuda:0")
 out = {}
 cases = [("small", 6000, 136, 240, 3, 1.5, 1.7), ("ragged", 5037, 100, 150, 1, 0.5, 1.0), ("tiny", 300, 64, 64, 2, 2.0, 1.0),

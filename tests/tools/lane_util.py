@@ -4,6 +4,8 @@ import sys, os, math
 sys.path.insert(0, os.getcwd())
 sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import torch, numpy as np
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 import active_gs_amd
 from active_gs_amd.synthetic import make_camera, make_room_scene, activate
 from active_gs_amd.camera import camera_matrices

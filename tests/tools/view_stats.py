@@ -1,5 +1,8 @@
 import sys, torch, numpy as np
 sys.path.insert(0, ".")
+import os
+from active_gs_amd import env_config
+env_config.apply_env(os.environ)   # the package itself reads no environment variable
 from active_gs_amd.synthetic import make_camera, make_room_scene, activate
 from active_gs_amd.camera import camera_matrices
 from oracle.surfel_oracle import OracleSettings, bin_instances, preprocess
