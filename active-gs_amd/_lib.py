@@ -161,6 +161,11 @@ class AgsLossConfig(C.Structure):
                 ("gt_frame_index", C.c_void_p)]
 
 
+class AgsLossEpilogue(C.Structure):
+    _fields_ = [("cfg", C.POINTER(AgsLossConfig)), ("gt_rgb", C.c_void_p), ("gt_depth", C.c_void_p), ("n_img", C.c_void_p),
+                ("d_rgb", C.c_void_p), ("d_depth", C.c_void_p), ("msum", C.c_void_p), ("accum", C.c_void_p)]
+
+
 class AgsNextIteration(C.Structure):
     _fields_ = [("uniforms", C.c_void_p), ("n_weights", C.c_int32), ("k", C.c_int32), ("first_random", C.c_int32),
                 ("views", C.c_int32), ("all_view", C.c_void_p), ("all_proj", C.c_void_p), ("dst_view", C.c_void_p),
@@ -190,7 +195,7 @@ class AgsCandidates(C.Structure):
     _fields_ = [("means", c_f32p), ("rotations", c_f32p), ("harmonics", c_f32p), ("select", C.c_void_p)]
 
 
-EXPORTS = ["ags_workspace_bytes", "ags_workspace_region", "ags_workspace_init", "ags_workspace_init_batch", "ags_workspace_discard_pass", "ags_forward", "ags_forward_batch",
+EXPORTS = ["ags_workspace_bytes", "ags_workspace_region", "ags_workspace_init", "ags_workspace_init_batch", "ags_workspace_discard_pass", "ags_forward", "ags_forward_batch", "ags_forward_batch_loss",
            "ags_forward_batch_workspace_bytes", "ags_backward", "ags_backward_batch", "ags_backward_rows", "ags_backward_fused_next", "ags_forward_resume", "ags_read_status", "ags_read_status_async", "ags_adam_step",
            "ags_adam_step_device", "ags_rows_segment_floats", "ags_rows_pack", "ags_rows_unpack", "ags_rows_index", "ags_adam_step_gathered", "ags_activate", "ags_activate_backward", "ags_loss_stage1", "ags_loss_stage2", "ags_stage_frames", "ags_loss_finish", "ags_loss_finish_next", "ags_zero_many", "ags_weighted_topk", "ags_facade_post", "ags_facade_post_batch", "ags_facade_post_backward", "ags_smooth_depth", "ags_densify_candidates",
            "ags_voxel_select_bytes", "ags_voxel_select", "ags_prune_keep", "ags_view_stats_update", "ags_confidences", "ags_compact_plan_bytes", "ags_compact_plan",
@@ -235,6 +240,10 @@ def load() -> C.CDLL:
     lib.ags_forward_batch.restype = C.c_int
     lib.ags_forward_batch.argtypes = [C.POINTER(AgsCamera), C.c_int32, C.POINTER(AgsGaussians), C.POINTER(AgsImages),
                                       C.POINTER(AgsPerGaussian), C.POINTER(AgsWorkspace), C.c_void_p]
+    lib.ags_forward_batch_loss.restype = C.c_int
+    lib.ags_forward_batch_loss.argtypes = [C.POINTER(AgsCamera), C.c_int32, C.POINTER(AgsGaussians), C.POINTER(AgsImages),
+                                           C.POINTER(AgsPerGaussian), C.POINTER(AgsWorkspace), C.POINTER(AgsLossEpilogue),
+                                           C.c_void_p]
     lib.ags_forward_batch_workspace_bytes.restype = C.c_size_t
     lib.ags_forward_batch_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64]
     lib.ags_backward.restype = C.c_int

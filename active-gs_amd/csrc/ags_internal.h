@@ -193,9 +193,18 @@ void ags_launch_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, con
 void ags_launch_tile_binning(const AgsFrame& F, const AgsGaussians& in, char* ws, const AgsLayout& L,
                              const AgsViewStride& vs, hipStream_t s);
 AgsIdList ags_sorted_ids(char* ws, const AgsLayout& L, int binning_mode);
+// ags_forward_batch_loss: what the forward blend kernel's epilogue needs of stage 1 of the loss head (loss.hip)
+struct AgsLossFuse {
+    const float* gt_rgb; const float* gt_depth;
+    float* n_img; float* d_rgb; float* d_depth;
+    int* msum; float* accum;
+    const long long* gt_index;     // view v's ground truth is frame gt_index[v] of the store (NULL: batch order)
+    int accum_stride;
+    float k_rgb, k_depth;          // w_rgb / (B 3 HW), w_depth / (B HW)
+};
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs,
-                           bool direct, hipStream_t s);
+                           bool direct, hipStream_t s, const AgsLossFuse* loss = nullptr);
 void ags_launch_rows_adam_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGaussians& in, char* ws,
                                      const AgsLayout& L, const int* radii, const AgsGaussianGrads& din,
                                      const AgsFrame& F2, const AgsCamera& cam2, char* ws2, const AgsLayout& L2, int* radii2,

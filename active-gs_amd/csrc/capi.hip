@@ -141,8 +141,8 @@ size_t ags_forward_batch_workspace_bytes(int32_t views, int32_t n, int32_t h, in
     return (size_t)views * ags_make_layout(n, h, w, max_instances).total;
 }
 
-int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* in, const AgsImages* out,
-                      const AgsPerGaussian* pg, const AgsWorkspace* ws, ags_stream_t stream) {
+static int ags_forward_batch_impl(const AgsCamera* cam, int32_t views, const AgsGaussians* in, const AgsImages* out,
+                                  const AgsPerGaussian* pg, const AgsWorkspace* ws, const AgsLossFuse* loss, ags_stream_t stream) {
     if (!cam || !in || !out || !pg || !ws || !ws->ptr || views < 1 || views > 65535) return AGS_E_INVALID;
     if (in->n <= 0 || cam->image_height <= 0 || cam->image_width <= 0) return AGS_E_INVALID;
     if (!cam->viewmatrix || !cam->projmatrix || !cam->bg || !pg->radii) return AGS_E_INVALID;
@@ -163,8 +163,33 @@ int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* i
     vs.ws = (long long)L.total; vs.px = (long long)cam->image_height * cam->image_width; vs.n = in->n; vs.views = views;
     ags_launch_preprocess(F, *cam, *in, base, L, *pg, direct ? 2 : 1, vs, s);
     if (direct) ags_launch_direct_sort(base, L, vs, s); else ags_launch_tile_binning(F, *in, base, L, vs, s);
-    ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, vs, direct, s);
+    ags_launch_render_fwd(F, *cam, base, L, ags_sorted_ids(base, L, ws->binning_mode), *out, *pg, vs, direct, s, loss);
     return ags_check_launch();
+}
+
+int ags_forward_batch(const AgsCamera* cam, int32_t views, const AgsGaussians* in, const AgsImages* out,
+                      const AgsPerGaussian* pg, const AgsWorkspace* ws, ags_stream_t stream) {
+    return ags_forward_batch_impl(cam, views, in, out, pg, ws, nullptr, stream);
+}
+
+int ags_forward_batch_loss(const AgsCamera* cam, int32_t views, const AgsGaussians* in, const AgsImages* out,
+                           const AgsPerGaussian* pg, const AgsWorkspace* ws, const AgsLossEpilogue* loss, ags_stream_t stream) {
+    if (!cam || !loss || !loss->cfg || cam->want_stats || cam->config) return AGS_E_INVALID;
+    const AgsLossConfig* c = loss->cfg;
+    if (c->image_height != cam->image_height || c->image_width != cam->image_width || c->batch_total < 1 ||
+        views < 1 || 5 + 2 * (views - 1) >= c->accum_stride)
+        return AGS_E_INVALID;
+    if (!loss->gt_rgb || !loss->gt_depth || !loss->n_img || !loss->d_rgb || !loss->d_depth || !loss->msum || !loss->accum)
+        return AGS_E_INVALID;
+    const float hw = (float)c->image_height * (float)c->image_width;
+    AgsLossFuse lf;
+    lf.gt_rgb = loss->gt_rgb; lf.gt_depth = loss->gt_depth; lf.n_img = loss->n_img; lf.d_rgb = loss->d_rgb;
+    lf.d_depth = loss->d_depth; lf.msum = loss->msum; lf.accum = loss->accum;
+    lf.gt_index = (const long long*)c->gt_frame_index; lf.accum_stride = c->accum_stride;
+    // the constants exactly as ags_k_loss_stage1 forms them: w / ((float)B * 3.f * (float)HW), w / ((float)B * (float)HW)
+    lf.k_rgb = c->w_rgb / ((float)c->batch_total * 3.f * hw);
+    lf.k_depth = c->w_depth / ((float)c->batch_total * hw);
+    return ags_forward_batch_impl(cam, views, in, out, pg, ws, &lf, stream);
 }
 
 static bool ags_adam_map_shaped(const AgsAdamTensors* t) {   // the five map tensors: 3n, 3n, 4n, n, 3n

@@ -180,14 +180,14 @@ __device__ __forceinline__ void ags_finalize_status(const AgsFinalize& fin, int 
     }
 }
 
-template <int SLOTS, bool STATS>
+template <int SLOTS, bool STATS, bool LOSS = false>
 __global__ __launch_bounds__(64) void ags_k_render_fwd(
     AgsFrame F, int normalize_depth, float weight_thres, const float* __restrict__ bgp,
     const float* __restrict__ mask, const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
     int id_stride, const AgsGeom* __restrict__ geom, AgsImages out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ importance, int* __restrict__ count, int num_tiles,
     uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_fill, AgsFinalize fin,
-    uint32_t tile_cap, AgsViewStride vs, int seen_only) {
+    uint32_t tile_cap, AgsViewStride vs, int seen_only, AgsLossFuse lf) {
     // seen_only (AGS_STATS_SEEN, an explicit argument - not a null `importance`, which the batched prologue below would
     // shift into a non-null bogus pointer for the views y >= 1): count[i] = 1 for every surfel with a counted pixel
     { // batched forward: this workgroup's view // (offsets are 0 for a single view)
@@ -198,6 +198,10 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
         if (mask) mask += po;
         out.rgb += 3 * po; out.normal += 3 * po; out.depth += po; out.opacity += po; out.confidence += po;
         if (STATS) { if (importance) importance += (size_t)blockIdx.y * (size_t)vs.n; count += (size_t)blockIdx.y * (size_t)vs.n; }
+        if constexpr (LOSS) {   // stage 1 of the loss head rides in the epilogue: this view's slices of its images
+            const size_t go = lf.gt_index ? (size_t)lf.gt_index[blockIdx.y] * (size_t)vs.px : po;
+            lf.gt_rgb += 3 * go; lf.gt_depth += go; lf.n_img += 3 * po; lf.d_rgb += 3 * po; lf.d_depth += po;
+        }
     }
     __shared__ AgsWaveStageQ<SLOTS, 64, STATS> st;
     const int lane = threadIdx.x;
@@ -325,19 +329,54 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
     AGS_TL_VAL(2, tl_w, 7, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32));
     const float bg0 = bgp[0], bg1 = bgp[1], bg2 = bgp[2];
     const size_t HW = (size_t)F.H * F.W;
+    [[maybe_unused]] float s_rgb = 0.f, s_dep = 0.f;   // LOSS: this wave's L1 sums
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int px = AGS_PX(s), py = AGS_PY(s);
         if (px < F.W && py < F.H) {
             const size_t o = (size_t)py * F.W + px;
             const float T = pix[s].T, A = 1.f - T;
-            out.rgb[o] = pix[s].c0 + T * bg0; out.rgb[HW + o] = pix[s].c1 + T * bg1; out.rgb[2 * HW + o] = pix[s].c2 + T * bg2;
+            const float c0 = pix[s].c0 + T * bg0, c1 = pix[s].c1 + T * bg1, c2 = pix[s].c2 + T * bg2;
+            const float dep = normalize_depth ? pix[s].d / fmaxf(A, AGS_DEPTH_A_EPS) : pix[s].d;
+            out.rgb[o] = c0; out.rgb[HW + o] = c1; out.rgb[2 * HW + o] = c2;
             out.normal[o] = pix[s].n0; out.normal[HW + o] = pix[s].n1; out.normal[2 * HW + o] = pix[s].n2;
-            out.depth[o] = normalize_depth ? pix[s].d / fmaxf(A, AGS_DEPTH_A_EPS) : pix[s].d;
+            out.depth[o] = dep;
             out.opacity[o] = A;
             out.confidence[o] = pix[s].cf;
             final_T[o] = T;
             n_contrib[o] = pix[s].last;
+            if constexpr (LOSS) {
+                // ags_k_loss_stage1 (loss.hip) on the values just stored - the same operations in the same order, with
+                // the roundings that file's -ffp-contract=off gives them (explicit __fmul_rn / __fadd_rn: no fused
+                // multiply-add may form here that does not form there)
+                const float mvis = A > 1e-3f ? 1.f : 0.f, mn = A > 1e-2f ? 1.f : 0.f;
+                const float nx = pix[s].n0, ny = pix[s].n1, nz = pix[s].n2;
+                const float nn = __fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz));
+                const float inv = mn / fmaxf(sqrtf(nn), 1e-12f);
+                lf.n_img[o] = __fmul_rn(nx, inv); lf.n_img[HW + o] = __fmul_rn(ny, inv); lf.n_img[2 * HW + o] = __fmul_rn(nz, inv);
+                const float cc[3] = {c0, c1, c2};
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float e = __fmul_rn(__fsub_rn(cc[ch], lf.gt_rgb[ch * HW + o]), mvis);
+                    s_rgb = __fadd_rn(s_rgb, fabsf(e));
+                    lf.d_rgb[ch * HW + o] = __fmul_rn(__fmul_rn(e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f), mvis), lf.k_rgb);
+                }
+                const float dg = lf.gt_depth[o];
+                const float md = dg > 0.f ? 1.f : 0.f;
+                const float e = __fmul_rn(__fsub_rn(dep, dg), md);
+                s_dep = __fadd_rn(s_dep, fabsf(e));
+                lf.d_depth[o] = __fmul_rn(__fmul_rn(e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f), md), lf.k_depth);
+                if (A > 1e-3f) atomicAdd(&lf.msum[o], 1);      // concurrent views into a pre-zeroed count
+            }
+        }
+    }
+    if constexpr (LOSS) {
+        const float t_rgb = ags_wave_sum(s_rgb), t_dep = ags_wave_sum(s_dep);
+        if (lane == 0) {
+            float* row = lf.accum + (size_t)(blockIdx.x & (AGS_LOSS_ACCUM_ROWS - 1)) * lf.accum_stride;
+            const int view = (int)blockIdx.y;
+            atomicAdd(&row[0], t_rgb); atomicAdd(&row[1], t_dep);
+            atomicAdd(&row[4 + 2 * view], t_rgb); atomicAdd(&row[5 + 2 * view], t_dep);
         }
     }
     AGS_TL(2, tl_w, 4);
@@ -866,7 +905,8 @@ static int ags_pick_slots(int num_tiles, const AgsTuning& tune) {
 
 template <int SLOTS>
 static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L, AgsIdList ids,
-                       const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs, bool direct, hipStream_t s) {
+                       const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs, bool direct, hipStream_t s,
+                       const AgsLossFuse* loss) {
     AgsFinalize fin = {nullptr, nullptr, 0u, 1u};
     if (direct) fin = AgsFinalize{(uint32_t*)(ws + L.status), (uint32_t*)(ws + L.totals), ags_direct_tile_cap(L), (uint32_t)L.tc_stride};
     const uint32_t tile_cap = direct ? ags_direct_tile_cap(L) : 0u;
@@ -880,12 +920,17 @@ static void launch_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, true>), grid, block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            seen_only ? nullptr : pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
-                           (uint32_t*)(ws + L.tile_fill), fin, tile_cap, vs, seen_only);
+                           (uint32_t*)(ws + L.tile_fill), fin, tile_cap, vs, seen_only, AgsLossFuse{});
+    else if (loss)
+        hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, false, true>), grid, block, 0, s, F, cam.normalize_depth,
+                           cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
+                           pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
+                           (uint32_t*)(ws + L.tile_fill), fin, tile_cap, vs, 0, *loss);
     else
         hipLaunchKernelGGL((ags_k_render_fwd<SLOTS, false>), grid, block, 0, s, F, cam.normalize_depth,
                            cam.weight_thres, cam.bg, cam.render_mask, ranges, ids.ids, ids.stride, geom, out, fT, nc,
                            pg.importance, pg.count, L.num_tiles, (uint32_t*)(ws + L.tile_count),
-                           (uint32_t*)(ws + L.tile_fill), fin, tile_cap, vs, 0);
+                           (uint32_t*)(ws + L.tile_fill), fin, tile_cap, vs, 0, AgsLossFuse{});
 }
 
 template <int SLOTS>
@@ -900,12 +945,12 @@ static void launch_bwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const 
 
 void ags_launch_render_fwd(const AgsFrame& F, const AgsCamera& cam, char* ws, const AgsLayout& L,
                            AgsIdList ids, const AgsImages& out, const AgsPerGaussian& pg, const AgsViewStride& vs,
-                           bool direct, hipStream_t s) {
+                           bool direct, hipStream_t s, const AgsLossFuse* loss) {
     // strips per wave by the number of tiles in flight: a batch of views fills the GPU like one big image
     switch (ags_pick_slots(L.num_tiles * vs.views, L.tune)) {
-        case 1: launch_fwd<1>(F, cam, ws, L, ids, out, pg, vs, direct, s); break;
-        case 2: launch_fwd<2>(F, cam, ws, L, ids, out, pg, vs, direct, s); break;
-        default: launch_fwd<4>(F, cam, ws, L, ids, out, pg, vs, direct, s); break;
+        case 1: launch_fwd<1>(F, cam, ws, L, ids, out, pg, vs, direct, s, loss); break;
+        case 2: launch_fwd<2>(F, cam, ws, L, ids, out, pg, vs, direct, s, loss); break;
+        default: launch_fwd<4>(F, cam, ws, L, ids, out, pg, vs, direct, s, loss); break;
     }
 }
 

@@ -30,6 +30,9 @@ def apply_env(env) -> dict:
     if env.get("AGS_MAPPER_DEFER_SETTLE") is not None:
         from .fused_map_trainer import FusedMapTrainer
         FusedMapTrainer.DEFER_SETTLE = changed["DEFER_SETTLE"] = env["AGS_MAPPER_DEFER_SETTLE"] != "0"
+    if env.get("AGS_FUSE_LOSS_STAGE1") is not None:
+        from .fused_map_trainer import FusedMapTrainer
+        FusedMapTrainer.FUSE_LOSS_STAGE1 = changed["FUSE_LOSS_STAGE1"] = env["AGS_FUSE_LOSS_STAGE1"] != "0"
     if env.get("AGS_FRAME_SAMPLER") is not None:
         from .gaussian_map import GaussianMap
         GaussianMap.FRAME_SAMPLER = changed["FRAME_SAMPLER"] = env["AGS_FRAME_SAMPLER"]

@@ -82,6 +82,19 @@ class FusedLoss:
             self.cfg.num_views = 0
             self.cfg.gt_frame_index = None
 
+    def epilogue(self, gt_rgb, gt_depth, buf: LossBuffers, gt_index=None) -> "_lib.AgsLossEpilogue":
+        """What ``ViewBatch.forward(views, loss=...)`` takes: stage 1 of the loss head as the epilogue of the forward blend
+        kernel (``ags_forward_batch_loss`` = ``ags_forward_batch`` + ``stage1_batch`` in one set of launches; ``msum`` must be
+        zero).  The struct points at this object's config: valid while ``self`` lives, reads ``batch_total`` at call time."""
+        if not hasattr(self, "_epi_cfg"):
+            self._epi_cfg = _lib.AgsLossConfig()
+        C.memmove(C.byref(self._epi_cfg), C.byref(self.cfg), C.sizeof(_lib.AgsLossConfig))
+        self._epi_cfg.gt_frame_index = ptr(gt_index)
+        e = _lib.AgsLossEpilogue(C.pointer(self._epi_cfg), ptr(gt_rgb), ptr(gt_depth), ptr(buf.n_img), ptr(buf.d_rgb),
+                                 ptr(buf.d_depth), ptr(self.msum), ptr(self.accum))
+        e._keep = (self._epi_cfg, gt_rgb, gt_depth, gt_index)
+        return e
+
     def stage2_batch(self, images: "_lib.AgsImages", gt_depth, buf: LossBuffers, views: int, gt_index=None) -> None:
         self.cfg.num_views = int(views)
         self.cfg.gt_frame_index = ptr(gt_index)

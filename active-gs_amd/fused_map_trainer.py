@@ -166,16 +166,25 @@ class FusedMapTrainer(GaussianMapTrainer):
         import math
 
         import numpy as np
-        # (pose, intrinsics and the far bound in ONE read-back when the frame lives on the device)
         dr = f.get("depth_range")
-        parts = [f["extrinsic"].detach().reshape(-1), f["intrinsic"].detach().reshape(-1)]
-        if torch.is_tensor(dr):
-            parts.append(dr.detach().reshape(-1).to(parts[0].device))
-        dt = torch.float64 if any(p_.dtype == torch.float64 for p_ in parts) else torch.float32   # (no conversion launches for float32 frames)
-        host = torch.cat([p_.to(dt) for p_ in parts]).cpu().numpy().astype(np.float64)
+        hp = f.get("_pose_host")
+        if hp is not None:
+            # the HOST-POSE form: the caller still has the pose on the host (the simulator made it
+            # there, mapper.py:94) - no read-back, so the render and the candidate kernels of this keyframe are enqueued
+            # while the GPU is still running the previous call's iterations
+            host = np.concatenate([np.asarray(x, dtype=np.float64).reshape(-1) for x in hp if x is not None])
+            if hp[2] is not None:
+                f["_far_host"] = float(host[25 + 1])
+        else:
+            # (pose, intrinsics and the far bound in ONE read-back when the frame lives on the device)
+            parts = [f["extrinsic"].detach().reshape(-1), f["intrinsic"].detach().reshape(-1)]
+            if torch.is_tensor(dr):
+                parts.append(dr.detach().reshape(-1).to(parts[0].device))
+            dt = torch.float64 if any(p_.dtype == torch.float64 for p_ in parts) else torch.float32   # (no conversion launches for float32 frames)
+            host = torch.cat([p_.to(dt) for p_ in parts]).cpu().numpy().astype(np.float64)
+            if torch.is_tensor(dr):
+                f["_far_host"] = float(host[25 + 1])
         host32 = host.astype(np.float32)
-        if torch.is_tensor(dr):
-            f["_far_host"] = float(host[25 + 1])
         k = host[16:25].tolist()
         det = (k[0] * (k[4] * k[8] - k[5] * k[7]) - k[1] * (k[3] * k[8] - k[5] * k[6]) + k[2] * (k[3] * k[7] - k[4] * k[6]))
         Ki = [(k[4] * k[8] - k[5] * k[7]) / det, (k[2] * k[7] - k[1] * k[8]) / det, (k[1] * k[5] - k[2] * k[4]) / det,
@@ -630,8 +639,26 @@ class FusedMapTrainer(GaussianMapTrainer):
         finally:
             self._phase("between")
 
+    @staticmethod
+    def _host_pose(frame: dict):
+        """(extrinsic, intrinsic, depth_range) as host arrays when the caller still has them there: CPU tensors / numpy arrays
+        under the usual keys, or under ``extrinsic_host`` / ``intrinsic_host`` / ``depth_range_host`` next to device copies."""
+        import numpy as np
+        out = []
+        for k in ("extrinsic", "intrinsic", "depth_range"):
+            v = frame.get(k + "_host", frame.get(k))
+            if torch.is_tensor(v):
+                if v.is_cuda:
+                    return None if k != "depth_range" else tuple(out) + (None,)
+                v = v.detach().numpy()
+            out.append(None if v is None else np.asarray(v))
+        return tuple(out) if out[0] is not None and out[1] is not None else None
+
     def _add_gaussians(self, frame: dict) -> int:
-        frame = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in frame.items()}
+        pose_host = self._host_pose(frame)
+        frame = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in frame.items() if not k.endswith("_host")}
+        if pose_host is not None:
+            frame["_pose_host"] = pose_host
         if self.frames and tuple(frame["rgb"].shape[-2:]) != tuple(self.frames[0]["rgb"].shape[-2:]):
             # (the reference stacks the sampled frames, /root/reference/mapping/utils.py:220-221,253-254: it cannot train such a set either)
             raise ValueError(f"keyframes of different image sizes cannot be trained together: {tuple(frame['rgb'].shape[-2:])} "
@@ -738,6 +765,7 @@ class FusedMapTrainer(GaussianMapTrainer):
     # that did overflow (rare: workspaces carry head-room) is then repeated from its snapshot - parameters, per-frame
     # errors, view statistics, random streams - exactly as the immediate check would have repeated it.
     DEFER_SETTLE = True
+    FUSE_LOSS_STAGE1 = True      # batched iterations: loss stage 1 as the epilogue of the forward blend kernel
 
     def _train_batched_checked(self, steps, snap, attempts: int, defer_ok: bool = False) -> None:
         for attempt in range(attempts):
@@ -869,10 +897,14 @@ class FusedMapTrainer(GaussianMapTrainer):
                 torch.index_select(all_rgb, 0, idx, out=gt_rgb[:B])
                 torch.index_select(all_depth, 0, idx, out=gt_depth[:B])
                 self._loss.msum.zero_()
-            batch.forward(B, touched=rows)
+            # stage 1 of the loss head in the forward blend kernel's epilogue (ags_forward_batch_loss): one launch and one
+            # re-read of four images less per iteration; bit-identical n_img / d_rgb / d_depth / msum
+            fuse = fast_stage and self.FUSE_LOSS_STAGE1
+            batch.forward(B, touched=rows, loss=self._loss.epilogue(all_rgb, all_depth, bufs, gt_index=idx) if fuse else None)
             images = batch._structs()[0]
             if fast_stage:
-                self._loss.stage1_batch(images, all_rgb, all_depth, bufs, B, gt_index=idx)
+                if not fuse:
+                    self._loss.stage1_batch(images, all_rgb, all_depth, bufs, B, gt_index=idx)
                 self._loss.stage2_batch(images, all_depth, bufs, B, gt_index=idx)
             else:
                 self._loss.stage1_batch(images, gt_rgb, gt_depth, bufs, B)

@@ -540,7 +540,7 @@ class ViewBatch:
         ws = _lib.workspace(ptr(self.workspace), self.workspace.numel(), self.max_instances, self.binning_mode, self.tuning)
         return im, pg, ws
 
-    def _enqueue_batched(self, views: Optional[int] = None, touched: Optional[RowSet] = None) -> None:
+    def _enqueue_batched(self, views: Optional[int] = None, touched: Optional[RowSet] = None, loss=None) -> None:
         lib = _lib.load()
         if self.want_stats:
             if int(self.want_stats) != STATS_SEEN:
@@ -548,13 +548,19 @@ class ViewBatch:
             self.count.zero_()
         cs, gs = self.cam.c_struct(), self.g.c_struct()
         im, pg, ws = self._structs(touched)
+        if loss is not None:     # an _lib.AgsLossEpilogue: stage 1 of the loss head rides in the blend kernel's epilogue
+            _lib.check(lib.ags_forward_batch_loss(C.byref(cs), self.num_views if views is None else int(views), C.byref(gs),
+                                                  C.byref(im), C.byref(pg), C.byref(ws), C.byref(loss), _stream()),
+                       "ags_forward_batch_loss")
+            return
         _lib.check(lib.ags_forward_batch(C.byref(cs), self.num_views if views is None else int(views), C.byref(gs),
                                          C.byref(im), C.byref(pg), C.byref(ws), _stream()), "ags_forward_batch")
 
-    def forward(self, views: Optional[int] = None, touched: Optional[RowSet] = None) -> None:
+    def forward(self, views: Optional[int] = None, touched: Optional[RowSet] = None, loss=None) -> None:
         """Render the first ``views`` poses currently held in ``viewmats`` / ``projmats`` (training
-        loops stage them with one index_select); ``touched``: see ``forward``."""
-        self._enqueue_batched(views, touched)
+        loops stage them with one index_select); ``touched``: see ``forward``; ``loss``: ``FusedLoss.epilogue(...)`` -
+        the forward also runs stage 1 of the loss head (``ags_forward_batch_loss``)."""
+        self._enqueue_batched(views, touched, loss)
 
     def backward(self, views: int, d_rgb, d_normal, d_depth, grads: "GaussianGrads", touched: Optional[RowSet] = None,
                  adam_tick=None, defer_rows: bool = False) -> None:

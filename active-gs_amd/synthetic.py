@@ -121,11 +121,15 @@ def make_camera(view: int, height: int, width: int, focal_px: float | None = Non
     return c2w, K
 
 
-def make_keyframes(count: int, height: int, width: int, device, gt_surfels: int = 400_000, room: str = "office0"):
+def make_keyframes(count: int, height: int, width: int, device, gt_surfels: int = 400_000, room: str = "office0",
+                   host_pose: bool = True):
     """``count`` RGB-D keyframes of the room stand-in as the simulator would hand them to ``GaussianMap.update``
     (/root/reference/mapping/mapper.py:95-101: dict of ``rgb (3,H,W)``, ``depth (1,H,W)``, ``extrinsic (4,4)`` camera-to-world,
     ``intrinsic (3,3)`` normalised, ``depth_range (2,)``), rendered from a dense, opaque ground-truth surfel room with this
-    library's own rasterizer (Replica / habitat are not available offline).  GPU only."""
+    library's own rasterizer (Replica / habitat are not available offline).  GPU only.
+    ``host_pose``: the frames also carry the pose as the simulator made it - on the HOST (``extrinsic_host``, ``intrinsic_host``,
+    ``depth_range_host``; /root/reference/mapping/mapper.py:94 has exactly these before line 95 moves the dict to the device):
+    the map then needs no read-back of the pose per keyframe."""
     from . import raster_api as api
     from .camera import camera_matrices
     dev = torch.device(device)
@@ -149,6 +153,8 @@ def make_keyframes(count: int, height: int, width: int, device, gt_surfels: int 
         depth = torch.where(st.opacity > 0.5, st.depth, torch.zeros_like(st.depth))
         frames.append(dict(rgb=st.rgb.clone().clamp(0, 1), depth=depth.clone(), extrinsic=c2w.to(dev),
                            intrinsic=K.to(dev), depth_range=torch.tensor([0.001, 10.0], device=dev)))
+        if host_pose:
+            frames[-1].update(extrinsic_host=c2w.clone(), intrinsic_host=K.clone(), depth_range_host=torch.tensor([0.001, 10.0]))
     return frames
 
 

@@ -470,7 +470,10 @@ def measure_c3(dev):
                 final_surfels=res["512x512"]["final_surfels"], kernels_busy=busy, **res,
                 what="GaussianMap(cfg, device).update(dataframe) x 50 keyframes (10 iterations each, batch 8 with 3 active frames, "
                      "prune every 5th keyframe) from an empty map, after two warm-up keyframes on a scratch map; the error-weighted "
-                     "frame draw on the device (the same distribution as the reference's np.random.choice)")
+                     "frame draw on the device (the same distribution as the reference's np.random.choice); the dataframe carries "
+                     "the pose on the host next to the device copies (extrinsic_host / intrinsic_host / depth_range_host - what "
+                     "mapper.py:94 holds before line 95; INTEGRATION.md section 3), images on the device",
+                pose="host")
 
 
 def flatten_scalars(out) -> None:

@@ -32,6 +32,10 @@ def main():
                     help="draw the error-weighted frames with the reference's np.random.choice on the host (one read-back "
                          "of the per-frame errors per iteration) instead of the same distribution on the GPU")
     ap.add_argument("--split", action="store_true", help="synchronise around growth and training to time them separately")
+    ap.add_argument("--repeat", type=int, default=1, help="run the loop this many times (one JSON line each)")
+    ap.add_argument("--device-pose", action="store_true",
+                    help="the dataframes carry the pose on the device only (the map reads it back per keyframe) instead of "
+                         "also on the host (INTEGRATION.md section 3: host-pose form)")
     args = ap.parse_args()
 
     from active_gs_amd import env_config
@@ -39,10 +43,11 @@ def main():
     from active_gs_amd.synthetic import make_keyframes, run_mapper_loop
     dev = torch.device("cuda:0")
     h, w = args.size
-    frames = make_keyframes(args.keyframes, h, w, dev, gt_surfels=args.gt_surfels)
-    np.random.seed(0)
-    print(json.dumps(run_mapper_loop(frames, steps=args.steps, draw="host" if args.host_sampler else "device",
-                                     warmup_frames=0 if args.no_warmup else 2, split=args.split)))
+    frames = make_keyframes(args.keyframes, h, w, dev, gt_surfels=args.gt_surfels, host_pose=not args.device_pose)
+    for rep in range(args.repeat):
+        np.random.seed(0)
+        print(json.dumps(run_mapper_loop(frames, steps=args.steps, draw="host" if args.host_sampler else "device",
+                                         warmup_frames=0 if (args.no_warmup or rep) else 2, split=args.split)), flush=True)
 
 
 if __name__ == "__main__":

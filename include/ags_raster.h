@@ -508,6 +508,26 @@ int ags_loss_stage2(const AgsLossConfig* cfg, const AgsImages* fwd, const float*
                     const int32_t* msum, float* d_normal, float* d_depth /* += */, float* accum,
                     ags_stream_t stream);
 
+/* Stage 1 of the loss head as the EPILOGUE of the forward blend kernel (the pixel's nine channels are still in registers
+ * there): ags_forward_batch followed by ags_loss_stage1(cfg with num_views = views, ..., view 0, first_view -1) in one
+ * set of launches - the same n_img / d_rgb / d_depth / msum bit for bit, the loss sums added per wave instead of per
+ * 256-pixel block (same totals up to float summation order).  `msum` must be zero on entry (atomic counting), the images
+ * in `out` are written as by ags_forward_batch (stage 2 and the blend backward read them).  cam->want_stats and
+ * cam->config must be off.  Replaces one full-image launch and its re-read of four images per training iteration
+ * (/root/reference/mapping/gaussian_map.py:94-124 between the render and the loss). */
+typedef struct AgsLossEpilogue {
+    const AgsLossConfig* cfg;   /* image size = the camera's; batch_total, weights, accum_stride, gt_frame_index as for ags_loss_stage1 */
+    const float* gt_rgb;        /* (views,3,H,W), or the whole keyframe store with cfg->gt_frame_index */
+    const float* gt_depth;      /* (views,1,H,W), or the store */
+    float* n_img;               /* (views,3,H,W) out */
+    float* d_rgb;               /* (views,3,H,W) out */
+    float* d_depth;             /* (views,1,H,W) out */
+    int32_t* msum;              /* (H,W), zero on entry */
+    float* accum;               /* AGS_LOSS_ACCUM_ROWS x accum_stride */
+} AgsLossEpilogue;
+int ags_forward_batch_loss(const AgsCamera* cam, int32_t views, const AgsGaussians* in, const AgsImages* out,
+                           const AgsPerGaussian* pg, const AgsWorkspace* ws, const AgsLossEpilogue* loss, ags_stream_t stream);
+
 /* The facade's post-processing alone (render_cuda_core, /root/reference/utils/operations.py:714-718, and
  * depth2normal, :172-219), for callers that keep the reference's loss head in torch:
  *   normal_out = normalize(normal_raw, dim 0, eps 1e-12) * (opacity > 1e-2)

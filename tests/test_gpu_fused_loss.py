@@ -307,3 +307,58 @@ def test_facade_post_kernel_matches_the_torch_statements(agslib, h, w):
         diff = (a - b).abs()
         assert float(diff.max()) <= 5e-5 * scale + 1e-6, (name, float(diff.max()), scale)
         assert float(diff.sum()) <= 1e-5 * float(b.abs().sum()) + 1e-6, (name, float(diff.sum()), float(b.abs().sum()))
+
+
+@pytest.mark.parametrize("h,w,views,use_index", [(64, 96, 3, True), (40, 52, 2, False), (136, 240, 4, True)])
+def test_loss_stage1_as_forward_epilogue_equals_the_separate_launch(agslib, h, w, views, use_index):
+    """``ags_forward_batch_loss``: stage 1 of the loss head as the epilogue of the forward blend kernel against
+    ``ags_forward_batch`` followed by ``ags_loss_stage1`` - the rendered images, the post-processed normal image, d_rgb,
+    d_depth and the visibility count bit for bit (same operations, same roundings), the L1 sums equal up to the order of
+    their additions (per wave of 64 pixels instead of per block of 256); partial tiles at the image border (40x52), the
+    ground truth read in place from a keyframe store through an index, and taken in batch order."""
+    from active_gs_amd import raster_api as api
+    from active_gs_amd.fused_loss import FusedLoss
+    from active_gs_amd.synthetic import make_room_scene, activate
+    dev = torch.device("cuda:0")
+    n = 6000
+    a = activate({k: v.to(dev) for k, v in make_room_scene(n, seed=4).items()})
+    a["scales"] = a["scales"] * 2.5
+    g = api.Gaussians(a["means"], a["scales"].contiguous(), a["rotations"], a["opacities"], a["colors"].contiguous(), a["confidences"])
+    _, S0 = room_case(16, h, w, view=0, seed=0)
+    gen = torch.Generator().manual_seed(5)
+    store = 6
+    gt_rgb = torch.rand(store, 3, h, w, generator=gen).to(dev)
+    gt_depth = (torch.rand(store, 1, h, w, generator=gen) * 3 - 0.3).to(dev)        # some pixels without ground truth (<= 0)
+    idx = torch.tensor([4, 0, 5, 2][:views], device=dev, dtype=torch.long) if use_index else None
+    if not use_index:
+        gt_rgb, gt_depth = gt_rgb[:views].contiguous(), gt_depth[:views].contiguous()
+    out = {}
+    for form in ("separate", "epilogue"):
+        batch = api.ViewBatch(g, views, h, w, S0.tanfovx, S0.tanfovy, S0.bg.to(dev), 1 << 20)
+        for v in range(views):
+            _, S = room_case(16, h, w, view=v, seed=0)
+            batch.viewmats[v].copy_(S.viewmatrix.to(dev)); batch.projmats[v].copy_(S.projmatrix.to(dev))
+        loss = FusedLoss(h, w, 2 * np.arctan(S0.tanfovx), 2 * np.arctan(S0.tanfovy), views, views, dev)
+        bufs = loss.alloc_batch(views)
+        for t in (bufs.n_img, bufs.d_rgb, bufs.d_depth):
+            t.fill_(7.0)
+        if form == "separate":
+            batch.forward(views)
+            loss.stage1_batch(batch._structs()[0], gt_rgb, gt_depth, bufs, views, gt_index=idx)
+        else:
+            batch.forward(views, loss=loss.epilogue(gt_rgb, gt_depth, bufs, gt_index=idx))
+        torch.cuda.synchronize()
+        assert int(batch.statuses(views)[:, 2].max()) == 0
+        out[form] = dict(rgb=batch.rgb.clone(), normal=batch.normal.clone(), depth=batch.depth.clone(), opacity=batch.opacity.clone(),
+                         n_img=bufs.n_img.clone(), d_rgb=bufs.d_rgb.clone(), d_depth=bufs.d_depth.clone(), msum=loss.msum.clone(),
+                         accum=loss.accum.sum(0).clone())
+    s, e = out["separate"], out["epilogue"]
+    for k in ("rgb", "normal", "depth", "opacity", "n_img", "d_rgb", "d_depth", "msum"):
+        assert torch.equal(s[k], e[k]), k
+    assert float(s["opacity"].max()) > 0.5 and int(s["msum"].max()) >= 1 and float(s["d_depth"].abs().max()) > 0
+    assert float(s["accum"][:2].min()) > 0 and torch.allclose(s["accum"], e["accum"], rtol=2e-5, atol=1e-6)
+    # argument checks: statistics cannot ride along, the accumulator rows must hold the views
+    batch.cam.want_stats = True
+    with pytest.raises(RuntimeError):
+        batch.forward(views, loss=loss.epilogue(gt_rgb, gt_depth, bufs, gt_index=idx))
+    batch.cam.want_stats = False

@@ -264,3 +264,39 @@ def test_class_api_on_the_less_travelled_paths(agslib):
     gc.train(steps=0)
     assert all(torch.equal(a, b) for a, b in zip(before, gc.get_params()))          # no iteration ran ...
     assert float((gc.view_supports - supports).sum()) > 0                             # ... post_processing did
+
+
+def test_host_pose_form_of_update_equals_the_device_pose_form(agslib):
+    """``update(dataframe)`` where the caller still has the pose on the host (CPU tensors under the usual keys, or
+    ``*_host`` keys next to device copies - what /root/reference/mapping/mapper.py:94 holds before line 95 moves the dict
+    to the device): the map reads nothing back for the camera, and the camera, the far bound and the map after two
+    keyframes are what the device-pose form gives (same matrices bit for bit: the algebra runs on the host either way)."""
+    from active_gs_amd.gaussian_map import GaussianMap
+    g = torch.load(os.path.join(GOLD, "mapper_loop.pt"))
+    maps = {}
+    for form in ("device", "host_keys", "cpu_pose"):
+        torch.manual_seed(0)
+        torch.cuda.manual_seed(0)
+        gm = GaussianMap(_ns(dict(g["cfg"])), DEV)
+        for k in range(2):
+            f = g["frames"][k]
+            d = _to_dev(f)
+            if form == "host_keys":
+                d.update({key + "_host": f[key].clone() for key in ("extrinsic", "intrinsic", "depth_range")})
+            elif form == "cpu_pose":
+                d.update({key: f[key].clone() for key in ("extrinsic", "intrinsic", "depth_range")})
+            gm.update(d)
+        tr = gm._trainer
+        assert all(("_pose_host" in fr) == (form != "device") for fr in tr.frames)
+        assert all(not any(k.endswith("_host") and k != "_pose_host" and k != "_far_host" for k in fr) for fr in tr.frames)
+        assert all(fr["extrinsic"].is_cuda and fr["intrinsic"].is_cuda for fr in tr.frames)
+        cams = [tr._camera(i) for i in range(2)]
+        maps[form] = dict(view=[c[0].viewmatrix.clone() for c in cams], proj=[c[0].projmatrix.clone() for c in cams],
+                          fov=[(c[1], c[2]) for c in cams], far=[fr.get("_far_host") for fr in tr.frames],
+                          n=gm.get_means.shape[0], perf=gm.training_performance.clone())
+    for form in ("host_keys", "cpu_pose"):
+        a, b = maps["device"], maps[form]
+        assert a["fov"] == b["fov"] and a["far"] == b["far"] and a["n"] == b["n"]
+        for x, y in zip(a["view"] + a["proj"], b["view"] + b["proj"]):
+            assert torch.equal(x, y)
+        assert torch.allclose(a["perf"], b["perf"], rtol=5e-3, atol=1e-5)
