@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libags_raster.so")
 SOURCES = ["preprocess.hip", "binning.hip", "render.hip", "adam.hip", "loss.hip", "densify.hip", "capi.hip"]
-HEADERS = ["ags_internal.h", "ags_experiments.h", "surfel_math.h", os.path.join("..", "..", "include", "ags_raster.h")]
+HEADERS = ["ags_internal.h", "ags_experiments.h", "surfel_math.h", "loss_pixel.h", os.path.join("..", "..", "include", "ags_raster.h")]
 # loss.hip must reproduce exact cancellations of the reference's un-fused torch ops (see ags_point)
 # render.hip: -fno-signed-zeros lets the compiler fold the `0 + x` of freshly zeroed accumulators
 # (-2.5 % step time); NaN / inf semantics are left alone.

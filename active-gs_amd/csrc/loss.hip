@@ -18,6 +18,7 @@
 //                        d_normal; consistency gradient wrt d2n(p) through the cross products onto the
 //                        depths of p and its 4 neighbours (gathered per 32x8 tile through LDS, added to d_depth)
 #include "ags_internal.h"
+#include "loss_pixel.h"
 
 struct AgsLossDev {
     int H, W, B;
@@ -79,24 +80,15 @@ __global__ __launch_bounds__(256) void ags_k_loss_stage1(
     const int p = blockIdx.x * 256 + threadIdx.x;
     float s_rgb = 0.f, s_dep = 0.f;
     if (p < HW) {
-        const float o = opacity[p];
-        const float mvis = o > 1e-3f ? 1.f : 0.f, mn = o > 1e-2f ? 1.f : 0.f;
-        const float nx = normal_raw[p], ny = normal_raw[HW + p], nz = normal_raw[2 * HW + p];
-        const float inv = mn / fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-12f);
-        n_img[p] = nx * inv; n_img[HW + p] = ny * inv; n_img[2 * HW + p] = nz * inv;
-        const float k_rgb = c.w_rgb / ((float)c.B * 3.f * (float)HW);
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const float e = (rgb[ch * HW + p] - gt_rgb[ch * HW + p]) * mvis;
-            s_rgb += fabsf(e);
-            d_rgb[ch * HW + p] = (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * mvis * k_rgb;
-        }
-        const float dg = gt_depth[p];
-        const float md = dg > 0.f ? 1.f : 0.f;
-        const float e = (depth[p] - dg) * md;
-        s_dep = fabsf(e);
-        d_depth[p] = (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * md * (c.w_depth / ((float)c.B * (float)HW));
-        const int v = o > 1e-3f ? 1 : 0;
+        const float k_rgb = c.w_rgb / ((float)c.B * 3.f * (float)HW), k_depth = c.w_depth / ((float)c.B * (float)HW);
+        const AgsStage1Pixel px = ags_loss_stage1_pixel(opacity[p], normal_raw[p], normal_raw[HW + p], normal_raw[2 * HW + p],
+                                                        rgb[p], rgb[HW + p], rgb[2 * HW + p], gt_rgb[p], gt_rgb[HW + p],
+                                                        gt_rgb[2 * HW + p], depth[p], gt_depth[p], k_rgb, k_depth);
+        n_img[p] = px.n[0]; n_img[HW + p] = px.n[1]; n_img[2 * HW + p] = px.n[2];
+        d_rgb[p] = px.d_rgb[0]; d_rgb[HW + p] = px.d_rgb[1]; d_rgb[2 * HW + p] = px.d_rgb[2];
+        d_depth[p] = px.d_depth;
+        s_rgb = px.s_rgb; s_dep = px.s_dep;
+        const int v = px.vis;
         if (first_view < 0) { if (v) atomicAdd(&msum[p], 1); }   // concurrent views into a pre-zeroed count
         else msum[p] = first_view ? v : msum[p] + v;
     }

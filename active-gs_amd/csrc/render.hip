@@ -24,6 +24,7 @@
 // band of tiles.  Counterpart of renderCUDA fwd/bwd in SURVEY.md §2.3; arithmetic in
 // surfel_math.h.
 #include "ags_internal.h"
+#include "loss_pixel.h"
 
 AGS_TL_DEFINE(render)
 AGS_PROBE_DEFINE()
@@ -346,27 +347,15 @@ __global__ __launch_bounds__(64) void ags_k_render_fwd(
             final_T[o] = T;
             n_contrib[o] = pix[s].last;
             if constexpr (LOSS) {
-                // ags_k_loss_stage1 (loss.hip) on the values just stored - the same operations in the same order, with
-                // the roundings that file's -ffp-contract=off gives them (explicit __fmul_rn / __fadd_rn: no fused
-                // multiply-add may form here that does not form there)
-                const float mvis = A > 1e-3f ? 1.f : 0.f, mn = A > 1e-2f ? 1.f : 0.f;
-                const float nx = pix[s].n0, ny = pix[s].n1, nz = pix[s].n2;
-                const float nn = __fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz));
-                const float inv = mn / fmaxf(sqrtf(nn), 1e-12f);
-                lf.n_img[o] = __fmul_rn(nx, inv); lf.n_img[HW + o] = __fmul_rn(ny, inv); lf.n_img[2 * HW + o] = __fmul_rn(nz, inv);
-                const float cc[3] = {c0, c1, c2};
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float e = __fmul_rn(__fsub_rn(cc[ch], lf.gt_rgb[ch * HW + o]), mvis);
-                    s_rgb = __fadd_rn(s_rgb, fabsf(e));
-                    lf.d_rgb[ch * HW + o] = __fmul_rn(__fmul_rn(e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f), mvis), lf.k_rgb);
-                }
-                const float dg = lf.gt_depth[o];
-                const float md = dg > 0.f ? 1.f : 0.f;
-                const float e = __fmul_rn(__fsub_rn(dep, dg), md);
-                s_dep = __fadd_rn(s_dep, fabsf(e));
-                lf.d_depth[o] = __fmul_rn(__fmul_rn(e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f), md), lf.k_depth);
-                if (A > 1e-3f) atomicAdd(&lf.msum[o], 1);      // concurrent views into a pre-zeroed count
+                // ags_k_loss_stage1 (loss.hip) on the values just stored: the same per-pixel function (loss_pixel.h)
+                const AgsStage1Pixel lp = ags_loss_stage1_pixel(A, pix[s].n0, pix[s].n1, pix[s].n2, c0, c1, c2, lf.gt_rgb[o],
+                                                                lf.gt_rgb[HW + o], lf.gt_rgb[2 * HW + o], dep, lf.gt_depth[o],
+                                                                lf.k_rgb, lf.k_depth);
+                lf.n_img[o] = lp.n[0]; lf.n_img[HW + o] = lp.n[1]; lf.n_img[2 * HW + o] = lp.n[2];
+                lf.d_rgb[o] = lp.d_rgb[0]; lf.d_rgb[HW + o] = lp.d_rgb[1]; lf.d_rgb[2 * HW + o] = lp.d_rgb[2];
+                lf.d_depth[o] = lp.d_depth;
+                s_rgb += lp.s_rgb; s_dep += lp.s_dep;
+                if (lp.vis) atomicAdd(&lf.msum[o], 1);          // concurrent views into a pre-zeroed count
             }
         }
     }

@@ -765,7 +765,11 @@ class FusedMapTrainer(GaussianMapTrainer):
     # that did overflow (rare: workspaces carry head-room) is then repeated from its snapshot - parameters, per-frame
     # errors, view statistics, random streams - exactly as the immediate check would have repeated it.
     DEFER_SETTLE = True
-    FUSE_LOSS_STAGE1 = True      # batched iterations: loss stage 1 as the epilogue of the forward blend kernel
+    # batched iterations: loss stage 1 as the epilogue of the forward blend kernel (ags_forward_batch_loss).  Built, bit-identical,
+    # MEASURED SLOWER on the mapper loop (0.3300 s against 0.3266 s for 500 iterations, profiles/r06_mapper_ab.md: the
+    # stand-alone launch streams four images at 29 us per eleven views, the epilogue adds four atomics per wave and the
+    # ground-truth reads to a kernel bound by vector-instruction issue): off by default
+    FUSE_LOSS_STAGE1 = False
 
     def _train_batched_checked(self, steps, snap, attempts: int, defer_ok: bool = False) -> None:
         for attempt in range(attempts):

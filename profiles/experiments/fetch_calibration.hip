@@ -2,6 +2,10 @@
 // Every kernel moves a KNOWN number of bytes over a working set far beyond the 256 MiB Infinity Cache (sources of
 // 1 GiB), so that cache hits cannot hide requests:
 //   read_stream16     64 lanes x 16 B coalesced (the per-Gaussian kernels' parameter rows, the images)
+//   read_stream4      64 lanes x 4 B coalesced (id lists, radii, one image channel row by row)
+//   read_stream8      64 lanes x 8 B coalesced (the (depth | id) keys)
+//   read_rows32       a wave reads an 8x8-pixel quadrant of a 2048-wide f32 image: eight 32-byte row segments (the blend
+//                     kernels' image reads: n_contrib, final_T, the image gradients)
 //   read_gather64     one 64-byte record per 4 lanes at a RANDOM record index (the blend kernels' AgsGeom gather)
 //   read_gather64_1l  one 64-byte record per LANE (four 16-byte loads: ags_k_preprocess_bwd_rows' record reads)
 //   read_gather16     16 B per lane at a random index
@@ -33,6 +37,33 @@ __global__ void read_stream16(const float4* __restrict__ src, size_t n16, float*
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
         const float4 v = src[i];
         acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+
+__global__ void read_stream4(const float* __restrict__ src, size_t n4, float* __restrict__ sink) {
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) acc += src[i];
+    if (acc == 123.456f) sink[0] = acc;
+}
+
+__global__ void read_stream8(const float2* __restrict__ src, size_t n8, float* __restrict__ sink) {
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 v = src[i];
+        acc += v.x + v.y;
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+
+// the image as rows of 2048 floats; wave q reads quadrant q: pixel (8 (q % 256) + (lane & 7), 8 (q / 256) + (lane >> 3))
+__global__ void read_rows32(const float* __restrict__ src, size_t quadrants, float* __restrict__ sink) {
+    float acc = 0.f;
+    const int lane = threadIdx.x & 63;
+    const size_t wave0 = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6, nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t q = wave0; q < quadrants; q += nw) {
+        const size_t x = 8 * (q % 256) + (lane & 7), y = 8 * (q / 256) + (lane >> 3);
+        acc += src[y * 2048 + x];
     }
     if (acc == 123.456f) sink[0] = acc;
 }
@@ -127,6 +158,9 @@ int main() {
     const int REP = 3;
     for (int r = 0; r < REP; ++r) {
         hipLaunchKernelGGL(read_stream16, grid, block, 0, 0, (const float4*)a, BYTES / 16, sink);
+        hipLaunchKernelGGL(read_stream4, grid, block, 0, 0, (const float*)a, BYTES / 4, sink);
+        hipLaunchKernelGGL(read_stream8, grid, block, 0, 0, (const float2*)a, BYTES / 8, sink);
+        hipLaunchKernelGGL(read_rows32, grid, block, 0, 0, (const float*)a, BYTES / 256, sink);
         hipLaunchKernelGGL(read_gather64, grid, block, 0, 0, (const float4*)a, (uint32_t)(BYTES / 64), TOUCH, sink);
         hipLaunchKernelGGL(read_gather64_1l, grid, block, 0, 0, (const float4*)a, (uint32_t)(BYTES / 64), TOUCH, sink);
         hipLaunchKernelGGL(read_gather16, grid, block, 0, 0, (const float4*)a, (uint32_t)(BYTES / 16), TOUCH, sink);
@@ -141,7 +175,8 @@ int main() {
         CHECK(hipDeviceSynchronize());
     }
     // algorithmic bytes per launch: {read, write}
-    printf("{\"read_stream16\": [%zu, 0], \"read_gather64\": [%zu, 0], \"read_gather64_1l\": [%zu, 0], \"read_gather16\": [%zu, 0], "
+    printf("{\"read_stream4\": [%zu, 0], \"read_stream8\": [%zu, 0], \"read_rows32\": [%zu, 0], ", BYTES, BYTES, BYTES);
+    printf("\"read_stream16\": [%zu, 0], \"read_gather64\": [%zu, 0], \"read_gather64_1l\": [%zu, 0], \"read_gather16\": [%zu, 0], "
            "\"read_gather4\": [%zu, 0], \"write_stream16\": [0, %zu], \"write_scatter64\": [0, %zu], \"write_scatter8\": [0, %zu], "
            "\"write_scatter4\": [0, %zu], \"atomic_noret4\": [%zu, %zu], \"atomic_noret64\": [%zu, %zu], \"atomic_ret4\": [%zu, %zu], "
            "\"_touches\": %zu, \"_bytes\": %zu}\n",

@@ -24,7 +24,7 @@ def test_camera_conventions_match_reference_renderer():
         assert torch.allclose(cm["projmatrix"], c["projection_matrices"], atol=1e-5)
         assert torch.equal(cm["campos"], c["cam_pos"])
         # row-vector convention: translation in the last row, w = view-space z
-        assert torch.allclose(cm["viewmatrix"][:, :3, 3], torch.zeros(3, 3))
+        assert torch.allclose(cm["viewmatrix"][:, :3, 3], torch.zeros(3, 3), atol=1e-6)   # (an LU inverse: not exact zeros on every host)
         assert torch.allclose(cm["projmatrix"][:, :, 3], cm["viewmatrix"][:, :, 2], atol=1e-6)
 
 

@@ -354,7 +354,7 @@ def test_loss_stage1_as_forward_epilogue_equals_the_separate_launch(agslib, h, w
                          accum=loss.accum.sum(0).clone())
     s, e = out["separate"], out["epilogue"]
     for k in ("rgb", "normal", "depth", "opacity", "n_img", "d_rgb", "d_depth", "msum"):
-        assert torch.equal(s[k], e[k]), k
+        assert torch.equal(s[k], e[k]), (k, float((s[k].float() - e[k].float()).abs().max()), int((s[k] != e[k]).sum()))
     assert float(s["opacity"].max()) > 0.5 and int(s["msum"].max()) >= 1 and float(s["d_depth"].abs().max()) > 0
     assert float(s["accum"][:2].min()) > 0 and torch.allclose(s["accum"], e["accum"], rtol=2e-5, atol=1e-6)
     # argument checks: statistics cannot ride along, the accumulator rows must hold the views
