@@ -476,6 +476,19 @@ def measure_c3(dev):
                 pose="host")
 
 
+def pmc_entry(e):
+    """(traffic, read, write, how) of one stage's entry of a committed counter file.  New files (profiles/pmc_exact_summary.py)
+    carry the memory-side bytes by REQUEST SIZE; files of earlier rounds carry FETCH_SIZE, which counts every read request at
+    64 bytes (profiles/r06_fetch_calibration.md): exact for isolated 64-byte gathers, half the bytes of whole 128-byte lines."""
+    if "read" in e:
+        return e.get("traffic"), e.get("read"), e.get("write"), ("read = 128 x TCC_EA0_RDREQ_128B + 64 x _64B + 32 x _32B, write = 64 x "
+                                                                 "TCC_EA0_WRREQ_64B + 32 x the other write requests: exact request sizes")
+    if "fetch_raw" in e:
+        return e.get("traffic"), 2 * e["fetch_raw"], e.get("write"), ("read = 2 x FETCH_SIZE: an UPPER bound (FETCH_SIZE counts every "
+                                                                      "request at 64 bytes; gathers move 64, streams 128)")
+    return None, None, None, "no entry for this stage"
+
+
 def flatten_scalars(out) -> None:
     """The driver's record keeps the SCALAR keys of `config`; the other workloads of the line live in nested objects
     (config.c3, config.dropin, config.secondary...).  Their headline figures are repeated here as top-level scalars of
@@ -945,12 +958,9 @@ def main():
         traffic = traffic_src = traffic_read = traffic_write = valu = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", PMC_HBM_FILE)))
-            traffic = pm.get(dom, {}).get("traffic")
-            traffic_read = 2 * pm.get(dom, {}).get("fetch_raw", 0) or None
-            traffic_write = pm.get(dom, {}).get("write")
-            traffic_src = f"profiles/{PMC_HBM_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
-                          f"session {pm.get('_session', '?')}; not collected in this run; read = 2 x FETCH_SIZE, the gfx950 " \
-                          "correction for wide reads)"
+            traffic, traffic_read, traffic_write, how = pmc_entry(pm.get(dom, {}))
+            traffic_src = f"profiles/{PMC_HBM_FILE} (rocprofv3 --pmc passes of this command, session {pm.get('_session', '?')}; " \
+                          f"not collected in this run; {how})"
         except Exception:
             pass
         try:
@@ -1117,11 +1127,11 @@ def main():
                           # profiles/experiments/c5_counters.sh (eager steps on a frozen scene; not collected in this run)
                     pm5 = json.load(open(os.path.join(ROOT, "profiles", PMC5_HBM_FILE)))
                     e5 = pm5.get(dom5, {})
-                    out["roofline"]["c5"].update(traffic=e5.get("traffic"), traffic_read=2 * e5.get("fetch_raw", 0) or None,
-                                                 traffic_write=e5.get("write"),
-                                                 traffic_source=f"profiles/{PMC5_HBM_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
-                                                                f"eager steps of configuration 5, session {pm5.get('_session', '?')}; not collected "
-                                                                "in this run; read = 2 x FETCH_SIZE)")
+                    t5_, r5_, w5_, how5 = pmc_entry(e5)
+                    out["roofline"]["c5"].update(traffic=t5_, traffic_read=r5_, traffic_write=w5_,
+                                                 traffic_source=f"profiles/{PMC5_HBM_FILE} (rocprofv3 --pmc passes over eager steps of "
+                                                                f"configuration 5, session {pm5.get('_session', '?')}; not collected in this "
+                                                                f"run; {how5})")
                 except Exception:
                     pass
             except Exception as e:
