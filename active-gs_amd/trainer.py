@@ -563,14 +563,26 @@ class SurfelTrainer:
     # spread over the waves, which the host cannot see; the visible FRACTION is the proxy it has.  The trainer reads its
     # views' status blocks every CHECK_EVERY steps anyway: it asks for the cull-first kernel while the views show less than
     # CULL_FIRST_BELOW of the rows - a tenth: below what a map grown by the mapper shows from inside, above C2's 7 %.
+    # Hysteresis: switched ON below CULL_FIRST_ON of the rows, OFF again only above CULL_FIRST_OFF - a trainer whose views sit
+    # at the threshold does not flip kernels at every look (both kernels give the same bits; a captured graph keeps the one
+    # it was recorded with, `cull_first_kernel()` says which one the next launch takes).
     CULL_FIRST_BELOW, CULL_FIRST_MIN_ROWS = 0.10, 1 << 16
+    CULL_FIRST_ON, CULL_FIRST_OFF = 0.08, 0.12
+
+    def cull_first_kernel(self) -> bool:
+        """Does the next per-Gaussian forward launch of this trainer take the cull-first kernel?"""
+        t = self.tuning if self.tuning is not None else _lib.default_tuning()
+        thr = int(t.cull_first_min_n)
+        return self.fused_activations and (thr == 1 or (thr == 0 and self.n >= (1 << 20)) or (thr > 1 and self.n >= thr))
 
     def _adapt_kernels(self, visible_per_view: float) -> None:
         if self.n < self.CULL_FIRST_MIN_ROWS or not self.fused_activations or getattr(self, "_tuning_pinned", False):
             return
         if _lib.cull_choice_pinned or not self.CULL_ADAPT:
             return                                    # the process's explicit choice stands
-        want = 1 if visible_per_view < self.CULL_FIRST_BELOW * self.n else 0      # AgsTuning.cull_first_min_n: 1 = always, 0 = default
+        now = 1 if (self.tuning is not None and self.tuning.cull_first_min_n == 1) else 0
+        frac = visible_per_view / max(self.n, 1)
+        want = 1 if frac < self.CULL_FIRST_ON else (0 if frac > self.CULL_FIRST_OFF else now)   # AgsTuning.cull_first_min_n: 1 = always, 0 = default
         if self.tuning is None:
             if want == 0:
                 return

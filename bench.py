@@ -452,7 +452,7 @@ def measure_c3(dev):
         del frames
         torch.cuda.empty_cache()
         busy = dict(seconds_with_marks=r["seconds"], gpu_bound_frac=r["gpu_bound_frac"], iterations_gpu_ms=r["iterations_gpu_ms"],
-                    phases=r["phases"],
+                    phases=r["phases"], device_mallocs=r["device_mallocs"],
                     what="this run, second pass of the 512x512 loop with event marks at the phase boundaries (~7 records per "
                          "keyframe): gpu_bound_frac = GPU-timeline time of the iterations / that pass's wall time - a LOWER bound "
                          "of the kernels-busy fraction (the host-bound phases also run kernels)")
@@ -507,6 +507,8 @@ def flatten_scalars(out) -> None:
             "c3_final_surfels_512": dig(cfg, "c3", "512x512", "final_surfels"),
             "c3_device_mallocs_512": dig(cfg, "c3", "512x512", "device_mallocs"),
             "c3_gpu_bound_frac": dig(cfg, "c3", "kernels_busy", "gpu_bound_frac"),
+            "c3_seconds_512_second_pass": dig(cfg, "c3", "kernels_busy", "seconds_with_marks"),
+            "c3_device_mallocs_512_second_pass": dig(cfg, "c3", "kernels_busy", "device_mallocs"),
             "c4_share_ms": dig(cfg, "secondary", "c4_share_ms"), "c5_ms": dig(cfg, "secondary", "c5_ms"),
             "c4_strong_ms": dig(cfg, "secondary", "strong", "c4", "ms_per_step"),
             "c5_strong_ms": dig(cfg, "secondary", "strong", "c5", "ms_per_step"),
@@ -809,6 +811,7 @@ def main():
     def capture(pipe):
         """-> (one_step, many_steps, steps per replay of many_steps, description)"""
         mode = "hipGraph replay"
+        timed_kernel["per_gaussian_forward"] = "ags_k_preprocess_cull" if trainer.cull_first_kernel() else "ags_k_preprocess<2>"
         one = trainer.capture([cam], grads_fn, cap, pipeline=pipe)
         in_graph = getattr(one, "collective_in_graph", False)
         if dist_on:
@@ -830,6 +833,9 @@ def main():
         return one, many, per, mode
 
     launch_mode = "eager" if args.eager else "hipGraph replay"
+    # which per-Gaussian forward kernel the timed graphs were recorded with (the trainer picks it from what its views show,
+    # SurfelTrainer._adapt_kernels: a graph keeps the kernel it was captured with)
+    timed_kernel = {"per_gaussian_forward": "ags_k_preprocess_cull" if trainer.cull_first_kernel() else "ags_k_preprocess<2>"}
     one_step, many_steps, per_replay = eager_step, None, 1
     pipe = args.pipeline and not dist_on and not args.no_pipeline and args.binning == "direct"
     if not args.eager:
@@ -926,12 +932,11 @@ def main():
         # BASELINE.json's configurations 4 and 5 at THIS number of ranks (strong scaling: the views of a step are dealt out
         # over the ranks); every rank takes part (collectives), rank 0 reports
         strong = {}
+        # A failure that only SOME ranks see (out of memory with 32 workspaces, an overflow on one rank's views) would leave
+        # the others waiting in the next collective until the watchdog: no per-rank recovery here - the exception ends the
+        # rank, torch.distributed.run ends the job, and the launcher prints the tail of every rank's stderr.
         for key, cfg in strong_configs().items():
-            try:
-                strong[key] = measure_strong(key, cfg, 10, dev, world, rank, dist_on)
-            except Exception as e:                      # (deterministic across ranks: same software, same sizes)
-                strong[key] = f"{type(e).__name__}: {e}"
-                torch.cuda.synchronize()
+            strong[key] = measure_strong(key, cfg, 10, dev, world, rank, dist_on)
 
     if rank == 0:
         T = ((H + 15) // 16) * ((W + 15) // 16)
@@ -1003,6 +1008,8 @@ def main():
                        "overflow_passes": int(info["overflow_passes"]), "profile_note": profile_note,
                        "binning": args.binning,
                        "launch": launch_mode,
+                       "per_gaussian_forward_kernel": timed_kernel["per_gaussian_forward"],
+                       "blend_backward_reduce": {v: k for k, v in _lib._BWD_NAMES.items() if k != "bf16_split"}[headline_reduce],
                        "optimizer": ("row-set Adam fused into the per-Gaussian backward (exact: untouched rows "
                                      f"have zero gradient and moments), {rows} member rows") if (rows is not None and not dist_on)
                                     else ("row-set Adam over the union of the ranks' member rows" if rows is not None

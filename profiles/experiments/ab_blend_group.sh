@@ -2,8 +2,14 @@
 # (one surfel per wave and iteration), per kernel under rocprofv3, interleaved repetitions on one box:
 #   C2 bench step, the mapper loop @512x512 (configuration 3: the reference's own shape), configuration 4's share, configuration 5
 # bash profiles/experiments/ab_blend_group.sh [reps]      -> stdout (tee into gpurun_out/)
+# PREREQUISITE: the tree has no blend_group switch any more - the 16-lane-group loops were measured, lost everywhere and
+# were taken out; they survive as profiles/experiments/r05_blend_group16.patch.  Apply that patch and
+# rebuild before running this script, or it compares two identical builds.
 reps=${1:-2}
-export R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
+export R=$GRAFT_REPO_ROOT
+if ! grep -q "blend_group" $R/include/ags_raster.h; then
+  echo "ab_blend_group.sh: include/ags_raster.h has no blend_group field - apply profiles/experiments/r05_blend_group16.patch and rebuild first" >&2; exit 2
+fi; cd /tmp && export TMPDIR=/tmp
 pat="render_fwd|render_bwd"
 run() { # label, command...
   label=$1; shift

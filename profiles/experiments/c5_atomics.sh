@@ -12,6 +12,9 @@
 # bash profiles/experiments/c5_atomics.sh <tag>   -> gpurun_out/<tag>_c5_atomics.md
 TAG=${1:-r00}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+for lib in base5 noatom; do
+  if [ ! -f $R/scratch/libags_$lib.so ]; then echo "c5_atomics.sh: scratch/libags_$lib.so is missing (see the header: both builds are made before the call)" >&2; exit 2; fi
+done
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/${TAG}_c5_atomics.md
 S=$R/profiles/experiments/c5_eager_steps.py
