@@ -481,8 +481,9 @@ def pmc_entry(e):
     carry the memory-side bytes by REQUEST SIZE; files of earlier rounds carry FETCH_SIZE, which counts every read request at
     64 bytes (profiles/r06_fetch_calibration.md): exact for isolated 64-byte gathers, half the bytes of whole 128-byte lines."""
     if "read" in e:
-        return e.get("traffic"), e.get("read"), e.get("write"), ("read = 128 x TCC_EA0_RDREQ_128B + 64 x _64B + 32 x _32B, write = 64 x "
-                                                                 "TCC_EA0_WRREQ_64B + 32 x the other write requests: exact request sizes")
+        return e.get("traffic"), e.get("read"), e.get("write"), (f"write = 64 x TCC_EA0_WRREQ_64B + 32 x the other write requests (exact); read between "
+                                                                 f"{e.get('read_lo')} (64 B per read request = FETCH_SIZE) and {e.get('read_hi')} (128 B per "
+                                                                 "request), the end this stage's access pattern sits at: profiles/r06_fetch_calibration.md")
     if "fetch_raw" in e:
         return e.get("traffic"), 2 * e["fetch_raw"], e.get("write"), ("read = 2 x FETCH_SIZE: an UPPER bound (FETCH_SIZE counts every "
                                                                       "request at 64 bytes; gathers move 64, streams 128)")

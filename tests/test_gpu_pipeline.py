@@ -300,6 +300,13 @@ def test_trainer_asks_for_the_cull_first_kernel_when_its_views_show_little(agsli
         res[mode] = (tr, [p.clone() for p in tr.params])
     ta, tp = res["adaptive"][0], res["pinned"][0]
     assert ta.tuning is not None and ta.tuning.cull_first_min_n == 1 and tp.tuning.cull_first_min_n == -1
+    assert ta.cull_first_kernel() and not tp.cull_first_kernel()
+    # hysteresis: on below 8 % of the rows, off above 12 %, unchanged in between - a trainer at the threshold does not flip
+    for frac, want in ((0.09, 1), (0.11, 1), (0.13, 0), (0.11, 0), (0.09, 0), (0.07, 1)):
+        ta._adapt_kernels(frac * n)
+        assert ta.tuning.cull_first_min_n == want, (frac, want)
+        tp._adapt_kernels(frac * n)
+        assert tp.tuning.cull_first_min_n == -1          # a caller's explicit selection is never adapted
     assert 0 < int(ta.rows.count.item()) == int(tp.rows.count.item()) < 0.1 * n
     init = make_room_scene(n, seed=5)
     for a, b, key in zip(res["adaptive"][1], res["pinned"][1], ("means", "scales", "rotations", "opacities", "harmonics")):
