@@ -933,11 +933,25 @@ def main():
         # BASELINE.json's configurations 4 and 5 at THIS number of ranks (strong scaling: the views of a step are dealt out
         # over the ranks); every rank takes part (collectives), rank 0 reports
         strong = {}
-        # A failure that only SOME ranks see (out of memory with 32 workspaces, an overflow on one rank's views) would leave
-        # the others waiting in the next collective until the watchdog: no per-rank recovery here - the exception ends the
-        # rank, torch.distributed.run ends the job, and the launcher prints the tail of every rank's stderr.
+        # These configurations are SECONDARY fields of the line: a failure that every rank sees alike (same software, same
+        # sizes: the likely kind) is recorded as text and the weak-scaled headline survives.  A failure only SOME ranks see
+        # (out of memory with 32 workspaces, an overflow on one rank's views) cannot be recovered from here - the peers sit in
+        # a collective the failed rank never joins, and the job ends with the watchdog's stack dump (AGS_BENCH_WATCHDOG).
+        # The ranks agree on the outcome (one all-reduce of a flag) before anybody starts the next configuration, so a rank
+        # that failed late - after the configuration's last collective - does not take its peers' next collectives apart.
         for key, cfg in strong_configs().items():
-            strong[key] = measure_strong(key, cfg, 10, dev, world, rank, dist_on)
+            try:
+                strong[key] = measure_strong(key, cfg, 10, dev, world, rank, dist_on)
+                failed = 0
+            except Exception as e:
+                strong[key] = f"{type(e).__name__}: {e}"
+                failed = 1
+                torch.cuda.synchronize()
+            # agree on the outcome before anybody starts the next configuration's collectives
+            flag = torch.tensor([failed], device=dev, dtype=torch.int32)
+            all_reduce_(flag, torch.distributed.ReduceOp.MAX)
+            if int(flag.item()) and not failed:
+                strong[key] = "another rank failed in this configuration (see its stderr)"
 
     if rank == 0:
         T = ((H + 15) // 16) * ((W + 15) // 16)
