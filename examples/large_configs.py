@@ -26,7 +26,6 @@ def run(tag, n, h, w, views, room, steps, warmup):
     raw = {k: v.to(dev) for k, v in make_room_scene(n, room=room, seed=0).items()}
     # AGS_FREEZE=1 (kernel A/B experiments): learning rates of zero - the scene stays what it is whatever a variant's
     # gradients are, so per-kernel times of different builds can be compared
-    import os
     lrs = dict(mean=0.0, scale=0.0, rotation=0.0, opacity=0.0, harmonic=0.0) if os.environ.get("AGS_FREEZE") == "1" else None
     trainer = SurfelTrainer(raw, lrs=lrs, view_streams=int(os.environ.get("AGS_VIEW_STREAMS", "4")))
     cams = []
