@@ -433,28 +433,29 @@ def measure_c3(dev):
     inside this process) and is labelled as such; the share of the wall time the GPU-bound phase covers is measured here."""
     from active_gs_amd.synthetic import make_keyframes, run_mapper_loop
     res = {}
-    for tag, (h, w) in (("512x512", (512, 512)), ("1200x680", (680, 1200))):
+
+    def first_pass(tag, h, w):
         frames = make_keyframes(50, h, w, dev)
         r = run_mapper_loop(frames, steps=10, draw="device", warmup_frames=2)
         res[tag] = dict(seconds=r["seconds"], ms_per_iteration=r["ms_per_iteration"], final_surfels=r["final_surfels"],
                         iterations=r["iterations"], mean_frame_error=r["mean_frame_error"], overflow_retries=r["overflow_retries"],
                         device_mallocs=r["device_mallocs"])
-        del frames
-        torch.cuda.empty_cache()
+        return frames
+
+    frames = first_pass("512x512", 512, 512)
     # Where the loop's wall time goes, from ONE run (no figure of a profiled run is divided by another run's clock): the
-    # same 512x512 loop once more with a HIP event + the host clock at every phase boundary.  The iterations are the
-    # GPU-bound phase (their GPU time is kernel time, the host enqueues them in a fifth of it); growth, a call's set-up and
-    # post-processing are host-bound (GPU-timeline time ~ host time: launches with the GPU waiting between them).
+    # same 512x512 loop ONCE MORE in this process - right behind the first pass, so the caching allocator holds every block
+    # the loop needs (device_mallocs: what a long-running process sees from its second mission on) - with a HIP event + the
+    # host clock at every phase boundary.  The iterations are the GPU-bound phase (their GPU time is kernel time, the host
+    # enqueues them in a fifth of it); growth, a call's set-up and post-processing are host-bound (GPU-timeline time ~ host
+    # time: launches with the GPU waiting between them).
     busy = None
     try:
-        frames = make_keyframes(50, 512, 512, dev)
         r = run_mapper_loop(frames, steps=10, draw="device", warmup_frames=0, phases=True)
-        del frames
-        torch.cuda.empty_cache()
         busy = dict(seconds_with_marks=r["seconds"], gpu_bound_frac=r["gpu_bound_frac"], iterations_gpu_ms=r["iterations_gpu_ms"],
                     phases=r["phases"], device_mallocs=r["device_mallocs"],
-                    what="this run, second pass of the 512x512 loop with event marks at the phase boundaries (~7 records per "
-                         "keyframe): gpu_bound_frac = GPU-timeline time of the iterations / that pass's wall time - a LOWER bound "
+                    what="this run, second pass of the 512x512 loop (allocator warm) with event marks at the phase boundaries (~7 records "
+                         "per keyframe): gpu_bound_frac = GPU-timeline time of the iterations / that pass's wall time - a LOWER bound "
                          "of the kernels-busy fraction (the host-bound phases also run kernels)")
         try:
             kb = json.load(open(os.path.join(ROOT, "profiles", "c3_kernels_busy.json")))
@@ -466,6 +467,11 @@ def measure_c3(dev):
     except Exception as e:
         busy = f"{type(e).__name__}: {e}"
         torch.cuda.synchronize()
+    del frames
+    torch.cuda.empty_cache()
+    frames = first_pass("1200x680", 680, 1200)
+    del frames
+    torch.cuda.empty_cache()
     return dict(seconds=res["512x512"]["seconds"], ms_per_iteration=res["512x512"]["ms_per_iteration"],
                 final_surfels=res["512x512"]["final_surfels"], kernels_busy=busy, **res,
                 what="GaussianMap(cfg, device).update(dataframe) x 50 keyframes (10 iterations each, batch 8 with 3 active frames, "
