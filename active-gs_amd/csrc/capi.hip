@@ -1,7 +1,7 @@
 // extern "C" entry points of libags_raster.so (include/ags_raster.h).
 #include "ags_internal.h"
 
-#define AGS_VERSION 101
+#define AGS_VERSION 102   // 102: ags_forward_batch_loss, AGS_BWD_BF16X3
 
 static int ags_check_launch() { return hipGetLastError() == hipSuccess ? AGS_OK : AGS_E_LAUNCH; }
 

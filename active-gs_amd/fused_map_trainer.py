@@ -810,7 +810,12 @@ class FusedMapTrainer(GaussianMapTrainer):
     def settle(self) -> bool:
         """Look at the workspace check a train() call left pending (see DEFER_SETTLE); repeats the call if it overflowed.
         Returns True when a call was repeated (the map's parameters are then not what they were a moment ago).  Cheap when
-        nothing is pending; waits for the GPU otherwise."""
+        nothing is pending; waits for the GPU otherwise.
+        A repeated call starts from its snapshot INCLUDING the random streams (numpy's global one when the host sampler is in
+        use, torch's CPU and device generators): they are rewound to where the call began, so draws a caller made from those
+        GLOBAL streams between train() returning and this look (it may run inside a later attribute read) are drawn again.
+        The reference seeds nothing (main.py, mapper.py), so no caller can depend on those streams; one that does should call
+        ``settle()`` right after ``train()`` / ``update()`` or set ``DEFER_SETTLE = False``."""
         p = self._pending_check
         if p is None:
             return False
