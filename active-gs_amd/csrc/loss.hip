@@ -282,7 +282,15 @@ __global__ __launch_bounds__(256) void ags_k_loss_finish(AgsLossDev c, float* __
     const int t = threadIdx.x;
     float s = 0.f;
     if (t < accum_stride) {
-        for (int r = 0; r < AGS_LOSS_ACCUM_ROWS; ++r) { s += accum[(size_t)r * accum_stride + t]; accum[(size_t)r * accum_stride + t] = 0.f; }
+        // all 64 rows are requested before the first one is added (one memory latency, not a chain of them: this workgroup
+        // is alone on the GPU while it runs), summed in row order, then cleared
+        float v[AGS_LOSS_ACCUM_ROWS];
+#pragma unroll
+        for (int r = 0; r < AGS_LOSS_ACCUM_ROWS; ++r) v[r] = accum[(size_t)r * accum_stride + t];
+#pragma unroll
+        for (int r = 0; r < AGS_LOSS_ACCUM_ROWS; ++r) s += v[r];
+#pragma unroll
+        for (int r = 0; r < AGS_LOSS_ACCUM_ROWS; ++r) accum[(size_t)r * accum_stride + t] = 0.f;
     }
     sums[t] = s;
     __syncthreads();
@@ -483,7 +491,15 @@ __global__ __launch_bounds__(256) void ags_k_loss_finish_next(AgsLossDev c, floa
     }
     float s = 0.f;
     if (t < accum_stride) {
-        for (int r = 0; r < AGS_LOSS_ACCUM_ROWS; ++r) { s += accum[(size_t)r * accum_stride + t]; accum[(size_t)r * accum_stride + t] = 0.f; }
+        // all 64 rows are requested before the first one is added (one memory latency, not a chain of them: this workgroup
+        // is alone on the GPU while it runs), summed in row order, then cleared
+        float v[AGS_LOSS_ACCUM_ROWS];
+#pragma unroll
+        for (int r = 0; r < AGS_LOSS_ACCUM_ROWS; ++r) v[r] = accum[(size_t)r * accum_stride + t];
+#pragma unroll
+        for (int r = 0; r < AGS_LOSS_ACCUM_ROWS; ++r) s += v[r];
+#pragma unroll
+        for (int r = 0; r < AGS_LOSS_ACCUM_ROWS; ++r) accum[(size_t)r * accum_stride + t] = 0.f;
     }
     key[t] = s;                      // (the draw's key array doubles as the sums' scratch)
     __syncthreads();
