@@ -58,7 +58,8 @@ class AgsGaussianGrads(C.Structure):
 
 class AgsTuning(C.Structure):
     _fields_ = [("bwd_reduce", C.c_int32), ("render_slots", C.c_int32), ("cull_first_min_n", C.c_int32),
-                ("tile_sort_no_wave", C.c_int32), ("bucket_no_scan", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("tile_sort_no_wave", C.c_int32), ("bucket_no_scan", C.c_int32), ("view_group", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 BWD_F32, BWD_BF16_SPLIT, BWD_VALU, BWD_BF16X3 = 0, 1, 2, 3
@@ -70,7 +71,8 @@ def tuning_from_env(env) -> AgsTuning:
     is a pure function of the mapping it is given: a launcher that wants the AGS_* variables INTEGRATION.md lists
     honoured (bench.py, the tests' conftest, experiment scripts) passes ``os.environ`` through ``env_config.apply_env``:
       AGS_BWD_REDUCE=f32|bf16|bf16x3|valu  (AGS_BWD_BF16=1 = bf16, AGS_BWD_MFMA=0 = valu)   blend backward's per-surfel sums
-      AGS_RENDER_SLOTS=1|2|4, AGS_PRE_CULL_MIN_N=<rows> (0: always), AGS_TSORT_NO_WAVE, AGS_BUCKET_NO_SCAN"""
+      AGS_RENDER_SLOTS=1|2|4, AGS_PRE_CULL_MIN_N=<rows> (0: always), AGS_VIEW_GROUP=<views per workgroup of a batched forward>,
+      AGS_TSORT_NO_WAVE, AGS_BUCKET_NO_SCAN"""
     t = AgsTuning()
     mode = env.get("AGS_BWD_REDUCE")
     if mode is not None:
@@ -86,6 +88,8 @@ def tuning_from_env(env) -> AgsTuning:
     if env.get("AGS_PRE_CULL_MIN_N") is not None:
         v = int(env["AGS_PRE_CULL_MIN_N"])
         t.cull_first_min_n = 1 if v <= 0 else min(v, 0x7FFFFFFF)
+    if env.get("AGS_VIEW_GROUP") is not None:
+        t.view_group = int(env["AGS_VIEW_GROUP"])
     t.tile_sort_no_wave = int(env.get("AGS_TSORT_NO_WAVE") is not None)
     t.bucket_no_scan = int(env.get("AGS_BUCKET_NO_SCAN") is not None)
     return t
@@ -110,10 +114,13 @@ def set_default_tuning(t: AgsTuning, cull_pinned: bool = False) -> None:
     _default_tuning, cull_choice_pinned = t, bool(cull_pinned)
 
 
-def make_tuning(bwd_reduce=None, render_slots=None, cull_first_min_n=None) -> AgsTuning:
-    """A copy of the default selection with some fields replaced (bwd_reduce: "f32" | "bf16" | "valu" or AGS_BWD_*)."""
+def make_tuning(bwd_reduce=None, render_slots=None, cull_first_min_n=None, view_group=None) -> AgsTuning:
+    """A copy of the default selection with some fields replaced (bwd_reduce: "f32" | "bf16x3" | "bf16" | "valu" or AGS_BWD_*;
+    view_group: views per workgroup of a batched forward's per-Gaussian stage, 1 = no sharing, 0 = chosen by the library)."""
     d = default_tuning()
-    t = AgsTuning(d.bwd_reduce, d.render_slots, d.cull_first_min_n, d.tile_sort_no_wave, d.bucket_no_scan)
+    t = AgsTuning(d.bwd_reduce, d.render_slots, d.cull_first_min_n, d.tile_sort_no_wave, d.bucket_no_scan, d.view_group)
+    if view_group is not None:
+        t.view_group = int(view_group)
     if bwd_reduce is not None:
         t.bwd_reduce = _BWD_NAMES[bwd_reduce] if isinstance(bwd_reduce, str) else int(bwd_reduce)
     if render_slots is not None:

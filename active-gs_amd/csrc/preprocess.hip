@@ -241,6 +241,107 @@ __global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess(
 }
 
 // ---------------------------------------------------------------------------------------
+// The forward per-Gaussian stage of a BATCH of views (ags_forward_batch: the views of a training iteration, a planner's
+// candidate views, the keyframes of a prune pass) with the rows' inputs loaded and activated ONCE for a group of views.
+// In ags_k_preprocess blockIdx.y is the view: every view's workgroup loads the same 256 rows (60 bytes each) and runs the
+// same activations (three exp, a normalisation, a sigmoid) before its own cull - eleven times per training iteration of
+// the mapper, a hundred times per planner step - and most of those row-views end at the cull.  Here blockIdx.y is a GROUP
+// of consecutive views: the workgroup keeps its rows in registers and walks the group's views - view transform and cull,
+// and only for the rows a view shows the exact stage (the same ags_preprocess_fwd on the same inputs: bit-identical
+// records), the record / radius writes and the wave-balanced key emission into THAT view's workspace.  One-pass binning
+// only (no block-level reductions: nothing between two views of the loop but a wave barrier).
+template <bool AGG>
+__global__ __launch_bounds__(AGS_PRE_THREADS) void ags_k_preprocess_views(
+    AgsFrame F, const float* __restrict__ Vp0, const float* __restrict__ Pp0, AgsGaussians in,
+    AgsGeom* __restrict__ geom0, int* __restrict__ radii0, uint32_t* __restrict__ tile_count0, float4* __restrict__ dgeom0,
+    AgsRowSet touched, AgsDirectEmit direct0, float* __restrict__ zero_importance, int* __restrict__ zero_count,
+    AgsViewStride vs, int views_per_group) {
+    ags_frame_flags(F);
+    __shared__ AgsEmitRec emit[AGS_PRE_THREADS];
+    __shared__ __attribute__((aligned(16))) float rows3[9 * AGS_PRE_THREADS];
+    const int bx = (int)blockIdx.x;
+    const int first = bx * AGS_PRE_THREADS;
+    const int i = first + threadIdx.x;
+    const int rows = min(AGS_PRE_THREADS, in.n - first);
+    float p[3], sc[3], col[3];
+    const int ic = i < in.n ? i : in.n - 1;
+    const float4 q4 = reinterpret_cast<const float4*>(in.rotations)[ic];
+    float opacity = in.opacities[ic];
+    const float conf = in.confidences[ic];
+    int was_member = touched.member ? touched.member[ic] : 1;
+    ags_load_rows3x3(in.means3D, in.scales, in.colors, first, rows, rows3, p, sc, col);
+    float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    if (in.raw_params) { float rv[3], qi; ags_activate_inplace(in, sc, q, opacity, rv, qi); }
+    const int v0 = (int)blockIdx.y * views_per_group;
+    const int v1 = min(v0 + views_per_group, vs.views);
+    const uint32_t wave_first = (uint32_t)(first + (threadIdx.x & ~63));
+    for (int v = v0; v < v1; ++v) {          // (workgroup-uniform)
+        const size_t wo = (size_t)v * (size_t)vs.ws;
+        const float* Vp = Vp0 + 16 * v;
+        const float* Pp = Pp0 + 16 * v;
+        int* radii = radii0 + (size_t)v * (size_t)vs.n;
+        AgsGeom* geom = geom0; uint32_t* tile_count = tile_count0; float4* dgeom = dgeom0;
+        AgsDirectEmit direct = direct0;
+        AGS_WS_SHIFT(geom, wo); AGS_WS_SHIFT(tile_count, wo); AGS_WS_SHIFT(dgeom, wo);
+        AGS_WS_SHIFT(direct.keys, wo); AGS_WS_SHIFT(direct.partial, wo); AGS_WS_SHIFT(direct.early, wo);
+        float V[16], P[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { V[k] = Vp[k]; P[k] = Pp[k]; }
+        if (zero_importance && i < in.n) {
+            zero_importance[(size_t)v * (size_t)vs.n + i] = 0.f;
+            zero_count[(size_t)v * (size_t)vs.n + i] = 0;
+        }
+        uint32_t cnt = 0, vis = 0;
+        uint32_t rx0 = 0, ry0 = 0, rwd = 1;
+        AgsGeom g;
+        g.mx = g.my = g.ca = g.cb = g.cc = g.o = 0.f; g.dc = 0.f;
+        if (i < in.n) {
+            int radius = 0, rc[4];
+            if (ags_preprocess_fwd(F, V, P, p, sc, q, opacity, col, conf, 0.f, 0.f, g, radius, rc)) {
+                float4* dst = reinterpret_cast<float4*>(geom + i);
+                dst[0] = make_float4(g.mx, g.my, g.ca, g.cb);
+                dst[1] = make_float4(g.cc, g.o, g.dc, g.gx);
+                dst[2] = make_float4(g.gy, g.r, g.g, g.b);
+                dst[3] = make_float4(g.nx, g.ny, g.nz, g.conf);
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                dgeom[4 * (size_t)i + 0] = z4; dgeom[4 * (size_t)i + 1] = z4;
+                dgeom[4 * (size_t)i + 2] = z4; dgeom[4 * (size_t)i + 3] = z4;
+                cnt = (uint32_t)((rc[2] - rc[0]) * (rc[3] - rc[1]));
+                rx0 = (uint32_t)rc[0]; ry0 = (uint32_t)rc[1]; rwd = (uint32_t)(rc[2] - rc[0]);
+                vis = 1;
+            }
+            radii[i] = radius;
+        }
+        if (touched.member) { // sticky row set of the optimisation loop: a row is inserted by the first view that shows it
+            const bool fresh = vis && was_member == 0 && atomicExch(&touched.member[i], 1) == 0;
+            if (vis) was_member = 1;
+            const unsigned long long mask = __ballot(fresh);
+            if (mask) { // wave-uniform
+                const int lane = threadIdx.x & 63;
+                int base = 0;
+                if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(touched.count, (int)__builtin_popcountll(mask));
+                base = __shfl(base, (int)__builtin_ctzll(mask));
+                if (fresh) touched.rows[base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = i;
+            }
+        }
+        const uint32_t ws = ags_wave_sum_u32(cnt), wv = ags_wave_sum_u32(vis);
+        const bool dense = AGS_DIRECT_AGG_LARGE != 0 && ws >= AGS_DIRECT_AGG_MIN_PAIRS;     // wave-uniform
+        ags_emit_tiles_balanced(emit + (threadIdx.x & ~63), cnt, rx0, ry0, rwd, __float_as_uint(g.dc), g, F.tiles_x,
+                                [&](bool hit, uint32_t t, uint32_t depth_bits, int owner_lane) {
+                                    uint32_t got;
+                                    if (AGG) got = ags_wave_agg_inc<1, true>(tile_count, t * direct.tc_stride, hit);
+                                    else if (dense) got = ags_wave_agg_inc<2, true>(tile_count, t * direct.tc_stride, hit);
+                                    else got = ags_wave_agg_inc<0, true>(tile_count, t * direct.tc_stride, hit);
+                                    if (hit && got < direct.tile_cap)
+                                        direct.keys[(size_t)t * direct.tile_cap + got] =
+                                            ((uint64_t)depth_bits << 32) | (wave_first + (uint32_t)owner_lane);
+                                    else if (hit) atomicMax(direct.early, got + 1u);
+                                });
+        if ((threadIdx.x & 63) == 0 && wv) atomicAdd(&direct.partial[AGS_PART(bx, AGS_PART_VIS)], wv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // The forward per-Gaussian stage for LARGE maps of which a view shows little (one-pass binning, raw parameters: the
 // trainers' configuration 4 / 5 shape - 1.5 M / 5 M surfels, 11-20 % visible, in random order).  In ags_k_preprocess a
 // lane owns a row from load to key emission: with one row in nine visible nearly every wave still has a visible lane and
@@ -1190,6 +1291,27 @@ void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGau
                            cam.viewmatrix, cam.projmatrix, in, (AgsGeom*)(ws + L.geom), radii, (uint32_t*)(ws + L.tile_count),
                            (float4*)(ws + L.dgeom), touched, direct, zero_importance, zero_count, vs);
         return;
+    }
+    // a BATCH of views under one-pass binning: the rows' inputs are loaded and activated once per GROUP of views
+    // (ags_k_preprocess_views).  AgsTuning.view_group: 0 = as many groups as fill the GPU with ~2 500 workgroups, 1 = one
+    // view per workgroup (ags_k_preprocess, blockIdx.y = view), k > 1 = k views per group
+    if (emit == 2 && vs.views > 1 && L.tune.view_group != 1) {
+        int per = L.tune.view_group;
+        if (per <= 0) {
+            int groups = (2500 + L.n_blocks - 1) / (L.n_blocks > 0 ? L.n_blocks : 1);
+            groups = groups < 1 ? 1 : (groups > vs.views ? vs.views : groups);
+            per = (vs.views + groups - 1) / groups;
+        }
+        if (per > 1) {
+            const dim3 grid(L.n_blocks, (vs.views + per - 1) / per);
+#define AGS_LAUNCH_VIEWS(AGG)                                                                                             \
+    hipLaunchKernelGGL((ags_k_preprocess_views<AGG>), grid, dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix, cam.projmatrix, in, \
+                       (AgsGeom*)(ws + L.geom), radii, (uint32_t*)(ws + L.tile_count), (float4*)(ws + L.dgeom), touched,    \
+                       direct, zero_importance, zero_count, vs, per)
+            if (agg) AGS_LAUNCH_VIEWS(true); else AGS_LAUNCH_VIEWS(false);
+#undef AGS_LAUNCH_VIEWS
+            return;
+        }
     }
     if (emit == 0) AGS_LAUNCH_PRE(0, false);
     else if (emit == 1) { if (agg) AGS_LAUNCH_PRE(1, true); else AGS_LAUNCH_PRE(1, false); }

@@ -492,7 +492,7 @@ void set_option(const std::string& name, double v) {
 void set_tuning(int64_t bwd_reduce, int64_t render_slots, int64_t cull_first_min_n, int64_t tile_sort_no_wave, int64_t bucket_no_scan) {
     std::lock_guard<std::mutex> g(mu);
     tuning = AgsTuning{(int32_t)bwd_reduce, (int32_t)render_slots, (int32_t)cull_first_min_n, (int32_t)tile_sort_no_wave,
-                       (int32_t)bucket_no_scan, {0, 0, 0}};
+                       (int32_t)bucket_no_scan, 0, {0, 0}};
 }
 
 double get_option(const std::string& name) {

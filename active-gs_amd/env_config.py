@@ -13,7 +13,7 @@ def apply_env(env) -> dict:
     if env.get("AGS_LIB_PATH"):
         _lib.lib_path_override = changed["lib_path"] = env["AGS_LIB_PATH"]
     tuning_keys = ("AGS_BWD_REDUCE", "AGS_BWD_BF16", "AGS_BWD_MFMA", "AGS_RENDER_SLOTS", "AGS_PRE_CULL_MIN_N",
-                   "AGS_TSORT_NO_WAVE", "AGS_BUCKET_NO_SCAN")
+                   "AGS_TSORT_NO_WAVE", "AGS_BUCKET_NO_SCAN", "AGS_VIEW_GROUP")
     if any(env.get(k) is not None for k in tuning_keys):
         _lib.set_default_tuning(_lib.tuning_from_env(env), cull_pinned=env.get("AGS_PRE_CULL_MIN_N") is not None)
         changed["tuning"] = {k: env[k] for k in tuning_keys if env.get(k) is not None}

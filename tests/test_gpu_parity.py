@@ -873,3 +873,49 @@ def test_sweep_of_sizes_flags_and_masks_matches_oracle(agslib, case):
         assert int(out[6].abs().sum()) == 0 and float(out[5].abs().sum()) == 0.0
     if any(float(t.grad.abs().sum()) > 0 for t in ins if t.grad is not None):
         _check_grads(ins, gin, what)
+
+
+@pytest.mark.parametrize("raw_params", [False, True])
+def test_batched_forward_shares_row_loads_across_views_bit_for_bit(agslib, raw_params):
+    """``ags_k_preprocess_views`` (a batch's per-Gaussian stage with the rows loaded and activated once per GROUP of views,
+    ``AgsTuning.view_group``) against one view per workgroup (``view_group = 1``): the same images, radii, counts, statistics
+    and status words whatever the group size (2, 5, all views in one group, the library's own choice), for activated and
+    for raw parameters, a map size that is no multiple of the workgroup, and the same row set (as a set)."""
+    from active_gs_amd import _lib, raster_api as api
+    from active_gs_amd.synthetic import activate, make_room_scene
+    dev = torch.device("cuda:0")
+    n, h, w, V = 70_001, 136, 240, 7
+    raw = {k: v.to(dev) for k, v in make_room_scene(n, seed=12).items()}
+    raw["scales"][:, :2] += 0.8
+    if raw_params:
+        a = activate(raw)
+        g = api.Gaussians(raw["means"], raw["scales"], raw["rotations"], raw["opacities"], raw["harmonics"].view(n, 3).contiguous(),
+                          a["confidences"].contiguous(), raw_params=True, scale_factor=0.01, max_scale=0.05)
+    else:
+        a = activate(raw)
+        g = api.Gaussians(*(a[k].contiguous() for k in ("means", "scales", "rotations", "opacities", "colors", "confidences")))
+    S = [room_case(16, h, w, view=v, seed=12)[1] for v in range(V)]
+    bg = S[0].bg.to(dev)
+    vm = torch.stack([s.viewmatrix for s in S]).to(dev)
+    pm = torch.stack([s.projmatrix for s in S]).to(dev)
+    out = {}
+    for group in (1, 2, 5, 64, 0):
+        batch = api.ViewBatch(g, V, h, w, S[0].tanfovx, S[0].tanfovy, bg, 1 << 21, want_stats=True,
+                              tuning=_lib.make_tuning(view_group=group))
+        batch.viewmats.copy_(vm); batch.projmats.copy_(pm)
+        rows = api.RowSet(n, dev)
+        batch.forward(V, touched=rows)
+        torch.cuda.synchronize()
+        st = batch.statuses(V)
+        assert int(st[:, 2].max()) == 0
+        k = int(rows.count.item())
+        out[group] = dict(rgb=batch.rgb.clone(), normal=batch.normal.clone(), depth=batch.depth.clone(), opacity=batch.opacity.clone(),
+                          confidence=batch.confidence.clone(), radii=batch.radii.clone(), count=batch.count.clone(),
+                          importance=batch.importance.clone(), status=st[:, [0, 3, 6]].clone(),
+                          rows=torch.sort(rows.rows[:k]).values.clone(), member=rows.member.clone())
+    ref = out[1]
+    assert float(ref["opacity"].max()) > 0.5 and int(ref["status"][:, 1].min()) > 100 and ref["rows"].numel() > 1000
+    for group, o in out.items():
+        for key in ("rgb", "normal", "depth", "opacity", "confidence", "radii", "count", "status", "rows", "member"):
+            assert torch.equal(ref[key], o[key]), (group, key)
+        assert torch.allclose(ref["importance"], o["importance"], rtol=1e-5, atol=1e-6), group      # (float atomics: order)
