@@ -116,7 +116,7 @@ def set_default_tuning(t: AgsTuning, cull_pinned: bool = False) -> None:
 
 def make_tuning(bwd_reduce=None, render_slots=None, cull_first_min_n=None, view_group=None) -> AgsTuning:
     """A copy of the default selection with some fields replaced (bwd_reduce: "f32" | "bf16x3" | "bf16" | "valu" or AGS_BWD_*;
-    view_group: views per workgroup of a batched forward's per-Gaussian stage, 1 = no sharing, 0 = chosen by the library)."""
+    view_group: k > 1 = a batched forward's per-Gaussian stage loads a row once for k consecutive views; 0 / 1 = off)."""
     d = default_tuning()
     t = AgsTuning(d.bwd_reduce, d.render_slots, d.cull_first_min_n, d.tile_sort_no_wave, d.bucket_no_scan, d.view_group)
     if view_group is not None:

@@ -1292,17 +1292,14 @@ void ags_launch_preprocess(const AgsFrame& F, const AgsCamera& cam, const AgsGau
                            (float4*)(ws + L.dgeom), touched, direct, zero_importance, zero_count, vs);
         return;
     }
-    // a BATCH of views under one-pass binning: the rows' inputs are loaded and activated once per GROUP of views
-    // (ags_k_preprocess_views).  AgsTuning.view_group: 0 = as many groups as fill the GPU with ~2 500 workgroups, 1 = one
-    // view per workgroup (ags_k_preprocess, blockIdx.y = view), k > 1 = k views per group
-    if (emit == 2 && vs.views > 1 && L.tune.view_group != 1) {
-        int per = L.tune.view_group;
-        if (per <= 0) {
-            int groups = (2500 + L.n_blocks - 1) / (L.n_blocks > 0 ? L.n_blocks : 1);
-            groups = groups < 1 ? 1 : (groups > vs.views ? vs.views : groups);
-            per = (vs.views + groups - 1) / groups;
-        }
-        if (per > 1) {
+    // a BATCH of views under one-pass binning, OPT-IN (AgsTuning.view_group = k > 1): the rows' inputs are loaded and
+    // activated once per group of k views (ags_k_preprocess_views).  Measured (profiles/r06_view_group_ab.md): the mapper's
+    // batch of eleven 512x512 views 80.9 -> 84.4 us (the time is the visible rows' projection and key emission, which one
+    // view per workgroup spreads over eleven times as many workgroups; the shared loads hit the L2 anyway), a planner's
+    // hundred 128x128 views 1.54 -> 1.39 ms.  0 / 1 = one view per workgroup (ags_k_preprocess, blockIdx.y = view).
+    if (emit == 2 && vs.views > 1 && L.tune.view_group > 1) {
+        const int per = L.tune.view_group;
+        {
             const dim3 grid(L.n_blocks, (vs.views + per - 1) / per);
 #define AGS_LAUNCH_VIEWS(AGG)                                                                                             \
     hipLaunchKernelGGL((ags_k_preprocess_views<AGG>), grid, dim3(AGS_PRE_THREADS), 0, s, F, cam.viewmatrix, cam.projmatrix, in, \

@@ -214,9 +214,9 @@ typedef struct AgsTuning {
                                 * culls on the means first; < 0 = never; 1 = always */
     int32_t tile_sort_no_wave; /* != 0: AGS_BIN_DIRECT always sorts with the 256-thread kernel (never one wave per tile) */
     int32_t bucket_no_scan;    /* != 0: AGS_BIN_TILE_SORT always runs the separate tile-scan launch */
-    int32_t view_group;        /* batched forward (ags_forward_batch, AGS_BIN_DIRECT): views whose per-Gaussian stage shares one
-                                * load + activation of the rows.  0 = chosen from the batch and map size, 1 = one view per
-                                * workgroup (no sharing), k > 1 = k consecutive views per workgroup.  Same records either way. */
+    int32_t view_group;        /* batched forward (ags_forward_batch, AGS_BIN_DIRECT): k > 1 = the per-Gaussian stage loads and
+                                * activates a row once for k consecutive views (opt-in: -10 % on a planner's hundred small
+                                * views, +4 % on the mapper's eleven); 0 / 1 = one view per workgroup.  Same records either way. */
     int32_t reserved[2];       /* 0 */
 } AgsTuning;
 

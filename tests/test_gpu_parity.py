@@ -879,7 +879,7 @@ def test_sweep_of_sizes_flags_and_masks_matches_oracle(agslib, case):
 def test_batched_forward_shares_row_loads_across_views_bit_for_bit(agslib, raw_params):
     """``ags_k_preprocess_views`` (a batch's per-Gaussian stage with the rows loaded and activated once per GROUP of views,
     ``AgsTuning.view_group``) against one view per workgroup (``view_group = 1``): the same images, radii, counts, statistics
-    and status words whatever the group size (2, 5, all views in one group, the library's own choice), for activated and
+    and status words whatever the group size (2, 5, all views in one group; 0 = the default, which is off), for activated and
     for raw parameters, a map size that is no multiple of the workgroup, and the same row set (as a set)."""
     from active_gs_amd import _lib, raster_api as api
     from active_gs_amd.synthetic import activate, make_room_scene
