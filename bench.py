@@ -686,6 +686,18 @@ def main():
     if "RANK" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
 
+    # The contract is ONE JSON line on stdout.  Libraries write to stdout too - RCCL prints a version banner (five lines,
+    # flushed from the C library's buffer when the process EXITS, i.e. behind the JSON line), GaussianMap.prune prints like
+    # the reference's - so from here on file descriptor 1 is stderr for everybody, and only emit_line() below writes to
+    # the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit_line(obj) -> None:
+        real_stdout.write(json.dumps(obj) + "\n")
+        real_stdout.flush()
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -810,8 +822,8 @@ def main():
                 strong[key] = {k: r[k] for k in ("exchange_path", "exchange_bytes_per_rank", "views_this_rank", "surfels",
                                                  "member_rows_this_rank", "replicas_identical")}
         if rank == 0:
-            print(json.dumps({"check": "ok", "n_gpus": world, "backend": backend if dist_on else None, "exchange_path": path,
-                              "ranks": identity, "refused_steps": refused0, "strong_configs": strong}))
+            emit_line({"check": "ok", "n_gpus": world, "backend": backend if dist_on else None, "exchange_path": path,
+                       "ranks": identity, "refused_steps": refused0, "strong_configs": strong})
         if dist_on:
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
@@ -1202,7 +1214,7 @@ def main():
             out["cpu_baseline"], out["parity"] = cpu_baseline(
                 raw_cpu, dict(tanx=tanx, tany=tany, bg=bg, view=cm["viewmatrix"][0], proj=cm["projmatrix"][0]), d_cpu, gpu_check)
         flatten_scalars(out)
-        print(json.dumps(out))
+        emit_line(out)
     if dist_on:
         torch.distributed.barrier()  # rank 0 may still be in the CPU-baseline leg; leave together
         torch.distributed.destroy_process_group()
