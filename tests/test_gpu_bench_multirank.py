@@ -78,6 +78,9 @@ def test_bench_single_rank_contract_fields(agslib):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    # the JSON line is ALL there is on stdout (whatever libraries print - RCCL's banner, the mapper's "delete n gaussians" -
+    # goes to stderr: bench.py hands file descriptor 1 to stderr and keeps the real stdout for this one line)
+    assert [l for l in r.stdout.splitlines() if l.strip()] == lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["vs_baseline"] is None
     assert "20 step(s) per graph, 1 replay(s) per sample" in d["config"]["launch"]
